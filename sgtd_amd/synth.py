@@ -1,0 +1,139 @@
+"""Deterministic synthetic keypoint / map generator.
+
+The reference's datasets (semantic-graph JSONs of MulRan / MCD / Apollo scans,
+README.md:45) are external downloads and not available offline, so benchmarks
+and parity tests run on synthetic *semantic keypoint* frames with the same
+layout the hot path consumes: per frame N instance centroids (xyz f32, sensor
+frame) + a class label per centroid (labels 3..11 as the reference's graph
+producer emits, src/sgtd/src/get_json.cpp:10-12,287-293; 0..12 for the "wild"
+mapping, get_json_wild.cpp:10-12).
+
+World model: static landmarks with density rho = N/(pi*50^2) on a square
+region; a closed Lissajous trajectory with poses every `spacing` metres folded
+so that (trajectory length * 100 m swath) ~= region area; map frame k observes
+the N landmarks nearest to pose k, expressed in the sensor frame (yaw =
+heading) with N(0, sigma_map) noise; a query re-observes the N landmarks
+nearest to a perturbed copy of a random map pose (uniform yaw, N(0,0.5 m)
+shift) with N(0, sigma_query) noise, ground truth = that map frame.
+All randomness: numpy PCG64 seeded with (20251121, stream).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+BASE_SEED = 20251121
+
+
+@dataclass
+class SynthMap:
+    xyz: np.ndarray        # (F, N, 3) float32, sensor frame
+    label: np.ndarray      # (F, N) uint32
+    pose: np.ndarray       # (F, 3) x, y, yaw
+    landmarks: np.ndarray  # (L, 3) float64 world
+    landmark_label: np.ndarray  # (L,) uint32
+
+
+@dataclass
+class SynthQueries:
+    xyz: np.ndarray     # (Q, N, 3) float32
+    label: np.ndarray   # (Q, N) uint32
+    gt_frame: np.ndarray  # (Q,) int64 — the map frame each query re-observes
+    pose: np.ndarray    # (Q, 3)
+
+
+def _rng(stream, sub=0):
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence([BASE_SEED, stream, sub])))
+
+
+def _trajectory(n_frames, spacing, swath):
+    """closed Lissajous resampled at equal arc length `spacing`"""
+    length = n_frames * spacing
+    side = max(np.sqrt(length * swath), 2.2 * swath)
+    amp = side / 2.0
+    t = np.linspace(0.0, 2 * np.pi, 200001)
+
+    def curve(p, a):
+        return a * np.sin(p * t), a * np.sin((p + 1) * t + np.pi / 2)
+
+    def arclen(p, a):
+        x, y = curve(p, a)
+        return np.sum(np.hypot(np.diff(x), np.diff(y)))
+
+    p = 1
+    while arclen(p, amp) < length and p < 4096:
+        p += 1
+    amp = amp * length / arclen(p, amp)  # arc length is linear in the amplitude
+    x, y = curve(p, amp)
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])
+    target = np.arange(n_frames) * spacing
+    px = np.interp(target, s, x)
+    py = np.interp(target, s, y)
+    ahead = np.minimum(target + 0.5, s[-1])
+    yaw = np.arctan2(np.interp(ahead, s, y) - py, np.interp(ahead, s, x) - px)
+    return np.stack([px, py, yaw], axis=1), amp
+
+
+def _observe(landmarks, labels, tree, pose, n_kp, sigma, rng):
+    """the n_kp landmarks nearest to each pose, in the sensor frame, noisy, f32, shuffled"""
+    _, idx = tree.query(pose[:, :2], k=n_kp)
+    idx = np.asarray(idx).reshape(pose.shape[0], n_kp)
+    perm = np.argsort(rng.random(idx.shape), axis=1)       # seeded shuffle per frame
+    idx = np.take_along_axis(idx, perm, axis=1)
+    pts = landmarks[idx]                                    # (F, N, 3) world
+    d = pts[:, :, :2] - pose[:, None, :2]
+    c, s = np.cos(-pose[:, 2])[:, None], np.sin(-pose[:, 2])[:, None]
+    out = np.empty_like(pts)
+    out[:, :, 0] = c * d[:, :, 0] - s * d[:, :, 1]
+    out[:, :, 1] = s * d[:, :, 0] + c * d[:, :, 1]
+    out[:, :, 2] = pts[:, :, 2]
+    out += rng.normal(0.0, sigma, size=out.shape)
+    return out.astype(np.float32), labels[idx].astype(np.uint32)
+
+
+def make_map(n_frames, n_kp=200, stream=1, spacing=2.0, swath=100.0, radius=50.0,
+             sigma=0.02, label_lo=3, label_hi=11, z_sigma=1.5):
+    from scipy.spatial import cKDTree
+
+    rng = _rng(stream, 0)
+    pose, amp = _trajectory(n_frames, spacing, swath)
+    rho = n_kp / (np.pi * radius * radius)
+    half = amp + 2.5 * radius
+    n_land = int(rho * (2 * half) ** 2)
+    landmarks = np.empty((n_land, 3))
+    landmarks[:, 0] = rng.uniform(-half, half, n_land)
+    landmarks[:, 1] = rng.uniform(-half, half, n_land)
+    landmarks[:, 2] = rng.normal(0.0, z_sigma, n_land)
+    lab = rng.integers(label_lo, label_hi + 1, n_land).astype(np.uint32)
+    tree = cKDTree(landmarks[:, :2])
+    xyz, label = _observe(landmarks, lab, tree, pose, n_kp, sigma, rng)
+    m = SynthMap(xyz=xyz, label=label, pose=pose, landmarks=landmarks, landmark_label=lab)
+    m._tree = tree
+    return m
+
+
+def make_queries(smap, n_queries, stream=1, sigma=0.05, shift_sigma=0.5, frames=None):
+    """queries re-observing random (or the given) map frames from perturbed poses"""
+    rng = _rng(stream, 1)
+    n_frames = smap.pose.shape[0]
+    if frames is None:
+        gt = rng.integers(0, n_frames, n_queries)
+    else:
+        gt = np.asarray(frames, dtype=np.int64)
+        n_queries = len(gt)
+    pose = smap.pose[gt].copy()
+    pose[:, :2] += rng.normal(0.0, shift_sigma, (n_queries, 2))
+    pose[:, 2] = rng.uniform(-np.pi, np.pi, n_queries)
+    n_kp = smap.xyz.shape[1]
+    xyz, label = _observe(smap.landmarks, smap.landmark_label, smap._tree, pose, n_kp, sigma, rng)
+    return SynthQueries(xyz=xyz, label=label, gt_frame=gt.astype(np.int64), pose=pose)
+
+
+def has_knn_ties(xyz, k):
+    """True if a frame has duplicate points or an exact f32 distance tie among
+    the k+1 nearest of any point (FLANN's tie order is unpinned: such frames
+    are excluded from golden fixtures)."""
+    x = np.asarray(xyz, dtype=np.float32)
+    d = x[:, None, :] - x[None, :, :]
+    d2 = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
+    part = np.sort(d2, axis=1)[:, :k + 1]
+    return bool(np.any(part[:, 1:] == part[:, :-1]))
