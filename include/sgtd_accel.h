@@ -1,0 +1,198 @@
+/*
+ * sgtd_accel.h — C ABI of the MI355X (gfx950) triangle-descriptor build +
+ * geometric-hash match engine.  This is the drop-in boundary for the hot path
+ * of Hfx-J/SGTD: the bodies of
+ *
+ *   STDescManager::BuildSingleScanSTD   src/sgtd/src/STDesc.cpp:174-315
+ *   STDescManager::AddSTDescs           src/sgtd/src/STDesc.cpp:149-172
+ *   STDescManager::candidate_selector   src/sgtd/src/STDesc.cpp:318-460
+ *
+ * (class declared at src/sgtd/include/desc/STDesc.h:342-440) forward to these
+ * entry points; the reference has no FFI layer of its own, the C++ class *is*
+ * the operator API.  INTEGRATION.md shows the adapter.
+ *
+ * Conventions: every function returns 0 (SGTD_OK) or a negative sgtd_status;
+ * nothing throws across the ABI; all output buffers are caller allocated and
+ * sized by the documented bounds; a handle is not thread safe (neither is the
+ * reference's manager).  All HIP work of a handle is issued on one stream
+ * (sgtd_set_stream).  There is NO CPU fallback: without a usable gfx950 device
+ * sgtd_create fails with SGTD_ERR_NO_DEVICE.
+ */
+#ifndef SGTD_ACCEL_H
+#define SGTD_ACCEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sgtd_status {
+  SGTD_OK = 0,
+  SGTD_ERR_INVALID = -1,      /* bad argument / config                         */
+  SGTD_ERR_NO_DEVICE = -2,    /* no HIP device / wrong architecture            */
+  SGTD_ERR_HIP = -3,          /* a HIP runtime call failed (see sgtd_last_error)*/
+  SGTD_ERR_CAPACITY = -4,     /* caller buffer too small                       */
+  SGTD_ERR_FRAME_LIMIT = -5,  /* frame id >= max_frame_n (MAX_FRAME_N, STDesc.h:33:
+                                 the reference indexes a fixed array there)   */
+  SGTD_ERR_UNSUPPORTED = -6,  /* configuration outside the kernels' envelope   */
+  SGTD_ERR_STATE = -7         /* call order (e.g. results before a query)      */
+} sgtd_status;
+
+/* ConfigSetting fields the path reads (STDesc.h:38-72); defaults in
+ * sgtd_default_config() are the shipped YAML (config/SG_localization.yaml:74-89) */
+typedef struct sgtd_config {
+  int32_t descriptor_near_num;   /* K, STDesc.cpp:179; 3 <= K <= 16            */
+  int32_t candidate_num;         /* STDesc.cpp:423; <= 64                      */
+  int32_t max_frame_n;           /* MAX_FRAME_N, STDesc.h:33 (runtime here)    */
+  int32_t device_id;             /* HIP device ordinal                         */
+  double descriptor_min_len;     /* STDesc.cpp:181                             */
+  double descriptor_max_len;     /* STDesc.cpp:180; *1000 must be < 2^21       */
+  double std_side_resolution;    /* STDesc.cpp:178                             */
+  double rough_dis_threshold;    /* STDesc.cpp:357                             */
+  uint32_t first_frame_id;       /* initial current_frame_id_ (STDesc.h:363 is 0);
+                                    a table shard of a multi-GPU map starts at
+                                    the first frame it owns                    */
+  uint32_t reserved;
+} sgtd_config;
+
+/* One descriptor = one STDesc (STDesc.h:75-97) without the unused covariance
+ * matrices, as a structure of caller-allocated arrays.  NULL members are
+ * skipped on output and read as zero on input (side, label, frame are
+ * mandatory on input). */
+typedef struct sgtd_desc_soa {
+  double *side;      /* [n*3] side_length_ (scaled, ascending)                */
+  double *angle;     /* [n*3] angle_                                          */
+  double *center;    /* [n*3] center_                                         */
+  float *vertex;     /* [n*9] vertex_A_,B_,C_ xyz (exact: they are f32 casts) */
+  int32_t *label;    /* [n*3] (int)vertex_attached_                           */
+  uint32_t *frame;   /* [n]   frame_id_                                       */
+  int32_t *node_id;  /* [n*3] node_id = {i, m, n}                             */
+} sgtd_desc_soa;
+
+typedef struct sgtd_stats {
+  int64_t n_entries;       /* E: descriptors in the table                      */
+  int64_t n_buckets;       /* U: distinct (cell,label code) keys               */
+  int64_t n_frames;        /* AddSTDescs calls so far                          */
+  int64_t last_queries;    /* query frames in the last batch                   */
+  int64_t last_D;          /* query descriptors in the last batch              */
+  int64_t last_P;          /* table entries visited (STDesc.cpp:372 iterations)*/
+  int64_t last_M;          /* rough matches (STDesc.cpp:378)                   */
+  int64_t last_cand_pairs; /* pairs in all candidate match lists               */
+  int64_t hbm_bytes_table; /* bytes of the hot (probed) table arrays           */
+  /* per-kernel device time of the last batch, ms (only when timing is enabled
+   * with sgtd_set_timing; measured with hipEvents on the handle's stream)     */
+  float ms_build, ms_probe, ms_scan, ms_emit, ms_topk, ms_assemble, ms_total;
+  int32_t overflowed;      /* last batch outgrew a work buffer and was re-run  */
+} sgtd_stats;
+
+typedef struct sgtd_engine *sgtd_handle;
+
+void sgtd_default_config(sgtd_config *cfg);
+int sgtd_create(const sgtd_config *cfg, sgtd_handle *out);
+int sgtd_destroy(sgtd_handle h);
+const char *sgtd_strerror(int status);
+/* text of the last HIP failure on this handle ("" if none) */
+const char *sgtd_last_error(sgtd_handle h);
+
+/* all work of the handle goes to this hipStream_t (NULL = the null stream) */
+int sgtd_set_stream(sgtd_handle h, void *hip_stream);
+/* enable per-kernel hipEvent timing (costs a few microseconds per launch) */
+int sgtd_set_timing(sgtd_handle h, int enabled);
+
+/* STDescManager::current_frame_id_ (STDesc.h:350) */
+int sgtd_current_frame_id(sgtd_handle h, uint32_t *out);
+
+/* ---- BuildSingleScanSTD (STDesc.cpp:174-315) --------------------------- */
+/* One frame: keypoints xyz[n*3] f32 + label[n] (the pcl::PointXYZL fields,
+ * utility.hpp:646-659), host memory.  Descriptors are stamped with the
+ * current frame id.  out arrays must hold sgtd_max_descs(h, n) descriptors.
+ * A frame with n < K yields 0 descriptors (the reference reads past its k-NN
+ * result there). */
+int64_t sgtd_max_descs(sgtd_handle h, int n_keypoints);
+int sgtd_build(sgtd_handle h, const float *xyz, const uint32_t *label, int n,
+               sgtd_desc_soa *out, int64_t capacity, int64_t *n_out);
+
+/* ---- AddSTDescs (STDesc.cpp:149-172) ------------------------------------ */
+/* Appends n host descriptors as one frame: current_frame_id_ is incremented
+ * first, entries keep the frame id stored in d->frame. */
+int sgtd_add(sgtd_handle h, const sgtd_desc_soa *d, int64_t n);
+
+/* Map construction, the caller's loop semantic_graph_localization.cpp:419-458
+ * for n_frames frames at once, entirely on the device: frame k (keypoints
+ * kp_off[k]..kp_off[k+1]) is built with frame id current_frame_id_ and added,
+ * then current_frame_id_++ .  xyz/label are host pointers unless
+ * device_ptrs != 0; kp_off is always a host array of n_frames+1 offsets. */
+int sgtd_add_frames(sgtd_handle h, const float *xyz, const uint32_t *label,
+                    const int64_t *kp_off, int n_frames, int device_ptrs);
+
+/* Sorts the appended entries into the probe layout (CSR by key + key hash).
+ * Idempotent; called implicitly by the first query after an add. */
+int sgtd_finalize(sgtd_handle h);
+
+/* ---- candidate_selector (STDesc.cpp:318-460) ---------------------------- */
+/* Fused query: for every query frame BuildSingleScanSTD (frame id =
+ * current_frame_id_, as semantic_graph_localization.cpp:592) followed by
+ * candidate_selector.  Enqueues on the stream and returns; results stay on the
+ * device until fetched with the sgtd_result_* calls (which synchronise).
+ * Inputs must stay valid until the first sgtd_result_* call returns. */
+int sgtd_query_frames(sgtd_handle h, const float *xyz, const uint32_t *label,
+                      const int64_t *kp_off, int n_queries, int device_ptrs);
+
+/* candidate_selector on caller-provided descriptors (one query frame). */
+int sgtd_query_descs(sgtd_handle h, const sgtd_desc_soa *q, int64_t nq);
+
+/* Results of the last query batch.  For query q:
+ *   n_cand[q]                      number of candidates (<= candidate_num)
+ *   cand_frame/cand_votes[q*cn+k]  match_id_.second / vote count, in the
+ *                                  reference's order (votes desc, frame asc)
+ *   pair_off[q*(cn+1)+k]           offsets of candidate k's match_list_ into
+ *                                  the pair arrays of query q
+ * where cn = candidate_num.  Any pointer may be NULL. */
+int sgtd_result_candidates(sgtd_handle h, int32_t *n_cand, int32_t *cand_frame,
+                           int32_t *cand_votes, int64_t *pair_off);
+/* Asynchronous device-to-device export of the candidate tables of the last
+ * batch into caller device buffers (int32 [n_queries*candidate_num] each;
+ * unused slots hold frame -1 / votes 0), enqueued on the handle's stream
+ * without synchronising: the multi-GPU path all-gathers them with RCCL. */
+int sgtd_export_candidates_dev(sgtd_handle h, int32_t *d_cand_frame, int32_t *d_cand_votes);
+/* number of query descriptors of query q (stds_vec.size()) */
+int sgtd_result_query_desc_count(sgtd_handle h, int q, int64_t *n);
+/* match_list_ pairs of query q, candidate after candidate, each in the
+ * reference's order: q_idx = index into the query's descriptors, db_entry =
+ * insertion index of the table entry (use sgtd_fetch_entries).  capacity in
+ * pairs; *n_pairs receives the total. */
+int sgtd_result_pairs(sgtd_handle h, int q, int32_t *q_idx, int64_t *db_entry,
+                      int64_t capacity, int64_t *n_pairs);
+/* the query's own descriptors (built on the device by sgtd_query_frames) */
+int sgtd_result_query_descs(sgtd_handle h, int q, sgtd_desc_soa *out,
+                            int64_t capacity, int64_t *n_out);
+/* per-frame vote counts of query q (match_array, STDesc.cpp:323,410):
+ * votes[f - frame_lo] for f in [frame_lo, frame_lo + n) */
+int sgtd_result_votes(sgtd_handle h, int q, uint32_t *votes, int64_t capacity,
+                      uint32_t *frame_lo, int64_t *n);
+/* all rough matches of query q in the reference's (i, cell, j) order
+ * (STDesc.cpp:378-384): q_idx, voxel_round index 0..26, db_entry, frame, dis.
+ * Diagnostic / parity output; any pointer may be NULL. */
+int sgtd_result_rough(sgtd_handle h, int q, int32_t *q_idx, int32_t *cell,
+                      int64_t *db_entry, uint32_t *frame, double *dis,
+                      int64_t capacity, int64_t *n_rough);
+
+/* table entries by insertion index (to rebuild pair<STDesc,STDesc>) */
+int sgtd_fetch_entries(sgtd_handle h, const int64_t *db_entry, int64_t n,
+                       sgtd_desc_soa *out);
+
+/* table layout for inspection: keys [U*4] = x,y,z,label code ascending by
+ * (code,x,y,z); bucket_off [U+1]; entry ids [E] in bucket order */
+int sgtd_table_dump(sgtd_handle h, int64_t *keys, int64_t *bucket_off,
+                    int64_t *entry_ids, int64_t cap_buckets, int64_t cap_entries);
+
+/* waits for the stream, re-runs the last batch with larger work buffers if it
+ * overflowed them, and fills the counters */
+int sgtd_sync(sgtd_handle h);
+int sgtd_get_stats(sgtd_handle h, sgtd_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

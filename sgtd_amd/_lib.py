@@ -1,0 +1,125 @@
+"""ctypes binding of libsgtd_accel.so (the C ABI in include/sgtd_accel.h).
+
+There is no fallback: if the shared library is missing, or no gfx950 device is
+usable, this module raises — the product path never computes on the CPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgtd_accel.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SGTD_OK = 0
+ERRORS = {-1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY",
+          -5: "FRAME_LIMIT", -6: "UNSUPPORTED", -7: "STATE"}
+
+# every symbol include/sgtd_accel.h declares
+SYMBOLS = [
+    "sgtd_default_config", "sgtd_create", "sgtd_destroy", "sgtd_strerror", "sgtd_last_error",
+    "sgtd_set_stream", "sgtd_set_timing", "sgtd_current_frame_id", "sgtd_max_descs", "sgtd_build",
+    "sgtd_add", "sgtd_add_frames", "sgtd_finalize", "sgtd_query_frames", "sgtd_query_descs",
+    "sgtd_result_candidates", "sgtd_export_candidates_dev", "sgtd_result_query_desc_count", "sgtd_result_pairs",
+    "sgtd_result_query_descs", "sgtd_result_votes", "sgtd_result_rough", "sgtd_fetch_entries",
+    "sgtd_table_dump", "sgtd_sync", "sgtd_get_stats",
+]
+
+
+class SgtdError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__("sgtd_accel: %s (%d) %s" % (ERRORS.get(status, "?"), status, detail))
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("descriptor_near_num", C.c_int32),
+        ("candidate_num", C.c_int32),
+        ("max_frame_n", C.c_int32),
+        ("device_id", C.c_int32),
+        ("descriptor_min_len", C.c_double),
+        ("descriptor_max_len", C.c_double),
+        ("std_side_resolution", C.c_double),
+        ("rough_dis_threshold", C.c_double),
+        ("first_frame_id", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class DescSoa(C.Structure):
+    _fields_ = [("side", C.c_void_p), ("angle", C.c_void_p), ("center", C.c_void_p),
+                ("vertex", C.c_void_p), ("label", C.c_void_p), ("frame", C.c_void_p),
+                ("node_id", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_entries", C.c_int64), ("n_buckets", C.c_int64), ("n_frames", C.c_int64),
+        ("last_queries", C.c_int64), ("last_D", C.c_int64), ("last_P", C.c_int64),
+        ("last_M", C.c_int64), ("last_cand_pairs", C.c_int64), ("hbm_bytes_table", C.c_int64),
+        ("ms_build", C.c_float), ("ms_probe", C.c_float), ("ms_scan", C.c_float),
+        ("ms_emit", C.c_float), ("ms_topk", C.c_float), ("ms_assemble", C.c_float),
+        ("ms_total", C.c_float), ("overflowed", C.c_int32),
+    ]
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of the in-tree shared library"""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+        os.path.join(os.path.dirname(_HERE), "include", "sgtd_accel.h")]
+    stale = (not os.path.exists(LIB_PATH) or
+             os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgtdError(-2, "libsgtd_accel.so is not built (run __graft_entry__.build() or "
+                            "make -C sgtd_amd/csrc); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.sgtd_default_config.argtypes = [C.POINTER(Config)]
+    L.sgtd_default_config.restype = None
+    L.sgtd_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.sgtd_destroy.argtypes = [vp]
+    L.sgtd_strerror.argtypes = [C.c_int]
+    L.sgtd_strerror.restype = C.c_char_p
+    L.sgtd_last_error.argtypes = [vp]
+    L.sgtd_last_error.restype = C.c_char_p
+    L.sgtd_set_stream.argtypes = [vp, vp]
+    L.sgtd_set_timing.argtypes = [vp, C.c_int]
+    L.sgtd_current_frame_id.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.sgtd_max_descs.argtypes = [vp, C.c_int]
+    L.sgtd_max_descs.restype = i64
+    L.sgtd_build.argtypes = [vp, vp, vp, C.c_int, C.POINTER(DescSoa), i64, C.POINTER(i64)]
+    L.sgtd_add.argtypes = [vp, C.POINTER(DescSoa), i64]
+    L.sgtd_add_frames.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int]
+    L.sgtd_finalize.argtypes = [vp]
+    L.sgtd_query_frames.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int]
+    L.sgtd_query_descs.argtypes = [vp, C.POINTER(DescSoa), i64]
+    L.sgtd_result_candidates.argtypes = [vp, vp, vp, vp, vp]
+    L.sgtd_export_candidates_dev.argtypes = [vp, vp, vp]
+    L.sgtd_result_query_desc_count.argtypes = [vp, C.c_int, C.POINTER(i64)]
+    L.sgtd_result_pairs.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(i64)]
+    L.sgtd_result_query_descs.argtypes = [vp, C.c_int, C.POINTER(DescSoa), i64, C.POINTER(i64)]
+    L.sgtd_result_votes.argtypes = [vp, C.c_int, vp, i64, C.POINTER(C.c_uint32), C.POINTER(i64)]
+    L.sgtd_result_rough.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
+    L.sgtd_fetch_entries.argtypes = [vp, vp, i64, C.POINTER(DescSoa)]
+    L.sgtd_table_dump.argtypes = [vp, vp, vp, vp, i64, i64]
+    L.sgtd_sync.argtypes = [vp]
+    L.sgtd_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    for name in SYMBOLS:
+        getattr(L, name)
+        if getattr(L, name).restype is C.c_int:
+            pass
+    _lib = L
+    return L

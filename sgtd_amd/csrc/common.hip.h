@@ -1,0 +1,93 @@
+// common.hip.h — shared device helpers for the gfx950 kernels.
+// wave = 64 lanes everywhere (CDNA4); compiled with -ffp-contract=off so that
+// every f32/f64 multiply-add below is two individually rounded operations,
+// exactly like the reference binary (built -O3 without -march, no FMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SGTD_WAVE 64
+#define SGTD_MAX_K 16
+#define SGTD_NCELL 27
+#define SGTD_MAX_CAND 64
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// constants of one engine, passed by value to kernels
+struct DevCfg {
+  int K;            // descriptor_near_num
+  int tpi;          // triplets per keypoint = C(K-1,2)
+  int cand_num;
+  double min_len, max_len, scale, rough;
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (SGTD_WAVE - 1); }
+
+__device__ __forceinline__ u64 lanemask_lt() {
+  return (1ull << lane_id()) - 1ull;
+}
+
+// Eigen 3.3 Vector3d::norm() association: sqrt((v0^2 + v1^2) + v2^2), each op
+// rounded (STDesc.cpp:357,369,374-376)
+__device__ __forceinline__ double norm3(double x, double y, double z) {
+  return sqrt((x * x + y * y) + z * z);
+}
+
+// 12-bit label code, Combinatorial_Binary_Encoding (STDesc.cpp:3-16)
+__host__ __device__ __forceinline__ u32 label_code(int a, int b, int c) {
+  return ((u32)(a & 15) << 8) | ((u32)(b & 15) << 4) | (u32)(c & 15);
+}
+
+// 60-bit table key: code | x | y | z (16 bits each cell coordinate); ascending
+// key order == (code, x, y, z) lexicographic, z-neighbours are adjacent keys
+__host__ __device__ __forceinline__ u64 pack_key(u32 code, u32 x, u32 y, u32 z) {
+  return ((u64)code << 48) | ((u64)x << 32) | ((u64)y << 16) | (u64)z;
+}
+
+__host__ __device__ __forceinline__ u64 mix64(u64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+
+struct HashSlot {  // 16 bytes
+  u64 key;
+  u32 start;
+  u32 len;
+};
+#define SGTD_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+// inclusive wave scan (64 lanes) by shuffles
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+  for (int d = 1; d < SGTD_WAVE; d <<= 1) {
+    u32 t = __shfl_up(v, d);
+    if (lane_id() >= d) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+  for (int d = SGTD_WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// Stable multi-split rank inside one wave: lanes with equal `digit` (BITS wide)
+// among the `valid` lanes form a group; returns the lane's rank inside its
+// group (in lane order) and the group size.  BITS ballots, no LDS.
+template <int BITS>
+__device__ __forceinline__ void wave_group_rank(u32 digit, bool valid, u32 &rank, u32 &count) {
+  u64 m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < BITS; b++) {
+    u64 bal = __ballot((digit >> b) & 1u);
+    m &= ((digit >> b) & 1u) ? bal : ~bal;
+  }
+  rank = __popcll(m & lanemask_lt());
+  count = __popcll(m);
+}

@@ -1,0 +1,974 @@
+// sgtd_accel.hip — C ABI (include/sgtd_accel.h) over the gfx950 kernels.
+// Host side: buffer ownership, launch order, result marshalling.  No CPU
+// compute path exists here: every entry point needs the HIP device.
+#include "../../include/sgtd_accel.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "build_kernel.hip.h"
+#include "common.hip.h"
+#include "table_kernels.hip.h"
+#include "probe_kernels.hip.h"
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct DescStore {
+  DevBuf side, angle, center, vertex, label, frame, node_id;
+  size_t cap = 0;
+  DescArrays view() const {
+    DescArrays a;
+    a.side = side.as<double>(); a.angle = angle.as<double>(); a.center = center.as<double>();
+    a.vertex = vertex.as<float>(); a.label = label.as<int>(); a.frame = frame.as<u32>();
+    a.node_id = node_id.as<int>();
+    return a;
+  }
+};
+
+enum { EV_START = 0, EV_BUILD, EV_PROBE, EV_SCAN, EV_EMIT, EV_TOPK, EV_ASSEMBLE, EV_COUNT };
+
+}  // namespace
+
+struct sgtd_engine {
+  sgtd_config cfg;
+  DevCfg dc;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int n_cus = 256;
+  bool timing = false;
+  hipEvent_t ev[EV_COUNT] = {};
+
+  // ---- table, insertion order (cold)
+  u32 current_frame_id = 0;
+  DescStore tab;
+  int64_t n_entries = 0;
+  int64_t n_add_calls = 0;
+  bool have_frames = false;
+  u32 frame_lo = 0, frame_hi = 0;
+  bool finalized = true;  // empty table is trivially final
+
+  // ---- table, probe layout (hot)
+  DevBuf s0, s1, s2, tframe, perm, hash, bucket_start, bucket_key;
+  u32 hash_mask = 0;
+  int64_t n_buckets = 0;
+  // sort scratch
+  DevBuf keyA, keyB, valA, valB, hist, digit_tot, flags, bad_flag;
+  std::vector<DevBuf> scan_lvl;
+
+  // ---- build scratch
+  DevBuf kp_off_dev, xyz_dev, label_dev, ws_keys, ws_slots, cnt_scan;
+  DescStore tmp;        // strided build output for map construction
+  DevBuf tmp_count;
+
+  // ---- query batch
+  DescStore qd;         // strided query descriptors
+  DevBuf q_count;
+  long long q_stride = 0;
+  int nq = 0;
+  bool batch_valid = false, batch_synced = false;
+  // inputs of the last batch (for a re-run after a work-buffer overflow)
+  int last_kind = 0;    // 1 frames, 2 descs
+  const float *last_xyz = nullptr;
+  const u32 *last_label = nullptr;
+  std::vector<long long> last_kp_off;
+  int last_max_n = 0;
+  DevBuf mask_words, mask_cursor, mask_ptr, n_visit, n_match, rec_off, votes, slot_of, overflow;
+  DevBuf q_M, q_P, q_base, rec_qi, rec_pos, rec_frame, rec_cell, rec_dis;
+  DevBuf n_cand, cand_frame, cand_votes, pair_off, pair_qi, pair_entry;
+  size_t mask_cap = (size_t)1 << 20;   // words
+  size_t rec_cap = (size_t)1 << 22;    // records
+  bool want_dis = false;
+  // host copies after sync
+  std::vector<u32> h_count, h_q_base, h_q_M;
+  std::vector<unsigned long long> h_q_P;
+  std::vector<int> h_n_cand, h_cand_frame, h_cand_votes;
+  std::vector<long long> h_pair_off;
+  sgtd_stats stats{};
+};
+
+namespace {
+
+#define HIPCHK(call)                                                          \
+  do {                                                                        \
+    hipError_t _s = (call);                                                   \
+    if (_s != hipSuccess) {                                                   \
+      e->err = std::string(#call) + ": " + hipGetErrorString(_s);             \
+      return SGTD_ERR_HIP;                                                    \
+    }                                                                         \
+  } while (0)
+#define CHK(call)                 \
+  do {                            \
+    int _r = (call);              \
+    if (_r != SGTD_OK) return _r; \
+  } while (0)
+
+int ensure(sgtd_engine *e, DevBuf &b, size_t bytes, bool keep = false) {
+  if (bytes <= b.bytes) return SGTD_OK;
+  size_t want = keep ? std::max(bytes, b.bytes + b.bytes / 2) : bytes;
+  void *np = nullptr;
+  HIPCHK(hipMalloc(&np, want));
+  if (keep && b.p && b.bytes) {
+    HIPCHK(hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = np;
+  b.bytes = want;
+  return SGTD_OK;
+}
+
+int ensure_store(sgtd_engine *e, DescStore &s, size_t cap, bool keep = false) {
+  if (cap <= s.cap) return SGTD_OK;
+  size_t want = keep ? std::max(cap, s.cap + s.cap / 2) : cap;
+  CHK(ensure(e, s.side, want * 3 * sizeof(double), keep));
+  CHK(ensure(e, s.angle, want * 3 * sizeof(double), keep));
+  CHK(ensure(e, s.center, want * 3 * sizeof(double), keep));
+  CHK(ensure(e, s.vertex, want * 9 * sizeof(float), keep));
+  CHK(ensure(e, s.label, want * 3 * sizeof(int), keep));
+  CHK(ensure(e, s.frame, want * sizeof(u32), keep));
+  CHK(ensure(e, s.node_id, want * 3 * sizeof(int), keep));
+  s.cap = want;
+  return SGTD_OK;
+}
+
+void free_buf(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+void free_store(DescStore &s) {
+  free_buf(s.side); free_buf(s.angle); free_buf(s.center); free_buf(s.vertex);
+  free_buf(s.label); free_buf(s.frame); free_buf(s.node_id);
+  s.cap = 0;
+}
+
+int grid_for(long long n, int threads) { return (int)((n + threads - 1) / threads); }
+
+// device-wide exclusive scan (u32), in place allowed
+int device_scan(sgtd_engine *e, const u32 *in, u32 *out, long long n, size_t lvl = 0) {
+  if (n <= 0) return SGTD_OK;
+  const long long per = (long long)SGTD_SCAN_THREADS * SGTD_SCAN_ITEMS;
+  const long long nb = (n + per - 1) / per;
+  if (nb == 1) {
+    scan_apply_kernel<<<1, SGTD_SCAN_THREADS, 0, e->stream>>>(in, out, nullptr, n);
+    HIPCHK(hipGetLastError());
+    return SGTD_OK;
+  }
+  if (e->scan_lvl.size() <= lvl) e->scan_lvl.resize(lvl + 1);
+  CHK(ensure(e, e->scan_lvl[lvl], (size_t)nb * sizeof(u32)));
+  u32 *sums = e->scan_lvl[lvl].as<u32>();
+  scan_reduce_kernel<<<(int)nb, SGTD_SCAN_THREADS, 0, e->stream>>>(in, sums, n);
+  HIPCHK(hipGetLastError());
+  CHK(device_scan(e, sums, sums, nb, lvl + 1));
+  sums = e->scan_lvl[lvl].as<u32>();
+  scan_apply_kernel<<<(int)nb, SGTD_SCAN_THREADS, 0, e->stream>>>(in, out, sums, n);
+  HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BuildSingleScanSTD launch for a batch of frames (inputs already on device)
+// ---------------------------------------------------------------------------
+int launch_build(sgtd_engine *e, const float *d_xyz, const u32 *d_label, const long long *d_kp_off,
+                 int n_frames, int max_n, u32 frame_id0, int frame_step, DescArrays out,
+                 long long out_stride, u32 *out_count) {
+  if (n_frames <= 0) return SGTD_OK;
+  if (max_n > 65535) return SGTD_ERR_UNSUPPORTED;
+  const int K = e->dc.K, tpi = e->dc.tpi;
+  long long max_t = (long long)std::max(max_n, 1) * tpi;
+  int max_slots = 64;
+  while (max_slots < max_t + 1) max_slots <<= 1;
+  const size_t lds_limit = 160 * 1024;
+  size_t lds_full = build_lds_bytes(std::max(max_n, 1), K, tpi, true, max_slots);
+  size_t lds_base = build_lds_bytes(std::max(max_n, 1), K, tpi, false, max_slots);
+  BuildParams P;
+  P.xyz = d_xyz; P.label = d_label; P.kp_off = d_kp_off; P.n_frames = n_frames;
+  P.frame_id0 = frame_id0; P.frame_id_step = frame_step; P.out_stride = out_stride;
+  P.out_count = out_count; P.max_n = std::max(max_n, 1); P.max_slots = max_slots;
+  P.ws_keys = nullptr; P.ws_slots = nullptr;
+  if (lds_full <= lds_limit) {
+    int per_cu = (int)std::max<size_t>(1, lds_limit / lds_full);
+    int grid = std::min(n_frames, e->n_cus * std::min(per_cu, 4));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&build_frames_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+    build_frames_kernel<true><<<grid, SGTD_BUILD_THREADS, lds_full, e->stream>>>(P, e->dc, out);
+  } else if (lds_base <= lds_limit) {
+    int grid = std::min(n_frames, e->n_cus * 2);
+    CHK(ensure(e, e->ws_keys, (size_t)grid * max_t * sizeof(u64)));
+    CHK(ensure(e, e->ws_slots, (size_t)grid * max_slots * sizeof(u32)));
+    P.ws_keys = e->ws_keys.as<u64>();
+    P.ws_slots = e->ws_slots.as<u32>();
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&build_frames_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+    build_frames_kernel<false><<<grid, SGTD_BUILD_THREADS, lds_base, e->stream>>>(P, e->dc, out);
+  } else {
+    return SGTD_ERR_UNSUPPORTED;
+  }
+  HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
+// uploads keypoints (or takes device pointers) and the offsets; returns views
+int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64_t *kp_off,
+                 int n_frames, int device_ptrs, const float **d_xyz, const u32 **d_label,
+                 int *max_n) {
+  std::vector<long long> off(n_frames + 1);
+  int mx = 0;
+  for (int f = 0; f <= n_frames; f++) off[f] = kp_off[f];
+  for (int f = 0; f < n_frames; f++) {
+    long long n = off[f + 1] - off[f];
+    if (n < 0 || n > 65535) return SGTD_ERR_INVALID;
+    mx = std::max(mx, (int)n);
+  }
+  *max_n = mx;
+  CHK(ensure(e, e->kp_off_dev, (size_t)(n_frames + 1) * sizeof(long long)));
+  HIPCHK(hipMemcpyAsync(e->kp_off_dev.p, off.data(), (size_t)(n_frames + 1) * sizeof(long long),
+                        hipMemcpyHostToDevice, e->stream));
+  // the staging vector dies at return: make the copy complete first
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const long long total = off[n_frames] - off[0];
+  if (device_ptrs) {
+    *d_xyz = xyz;
+    *d_label = label;
+  } else {
+    CHK(ensure(e, e->xyz_dev, (size_t)std::max<long long>(total + off[0], 1) * 3 * sizeof(float)));
+    CHK(ensure(e, e->label_dev, (size_t)std::max<long long>(total + off[0], 1) * sizeof(u32)));
+    if (total > 0) {
+      HIPCHK(hipMemcpyAsync(e->xyz_dev.as<float>() + off[0] * 3, xyz + off[0] * 3,
+                            (size_t)total * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->label_dev.as<u32>() + off[0], label + off[0], (size_t)total * sizeof(u32),
+                            hipMemcpyHostToDevice, e->stream));
+    }
+    *d_xyz = e->xyz_dev.as<float>();
+    *d_label = e->label_dev.as<u32>();
+  }
+  return SGTD_OK;
+}
+
+// device SoA range -> caller SoA (NULL members skipped)
+int copy_out(sgtd_engine *e, const DescStore &s, size_t first, size_t n, sgtd_desc_soa *out, size_t dst0) {
+  if (n == 0) return SGTD_OK;
+#define CP(field, T, w)                                                                       \
+  if (out->field)                                                                             \
+    HIPCHK(hipMemcpyAsync(out->field + dst0 * (w), s.field.as<T>() + first * (w),             \
+                          n * (w) * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+  CP(side, double, 3) CP(angle, double, 3) CP(center, double, 3) CP(vertex, float, 9)
+  CP(label, int, 3) CP(frame, u32, 1) CP(node_id, int, 3)
+#undef CP
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SGTD_OK;
+}
+
+int copy_in(sgtd_engine *e, DescStore &s, size_t first, size_t n, const sgtd_desc_soa *in) {
+  if (n == 0) return SGTD_OK;
+#define CP(field, T, w)                                                                        \
+  if (in->field)                                                                               \
+    HIPCHK(hipMemcpyAsync(s.field.as<T>() + first * (w), in->field, n * (w) * sizeof(T),       \
+                          hipMemcpyHostToDevice, e->stream));                                  \
+  else                                                                                         \
+    HIPCHK(hipMemsetAsync(s.field.as<T>() + first * (w), 0, n * (w) * sizeof(T), e->stream));
+  CP(side, double, 3) CP(angle, double, 3) CP(center, double, 3) CP(vertex, float, 9)
+  CP(label, int, 3) CP(frame, u32, 1) CP(node_id, int, 3)
+#undef CP
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SGTD_OK;
+}
+
+void note_frames(sgtd_engine *e, u32 lo, u32 hi) {
+  if (!e->have_frames) {
+    e->frame_lo = lo; e->frame_hi = hi; e->have_frames = true;
+  } else {
+    e->frame_lo = std::min(e->frame_lo, lo);
+    e->frame_hi = std::max(e->frame_hi, hi);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// finalize: sort + CSR + hash
+// ---------------------------------------------------------------------------
+int do_finalize(sgtd_engine *e) {
+  if (e->finalized) return SGTD_OK;
+  const long long E = e->n_entries;
+  if (E >= (1ll << 32) - 2) return SGTD_ERR_UNSUPPORTED;
+  e->n_buckets = 0;
+  e->hash_mask = 1023;
+  if (E == 0) {
+    CHK(ensure(e, e->hash, (size_t)1024 * sizeof(HashSlot)));
+    HIPCHK(hipMemsetAsync(e->hash.p, 0xFF, (size_t)1024 * sizeof(HashSlot), e->stream));
+    e->finalized = true;
+    return SGTD_OK;
+  }
+  CHK(ensure(e, e->keyA, (size_t)E * sizeof(u64)));
+  CHK(ensure(e, e->keyB, (size_t)E * sizeof(u64)));
+  CHK(ensure(e, e->valA, (size_t)E * sizeof(u32)));
+  CHK(ensure(e, e->valB, (size_t)E * sizeof(u32)));
+  CHK(ensure(e, e->bad_flag, sizeof(int)));
+  CHK(ensure(e, e->digit_tot, 256 * sizeof(u32)));
+  HIPCHK(hipMemsetAsync(e->bad_flag.p, 0, sizeof(int), e->stream));
+  make_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.side.as<double>(), e->tab.label.as<int>(),
+                                                             e->keyA.as<u64>(), e->valA.as<u32>(), E,
+                                                             e->bad_flag.as<int>());
+  HIPCHK(hipGetLastError());
+  int bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, e->bad_flag.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (bad) return SGTD_ERR_UNSUPPORTED;  // a cell coordinate beyond 16 bits
+
+  const int nblocks = (int)((E + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
+  CHK(ensure(e, e->hist, (size_t)256 * nblocks * sizeof(u32)));
+  u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
+  u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
+  std::vector<u32> tot(256);
+  for (int pass = 0; pass < 8; pass++) {
+    const int shift = pass * 8;
+    if (shift >= 60) break;
+    u32 *hist = e->hist.as<u32>();
+    radix_hist_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, E, shift, hist, nblocks);
+    HIPCHK(hipGetLastError());
+    radix_digit_totals_kernel<<<256, SGTD_SCAN_THREADS, 0, e->stream>>>(hist, nblocks, e->digit_tot.as<u32>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(tot.data(), e->digit_tot.p, 256 * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    bool constant = false;
+    for (int d = 0; d < 256; d++)
+      if ((long long)tot[d] == E) constant = true;
+    if (constant) continue;  // every key has the same digit here: the pass is the identity
+    CHK(device_scan(e, hist, hist, (long long)256 * nblocks));
+    radix_scatter_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, E, shift,
+                                                                       e->hist.as<u32>(), nblocks);
+    HIPCHK(hipGetLastError());
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  // hot arrays
+  CHK(ensure(e, e->s0, (size_t)E * sizeof(double)));
+  CHK(ensure(e, e->s1, (size_t)E * sizeof(double)));
+  CHK(ensure(e, e->s2, (size_t)E * sizeof(double)));
+  CHK(ensure(e, e->tframe, (size_t)E * sizeof(u32)));
+  CHK(ensure(e, e->perm, (size_t)E * sizeof(u32)));
+  HIPCHK(hipMemcpyAsync(e->perm.p, vin, (size_t)E * sizeof(u32), hipMemcpyDeviceToDevice, e->stream));
+  gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->perm.as<u32>(), e->tab.side.as<double>(),
+                                                              e->tab.frame.as<u32>(), e->s0.as<double>(),
+                                                              e->s1.as<double>(), e->s2.as<double>(),
+                                                              e->tframe.as<u32>(), E);
+  HIPCHK(hipGetLastError());
+  // buckets
+  CHK(ensure(e, e->flags, (size_t)E * sizeof(u32)));
+  head_flags_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, e->flags.as<u32>(), E);
+  HIPCHK(hipGetLastError());
+  u32 last_flag = 0, last_excl = 0;
+  HIPCHK(hipMemcpyAsync(&last_flag, e->flags.as<u32>() + (E - 1), sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  CHK(device_scan(e, e->flags.as<u32>(), e->flags.as<u32>(), E));
+  HIPCHK(hipMemcpyAsync(&last_excl, e->flags.as<u32>() + (E - 1), sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const u32 U = last_excl + last_flag;
+  e->n_buckets = U;
+  CHK(ensure(e, e->bucket_start, (size_t)(U + 1) * sizeof(u32)));
+  CHK(ensure(e, e->bucket_key, (size_t)U * sizeof(u64)));
+  bucket_starts_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, e->flags.as<u32>(), e->bucket_start.as<u32>(),
+                                                                 e->bucket_key.as<u64>(), E);
+  HIPCHK(hipGetLastError());
+  u32 cap = 1024;
+  while (cap < 2ull * U) cap <<= 1;
+  e->hash_mask = cap - 1;
+  CHK(ensure(e, e->hash, (size_t)cap * sizeof(HashSlot)));
+  HIPCHK(hipMemsetAsync(e->hash.p, 0xFF, (size_t)cap * sizeof(HashSlot), e->stream));
+  hash_insert_kernel<<<grid_for(U, 256), 256, 0, e->stream>>>(e->bucket_key.as<u64>(), e->bucket_start.as<u32>(), U,
+                                                               (u32)E, e->hash.as<HashSlot>(), e->hash_mask);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->finalized = true;
+  return SGTD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the query pipeline on descriptors already in e->qd (strided)
+// ---------------------------------------------------------------------------
+int rec_alloc(sgtd_engine *e) {
+  CHK(ensure(e, e->mask_words, e->mask_cap * sizeof(u64)));
+  CHK(ensure(e, e->rec_qi, e->rec_cap * sizeof(u32)));
+  CHK(ensure(e, e->rec_pos, e->rec_cap * sizeof(u32)));
+  CHK(ensure(e, e->rec_frame, e->rec_cap * sizeof(u32)));
+  CHK(ensure(e, e->rec_cell, e->rec_cap));
+  if (e->want_dis) CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
+  CHK(ensure(e, e->pair_qi, e->rec_cap * sizeof(u32)));
+  CHK(ensure(e, e->pair_entry, e->rec_cap * sizeof(u32)));
+  return SGTD_OK;
+}
+
+int launch_select(sgtd_engine *e) {
+  const int nq = e->nq;
+  const long long n_slots = (long long)nq * e->q_stride;
+  const int cn = e->dc.cand_num;
+  const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
+  CHK(ensure(e, e->mask_cursor, sizeof(u32)));
+  CHK(ensure(e, e->overflow, 2 * sizeof(int)));
+  CHK(ensure(e, e->mask_ptr, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
+  CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
+  CHK(ensure(e, e->n_match, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
+  CHK(ensure(e, e->rec_off, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
+  CHK(ensure(e, e->votes, (size_t)nq * span * sizeof(u32)));
+  CHK(ensure(e, e->slot_of, (size_t)nq * span));
+  CHK(ensure(e, e->q_M, (size_t)nq * sizeof(u32)));
+  CHK(ensure(e, e->q_P, (size_t)nq * sizeof(unsigned long long)));
+  CHK(ensure(e, e->q_base, (size_t)(nq + 1) * sizeof(u32)));
+  CHK(ensure(e, e->n_cand, (size_t)nq * sizeof(int)));
+  CHK(ensure(e, e->cand_frame, (size_t)nq * cn * sizeof(int)));
+  CHK(ensure(e, e->cand_votes, (size_t)nq * cn * sizeof(int)));
+  CHK(ensure(e, e->pair_off, (size_t)nq * (cn + 1) * sizeof(long long)));
+  CHK(rec_alloc(e));
+
+  HIPCHK(hipMemsetAsync(e->mask_cursor.p, 0, sizeof(u32), e->stream));
+  HIPCHK(hipMemsetAsync(e->overflow.p, 0, 2 * sizeof(int), e->stream));
+  HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));
+  HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
+  HIPCHK(hipMemsetAsync(e->cand_frame.p, 0xFF, (size_t)nq * cn * sizeof(int), e->stream));
+  HIPCHK(hipMemsetAsync(e->cand_votes.p, 0, (size_t)nq * cn * sizeof(int), e->stream));
+
+  TableView T;
+  T.s0 = e->s0.as<double>(); T.s1 = e->s1.as<double>(); T.s2 = e->s2.as<double>();
+  T.frame = e->tframe.as<u32>(); T.perm = e->perm.as<u32>();
+  T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
+  T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = span;
+  QueryView Q;
+  Q.side = e->qd.side.as<double>(); Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
+  Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = nq;
+  ProbeBuffers B;
+  B.mask_words = e->mask_words.as<u64>();
+  B.mask_cap = (u32)std::min<size_t>(e->mask_cap, 0xFFFFFFFFu);
+  B.mask_cursor = e->mask_cursor.as<u32>(); B.mask_ptr = e->mask_ptr.as<u32>();
+  B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
+  B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
+  RecordArrays R;
+  R.qi = e->rec_qi.as<u32>(); R.pos = e->rec_pos.as<u32>(); R.frame = e->rec_frame.as<u32>();
+  R.cell = e->rec_cell.as<unsigned char>(); R.dis = e->want_dis ? e->rec_dis.as<double>() : nullptr;
+
+  constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
+  long long want_blocks = (n_slots + NW - 1) / NW;
+  int grid = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)e->n_cus * 8));
+  probe_kernel<<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(T, Q, B, e->dc.rough);
+  HIPCHK(hipGetLastError());
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
+  query_offsets_kernel<<<nq, 256, 0, e->stream>>>(Q, B.n_match, B.n_visit, e->rec_off.as<u32>(),
+                                                   e->q_M.as<u32>(), e->q_P.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_M.as<u32>(), e->q_base.as<u32>(), nq,
+                                               (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFFFu), B.overflow);
+  HIPCHK(hipGetLastError());
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
+  emit_kernel<<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(T, Q, B, e->rec_off.as<u32>(), e->q_base.as<u32>(), R);
+  HIPCHK(hipGetLastError());
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_EMIT], e->stream));
+  topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, T.frame_lo, cn, e->n_cand.as<int>(),
+                                          e->cand_frame.as<int>(), e->cand_votes.as<int>(),
+                                          e->slot_of.as<unsigned char>());
+  HIPCHK(hipGetLastError());
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
+  assemble_kernel<<<nq, 256, 0, e->stream>>>(e->q_base.as<u32>(), R, e->slot_of.as<unsigned char>(), span,
+                                              T.frame_lo, T.perm, cn, e->n_cand.as<int>(),
+                                              e->pair_off.as<long long>(), e->pair_qi.as<u32>(),
+                                              e->pair_entry.as<u32>(), B.overflow);
+  HIPCHK(hipGetLastError());
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_ASSEMBLE], e->stream));
+  e->batch_valid = true;
+  e->batch_synced = false;
+  return SGTD_OK;
+}
+
+int enqueue_frames(sgtd_engine *e) {
+  // (re)runs the last frames batch: build on device, then select
+  const int nq = e->nq;
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));
+  CHK(launch_build(e, e->last_xyz, e->last_label, e->kp_off_dev.as<long long>(), nq, e->last_max_n,
+                   e->current_frame_id, 0, e->qd.view(), e->q_stride, e->q_count.as<u32>()));
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_BUILD], e->stream));
+  return launch_select(e);
+}
+
+int sync_batch(sgtd_engine *e) {
+  if (!e->batch_valid) return SGTD_ERR_STATE;
+  if (e->batch_synced) return SGTD_OK;
+  e->stats.overflowed = 0;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    int ovf[2] = {0, 0};
+    u32 cursor = 0, total = 0;
+    HIPCHK(hipMemcpyAsync(ovf, e->overflow.p, sizeof(ovf), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&cursor, e->mask_cursor.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&total, e->q_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!ovf[0] && !ovf[1]) break;
+    e->stats.overflowed = 1;
+    if (attempt == 7) return SGTD_ERR_CAPACITY;
+    if (ovf[0]) e->mask_cap = std::max<size_t>(e->mask_cap * 2, (size_t)cursor + (cursor >> 2) + 4096);
+    if (ovf[1]) e->rec_cap = std::max<size_t>(e->rec_cap * 2, (size_t)total + (total >> 3) + 4096);
+    if (e->mask_cap > 0xFFFFFFF0ull || e->rec_cap > 0xFFFFFFF0ull) return SGTD_ERR_CAPACITY;
+    if (e->last_kind == 1) CHK(enqueue_frames(e)); else CHK(launch_select(e));
+  }
+  const int nq = e->nq, cn = e->dc.cand_num;
+  e->h_count.resize(nq); e->h_q_base.resize(nq + 1); e->h_q_M.resize(nq); e->h_q_P.resize(nq);
+  e->h_n_cand.resize(nq); e->h_cand_frame.resize((size_t)nq * cn); e->h_cand_votes.resize((size_t)nq * cn);
+  e->h_pair_off.resize((size_t)nq * (cn + 1));
+  HIPCHK(hipMemcpyAsync(e->h_count.data(), e->q_count.p, nq * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_q_base.data(), e->q_base.p, (nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_q_M.data(), e->q_M.p, nq * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_q_P.data(), e->q_P.p, nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_n_cand.data(), e->n_cand.p, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_cand_frame.data(), e->cand_frame.p, (size_t)nq * cn * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_cand_votes.data(), e->cand_votes.p, (size_t)nq * cn * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_pair_off.data(), e->pair_off.p, (size_t)nq * (cn + 1) * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  sgtd_stats &s = e->stats;
+  s.last_queries = nq;
+  s.last_D = 0; s.last_P = 0; s.last_M = 0; s.last_cand_pairs = 0;
+  for (int q = 0; q < nq; q++) {
+    s.last_D += e->h_count[q];
+    s.last_P += (int64_t)e->h_q_P[q];
+    s.last_M += e->h_q_M[q];
+    s.last_cand_pairs += e->h_pair_off[(size_t)q * (cn + 1) + cn];
+  }
+  if (e->timing) {
+    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[b]); return ms; };
+    if (e->last_kind == 1) { s.ms_build = el(EV_START, EV_BUILD); s.ms_probe = el(EV_BUILD, EV_PROBE); }
+    else { s.ms_build = 0; s.ms_probe = el(EV_START, EV_PROBE); }
+    s.ms_scan = el(EV_PROBE, EV_SCAN); s.ms_emit = el(EV_SCAN, EV_EMIT);
+    s.ms_topk = el(EV_EMIT, EV_TOPK); s.ms_assemble = el(EV_TOPK, EV_ASSEMBLE);
+    s.ms_total = el(EV_START, EV_ASSEMBLE);
+  }
+  e->batch_synced = true;
+  return SGTD_OK;
+}
+
+int check_cfg(const sgtd_config *c) {
+  if (c->descriptor_near_num < 3 || c->descriptor_near_num > SGTD_MAX_K) return SGTD_ERR_UNSUPPORTED;
+  if (c->candidate_num < 1 || c->candidate_num > SGTD_MAX_CAND) return SGTD_ERR_UNSUPPORTED;
+  if (c->max_frame_n < 1) return SGTD_ERR_INVALID;
+  if (!(c->std_side_resolution > 0) || !(c->descriptor_max_len > 0)) return SGTD_ERR_INVALID;
+  if (!(c->descriptor_max_len * 1000.0 < 2097151.0)) return SGTD_ERR_UNSUPPORTED;
+  if (!(c->descriptor_max_len / c->std_side_resolution + 2.0 < 65535.0)) return SGTD_ERR_UNSUPPORTED;
+  return SGTD_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+void sgtd_default_config(sgtd_config *cfg) {
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->descriptor_near_num = 10;
+  cfg->candidate_num = 50;
+  cfg->max_frame_n = 20000;
+  cfg->device_id = 0;
+  cfg->descriptor_min_len = 0.5;
+  cfg->descriptor_max_len = 50.0;
+  cfg->std_side_resolution = 1.0;
+  cfg->rough_dis_threshold = 0.03;
+  cfg->first_frame_id = 0;
+}
+
+const char *sgtd_strerror(int status) {
+  switch (status) {
+    case SGTD_OK: return "ok";
+    case SGTD_ERR_INVALID: return "invalid argument";
+    case SGTD_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+    case SGTD_ERR_HIP: return "HIP runtime error";
+    case SGTD_ERR_CAPACITY: return "buffer capacity exceeded";
+    case SGTD_ERR_FRAME_LIMIT: return "frame id beyond max_frame_n";
+    case SGTD_ERR_UNSUPPORTED: return "configuration outside the kernels' envelope";
+    case SGTD_ERR_STATE: return "call order";
+    default: return "unknown status";
+  }
+}
+
+const char *sgtd_last_error(sgtd_handle h) { return h ? h->err.c_str() : ""; }
+
+int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
+  if (!cfg || !out) return SGTD_ERR_INVALID;
+  *out = nullptr;
+  int r = check_cfg(cfg);
+  if (r != SGTD_OK) return r;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SGTD_ERR_NO_DEVICE;
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return SGTD_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess) return SGTD_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SGTD_ERR_NO_DEVICE;
+  if (hipSetDevice(cfg->device_id) != hipSuccess) return SGTD_ERR_NO_DEVICE;
+  sgtd_engine *e = new sgtd_engine();
+  e->cfg = *cfg;
+  e->dc.K = cfg->descriptor_near_num;
+  e->dc.tpi = (cfg->descriptor_near_num - 1) * (cfg->descriptor_near_num - 2) / 2;
+  e->dc.cand_num = cfg->candidate_num;
+  e->dc.min_len = cfg->descriptor_min_len;
+  e->dc.max_len = cfg->descriptor_max_len;
+  e->dc.scale = 1.0 / cfg->std_side_resolution;  // STDesc.cpp:178
+  e->dc.rough = cfg->rough_dis_threshold;
+  e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  e->current_frame_id = cfg->first_frame_id;
+  for (int i = 0; i < EV_COUNT; i++)
+    if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
+  *out = e;
+  return SGTD_OK;
+}
+
+int sgtd_destroy(sgtd_handle e) {
+  if (!e) return SGTD_OK;
+  (void)hipSetDevice(e->cfg.device_id);
+  (void)hipStreamSynchronize(e->stream);
+  free_store(e->tab); free_store(e->tmp); free_store(e->qd);
+  DevBuf *bufs[] = {&e->s0, &e->s1, &e->s2, &e->tframe, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
+                    &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
+                    &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
+                    &e->tmp_count, &e->q_count, &e->mask_words, &e->mask_cursor, &e->mask_ptr, &e->n_visit,
+                    &e->n_match, &e->rec_off, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_base,
+                    &e->rec_qi, &e->rec_pos, &e->rec_frame, &e->rec_cell, &e->rec_dis, &e->n_cand, &e->cand_frame,
+                    &e->cand_votes, &e->pair_off, &e->pair_qi, &e->pair_entry};
+  for (DevBuf *b : bufs) free_buf(*b);
+  for (auto &b : e->scan_lvl) free_buf(b);
+  for (int i = 0; i < EV_COUNT; i++)
+    if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+  delete e;
+  return SGTD_OK;
+}
+
+int sgtd_set_stream(sgtd_handle e, void *hip_stream) {
+  if (!e) return SGTD_ERR_INVALID;
+  e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return SGTD_OK;
+}
+
+int sgtd_set_timing(sgtd_handle e, int enabled) {
+  if (!e) return SGTD_ERR_INVALID;
+  e->timing = enabled != 0;
+  return SGTD_OK;
+}
+
+int sgtd_current_frame_id(sgtd_handle e, uint32_t *out) {
+  if (!e || !out) return SGTD_ERR_INVALID;
+  *out = e->current_frame_id;
+  return SGTD_OK;
+}
+
+int64_t sgtd_max_descs(sgtd_handle e, int n_keypoints) {
+  if (!e || n_keypoints < 0) return 0;
+  return (int64_t)n_keypoints * e->dc.tpi;
+}
+
+int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sgtd_desc_soa *out,
+               int64_t capacity, int64_t *n_out) {
+  if (!e || !out || !n_out || n < 0 || (n > 0 && (!xyz || !label))) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  *n_out = 0;
+  if (n == 0) return SGTD_OK;
+  int64_t off[2] = {0, n};
+  const float *dx; const u32 *dl; int max_n;
+  CHK(stage_inputs(e, xyz, label, off, 1, 0, &dx, &dl, &max_n));
+  const long long stride = (long long)n * e->dc.tpi;
+  CHK(ensure_store(e, e->tmp, (size_t)std::max<long long>(stride, 1)));
+  CHK(ensure(e, e->tmp_count, sizeof(u32)));
+  CHK(launch_build(e, dx, dl, e->kp_off_dev.as<long long>(), 1, max_n, e->current_frame_id, 0,
+                   e->tmp.view(), stride, e->tmp_count.as<u32>()));
+  u32 cnt = 0;
+  HIPCHK(hipMemcpyAsync(&cnt, e->tmp_count.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *n_out = cnt;
+  if ((int64_t)cnt > capacity) return SGTD_ERR_CAPACITY;
+  return copy_out(e, e->tmp, 0, cnt, out, 0);
+}
+
+int sgtd_add(sgtd_handle e, const sgtd_desc_soa *d, int64_t n) {
+  if (!e || n < 0 || (n > 0 && (!d || !d->side || !d->label || !d->frame))) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  u32 lo = 0xFFFFFFFFu, hi = 0;
+  for (int64_t i = 0; i < n; i++) {
+    lo = std::min(lo, d->frame[i]);
+    hi = std::max(hi, d->frame[i]);
+  }
+  if (n > 0 && hi >= (u32)e->cfg.max_frame_n) return SGTD_ERR_FRAME_LIMIT;
+  e->current_frame_id++;  // STDesc.cpp:151, before anything is inserted
+  e->n_add_calls++;
+  if (n == 0) return SGTD_OK;
+  CHK(ensure_store(e, e->tab, (size_t)(e->n_entries + n), true));
+  CHK(copy_in(e, e->tab, (size_t)e->n_entries, (size_t)n, d));
+  e->n_entries += n;
+  note_frames(e, lo, hi);
+  e->finalized = false;
+  e->batch_valid = false;
+  return SGTD_OK;
+}
+
+int sgtd_add_frames(sgtd_handle e, const float *xyz, const uint32_t *label, const int64_t *kp_off,
+                    int n_frames, int device_ptrs) {
+  if (!e || n_frames < 0 || !kp_off) return SGTD_ERR_INVALID;
+  if (n_frames == 0) return SGTD_OK;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if ((uint64_t)e->current_frame_id + (uint64_t)n_frames > (uint64_t)e->cfg.max_frame_n)
+    return SGTD_ERR_FRAME_LIMIT;
+  const int chunk = 512;
+  for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+    const int nf = std::min(chunk, n_frames - f0);
+    const float *dx; const u32 *dl; int max_n;
+    CHK(stage_inputs(e, xyz, label, kp_off + f0, nf, device_ptrs, &dx, &dl, &max_n));
+    const long long stride = (long long)std::max(max_n, 1) * e->dc.tpi;
+    CHK(ensure_store(e, e->tmp, (size_t)stride * nf));
+    CHK(ensure(e, e->tmp_count, (size_t)nf * sizeof(u32)));
+    CHK(ensure(e, e->cnt_scan, (size_t)nf * sizeof(u32)));
+    CHK(launch_build(e, dx, dl, e->kp_off_dev.as<long long>(), nf, max_n, e->current_frame_id, 1,
+                     e->tmp.view(), stride, e->tmp_count.as<u32>()));
+    std::vector<u32> cnt(nf);
+    HIPCHK(hipMemcpyAsync(cnt.data(), e->tmp_count.p, (size_t)nf * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<u32> goff(nf);
+    long long total = 0;
+    for (int f = 0; f < nf; f++) { goff[f] = (u32)total; total += cnt[f]; }
+    if (e->n_entries + total >= (1ll << 32) - 2) return SGTD_ERR_UNSUPPORTED;
+    CHK(ensure_store(e, e->tab, (size_t)(e->n_entries + total), true));
+    HIPCHK(hipMemcpyAsync(e->cnt_scan.p, goff.data(), (size_t)nf * sizeof(u32), hipMemcpyHostToDevice, e->stream));
+    AppendParams A;
+    A.in_stride = stride; A.count = e->tmp_count.as<u32>(); A.goff = e->cnt_scan.as<u32>(); A.g0 = e->n_entries;
+    append_descs_kernel<<<nf, 256, 0, e->stream>>>(A, e->tmp.view(), e->tab.view());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));  // goff staging vector dies here
+    e->n_entries += total;
+    note_frames(e, e->current_frame_id, e->current_frame_id + (u32)nf - 1);
+    e->current_frame_id += (u32)nf;   // one AddSTDescs (:151) per frame
+    e->n_add_calls += nf;
+  }
+  e->finalized = false;
+  e->batch_valid = false;
+  return SGTD_OK;
+}
+
+int sgtd_finalize(sgtd_handle e) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  return do_finalize(e);
+}
+
+int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, const int64_t *kp_off,
+                      int n_queries, int device_ptrs) {
+  if (!e || n_queries <= 0 || !kp_off || !xyz || !label) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(do_finalize(e));
+  const float *dx; const u32 *dl; int max_n;
+  CHK(stage_inputs(e, xyz, label, kp_off, n_queries, device_ptrs, &dx, &dl, &max_n));
+  e->nq = n_queries;
+  e->q_stride = (long long)std::max(max_n, 1) * e->dc.tpi;
+  e->last_kind = 1; e->last_xyz = dx; e->last_label = dl; e->last_max_n = max_n;
+  CHK(ensure_store(e, e->qd, (size_t)e->q_stride * n_queries));
+  CHK(ensure(e, e->q_count, (size_t)n_queries * sizeof(u32)));
+  return enqueue_frames(e);
+}
+
+int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
+  if (!e || nq < 0 || (nq > 0 && (!q || !q->side || !q->label || !q->frame))) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(do_finalize(e));
+  e->nq = 1;
+  e->q_stride = std::max<long long>(nq, 1);
+  e->last_kind = 2;
+  CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
+  CHK(ensure(e, e->q_count, sizeof(u32)));
+  CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
+  u32 cnt = (u32)nq;
+  HIPCHK(hipMemcpyAsync(e->q_count.p, &cnt, sizeof(u32), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));
+  return launch_select(e);
+}
+
+int sgtd_sync(sgtd_handle e) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->batch_valid) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGTD_OK;
+  }
+  return sync_batch(e);
+}
+
+int sgtd_result_candidates(sgtd_handle e, int32_t *n_cand, int32_t *cand_frame, int32_t *cand_votes,
+                           int64_t *pair_off) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(sync_batch(e));
+  const int nq = e->nq, cn = e->dc.cand_num;
+  if (n_cand) std::memcpy(n_cand, e->h_n_cand.data(), nq * sizeof(int));
+  if (cand_frame) std::memcpy(cand_frame, e->h_cand_frame.data(), (size_t)nq * cn * sizeof(int));
+  if (cand_votes) std::memcpy(cand_votes, e->h_cand_votes.data(), (size_t)nq * cn * sizeof(int));
+  if (pair_off)
+    for (size_t i = 0; i < (size_t)nq * (cn + 1); i++) pair_off[i] = e->h_pair_off[i];
+  return SGTD_OK;
+}
+
+int sgtd_export_candidates_dev(sgtd_handle e, int32_t *d_cand_frame, int32_t *d_cand_votes) {
+  if (!e || !d_cand_frame || !d_cand_votes) return SGTD_ERR_INVALID;
+  if (!e->batch_valid) return SGTD_ERR_STATE;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  const size_t bytes = (size_t)e->nq * e->dc.cand_num * sizeof(int);
+  HIPCHK(hipMemcpyAsync(d_cand_frame, e->cand_frame.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(d_cand_votes, e->cand_votes.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+  return SGTD_OK;
+}
+
+int sgtd_result_query_desc_count(sgtd_handle e, int q, int64_t *n) {
+  if (!e || !n) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(sync_batch(e));
+  if (q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  *n = e->h_count[q];
+  return SGTD_OK;
+}
+
+int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, int64_t capacity,
+                      int64_t *n_pairs) {
+  if (!e || !n_pairs) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(sync_batch(e));
+  if (q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num;
+  const int64_t n = e->h_pair_off[(size_t)q * (cn + 1) + cn];
+  *n_pairs = n;
+  if (n > capacity) return SGTD_ERR_CAPACITY;
+  if (n == 0) return SGTD_OK;
+  std::vector<u32> qi(n), en(n);
+  HIPCHK(hipMemcpyAsync(qi.data(), e->pair_qi.as<u32>() + e->h_q_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(en.data(), e->pair_entry.as<u32>() + e->h_q_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int64_t i = 0; i < n; i++) {
+    if (q_idx) q_idx[i] = (int32_t)qi[i];
+    if (db_entry) db_entry[i] = (int64_t)en[i];
+  }
+  return SGTD_OK;
+}
+
+int sgtd_result_query_descs(sgtd_handle e, int q, sgtd_desc_soa *out, int64_t capacity, int64_t *n_out) {
+  if (!e || !out || !n_out) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(sync_batch(e));
+  if (q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  *n_out = e->h_count[q];
+  if (*n_out > capacity) return SGTD_ERR_CAPACITY;
+  return copy_out(e, e->qd, (size_t)q * e->q_stride, e->h_count[q], out, 0);
+}
+
+int sgtd_result_votes(sgtd_handle e, int q, uint32_t *votes, int64_t capacity, uint32_t *frame_lo, int64_t *n) {
+  if (!e || !n) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(sync_batch(e));
+  if (q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
+  *n = span;
+  if (frame_lo) *frame_lo = e->have_frames ? e->frame_lo : 0;
+  if (!votes) return SGTD_OK;
+  if ((int64_t)span > capacity) return SGTD_ERR_CAPACITY;
+  HIPCHK(hipMemcpyAsync(votes, e->votes.as<u32>() + (size_t)q * span, (size_t)span * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SGTD_OK;
+}
+
+int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64_t *db_entry, uint32_t *frame,
+                      double *dis, int64_t capacity, int64_t *n_rough) {
+  if (!e || !n_rough) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (dis && !e->want_dis) {
+    // distances are a diagnostic output: switch them on and re-run the batch
+    e->want_dis = true;
+    if (!e->batch_valid) return SGTD_ERR_STATE;
+    CHK(rec_alloc(e));
+    if (e->last_kind == 1) CHK(enqueue_frames(e)); else CHK(launch_select(e));
+  }
+  CHK(sync_batch(e));
+  if (q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  const int64_t n = e->h_q_M[q];
+  *n_rough = n;
+  if (n > capacity) return SGTD_ERR_CAPACITY;
+  if (n == 0) return SGTD_OK;
+  const size_t base = e->h_q_base[q];
+  std::vector<u32> a(n), p(n), g(n);
+  std::vector<unsigned char> c(n);
+  HIPCHK(hipMemcpyAsync(a.data(), e->rec_qi.as<u32>() + base, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(p.data(), e->rec_pos.as<u32>() + base, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(c.data(), e->rec_cell.as<unsigned char>() + base, n, hipMemcpyDeviceToHost, e->stream));
+  if (frame) HIPCHK(hipMemcpyAsync(frame, e->rec_frame.as<u32>() + base, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  if (dis) HIPCHK(hipMemcpyAsync(dis, e->rec_dis.as<double>() + base, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (db_entry) {
+    std::vector<u32> perm(e->n_entries);
+    HIPCHK(hipMemcpy(perm.data(), e->perm.p, (size_t)e->n_entries * sizeof(u32), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) db_entry[i] = perm[p[i]];
+  }
+  for (int64_t i = 0; i < n; i++) {
+    if (q_idx) q_idx[i] = (int32_t)a[i];
+    if (cell) cell[i] = c[i];
+  }
+  return SGTD_OK;
+}
+
+int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_desc_soa *out) {
+  if (!e || n < 0 || (n > 0 && (!db_entry || !out))) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  // contiguous runs are copied as one range; scattered ids one by one
+  int64_t i = 0;
+  while (i < n) {
+    if (db_entry[i] < 0 || db_entry[i] >= e->n_entries) return SGTD_ERR_INVALID;
+    int64_t j = i + 1;
+    while (j < n && db_entry[j] == db_entry[j - 1] + 1) j++;
+    CHK(copy_out(e, e->tab, (size_t)db_entry[i], (size_t)(j - i), out, (size_t)i));
+    i = j;
+  }
+  return SGTD_OK;
+}
+
+int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *entry_ids,
+                    int64_t cap_buckets, int64_t cap_entries) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(do_finalize(e));
+  const int64_t U = e->n_buckets, E = e->n_entries;
+  if (U > cap_buckets || E > cap_entries) return SGTD_ERR_CAPACITY;
+  if (E == 0) { if (bucket_off) bucket_off[0] = 0; return SGTD_OK; }
+  std::vector<u64> k(U);
+  std::vector<u32> st(U), pm(E);
+  HIPCHK(hipMemcpy(k.data(), e->bucket_key.p, U * sizeof(u64), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(st.data(), e->bucket_start.p, U * sizeof(u32), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(pm.data(), e->perm.p, E * sizeof(u32), hipMemcpyDeviceToHost));
+  for (int64_t u = 0; u < U; u++) {
+    if (keys) {
+      keys[u * 4 + 0] = (int64_t)((k[u] >> 32) & 0xFFFF);
+      keys[u * 4 + 1] = (int64_t)((k[u] >> 16) & 0xFFFF);
+      keys[u * 4 + 2] = (int64_t)(k[u] & 0xFFFF);
+      keys[u * 4 + 3] = (int64_t)(k[u] >> 48);
+    }
+    if (bucket_off) bucket_off[u] = st[u];
+  }
+  if (bucket_off) bucket_off[U] = E;
+  if (entry_ids)
+    for (int64_t p = 0; p < E; p++) entry_ids[p] = pm[p];
+  return SGTD_OK;
+}
+
+int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
+  if (!e || !out) return SGTD_ERR_INVALID;
+  e->stats.n_entries = e->n_entries;
+  e->stats.n_buckets = e->n_buckets;
+  e->stats.n_frames = e->n_add_calls;
+  e->stats.hbm_bytes_table = e->n_entries * 28;
+  *out = e->stats;
+  return SGTD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+"""Multi-GPU form of candidate_selector: the map's hash table is sharded by
+frame range, one process per GPU, candidates gathered with RCCL.
+
+Sharding: rank r owns map frames [lo_r, hi_r) and holds a
+complete table for them, so every vote of a frame is counted on exactly one
+rank and the final vote of each of its frames is local.  Per query batch each
+rank probes its shard with all queries, takes its local top-`candidate_num`
+(votes desc, frame id asc, >= 5 votes — STDesc.cpp:423-433), then ONE
+all_gather of the (frame, votes) tables (candidate_num * 8 B per query and
+rank) and an identical merge on every rank reproduce the single-table
+candidate list bit for bit: the global top-k of disjoint frame sets is the
+top-k of the union of the local top-k lists.  The match lists of the winners
+stay on their owner rank (`owner_of`).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames, world, rank):
+    """contiguous frame range [lo, hi) of `rank`"""
+    return rank * n_frames // world, (rank + 1) * n_frames // world
+
+
+def owner_of(frame, n_frames, world):
+    """rank whose shard holds `frame` (inverse of shard_range)"""
+    r = min(world - 1, (int(frame) * world) // max(n_frames, 1))
+    while frame < shard_range(n_frames, world, r)[0]:
+        r -= 1
+    while frame >= shard_range(n_frames, world, r)[1]:
+        r += 1
+    return r
+
+
+def merge_candidates(frames, votes, cand_num, min_votes=5):
+    """frames, votes: int32 tensors [W, Q, cn] of per-rank candidate tables (unused
+    slots: frame -1 / votes 0).  Returns (frames [Q, cand_num], votes [Q, cand_num],
+    n_cand [Q]) in the reference's order: votes descending, ties -> lowest frame id."""
+    w, q, cn = frames.shape
+    f = frames.permute(1, 0, 2).reshape(q, w * cn).to(torch.int64)
+    v = votes.permute(1, 0, 2).reshape(q, w * cn).to(torch.int64)
+    valid = (f >= 0) & (v >= min_votes)
+    key = torch.where(valid, (v << 32) | (0xFFFFFFFF - f), torch.full_like(v, -1))
+    key, _ = torch.sort(key, dim=1, descending=True)
+    key = key[:, :cand_num]
+    ok = key >= 0
+    out_v = torch.where(ok, key >> 32, torch.zeros_like(key)).to(torch.int32)
+    out_f = torch.where(ok, 0xFFFFFFFF - (key & 0xFFFFFFFF), torch.full_like(key, -1)).to(torch.int32)
+    return out_f, out_v, ok.sum(dim=1).to(torch.int32)
+
+
+def gather_and_merge(local_frames, local_votes, cand_num, group=None):
+    """all_gather of the local candidate tables [Q, cn] (RCCL on GPUs, gloo on CPU)
+    followed by the merge; every rank returns the same global candidate list"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return merge_candidates(local_frames[None], local_votes[None], cand_num)
+    # one collective: frames and votes travel together
+    packed = torch.stack([local_frames, local_votes]).contiguous()
+    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    return merge_candidates(out[:, 0], out[:, 1], cand_num)
+
+
+class ShardedMap:
+    """one rank's shard of the map + the collective query (one process per GPU)"""
+
+    def __init__(self, n_frames_total, rank, world, device_id=0, **cfg):
+        from .manager import STDescManager
+        self.n_frames, self.rank, self.world = n_frames_total, rank, world
+        self.lo, self.hi = shard_range(n_frames_total, world, rank)
+        cfg.setdefault("max_frame_n", max(20000, n_frames_total + 1))
+        self.mgr = STDescManager(first_frame_id=self.lo, device_id=device_id, **cfg)
+        self.cand_num = self.mgr.config_setting_["candidate_num"]
+        self._bufs = None
+
+    def add_shard_frames(self, xyz, label, kp_off=None):
+        """xyz/label of THIS rank's frames [lo, hi) in frame order"""
+        self.mgr.add_frames(xyz, label, kp_off)
+        self.mgr.finalize()
+
+    def query(self, xyz, label, kp_off=None):
+        """all ranks pass the same query batch; returns the global candidate list
+        (frames, votes, n_cand) as device tensors, identical on every rank"""
+        self.mgr.query_frames(xyz, label, kp_off, fetch=False)
+        nq = self.mgr._nq
+        dev = torch.device("cuda", self.mgr.config_setting_["device_id"])
+        if self._bufs is None or self._bufs[0].shape[0] != nq:
+            self._bufs = (torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev),
+                          torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev))
+        self.mgr.export_candidates(*self._bufs)
+        return gather_and_merge(self._bufs[0], self._bufs[1], self.cand_num)

@@ -1,0 +1,288 @@
+"""Host-side mirror of the reference's operator API for the hot path.
+
+`STDescManager` keeps the reference class's method names and argument meaning
+(src/sgtd/include/desc/STDesc.h:342-440):
+
+    BuildSingleScanSTD(cloud)  -> descriptors          STDesc.cpp:174-315
+    AddSTDescs(descriptors)                            STDesc.cpp:149-172
+    candidate_selector(descs)  -> [STDMatchList]       STDesc.cpp:318-460
+
+plus the batched, device-resident forms the GPU wants (`add_frames`,
+`query_frames`).  Everything computes in libsgtd_accel.so (HIP, gfx950); this
+file only marshals numpy / torch buffers through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, DescSoa, SgtdError, Stats
+
+DEFAULTS = dict(descriptor_near_num=10, candidate_num=50, max_frame_n=20000, device_id=0,
+                descriptor_min_len=0.5, descriptor_max_len=50.0, std_side_resolution=1.0,
+                rough_dis_threshold=0.03, first_frame_id=0)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Descs:
+    """descriptor structure-of-arrays (layout of sgtd_desc_soa), numpy backed"""
+
+    FIELDS = (("side", np.float64, 3), ("angle", np.float64, 3), ("center", np.float64, 3),
+              ("vertex", np.float32, 9), ("label", np.int32, 3), ("frame", np.uint32, 1),
+              ("node_id", np.int32, 3))
+
+    def __init__(self, n):
+        self.n = int(n)
+        for name, dt, w in self.FIELDS:
+            setattr(self, name, np.zeros((self.n, w) if w > 1 else (self.n,), dtype=dt))
+
+    def soa(self):
+        s = DescSoa()
+        for name, _, _ in self.FIELDS:
+            setattr(s, name, _p(getattr(self, name)))
+        return s
+
+    def head(self, n):
+        out = Descs(0)
+        out.n = int(n)
+        for name, _, _ in self.FIELDS:
+            setattr(out, name, np.ascontiguousarray(getattr(self, name)[:n]))
+        return out
+
+    def take(self, idx):
+        out = Descs(0)
+        out.n = len(idx)
+        for name, _, _ in self.FIELDS:
+            setattr(out, name, np.ascontiguousarray(getattr(self, name)[idx]))
+        return out
+
+
+class STDMatchList:
+    """STDMatchList (STDesc.h:120-124): match_id_ = (query frame id, map frame id);
+    match_list_ as (query descriptor index, table entry index) pairs in order"""
+
+    def __init__(self, query_frame, map_frame, votes, q_idx, db_entry):
+        self.match_id_ = (int(query_frame), int(map_frame))
+        self.votes = int(votes)
+        self.q_idx = q_idx
+        self.db_entry = db_entry
+
+    def __len__(self):
+        return len(self.q_idx)
+
+
+class BatchResult:
+    """candidate_selector output of a batch of query frames (host copies)"""
+
+    def __init__(self, n_cand, cand_frame, cand_votes, pair_off, query_frame_id):
+        self.n_cand = n_cand
+        self.cand_frame = cand_frame
+        self.cand_votes = cand_votes
+        self.pair_off = pair_off
+        self.query_frame_id = query_frame_id
+
+    def top1(self):
+        """map frame with the most votes per query (-1 if no candidate)"""
+        return np.where(self.n_cand > 0, self.cand_frame[:, 0], -1)
+
+
+class STDescManager:
+    def __init__(self, **kw):
+        cfg = dict(DEFAULTS)
+        cfg.update(kw)
+        self.config_setting_ = cfg
+        self._L = _lib.lib()
+        c = Config(**cfg)
+        h = C.c_void_p()
+        self._h = None
+        self._check(self._L.sgtd_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._keep = None
+
+    def close(self):
+        if self._h is not None:
+            self._L.sgtd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status):
+        if status != 0:
+            detail = ""
+            if self._h is not None:
+                detail = self._L.sgtd_last_error(self._h).decode()
+            raise SgtdError(status, detail)
+
+    # ---- plumbing -------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._check(self._L.sgtd_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_timing(self, on):
+        self._check(self._L.sgtd_set_timing(self._h, int(bool(on))))
+
+    @property
+    def current_frame_id_(self):
+        v = C.c_uint32(0)
+        self._check(self._L.sgtd_current_frame_id(self._h, C.byref(v)))
+        return v.value
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.sgtd_get_stats(self._h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def sync(self):
+        self._check(self._L.sgtd_sync(self._h))
+
+    # ---- BuildSingleScanSTD ----------------------------------------------
+    def BuildSingleScanSTD(self, xyz, label):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        label = np.ascontiguousarray(label, dtype=np.uint32)
+        n = xyz.shape[0]
+        cap = self._L.sgtd_max_descs(self._h, n)
+        d = Descs(cap)
+        s = d.soa()
+        n_out = C.c_int64(0)
+        self._check(self._L.sgtd_build(self._h, _p(xyz), _p(label), n, C.byref(s), cap, C.byref(n_out)))
+        return d.head(n_out.value)
+
+    # ---- AddSTDescs -------------------------------------------------------
+    def AddSTDescs(self, d):
+        s = d.soa()
+        self._check(self._L.sgtd_add(self._h, C.byref(s), d.n))
+
+    def add_frames(self, xyz, label, kp_off=None):
+        """BuildSingleScanSTD + AddSTDescs for a whole run of frames on the device
+        (the caller's map loop, semantic_graph_localization.cpp:419-458).
+        xyz (F,N,3)/(total,3) numpy or torch.cuda tensor; kp_off None => uniform N."""
+        xp, lp, off, nf, dev = self._frames_args(xyz, label, kp_off)
+        self._check(self._L.sgtd_add_frames(self._h, xp, lp, _p(off), nf, dev))
+
+    def finalize(self):
+        self._check(self._L.sgtd_finalize(self._h))
+
+    def _frames_args(self, xyz, label, kp_off):
+        is_torch = hasattr(xyz, "data_ptr")
+        if is_torch:
+            assert xyz.is_cuda and label.is_cuda and xyz.is_contiguous() and label.is_contiguous()
+            shape = tuple(xyz.shape)
+            xp, lp, dev = C.c_void_p(xyz.data_ptr()), C.c_void_p(label.data_ptr()), 1
+            self._keep = (xyz, label)
+        else:
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            label = np.ascontiguousarray(label, dtype=np.uint32)
+            shape = xyz.shape
+            xp, lp, dev = _p(xyz), _p(label), 0
+            self._keep = (xyz, label)
+        if kp_off is None:
+            assert len(shape) == 3
+            nf, n = shape[0], shape[1]
+            off = np.arange(nf + 1, dtype=np.int64) * n
+        else:
+            off = np.ascontiguousarray(kp_off, dtype=np.int64)
+            nf = len(off) - 1
+        return xp, lp, off, nf, dev
+
+    # ---- candidate_selector -------------------------------------------------
+    def query_frames(self, xyz, label, kp_off=None, fetch=True):
+        """fused BuildSingleScanSTD + candidate_selector for a batch of query frames
+        (semantic_graph_localization.cpp:592,601 -> STDesc.cpp:98).  Asynchronous when
+        fetch=False (results via .results())."""
+        xp, lp, off, nq, dev = self._frames_args(xyz, label, kp_off)
+        self._nq = nq
+        self._check(self._L.sgtd_query_frames(self._h, xp, lp, _p(off), nq, dev))
+        return self.results() if fetch else None
+
+    def results(self):
+        nq, cn = self._nq, self.config_setting_["candidate_num"]
+        n_cand = np.zeros(nq, np.int32)
+        cf = np.zeros((nq, cn), np.int32)
+        cv = np.zeros((nq, cn), np.int32)
+        po = np.zeros((nq, cn + 1), np.int64)
+        self._check(self._L.sgtd_result_candidates(self._h, _p(n_cand), _p(cf), _p(cv), _p(po)))
+        return BatchResult(n_cand, cf, cv, po, self.current_frame_id_)
+
+    def export_candidates(self, d_frame, d_votes):
+        """async D2D copy of the (n_queries, candidate_num) int32 candidate tables into
+        torch.cuda tensors (no host synchronisation)"""
+        self._check(self._L.sgtd_export_candidates_dev(self._h, C.c_void_p(d_frame.data_ptr()),
+                                                       C.c_void_p(d_votes.data_ptr())))
+
+    def result_pairs(self, q, res):
+        cn = self.config_setting_["candidate_num"]
+        n = int(res.pair_off[q, cn])
+        qi = np.zeros(n, np.int32)
+        de = np.zeros(n, np.int64)
+        got = C.c_int64(0)
+        self._check(self._L.sgtd_result_pairs(self._h, q, _p(qi), _p(de), n, C.byref(got)))
+        return qi, de
+
+    def result_query_descs(self, q):
+        n = C.c_int64(0)
+        self._check(self._L.sgtd_result_query_desc_count(self._h, q, C.byref(n)))
+        d = Descs(n.value)
+        s = d.soa()
+        got = C.c_int64(0)
+        self._check(self._L.sgtd_result_query_descs(self._h, q, C.byref(s), n.value, C.byref(got)))
+        return d
+
+    def result_votes(self, q):
+        lo = C.c_uint32(0)
+        n = C.c_int64(0)
+        self._check(self._L.sgtd_result_votes(self._h, q, None, 0, C.byref(lo), C.byref(n)))
+        v = np.zeros(n.value, np.uint32)
+        self._check(self._L.sgtd_result_votes(self._h, q, _p(v), n.value, C.byref(lo), C.byref(n)))
+        return lo.value, v
+
+    def result_rough(self, q, with_dis=True):
+        n = C.c_int64(0)
+        st = self._L.sgtd_result_rough(self._h, q, None, None, None, None, None, 0, C.byref(n))
+        if st not in (0, -4):
+            self._check(st)
+        m = n.value
+        out = dict(q_idx=np.zeros(m, np.int32), cell=np.zeros(m, np.int32),
+                   db_entry=np.zeros(m, np.int64), frame=np.zeros(m, np.uint32),
+                   dis=np.zeros(m, np.float64) if with_dis else None)
+        self._check(self._L.sgtd_result_rough(self._h, q, _p(out["q_idx"]), _p(out["cell"]),
+                                              _p(out["db_entry"]), _p(out["frame"]),
+                                              _p(out["dis"]), m, C.byref(n)))
+        return out
+
+    def candidate_selector(self, stds_vec):
+        """one query frame given as descriptors -> list of STDMatchList"""
+        s = stds_vec.soa()
+        self._nq = 1
+        self._check(self._L.sgtd_query_descs(self._h, C.byref(s), stds_vec.n))
+        res = self.results()
+        qi, de = self.result_pairs(0, res)
+        out = []
+        for k in range(int(res.n_cand[0])):
+            lo, hi = res.pair_off[0, k], res.pair_off[0, k + 1]
+            out.append(STDMatchList(self.current_frame_id_, res.cand_frame[0, k], res.cand_votes[0, k],
+                                    qi[lo:hi], de[lo:hi]))
+        return out
+
+    # ---- table access -------------------------------------------------------
+    def fetch_entries(self, db_entry):
+        db_entry = np.ascontiguousarray(db_entry, dtype=np.int64)
+        d = Descs(len(db_entry))
+        s = d.soa()
+        self._check(self._L.sgtd_fetch_entries(self._h, _p(db_entry), len(db_entry), C.byref(s)))
+        return d
+
+    def table_dump(self):
+        self.finalize()
+        st = self.stats()
+        u, e = st["n_buckets"], st["n_entries"]
+        keys = np.zeros((u, 4), np.int64)
+        off = np.zeros(u + 1, np.int64)
+        ids = np.zeros(e, np.int64)
+        self._check(self._L.sgtd_table_dump(self._h, _p(keys), _p(off), _p(ids), u, e))
+        return keys, off, ids
