@@ -1,19 +1,20 @@
 // probe_kernels.hip.h — candidate_selector (src/sgtd/src/STDesc.cpp:318-460)
 //
-//   probe     (:351-400) one wavefront per query descriptor: 27 lanes resolve
-//             the 27 cells (truncating (int)(side+inc), gate ||side-centre||<1.5,
-//             hash lookup key -> bucket), then all 64 lanes stream the
-//             concatenated bucket ranges coalesced from the 28-B/entry hot
-//             arrays; __ballot of the match predicate is stored as one 64-bit
-//             mask word per 64 visited entries; votes by atomicAdd (:404-420)
-//   offsets   per-query exclusive scan of the match counts => deterministic
-//             positions in the reference's (i, cell, j) order
-//   emit      replays the mask words (no table reads for the predicate) and
-//             writes the ordered rough-match records by ballot/popcount prefix
-//   topk      (:423-433) candidate_num rounds of arg-max over the vote
-//             histogram: votes desc, frame id asc, stop below 5 votes
-//   assemble  (:434-449) stable split of the ordered records by candidate slot
-//             (wave_group_rank) => match_list_ of every candidate in order
+//   probe     (:351-400) work item = (query, chunk of 128 query descriptors),
+//             dequeued by persistent workgroups; one wavefront per descriptor:
+//             27 lanes resolve the 27 cells (truncating (int)(side+inc), gate
+//             ||side-centre|| < 1.5, hash lookup key -> bucket), then all 64
+//             lanes stream the concatenated bucket ranges coalesced from the
+//             28-B/entry hot arrays.  Matches are compacted in (cell, j) order
+//             by __ballot/popcount prefix into a per-descriptor list (frame,
+//             entry), votes (:404-420) go to an LDS histogram per work item
+//             that is flushed with one global atomic per touched frame.
+//   topk      (:423-433) candidate_num rounds of arg-max over the votes:
+//             votes desc, frame id asc, stop below 5 votes
+//   assemble  (:434-449) per tile of 32 descriptors: count matches per
+//             candidate slot, scan over tiles, then write every candidate's
+//             match_list_ in the reference's (i, cell, j) order — a stable
+//             split by slot done with wave_group_rank ballots
 #pragma once
 #include "common.hip.h"
 
@@ -38,18 +39,24 @@ struct QueryView {
 };
 
 struct ProbeBuffers {
-  u64 *mask_words;      // [mask_cap]
-  u32 mask_cap;
-  u32 *mask_cursor;     // global slab cursor
-  u32 *mask_ptr;        // [n_slots] first mask word of descriptor
-  u32 *n_visit;         // [n_slots] entries visited by descriptor (T_d)
+  u32 *rec_frame;       // [rec_cap] frame id of a match
+  u32 *rec_entry;       // [rec_cap] sorted table position of a match
+  unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
+  double *rec_dis;      // [rec_cap] distance (diagnostic build only)
+  u32 rec_cap;
+  u32 *rec_cursor;      // global slab cursor
+  u32 *item_cursor;     // work queue head
+  u32 *list_ptr;        // [n_slots] first record of descriptor
+  u32 *n_visit;         // [n_slots] entries visited by descriptor
   u32 *n_match;         // [n_slots] matches of descriptor
   u32 *votes;           // [n_queries * frame_span]
-  int *overflow;        // [2]: 0 mask words, 1 records
+  int *overflow;        // [2]: 0 match records, 1 candidate pairs
 };
 
 #define SGTD_PROBE_THREADS 256
-#define SGTD_MASK_SLAB 512u   // mask words a wave takes from the global cursor at once
+#define SGTD_PROBE_CHUNK 128    // query descriptors per work item
+#define SGTD_REC_SLAB 2048u     // match records a wave takes from the global cursor at once
+#define SGTD_TILE_DESCS 32      // query descriptors per assemble tile
 
 // resolves the 27 cells of one query descriptor; lane c < 27 returns its
 // bucket (start,len) (len = 0 if gated out / absent) — STDesc.cpp:358-371
@@ -76,9 +83,10 @@ __device__ __forceinline__ void resolve_cells(const TableView &T, double q0, dou
 }
 
 // position `pos` in the concatenation of the 27 ranges -> (cell, entry index)
-__device__ __forceinline__ void locate(const u32 *cell_off /*[28] LDS*/, const u32 *cell_start,
+__device__ __forceinline__ void locate(const u32 *cell_off /*[32] LDS*/, const u32 *cell_start,
                                        u32 pos, int &cell, u32 &entry) {
-  // branch-free binary search for the last cell with off <= pos (offsets ascending)
+  // branch-free binary search for the last cell with off <= pos (offsets ascending,
+  // entries 27..31 are UINT_MAX)
   int c = 0;
   if (cell_off[c + 16] <= pos) c += 16;
   if (cell_off[c + 8] <= pos) c += 8;
@@ -89,186 +97,105 @@ __device__ __forceinline__ void locate(const u32 *cell_off /*[28] LDS*/, const u
   entry = cell_start[c] + (pos - cell_off[c]);
 }
 
+template <bool LDS_VOTES, bool DIAG>
 __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, QueryView Q,
-                                                                   ProbeBuffers B, double rough) {
+                                                                   ProbeBuffers B, double rough,
+                                                                   int chunks_per_query) {
   constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
+  extern __shared__ u32 s_hist[];  // [frame_span] when LDS_VOTES
   __shared__ u32 s_off[NW][32];    // exclusive offsets, padded to 32 with UINT_MAX
   __shared__ u32 s_start[NW][32];
-  const int lane = lane_id(), wid = threadIdx.x >> 6;
-  const long long n_waves = (long long)gridDim.x * NW;
-  const long long n_slots = (long long)Q.n_queries * Q.stride;
-  u32 slab_next = 0, slab_end = 0;  // this wave's private mask-word slab
+  __shared__ u32 s_item;
+  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const u32 n_items = (u32)Q.n_queries * (u32)chunks_per_query;
+  u32 slab_next = 0, slab_end = 0;  // this wave's private record slab
 
-  for (long long d = (long long)blockIdx.x * NW + wid; d < n_slots; d += n_waves) {
-    const int q = (int)(d / Q.stride);
-    const u32 i = (u32)(d - (long long)q * Q.stride);
-    if (i >= Q.count[q]) continue;   // wave-uniform
-    const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
-    const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
-    const u32 qframe = Q.frame[d];
-    const double thr = norm3(q0, q1, q2) * rough;   // :356-357
-
-    u32 start, len;
-    resolve_cells(T, q0, q1, q2, code, start, len);
-    const u32 inc = wave_incl_scan(len);
-    const u32 total = __shfl(inc, SGTD_WAVE - 1);
-    if (lane < 32) {
-      s_off[wid][lane] = (lane < SGTD_NCELL) ? inc - len : 0xFFFFFFFFu;
-      s_start[wid][lane] = start;
+  while (true) {
+    if (tid == 0) s_item = atomicAdd(B.item_cursor, 1u);
+    __syncthreads();
+    const u32 item = s_item;
+    if (item >= n_items) break;
+    const int q = (int)(item / (u32)chunks_per_query);
+    const u32 d_first = (item - (u32)q * (u32)chunks_per_query) * SGTD_PROBE_CHUNK;
+    const u32 cnt = Q.count[q];
+    if (d_first >= cnt) { __syncthreads(); continue; }
+    const u32 d_last = min(d_first + SGTD_PROBE_CHUNK, cnt);
+    if (LDS_VOTES) {
+      for (u32 f = tid; f < T.frame_span; f += SGTD_PROBE_THREADS) s_hist[f] = 0;
     }
-    const u32 n_words = (total + 63u) >> 6;
-    // mask words from the wave-private slab (one global atomic per SGTD_MASK_SLAB words)
-    u32 mbase = 0;
-    if (n_words) {
-      if (slab_next + n_words > slab_end) {
-        u32 take = n_words > SGTD_MASK_SLAB ? n_words : SGTD_MASK_SLAB;
+    __syncthreads();
+    u32 *votes = B.votes + (size_t)q * T.frame_span;
+
+    for (u32 i = d_first + wid; i < d_last; i += NW) {
+      const long long d = (long long)q * Q.stride + i;
+      const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
+      const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
+      const u32 qframe = Q.frame[d];
+      const double thr = norm3(q0, q1, q2) * rough;   // :356-357
+
+      u32 start, len;
+      resolve_cells(T, q0, q1, q2, code, start, len);
+      const u32 inc = wave_incl_scan(len);
+      const u32 total = __shfl(inc, SGTD_WAVE - 1);
+      if (lane < 32) {
+        s_off[wid][lane] = (lane < SGTD_NCELL) ? inc - len : 0xFFFFFFFFu;
+        s_start[wid][lane] = start;
+      }
+      // records of one descriptor are contiguous: make sure the slab can take
+      // the worst case (every visited entry matches)
+      if (total && slab_next + total > slab_end) {
+        const u32 take = total > SGTD_REC_SLAB ? total : SGTD_REC_SLAB;
         u32 got = 0;
-        if (lane == 0) got = atomicAdd(B.mask_cursor, take);
+        if (lane == 0) got = atomicAdd(B.rec_cursor, take);
         got = __shfl(got, 0);
         slab_next = got; slab_end = got + take;
       }
-      mbase = slab_next;
-      slab_next += n_words;
-    }
-    const bool fits = (unsigned long long)mbase + n_words <= (unsigned long long)B.mask_cap;
-    if (!fits && lane == 0) B.overflow[0] = 1;
-    __builtin_amdgcn_wave_barrier();
+      const bool fits = (unsigned long long)slab_next + total <= (unsigned long long)B.rec_cap;
+      if (!fits && lane == 0) B.overflow[0] = 1;
+      __builtin_amdgcn_wave_barrier();
 
-    u32 matches = 0;
-    u32 *votes = B.votes + (size_t)q * T.frame_span;
-    for (u32 w = 0; w < n_words; w++) {
-      const u32 pos = (w << 6) + lane;
-      bool hit = false;
-      if (pos < total) {
-        int cell; u32 e;
-        locate(s_off[wid], s_start[wid], pos, cell, e);
-        const double dx = q0 - T.s0[e], dy = q1 - T.s1[e], dz = q2 - T.s2[e];
-        const u32 fr = T.frame[e];
-        // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-        hit = (qframe != fr) && (norm3(dx, dy, dz) < thr);        // :374-378
-        if (hit) atomicAdd(&votes[fr - T.frame_lo], 1u);          // :410
+      u32 matches = 0;
+      const u32 n_words = (total + 63u) >> 6;
+      for (u32 w = 0; w < n_words; w++) {
+        const u32 pos = (w << 6) + lane;
+        bool hit = false;
+        u32 e = 0, fr = 0; int cell = 0; double dis = 0;
+        if (pos < total) {
+          locate(s_off[wid], s_start[wid], pos, cell, e);
+          const double dx = q0 - T.s0[e], dy = q1 - T.s1[e], dz = q2 - T.s2[e];
+          fr = T.frame[e];
+          dis = norm3(dx, dy, dz);
+          // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
+          hit = (qframe != fr) && (dis < thr);                    // :374-378
+        }
+        if (hit) {                                                // :410
+          if (LDS_VOTES) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
+          else atomicAdd(&votes[fr - T.frame_lo], 1u);
+        }
+        const u64 m = __ballot(hit);
+        if (hit && fits) {
+          const u32 o = slab_next + matches + __popcll(m & lanemask_lt());
+          B.rec_frame[o] = fr;
+          B.rec_entry[o] = e;
+          if (DIAG) { B.rec_cell[o] = (unsigned char)cell; B.rec_dis[o] = dis; }
+        }
+        matches += __popcll(m);
       }
-      const u64 m = __ballot(hit);
-      matches += __popcll(m);
-      if (lane == 0 && fits) B.mask_words[mbase + w] = m;
+      if (lane == 0) {
+        B.list_ptr[d] = slab_next;
+        B.n_visit[d] = total;
+        B.n_match[d] = fits ? matches : 0;
+      }
+      if (fits) slab_next += matches;
+      __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) {
-      B.mask_ptr[d] = mbase;
-      B.n_visit[d] = total;
-      B.n_match[d] = fits ? matches : 0;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// per query: exclusive scan of n_match over its descriptors -> rec_off[d]
-// (relative to the query), totals M_q and P_q; one workgroup per query
-__global__ __launch_bounds__(256) void query_offsets_kernel(QueryView Q, const u32 *n_match,
-                                                            const u32 *n_visit, u32 *rec_off,
-                                                            u32 *q_M, unsigned long long *q_P) {
-  __shared__ u32 lds[256 / SGTD_WAVE + 1];
-  const int q = blockIdx.x;
-  const u32 cnt = Q.count[q];
-  const size_t base = (size_t)q * Q.stride;
-  u32 carry = 0;
-  unsigned long long visits = 0;
-  for (u32 i0 = 0; i0 < cnt; i0 += 256) {
-    const u32 i = i0 + threadIdx.x;
-    const u32 v = (i < cnt) ? n_match[base + i] : 0;
-    if (i < cnt) visits += n_visit[base + i];
-    u32 tot;
-    const u32 ex = block_excl_scan(v, lds, tot);
-    if (i < cnt) rec_off[base + i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) q_M[q] = carry;
-  // block sum of visits
-  __shared__ unsigned long long vs[256];
-  vs[threadIdx.x] = visits;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) vs[threadIdx.x] += vs[threadIdx.x + s];
     __syncthreads();
-  }
-  if (threadIdx.x == 0) q_P[q] = vs[0];
-}
-
-// exclusive scan of q_M over queries (n_queries small): q_base[q], q_base[n] = total
-__global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_M, u32 *q_base, int n_queries,
-                                                         u32 rec_cap, int *overflow) {
-  __shared__ u32 lds[256 / SGTD_WAVE + 1];
-  u32 carry = 0;
-  for (int q0 = 0; q0 < n_queries; q0 += 256) {
-    const int q = q0 + threadIdx.x;
-    const u32 v = (q < n_queries) ? q_M[q] : 0;
-    u32 tot;
-    const u32 ex = block_excl_scan(v, lds, tot);
-    if (q < n_queries) q_base[q] = carry + ex;
-    // u32 overflow of the running sum would corrupt offsets: flag it
-    if (carry + tot < carry && threadIdx.x == 0) overflow[1] = 1;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    q_base[n_queries] = carry;
-    if (carry > rec_cap) overflow[1] = 1;
-  }
-}
-
-struct RecordArrays {
-  u32 *qi;      // query descriptor index inside its query
-  u32 *pos;     // sorted table position p
-  u32 *frame;   // frame id of the entry
-  unsigned char *cell;  // voxel_round index (diagnostic)
-  double *dis;  // optional (diagnostic), may be null
-};
-
-// replays the mask words of every descriptor and writes its matches at the
-// deterministic offset q_base[q] + rec_off[d] + rank: global (i, cell, j) order
-__global__ __launch_bounds__(SGTD_PROBE_THREADS) void emit_kernel(TableView T, QueryView Q,
-                                                                  ProbeBuffers B, const u32 *rec_off,
-                                                                  const u32 *q_base, RecordArrays R) {
-  constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
-  __shared__ u32 s_off[NW][32];
-  __shared__ u32 s_start[NW][32];
-  if (B.overflow[0] || B.overflow[1]) return;
-  const int lane = lane_id(), wid = threadIdx.x >> 6;
-  const long long n_waves = (long long)gridDim.x * NW;
-  const long long n_slots = (long long)Q.n_queries * Q.stride;
-  for (long long d = (long long)blockIdx.x * NW + wid; d < n_slots; d += n_waves) {
-    const int q = (int)(d / Q.stride);
-    const u32 i = (u32)(d - (long long)q * Q.stride);
-    if (i >= Q.count[q]) continue;
-    if (B.n_match[d] == 0) continue;
-    const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
-    const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
-    u32 start, len;
-    resolve_cells(T, q0, q1, q2, code, start, len);
-    const u32 inc = wave_incl_scan(len);
-    const u32 total = __shfl(inc, SGTD_WAVE - 1);
-    if (lane < 32) {
-      s_off[wid][lane] = (lane < SGTD_NCELL) ? inc - len : 0xFFFFFFFFu;
-      s_start[wid][lane] = start;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const u32 n_words = (total + 63u) >> 6;
-    const u32 mbase = B.mask_ptr[d];
-    size_t out = (size_t)q_base[q] + rec_off[d];
-    for (u32 w = 0; w < n_words; w++) {
-      const u64 m = B.mask_words[mbase + w];
-      if (m == 0) continue;
-      if ((m >> lane) & 1ull) {
-        int cell; u32 e;
-        locate(s_off[wid], s_start[wid], (w << 6) + lane, cell, e);
-        const size_t o = out + __popcll(m & lanemask_lt());
-        R.qi[o] = i;
-        R.pos[o] = e;
-        R.frame[o] = T.frame[e];
-        R.cell[o] = (unsigned char)cell;
-        if (R.dis) R.dis[o] = norm3(q0 - T.s0[e], q1 - T.s1[e], q2 - T.s2[e]);
+    if (LDS_VOTES) {
+      for (u32 f = tid; f < T.frame_span; f += SGTD_PROBE_THREADS) {
+        const u32 v = s_hist[f];
+        if (v) atomicAdd(&votes[f], v);
       }
-      out += __popcll(m);
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -278,7 +205,6 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
                                                    int cand_num, int *n_cand, int *cand_frame,
                                                    int *cand_votes, unsigned char *slot_of_all) {
   __shared__ u64 red[256 / SGTD_WAVE];
-  __shared__ u64 picked[SGTD_MAX_CAND];
   __shared__ int n_picked;
   const int q = blockIdx.x;
   const u32 *votes = votes_all + (size_t)q * frame_span;
@@ -306,7 +232,6 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
       const u32 v = (u32)(b >> 32);
       if (v >= 5) {   // max_vote > 1 && max_vote >= 5 (:427,433)
         const u32 f = 0xFFFFFFFFu - (u32)(b & 0xFFFFFFFFu);
-        picked[n_picked] = b;
         slot_of[f] = (unsigned char)n_picked;
         cand_frame[q * cand_num + n_picked] = (int)(f + frame_lo);
         cand_votes[q * cand_num + n_picked] = (int)v;
@@ -314,78 +239,207 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
       } else {
         n_picked |= 0x40000000;  // stop marker
       }
+      __threadfence_block();
     }
     __syncthreads();
     if (n_picked & 0x40000000) break;
-    __threadfence_block();
   }
   if (threadIdx.x == 0) n_cand[q] = n_picked & 0x3FFFFFFF;
 }
 
-// stable split of a query's ordered rough matches by candidate slot:
-// pair_off[q][k] offsets (relative to q_base[q]) and (q_idx, db_entry) pairs
-__global__ __launch_bounds__(256) void assemble_kernel(const u32 *q_base, RecordArrays R,
-                                                       const unsigned char *slot_of_all, u32 frame_span,
-                                                       u32 frame_lo, const u32 *perm, int cand_num,
-                                                       const int *n_cand, long long *pair_off,
-                                                       u32 *pair_qi, u32 *pair_entry, const int *overflow) {
+// rows[dd][s] += matches of descriptor d_first+dd that belong to candidate slot s
+__device__ __forceinline__ void tile_count_rows(const QueryView &Q, const ProbeBuffers &B,
+                                                const unsigned char *slot_of, u32 frame_lo, int q,
+                                                u32 d_first, u32 d_last, u32 (*rows)[64]) {
   constexpr int NW = 256 / SGTD_WAVE;
-  __shared__ u32 run[64];
-  __shared__ u32 wcount[NW][64];
-  __shared__ u32 hist[64];
-  if (overflow[0] || overflow[1]) return;
-  const int q = blockIdx.x, tid = threadIdx.x, wid = tid >> 6;
-  const unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
-  const u32 lo = q_base[q], hi = q_base[q + 1];
-  const int nc = n_cand[q];
-  if (tid < 64) hist[tid] = 0;
-  __syncthreads();
-  // pass A: candidate histogram
-  for (u32 r = lo + tid; r < hi; r += 256) {
-    const unsigned char s = slot_of[R.frame[r] - frame_lo];
-    if (s != 0xFF) atomicAdd(&hist[s], 1u);
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  for (u32 i = d_first + wid; i < d_last; i += NW) {
+    const long long d = (long long)q * Q.stride + i;
+    const u32 n = B.n_match[d], p0 = B.list_ptr[d], dd = i - d_first;
+    for (u32 k0 = 0; k0 < n; k0 += SGTD_WAVE) {
+      const u32 k = k0 + lane;
+      unsigned char s = 0xFF;
+      if (k < n) s = slot_of[B.rec_frame[p0 + k] - frame_lo];
+      u32 rank, count;
+      wave_group_rank<6>((u32)s & 63u, s != 0xFF, rank, count);
+      if (s != 0xFF && rank == 0) rows[dd][s] += count;   // one lane per slot, row owned by this wave
+    }
   }
+}
+
+// pass 1: tile_count[(q*tiles+tile)*64 + s] = matches of the tile in slot s;
+// also the per-query sums of visited entries / matches for the statistics
+__global__ __launch_bounds__(256) void tile_count_kernel(QueryView Q, ProbeBuffers B,
+                                                         const unsigned char *slot_of_all, u32 frame_span,
+                                                         u32 frame_lo, int tiles_per_query, u32 *tile_count,
+                                                         u32 *q_M, unsigned long long *q_P) {
+  __shared__ u32 rows[SGTD_TILE_DESCS][64];
+  if (B.overflow[0]) return;
+  const int q = blockIdx.x / tiles_per_query, tile = blockIdx.x % tiles_per_query;
+  const int tid = threadIdx.x;
+  const u32 cnt = Q.count[q];
+  const u32 d_first = (u32)tile * SGTD_TILE_DESCS;
+  u32 *out = tile_count + ((size_t)q * tiles_per_query + tile) * 64;
+  if (d_first >= cnt) {
+    if (tid < 64) out[tid] = 0;
+    return;
+  }
+  const u32 d_last = min(d_first + SGTD_TILE_DESCS, cnt);
+  for (int k = tid; k < SGTD_TILE_DESCS * 64; k += 256) (&rows[0][0])[k] = 0;
   __syncthreads();
-  if (tid == 0) {
+  tile_count_rows(Q, B, slot_of_all + (size_t)q * frame_span, frame_lo, q, d_first, d_last, rows);
+  __syncthreads();
+  if (tid < 64) {
+    u32 tot = 0;
+    for (u32 dd = 0; dd < d_last - d_first; dd++) tot += rows[dd][tid];
+    out[tid] = tot;
+  }
+  if (tid < (int)(d_last - d_first)) {
+    const long long d = (long long)q * Q.stride + d_first + tid;
+    atomicAdd(&q_M[q], B.n_match[d]);
+    atomicAdd(&q_P[q], (unsigned long long)B.n_visit[d]);
+  }
+}
+
+// per query: exclusive scan of tile_count over tiles (in place) per slot, then
+// over slots: pair_off[q][k] (relative to the query's first pair), q_pairs[q]
+__global__ __launch_bounds__(64) void tile_scan_kernel(u32 *tile_count, int tiles_per_query, int cand_num,
+                                                       const int *n_cand, long long *pair_off, u32 *q_pairs,
+                                                       const int *overflow) {
+  __shared__ u32 tot[64];
+  if (overflow[0]) return;
+  const int q = blockIdx.x, s = threadIdx.x;
+  u32 *tc = tile_count + (size_t)q * tiles_per_query * 64;
+  u32 run = 0;
+  int t = 0;
+  for (; t + 8 <= tiles_per_query; t += 8) {
+    u32 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = tc[(size_t)(t + k) * 64 + s];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { tc[(size_t)(t + k) * 64 + s] = run; run += v[k]; }
+  }
+  for (; t < tiles_per_query; t++) { u32 v = tc[(size_t)t * 64 + s]; tc[(size_t)t * 64 + s] = run; run += v; }
+  tot[s] = run;
+  __syncthreads();
+  if (s == 0) {
+    const int nc = n_cand[q];
     u32 acc = 0;
-    for (int k = 0; k < nc; k++) {
-      run[k] = acc;
+    for (int k = 0; k <= cand_num; k++) {
       pair_off[(size_t)q * (cand_num + 1) + k] = acc;
-      acc += hist[k];
+      if (k < nc) acc += tot[k];
     }
-    for (int k = nc; k <= cand_num; k++) pair_off[(size_t)q * (cand_num + 1) + k] = acc;
-    for (int k = nc; k < 64; k++) run[k] = acc;
+    q_pairs[q] = acc;
+  }
+}
+
+// exclusive scan of q_pairs over queries: q_pair_base[q], [n] = total
+__global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32 *q_pair_base, int n_queries,
+                                                         u32 pair_cap, int *overflow) {
+  __shared__ u32 lds[256 / SGTD_WAVE + 1];
+  if (overflow[0]) return;
+  u32 carry = 0;
+  bool wrapped = false;
+  for (int q0 = 0; q0 < n_queries; q0 += 256) {
+    const int q = q0 + threadIdx.x;
+    const u32 v = (q < n_queries) ? q_pairs[q] : 0;
+    u32 tot;
+    const u32 ex = block_excl_scan(v, lds, tot);
+    if (q < n_queries) q_pair_base[q] = carry + ex;
+    if (carry + tot < carry) wrapped = true;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    q_pair_base[n_queries] = carry;
+    if (wrapped || carry > pair_cap) overflow[1] = 1;
+  }
+}
+
+// pass 2: every candidate's match_list_ in (i, cell, j) order (:437-449)
+__global__ __launch_bounds__(256) void tile_write_kernel(QueryView Q, ProbeBuffers B,
+                                                         const unsigned char *slot_of_all, u32 frame_span,
+                                                         u32 frame_lo, const u32 *perm, int tiles_per_query,
+                                                         const u32 *tile_excl, int cand_num,
+                                                         const long long *pair_off, const u32 *q_pair_base,
+                                                         u32 *pair_qi, u32 *pair_entry) {
+  constexpr int NW = 256 / SGTD_WAVE;
+  __shared__ u32 rows[SGTD_TILE_DESCS][64];
+  if (B.overflow[0] || B.overflow[1]) return;
+  const int q = blockIdx.x / tiles_per_query, tile = blockIdx.x % tiles_per_query;
+  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const u32 cnt = Q.count[q];
+  const u32 d_first = (u32)tile * SGTD_TILE_DESCS;
+  if (d_first >= cnt) return;
+  const u32 d_last = min(d_first + SGTD_TILE_DESCS, cnt);
+  const unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
+  for (int k = tid; k < SGTD_TILE_DESCS * 64; k += 256) (&rows[0][0])[k] = 0;
+  __syncthreads();
+  tile_count_rows(Q, B, slot_of, frame_lo, q, d_first, d_last, rows);
+  __syncthreads();
+  if (tid < 64) {
+    // counts -> absolute first output position of (descriptor, slot)
+    u32 run = 0;
+    if (tid < cand_num)
+      run = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + tid] +
+            tile_excl[((size_t)q * tiles_per_query + tile) * 64 + tid];
+    for (u32 dd = 0; dd < d_last - d_first; dd++) {
+      const u32 c = rows[dd][tid];
+      rows[dd][tid] = run;
+      run += c;
+    }
   }
   __syncthreads();
-  // pass B: stable scatter, 256 records per round
-  for (u32 r0 = lo; r0 < hi; r0 += 256) {
-    if (tid < 64) {
-#pragma unroll
-      for (int w = 0; w < NW; w++) wcount[w][tid] = 0;
+  for (u32 i = d_first + wid; i < d_last; i += NW) {
+    const long long d = (long long)q * Q.stride + i;
+    const u32 n = B.n_match[d], p0 = B.list_ptr[d], dd = i - d_first;
+    for (u32 k0 = 0; k0 < n; k0 += SGTD_WAVE) {
+      const u32 k = k0 + lane;
+      unsigned char s = 0xFF;
+      u32 e = 0;
+      if (k < n) {
+        s = slot_of[B.rec_frame[p0 + k] - frame_lo];
+        e = B.rec_entry[p0 + k];
+      }
+      u32 rank, count;
+      wave_group_rank<6>((u32)s & 63u, s != 0xFF, rank, count);
+      u32 base = 0;
+      if (s != 0xFF) base = rows[dd][s];
+      __builtin_amdgcn_wave_barrier();
+      if (s != 0xFF) {
+        const u32 o = base + rank;
+        pair_qi[o] = i;
+        pair_entry[o] = perm[e];
+        if (rank == 0) rows[dd][s] = base + count;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    const u32 r = r0 + tid;
-    unsigned char s = 0xFF;
-    if (r < hi) s = slot_of[R.frame[r] - frame_lo];
-    const bool valid = s != 0xFF;
-    u32 rank, count;
-    wave_group_rank<6>((u32)s & 63u, valid, rank, count);
-    if (valid && rank == 0) wcount[wid][s] = count;
-    __syncthreads();
-    if (valid) {
-      u32 p = run[s] + rank;
-#pragma unroll
-      for (int w = 0; w < NW; w++)
-        if (w < wid) p += wcount[w][s];
-      pair_qi[(size_t)lo + p] = R.qi[r];
-      pair_entry[(size_t)lo + p] = perm[R.pos[r]];
+  }
+}
+
+// diagnostic: the ordered rough-match list of ONE query (reference order i, cell, j)
+__global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuffers B, const u32 *perm, int q,
+                                                           u32 *out_qi, u32 *out_entry, u32 *out_frame,
+                                                           unsigned char *out_cell, double *out_dis) {
+  __shared__ u32 lds[256 / SGTD_WAVE + 1];
+  const u32 cnt = Q.count[q];
+  u32 carry = 0;
+  for (u32 i0 = 0; i0 < cnt; i0 += 256) {
+    const u32 i = i0 + threadIdx.x;
+    const long long d = (long long)q * Q.stride + i;
+    const u32 n = (i < cnt) ? B.n_match[d] : 0;
+    u32 tot;
+    const u32 ex = block_excl_scan(n, lds, tot);
+    if (i < cnt) {
+      const u32 p0 = B.list_ptr[d];
+      for (u32 k = 0; k < n; k++) {
+        const u32 o = carry + ex + k;
+        out_qi[o] = i;
+        out_entry[o] = perm[B.rec_entry[p0 + k]];
+        out_frame[o] = B.rec_frame[p0 + k];
+        if (out_cell) out_cell[o] = B.rec_cell[p0 + k];
+        if (out_dis) out_dis[o] = B.rec_dis[p0 + k];
+      }
     }
-    __syncthreads();
-    if (tid < 64) {
-      u32 add = 0;
-#pragma unroll
-      for (int w = 0; w < NW; w++) add += wcount[w][tid];
-      run[tid] += add;
-    }
+    carry += tot;
   }
 }

@@ -36,7 +36,7 @@ struct DescStore {
   }
 };
 
-enum { EV_START = 0, EV_BUILD, EV_PROBE, EV_SCAN, EV_EMIT, EV_TOPK, EV_ASSEMBLE, EV_COUNT };
+enum { EV_START = 0, EV_BUILD, EV_PROBE, EV_TOPK, EV_COUNT_T, EV_SCAN, EV_WRITE, EV_COUNT };
 
 }  // namespace
 
@@ -83,14 +83,15 @@ struct sgtd_engine {
   const u32 *last_label = nullptr;
   std::vector<long long> last_kp_off;
   int last_max_n = 0;
-  DevBuf mask_words, mask_cursor, mask_ptr, n_visit, n_match, rec_off, votes, slot_of, overflow;
-  DevBuf q_M, q_P, q_base, rec_qi, rec_pos, rec_frame, rec_cell, rec_dis;
+  DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
+  DevBuf q_M, q_P, q_pairs, q_pair_base, tile_count, rec_frame, rec_entry, rec_cell, rec_dis;
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pair_qi, pair_entry;
-  size_t mask_cap = (size_t)1 << 20;   // words
-  size_t rec_cap = (size_t)1 << 22;    // records
-  bool want_dis = false;
+  DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
+  size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
+  size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
+  bool diag = false;                   // diagnostic probe build: cell index + distance per match
   // host copies after sync
-  std::vector<u32> h_count, h_q_base, h_q_M;
+  std::vector<u32> h_count, h_pair_base, h_q_M;
   std::vector<unsigned long long> h_q_P;
   std::vector<int> h_n_cand, h_cand_frame, h_cand_votes;
   std::vector<long long> h_pair_off;
@@ -396,15 +397,45 @@ int do_finalize(sgtd_engine *e) {
 // the query pipeline on descriptors already in e->qd (strided)
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e) {
-  CHK(ensure(e, e->mask_words, e->mask_cap * sizeof(u64)));
-  CHK(ensure(e, e->rec_qi, e->rec_cap * sizeof(u32)));
-  CHK(ensure(e, e->rec_pos, e->rec_cap * sizeof(u32)));
   CHK(ensure(e, e->rec_frame, e->rec_cap * sizeof(u32)));
-  CHK(ensure(e, e->rec_cell, e->rec_cap));
-  if (e->want_dis) CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
-  CHK(ensure(e, e->pair_qi, e->rec_cap * sizeof(u32)));
-  CHK(ensure(e, e->pair_entry, e->rec_cap * sizeof(u32)));
+  CHK(ensure(e, e->rec_entry, e->rec_cap * sizeof(u32)));
+  if (e->diag) {
+    CHK(ensure(e, e->rec_cell, e->rec_cap));
+    CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
+  }
+  CHK(ensure(e, e->pair_qi, e->pair_cap * sizeof(u32)));
+  CHK(ensure(e, e->pair_entry, e->pair_cap * sizeof(u32)));
   return SGTD_OK;
+}
+
+struct Views {
+  TableView T;
+  QueryView Q;
+  ProbeBuffers B;
+  u32 span;
+  int tiles_per_query;
+};
+
+Views make_views(sgtd_engine *e) {
+  Views v;
+  v.span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
+  TableView &T = v.T;
+  T.s0 = e->s0.as<double>(); T.s1 = e->s1.as<double>(); T.s2 = e->s2.as<double>();
+  T.frame = e->tframe.as<u32>(); T.perm = e->perm.as<u32>();
+  T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
+  T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
+  QueryView &Q = v.Q;
+  Q.side = e->qd.side.as<double>(); Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
+  Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq;
+  ProbeBuffers &B = v.B;
+  B.rec_frame = e->rec_frame.as<u32>(); B.rec_entry = e->rec_entry.as<u32>();
+  B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
+  B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
+  B.rec_cursor = e->cursors.as<u32>(); B.item_cursor = e->cursors.as<u32>() + 1;
+  B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
+  B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
+  v.tiles_per_query = (int)((e->q_stride + SGTD_TILE_DESCS - 1) / SGTD_TILE_DESCS);
+  return v;
 }
 
 int launch_select(sgtd_engine *e) {
@@ -412,75 +443,82 @@ int launch_select(sgtd_engine *e) {
   const long long n_slots = (long long)nq * e->q_stride;
   const int cn = e->dc.cand_num;
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
-  CHK(ensure(e, e->mask_cursor, sizeof(u32)));
+  const int tiles = (int)((e->q_stride + SGTD_TILE_DESCS - 1) / SGTD_TILE_DESCS);
+  CHK(ensure(e, e->cursors, 2 * sizeof(u32)));
   CHK(ensure(e, e->overflow, 2 * sizeof(int)));
-  CHK(ensure(e, e->mask_ptr, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
+  CHK(ensure(e, e->list_ptr, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->n_match, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
-  CHK(ensure(e, e->rec_off, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->votes, (size_t)nq * span * sizeof(u32)));
   CHK(ensure(e, e->slot_of, (size_t)nq * span));
   CHK(ensure(e, e->q_M, (size_t)nq * sizeof(u32)));
   CHK(ensure(e, e->q_P, (size_t)nq * sizeof(unsigned long long)));
-  CHK(ensure(e, e->q_base, (size_t)(nq + 1) * sizeof(u32)));
+  CHK(ensure(e, e->q_pairs, (size_t)nq * sizeof(u32)));
+  CHK(ensure(e, e->q_pair_base, (size_t)(nq + 1) * sizeof(u32)));
+  CHK(ensure(e, e->tile_count, (size_t)nq * tiles * 64 * sizeof(u32)));
   CHK(ensure(e, e->n_cand, (size_t)nq * sizeof(int)));
   CHK(ensure(e, e->cand_frame, (size_t)nq * cn * sizeof(int)));
   CHK(ensure(e, e->cand_votes, (size_t)nq * cn * sizeof(int)));
   CHK(ensure(e, e->pair_off, (size_t)nq * (cn + 1) * sizeof(long long)));
   CHK(rec_alloc(e));
 
-  HIPCHK(hipMemsetAsync(e->mask_cursor.p, 0, sizeof(u32), e->stream));
+  HIPCHK(hipMemsetAsync(e->cursors.p, 0, 2 * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->overflow.p, 0, 2 * sizeof(int), e->stream));
   HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
   HIPCHK(hipMemsetAsync(e->cand_frame.p, 0xFF, (size_t)nq * cn * sizeof(int), e->stream));
   HIPCHK(hipMemsetAsync(e->cand_votes.p, 0, (size_t)nq * cn * sizeof(int), e->stream));
+  HIPCHK(hipMemsetAsync(e->q_M.p, 0, (size_t)nq * sizeof(u32), e->stream));
+  HIPCHK(hipMemsetAsync(e->q_P.p, 0, (size_t)nq * sizeof(unsigned long long), e->stream));
 
-  TableView T;
-  T.s0 = e->s0.as<double>(); T.s1 = e->s1.as<double>(); T.s2 = e->s2.as<double>();
-  T.frame = e->tframe.as<u32>(); T.perm = e->perm.as<u32>();
-  T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
-  T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = span;
-  QueryView Q;
-  Q.side = e->qd.side.as<double>(); Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
-  Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = nq;
-  ProbeBuffers B;
-  B.mask_words = e->mask_words.as<u64>();
-  B.mask_cap = (u32)std::min<size_t>(e->mask_cap, 0xFFFFFFFFu);
-  B.mask_cursor = e->mask_cursor.as<u32>(); B.mask_ptr = e->mask_ptr.as<u32>();
-  B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
-  B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
-  RecordArrays R;
-  R.qi = e->rec_qi.as<u32>(); R.pos = e->rec_pos.as<u32>(); R.frame = e->rec_frame.as<u32>();
-  R.cell = e->rec_cell.as<unsigned char>(); R.dis = e->want_dis ? e->rec_dis.as<double>() : nullptr;
-
-  constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
-  long long want_blocks = (n_slots + NW - 1) / NW;
-  int grid = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)e->n_cus * 8));
-  probe_kernel<<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(T, Q, B, e->dc.rough);
+  Views v = make_views(e);
+  const int chunks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
+  const long long n_items = (long long)nq * chunks;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(n_items, (long long)e->n_cus * 8));
+  const size_t hist_bytes = (size_t)span * sizeof(u32);
+  const bool lds_votes = hist_bytes <= 150 * 1024;
+  if (lds_votes) {
+    if (e->diag) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+      probe_kernel<true, true><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+    } else {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+      probe_kernel<true, false><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+    }
+  } else {
+    if (e->diag)
+      probe_kernel<false, true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+    else
+      probe_kernel<false, false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+  }
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
-  query_offsets_kernel<<<nq, 256, 0, e->stream>>>(Q, B.n_match, B.n_visit, e->rec_off.as<u32>(),
-                                                   e->q_M.as<u32>(), e->q_P.as<unsigned long long>());
-  HIPCHK(hipGetLastError());
-  query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_M.as<u32>(), e->q_base.as<u32>(), nq,
-                                               (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFFFu), B.overflow);
-  HIPCHK(hipGetLastError());
-  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
-  emit_kernel<<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(T, Q, B, e->rec_off.as<u32>(), e->q_base.as<u32>(), R);
-  HIPCHK(hipGetLastError());
-  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_EMIT], e->stream));
-  topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, T.frame_lo, cn, e->n_cand.as<int>(),
+  topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, v.T.frame_lo, cn, e->n_cand.as<int>(),
                                           e->cand_frame.as<int>(), e->cand_votes.as<int>(),
                                           e->slot_of.as<unsigned char>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
-  assemble_kernel<<<nq, 256, 0, e->stream>>>(e->q_base.as<u32>(), R, e->slot_of.as<unsigned char>(), span,
-                                              T.frame_lo, T.perm, cn, e->n_cand.as<int>(),
-                                              e->pair_off.as<long long>(), e->pair_qi.as<u32>(),
-                                              e->pair_entry.as<u32>(), B.overflow);
+  tile_count_kernel<<<nq * tiles, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
+                                                        tiles, e->tile_count.as<u32>(), e->q_M.as<u32>(),
+                                                        e->q_P.as<unsigned long long>());
   HIPCHK(hipGetLastError());
-  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_ASSEMBLE], e->stream));
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
+  tile_scan_kernel<<<nq, 64, 0, e->stream>>>(e->tile_count.as<u32>(), tiles, cn, e->n_cand.as<int>(),
+                                              e->pair_off.as<long long>(), e->q_pairs.as<u32>(),
+                                              e->overflow.as<int>());
+  HIPCHK(hipGetLastError());
+  query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
+                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
+  HIPCHK(hipGetLastError());
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
+  tile_write_kernel<<<nq * tiles, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
+                                                        v.T.perm, tiles, e->tile_count.as<u32>(), cn,
+                                                        e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
+                                                        e->pair_qi.as<u32>(), e->pair_entry.as<u32>());
+  HIPCHK(hipGetLastError());
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
   e->batch_valid = true;
   e->batch_synced = false;
   return SGTD_OK;
@@ -496,6 +534,12 @@ int enqueue_frames(sgtd_engine *e) {
   return launch_select(e);
 }
 
+int rerun(sgtd_engine *e) {
+  if (e->last_kind == 1) return enqueue_frames(e);
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));
+  return launch_select(e);
+}
+
 int sync_batch(sgtd_engine *e) {
   if (!e->batch_valid) return SGTD_ERR_STATE;
   if (e->batch_synced) return SGTD_OK;
@@ -504,23 +548,23 @@ int sync_batch(sgtd_engine *e) {
     int ovf[2] = {0, 0};
     u32 cursor = 0, total = 0;
     HIPCHK(hipMemcpyAsync(ovf, e->overflow.p, sizeof(ovf), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&cursor, e->mask_cursor.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&total, e->q_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&cursor, e->cursors.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!ovf[0] && !ovf[1]) break;
     e->stats.overflowed = 1;
     if (attempt == 7) return SGTD_ERR_CAPACITY;
-    if (ovf[0]) e->mask_cap = std::max<size_t>(e->mask_cap * 2, (size_t)cursor + (cursor >> 2) + 4096);
-    if (ovf[1]) e->rec_cap = std::max<size_t>(e->rec_cap * 2, (size_t)total + (total >> 3) + 4096);
-    if (e->mask_cap > 0xFFFFFFF0ull || e->rec_cap > 0xFFFFFFF0ull) return SGTD_ERR_CAPACITY;
-    if (e->last_kind == 1) CHK(enqueue_frames(e)); else CHK(launch_select(e));
+    if (ovf[0]) e->rec_cap = std::max<size_t>(e->rec_cap * 2, (size_t)cursor + (cursor >> 2) + 65536);
+    else if (ovf[1]) e->pair_cap = std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536);
+    if (e->rec_cap > 0xFFFFFFF0ull || e->pair_cap > 0xFFFFFFF0ull) return SGTD_ERR_CAPACITY;
+    CHK(rerun(e));
   }
   const int nq = e->nq, cn = e->dc.cand_num;
-  e->h_count.resize(nq); e->h_q_base.resize(nq + 1); e->h_q_M.resize(nq); e->h_q_P.resize(nq);
+  e->h_count.resize(nq); e->h_pair_base.resize(nq + 1); e->h_q_M.resize(nq); e->h_q_P.resize(nq);
   e->h_n_cand.resize(nq); e->h_cand_frame.resize((size_t)nq * cn); e->h_cand_votes.resize((size_t)nq * cn);
   e->h_pair_off.resize((size_t)nq * (cn + 1));
   HIPCHK(hipMemcpyAsync(e->h_count.data(), e->q_count.p, nq * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_q_base.data(), e->q_base.p, (nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_pair_base.data(), e->q_pair_base.p, (nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_q_M.data(), e->q_M.p, nq * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_q_P.data(), e->q_P.p, nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_n_cand.data(), e->n_cand.p, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -541,13 +585,14 @@ int sync_batch(sgtd_engine *e) {
     auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[b]); return ms; };
     if (e->last_kind == 1) { s.ms_build = el(EV_START, EV_BUILD); s.ms_probe = el(EV_BUILD, EV_PROBE); }
     else { s.ms_build = 0; s.ms_probe = el(EV_START, EV_PROBE); }
-    s.ms_scan = el(EV_PROBE, EV_SCAN); s.ms_emit = el(EV_SCAN, EV_EMIT);
-    s.ms_topk = el(EV_EMIT, EV_TOPK); s.ms_assemble = el(EV_TOPK, EV_ASSEMBLE);
-    s.ms_total = el(EV_START, EV_ASSEMBLE);
+    s.ms_topk = el(EV_PROBE, EV_TOPK); s.ms_count = el(EV_TOPK, EV_COUNT_T);
+    s.ms_scan = el(EV_COUNT_T, EV_SCAN); s.ms_write = el(EV_SCAN, EV_WRITE);
+    s.ms_total = el(EV_START, EV_WRITE);
   }
   e->batch_synced = true;
   return SGTD_OK;
 }
+
 
 int check_cfg(const sgtd_config *c) {
   if (c->descriptor_near_num < 3 || c->descriptor_near_num > SGTD_MAX_K) return SGTD_ERR_UNSUPPORTED;
@@ -632,9 +677,10 @@ int sgtd_destroy(sgtd_handle e) {
   DevBuf *bufs[] = {&e->s0, &e->s1, &e->s2, &e->tframe, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->mask_words, &e->mask_cursor, &e->mask_ptr, &e->n_visit,
-                    &e->n_match, &e->rec_off, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_base,
-                    &e->rec_qi, &e->rec_pos, &e->rec_frame, &e->rec_cell, &e->rec_dis, &e->n_cand, &e->cand_frame,
+                    &e->tmp_count, &e->q_count, &e->cursors, &e->list_ptr, &e->n_visit,
+                    &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
+                    &e->tile_count, &e->rec_frame, &e->rec_entry, &e->rec_cell, &e->rec_dis, &e->rough_qi,
+                    &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
                     &e->cand_votes, &e->pair_off, &e->pair_qi, &e->pair_entry};
   for (DevBuf *b : bufs) free_buf(*b);
   for (auto &b : e->scan_lvl) free_buf(b);
@@ -845,8 +891,8 @@ int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, i
   if (n > capacity) return SGTD_ERR_CAPACITY;
   if (n == 0) return SGTD_OK;
   std::vector<u32> qi(n), en(n);
-  HIPCHK(hipMemcpyAsync(qi.data(), e->pair_qi.as<u32>() + e->h_q_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(en.data(), e->pair_entry.as<u32>() + e->h_q_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(qi.data(), e->pair_qi.as<u32>() + e->h_pair_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(en.data(), e->pair_entry.as<u32>() + e->h_pair_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int64_t i = 0; i < n; i++) {
     if (q_idx) q_idx[i] = (int32_t)qi[i];
@@ -884,12 +930,13 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
                       double *dis, int64_t capacity, int64_t *n_rough) {
   if (!e || !n_rough) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
-  if (dis && !e->want_dis) {
-    // distances are a diagnostic output: switch them on and re-run the batch
-    e->want_dis = true;
-    if (!e->batch_valid) return SGTD_ERR_STATE;
+  if (!e->batch_valid) return SGTD_ERR_STATE;
+  if ((dis || cell) && !e->diag) {
+    // cell index and distance per match come from the diagnostic probe build:
+    // switch it on and re-run the batch
+    e->diag = true;
     CHK(rec_alloc(e));
-    if (e->last_kind == 1) CHK(enqueue_frames(e)); else CHK(launch_select(e));
+    CHK(rerun(e));
   }
   CHK(sync_batch(e));
   if (q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
@@ -897,22 +944,30 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
   *n_rough = n;
   if (n > capacity) return SGTD_ERR_CAPACITY;
   if (n == 0) return SGTD_OK;
-  const size_t base = e->h_q_base[q];
-  std::vector<u32> a(n), p(n), g(n);
-  std::vector<unsigned char> c(n);
-  HIPCHK(hipMemcpyAsync(a.data(), e->rec_qi.as<u32>() + base, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(p.data(), e->rec_pos.as<u32>() + base, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(c.data(), e->rec_cell.as<unsigned char>() + base, n, hipMemcpyDeviceToHost, e->stream));
-  if (frame) HIPCHK(hipMemcpyAsync(frame, e->rec_frame.as<u32>() + base, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  if (dis) HIPCHK(hipMemcpyAsync(dis, e->rec_dis.as<double>() + base, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (db_entry) {
-    std::vector<u32> perm(e->n_entries);
-    HIPCHK(hipMemcpy(perm.data(), e->perm.p, (size_t)e->n_entries * sizeof(u32), hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; i++) db_entry[i] = perm[p[i]];
+  CHK(ensure(e, e->rough_qi, n * sizeof(u32)));
+  CHK(ensure(e, e->rough_entry, n * sizeof(u32)));
+  CHK(ensure(e, e->rough_frame, n * sizeof(u32)));
+  if (e->diag) {
+    CHK(ensure(e, e->rough_cell, n));
+    CHK(ensure(e, e->rough_dis, n * sizeof(double)));
   }
+  Views v = make_views(e);
+  rough_gather_kernel<<<1, 256, 0, e->stream>>>(v.Q, v.B, v.T.perm, q, e->rough_qi.as<u32>(), e->rough_entry.as<u32>(),
+                                                 e->rough_frame.as<u32>(),
+                                                 e->diag ? e->rough_cell.as<unsigned char>() : nullptr,
+                                                 e->diag ? e->rough_dis.as<double>() : nullptr);
+  HIPCHK(hipGetLastError());
+  std::vector<u32> a(n), g(n);
+  std::vector<unsigned char> c(n);
+  HIPCHK(hipMemcpyAsync(a.data(), e->rough_qi.p, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(g.data(), e->rough_entry.p, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  if (cell) HIPCHK(hipMemcpyAsync(c.data(), e->rough_cell.p, n, hipMemcpyDeviceToHost, e->stream));
+  if (frame) HIPCHK(hipMemcpyAsync(frame, e->rough_frame.p, n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  if (dis) HIPCHK(hipMemcpyAsync(dis, e->rough_dis.p, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   for (int64_t i = 0; i < n; i++) {
     if (q_idx) q_idx[i] = (int32_t)a[i];
+    if (db_entry) db_entry[i] = (int64_t)g[i];
     if (cell) cell[i] = c[i];
   }
   return SGTD_OK;
