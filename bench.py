@@ -210,7 +210,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "probe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": probe_bytes,
-                         "P_visited": P, "M_matches": M, "D_query_descs": D, "kernel_ms": kern_ms},
+                         "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"], "kernel_ms": kern_ms},
         }
         if world == 1:
             out["recall"] = recall(smap, queries, top1)

@@ -20,6 +20,7 @@ struct DescArrays {
   int *label;                     // [cap*3]
   u32 *frame;                     // [cap]
   int *node_id;                   // [cap*3]
+  double *thr2;                   // [cap] squared match threshold (query descriptors only; may be null)
 };
 
 #define SGTD_BUILD_THREADS 256
@@ -256,6 +257,8 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
       out.label[o * 3 + 1] = (int)(double)__float_as_uint(B.w);
       out.label[o * 3 + 2] = (int)(double)__float_as_uint(C.w);
       out.frame[o] = frame_id;
+      if (out.thr2)   // dis_threshold of :356-357 in squared, comparison-exact form
+        out.thr2[o] = sq_threshold(norm3(cfg.scale * a, cfg.scale * b, cfg.scale * c) * cfg.rough);
       out.node_id[o * 3 + 0] = i; out.node_id[o * 3 + 1] = m; out.node_id[o * 3 + 2] = nn;
     }
   }

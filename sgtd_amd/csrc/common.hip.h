@@ -54,6 +54,29 @@ __host__ __device__ __forceinline__ u64 mix64(u64 k) {
   return k;
 }
 
+// one table entry in the probe layout: 32 bytes, two 16-B loads per lane
+struct __attribute__((aligned(32))) HotEntry {
+  double s0, s1, s2;  // side_length_ (scaled)
+  u32 frame;          // frame_id_
+  u32 g;              // insertion index (bucket order == ascending g)
+};
+
+// smallest y with sqrt_rn(y) >= thr:  (sqrt_rn(d2) < thr)  <=>  (d2 < y), because the
+// correctly rounded sqrt is monotone.  Lets the per-entry test of STDesc.cpp:374-378
+// compare squared distances bit-exactly, without a per-entry sqrt.
+__device__ __forceinline__ double sq_threshold(double thr) {
+  if (!(thr > 0.0)) return 0.0;              // dis < thr is never true
+  double y = thr * thr;
+  if (!(y > 0.0)) return y;                  // underflow: sqrt(0) = 0 < thr, nothing below 0
+  if (!(y < __builtin_inf())) return y;      // overflow: every finite d2 is below
+  while (y > 0.0 && sqrt(y) >= thr) y = __longlong_as_double(__double_as_longlong(y) - 1);
+  while (true) {
+    const double up = __longlong_as_double(__double_as_longlong(y) + 1);
+    if (!(sqrt(up) < thr)) return up;
+    y = up;
+  }
+}
+
 struct HashSlot {  // 16 bytes
   u64 key;
   u32 start;

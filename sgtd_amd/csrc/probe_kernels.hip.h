@@ -4,24 +4,28 @@
 //             dequeued by persistent workgroups; one wavefront per descriptor:
 //             27 lanes resolve the 27 cells (truncating (int)(side+inc), gate
 //             ||side-centre|| < 1.5, hash lookup key -> bucket), then all 64
-//             lanes stream the concatenated bucket ranges coalesced from the
-//             28-B/entry hot arrays.  Matches are compacted in (cell, j) order
-//             by __ballot/popcount prefix into a per-descriptor list (frame,
-//             entry), votes (:404-420) go to an LDS histogram per work item
-//             that is flushed with one global atomic per touched frame.
+//             lanes stream the concatenated bucket ranges from the 32-B/entry
+//             probe layout (two 16-B loads per lane, 4 x 64 entries in flight).
+//             The distance test runs on squared values against the exact
+//             squared threshold (common.hip.h sq_threshold) — no per-entry sqrt.
+//             Matches are compacted in (cell, j) order by __ballot/popcount
+//             prefix into a per-descriptor list of (frame, entry) records;
+//             votes (:404-420) go to an LDS histogram per work item that is
+//             flushed with one global atomic per touched frame.
 //   topk      (:423-433) candidate_num rounds of arg-max over the votes:
 //             votes desc, frame id asc, stop below 5 votes
-//   assemble  (:434-449) per tile of 32 descriptors: count matches per
-//             candidate slot, scan over tiles, then write every candidate's
-//             match_list_ in the reference's (i, cell, j) order — a stable
-//             split by slot done with wave_group_rank ballots
+//   assemble  (:434-449) one wavefront per 128-descriptor block walks the
+//             block's match lists as one flattened stream: pass 1 counts
+//             matches per candidate slot, a scan over blocks gives every
+//             (block, slot) its output range, pass 2 writes each candidate's
+//             match_list_ in the reference's (i, cell, j) order — a stable split
+//             by slot done with wave_group_rank ballots, running positions in
+//             lane registers
 #pragma once
 #include "common.hip.h"
 
 struct TableView {
-  const double *s0, *s1, *s2;  // [E] sorted order
-  const u32 *frame;            // [E]
-  const u32 *perm;             // [E] sorted position -> insertion index
+  const HotEntry *ent;         // [E] sorted by key, insertion order inside a bucket
   const HashSlot *hash;
   u32 hash_mask;
   u32 n_entries;
@@ -31,6 +35,7 @@ struct TableView {
 
 struct QueryView {
   const double *side;   // [n_slots*3]
+  const double *thr2;   // [n_slots] exact squared threshold of the descriptor
   const int *label;     // [n_slots*3]
   const u32 *frame;     // [n_slots]
   const u32 *count;     // [n_queries] descriptors per query
@@ -39,8 +44,7 @@ struct QueryView {
 };
 
 struct ProbeBuffers {
-  u32 *rec_frame;       // [rec_cap] frame id of a match
-  u32 *rec_entry;       // [rec_cap] sorted table position of a match
+  u64 *rec;             // [rec_cap] match record: frame << 32 | insertion index
   unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
@@ -54,9 +58,10 @@ struct ProbeBuffers {
 };
 
 #define SGTD_PROBE_THREADS 256
-#define SGTD_PROBE_CHUNK 128    // query descriptors per work item
+#define SGTD_PROBE_CHUNK 128    // query descriptors per work item = per assemble block
 #define SGTD_REC_SLAB 2048u     // match records a wave takes from the global cursor at once
-#define SGTD_TILE_DESCS 32      // query descriptors per assemble tile
+#define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
+#define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
 
 // resolves the 27 cells of one query descriptor; lane c < 27 returns its
 // bucket (start,len) (len = 0 if gated out / absent) — STDesc.cpp:358-371
@@ -67,8 +72,10 @@ __device__ __forceinline__ void resolve_cells(const TableView &T, double q0, dou
   if (c < SGTD_NCELL) {
     const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
     const int x = (int)(q0 + (double)ix), y = (int)(q1 + (double)iy), z = (int)(q2 + (double)iz);
-    const double cx = (double)x + 0.5, cy = (double)y + 0.5, cz = (double)z + 0.5;
-    const bool gate = norm3(q0 - cx, q1 - cy, q2 - cz) < 1.5;        // :366-369
+    const double dx = q0 - ((double)x + 0.5), dy = q1 - ((double)y + 0.5), dz = q2 - ((double)z + 0.5);
+    // ||side - centre|| < 1.5 (:366-369): sqrt_rn(y) < 1.5 <=> y < 2.25 exactly
+    // (sqrt(2.25) = 1.5 and sqrt(pred(2.25)) rounds below 1.5)
+    const bool gate = ((dx * dx + dy * dy) + dz * dz) < 2.25;
     if (gate && x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
       const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
       u32 h = (u32)mix64(key) & T.hash_mask;
@@ -126,12 +133,17 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, 
     __syncthreads();
     u32 *votes = B.votes + (size_t)q * T.frame_span;
 
-    for (u32 i = d_first + wid; i < d_last; i += NW) {
+    // wave w owns the contiguous block [d_first + 32 w, +32): its match lists
+    // land back to back in the wave's slab
+    const u32 w_first = d_first + (u32)wid * (SGTD_PROBE_CHUNK / NW);
+    const u32 w_last = min(w_first + (u32)(SGTD_PROBE_CHUNK / NW), d_last);
+    for (u32 i = w_first; i < w_last; i++) {
       const long long d = (long long)q * Q.stride + i;
       const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
       const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
       const u32 qframe = Q.frame[d];
-      const double thr = norm3(q0, q1, q2) * rough;   // :356-357
+      const double thr2 = Q.thr2[d];                    // squared form of :356-357
+      const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;
 
       u32 start, len;
       resolve_cells(T, q0, q1, q2, code, start, len);
@@ -156,30 +168,48 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, 
 
       u32 matches = 0;
       const u32 n_words = (total + 63u) >> 6;
-      for (u32 w = 0; w < n_words; w++) {
-        const u32 pos = (w << 6) + lane;
-        bool hit = false;
-        u32 e = 0, fr = 0; int cell = 0; double dis = 0;
-        if (pos < total) {
-          locate(s_off[wid], s_start[wid], pos, cell, e);
-          const double dx = q0 - T.s0[e], dy = q1 - T.s1[e], dz = q2 - T.s2[e];
-          fr = T.frame[e];
-          dis = norm3(dx, dy, dz);
-          // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-          hit = (qframe != fr) && (dis < thr);                    // :374-378
+      // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
+      // issued before the first use so that several KB per wave are in flight
+      for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
+        double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
+        int cell[SGTD_PROBE_UNROLL];
+        bool valid[SGTD_PROBE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+          const u32 pos = ((w0 + u) << 6) + lane;
+          valid[u] = pos < total;
+          u32 e;
+          locate(s_off[wid], s_start[wid], valid[u] ? pos : 0u, cell[u], e);
+          if (!valid[u]) e = 0;   // entry 0 always exists when total > 0
+          const double2 *p = reinterpret_cast<const double2 *>(T.ent + e);
+          v01[u] = p[0];          // s0, s1
+          v2x[u] = p[1];          // s2, {frame, g}
         }
-        if (hit) {                                                // :410
-          if (LDS_VOTES) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
-          else atomicAdd(&votes[fr - T.frame_lo], 1u);
+#pragma unroll
+        for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+          if (w0 + u < n_words) {   // wave-uniform
+            const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
+            const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
+            const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
+            const u32 fr = (u32)fg;
+            // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
+            bool hit;
+            double dis = 0.0;
+            if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
+            else hit = valid[u] && (qframe != fr) && (d2 < thr2);
+            if (hit) {                                                      // :410
+              if (LDS_VOTES) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
+              else atomicAdd(&votes[fr - T.frame_lo], 1u);
+            }
+            const u64 m = __ballot(hit);
+            if (hit && fits) {
+              const u32 o = slab_next + matches + __popcll(m & lanemask_lt());
+              B.rec[o] = (fg << 32) | (fg >> 32);   // frame << 32 | g
+              if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
+            }
+            matches += __popcll(m);
+          }
         }
-        const u64 m = __ballot(hit);
-        if (hit && fits) {
-          const u32 o = slab_next + matches + __popcll(m & lanemask_lt());
-          B.rec_frame[o] = fr;
-          B.rec_entry[o] = e;
-          if (DIAG) { B.rec_cell[o] = (unsigned char)cell; B.rec_dis[o] = dis; }
-        }
-        matches += __popcll(m);
       }
       if (lane == 0) {
         B.list_ptr[d] = slab_next;
@@ -247,79 +277,135 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
   if (threadIdx.x == 0) n_cand[q] = n_picked & 0x3FFFFFFF;
 }
 
-// rows[dd][s] += matches of descriptor d_first+dd that belong to candidate slot s
-__device__ __forceinline__ void tile_count_rows(const QueryView &Q, const ProbeBuffers &B,
-                                                const unsigned char *slot_of, u32 frame_lo, int q,
-                                                u32 d_first, u32 d_last, u32 (*rows)[64]) {
+// ---------------------------------------------------------------------------
+// assemble: one wavefront per block of SGTD_PROBE_CHUNK query descriptors.
+// Workgroup b -> (query, group of 4 blocks) with b % 8 == query % 8, so that all
+// workgroups of a query run on one XCD (workgroups are dealt round-robin over
+// the 8 XCDs) and the partial output lines of neighbouring blocks merge in
+// that XCD's L2 — a speed choice only, results do not depend on placement.
+// ---------------------------------------------------------------------------
+struct BlockId {
+  int q;          // query
+  int blk;        // 128-descriptor block inside the query
+  bool valid;
+};
+
+__device__ __forceinline__ BlockId assemble_block(int n_queries, int blocks_per_query) {
   constexpr int NW = 256 / SGTD_WAVE;
+  const int groups = (blocks_per_query + NW - 1) / NW;       // workgroups per query
+  const int b = blockIdx.x, x = b & 7, r = b >> 3;
+  BlockId id;
+  id.q = (r / groups) * 8 + x;
+  id.blk = (r % groups) * NW + (int)(threadIdx.x >> 6);
+  id.valid = id.q < n_queries && id.blk < blocks_per_query;
+  return id;
+}
+
+// the 32-descriptor sub-block [d0, d0+32) of query q: prefix of n_match and list
+// pointers into LDS; returns the number of records
+__device__ __forceinline__ u32 sub_open(const QueryView &Q, const ProbeBuffers &B, int q, u32 d0, u32 cnt,
+                                        u32 *s_pre /*[32]*/, u32 *s_ptr /*[32]*/, u32 &visits) {
+  const int lane = lane_id();
+  u32 n = 0, p = 0, v = 0;
+  if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
+    const long long d = (long long)q * Q.stride + d0 + lane;
+    n = B.n_match[d]; p = B.list_ptr[d]; v = B.n_visit[d];
+  }
+  const u32 inc = wave_incl_scan(n);
+  const u32 R = __shfl(inc, SGTD_WAVE - 1);
+  visits += wave_sum(v);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 32) { s_pre[lane] = inc - n; s_ptr[lane] = p; }
+  __builtin_amdgcn_wave_barrier();
+  return R;
+}
+
+// record r of the sub-block -> (descriptor index inside it, record address)
+__device__ __forceinline__ void sub_locate(const u32 *s_pre, const u32 *s_ptr, u32 r, u32 &dd, u32 &addr) {
+  // last dd with pre[dd] <= r (descriptors without matches share offsets and are skipped)
+  u32 c = 0;
+  if (s_pre[16] <= r) c = 16;
+  if (s_pre[c + 8] <= r) c += 8;
+  if (s_pre[c + 4] <= r) c += 4;
+  if (s_pre[c + 2] <= r) c += 2;
+  if (s_pre[c + 1] <= r) c += 1;
+  dd = c;
+  addr = s_ptr[c] + (r - s_pre[c]);
+}
+
+// pass 1: blk_count[(q*blocks+blk)*64 + s] = matches of the block in slot s;
+// also the per-query sums of visited entries / matches for the statistics
+__global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuffers B,
+                                                          const unsigned char *slot_of_all, u32 frame_span,
+                                                          u32 frame_lo, int blocks_per_query, u32 *blk_count,
+                                                          u32 *q_M, unsigned long long *q_P) {
+  constexpr int NW = 256 / SGTD_WAVE;
+  __shared__ u32 s_pre[NW][32];
+  __shared__ u32 s_ptr[NW][32];
+  __shared__ u32 s_hist[NW][64];
+  if (B.overflow[0]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
-  for (u32 i = d_first + wid; i < d_last; i += NW) {
-    const long long d = (long long)q * Q.stride + i;
-    const u32 n = B.n_match[d], p0 = B.list_ptr[d], dd = i - d_first;
-    for (u32 k0 = 0; k0 < n; k0 += SGTD_WAVE) {
-      const u32 k = k0 + lane;
-      unsigned char s = 0xFF;
-      if (k < n) s = slot_of[B.rec_frame[p0 + k] - frame_lo];
-      u32 rank, count;
-      wave_group_rank<6>((u32)s & 63u, s != 0xFF, rank, count);
-      if (s != 0xFF && rank == 0) rows[dd][s] += count;   // one lane per slot, row owned by this wave
+  const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
+  if (!id.valid) return;
+  const int q = id.q;
+  const u32 cnt = Q.count[q];
+  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
+  u32 *out = blk_count + ((size_t)q * blocks_per_query + id.blk) * 64;
+  if (d_first >= cnt) { out[lane] = 0; return; }
+  const unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
+  s_hist[wid][lane] = 0;
+  u32 visits = 0, total = 0;
+  for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
+    const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
+    total += R;
+    for (u32 r0 = 0; r0 < R; r0 += 2 * SGTD_WAVE) {
+      u32 fr[2]; bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const u32 r = r0 + u * SGTD_WAVE + lane;
+        ok[u] = r < R;
+        u32 dd, addr;
+        sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
+        fr[u] = (u32)(B.rec[addr] >> 32);
+      }
+      unsigned char sl[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) sl[u] = ok[u] ? slot_of[fr[u] - frame_lo] : (unsigned char)0xFF;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        u32 rank, count;
+        wave_group_rank<6>((u32)sl[u] & 63u, sl[u] != 0xFF, rank, count);
+        if (sl[u] != 0xFF && rank == 0) s_hist[wid][sl[u]] += count;
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
-}
-
-// pass 1: tile_count[(q*tiles+tile)*64 + s] = matches of the tile in slot s;
-// also the per-query sums of visited entries / matches for the statistics
-__global__ __launch_bounds__(256) void tile_count_kernel(QueryView Q, ProbeBuffers B,
-                                                         const unsigned char *slot_of_all, u32 frame_span,
-                                                         u32 frame_lo, int tiles_per_query, u32 *tile_count,
-                                                         u32 *q_M, unsigned long long *q_P) {
-  __shared__ u32 rows[SGTD_TILE_DESCS][64];
-  if (B.overflow[0]) return;
-  const int q = blockIdx.x / tiles_per_query, tile = blockIdx.x % tiles_per_query;
-  const int tid = threadIdx.x;
-  const u32 cnt = Q.count[q];
-  const u32 d_first = (u32)tile * SGTD_TILE_DESCS;
-  u32 *out = tile_count + ((size_t)q * tiles_per_query + tile) * 64;
-  if (d_first >= cnt) {
-    if (tid < 64) out[tid] = 0;
-    return;
-  }
-  const u32 d_last = min(d_first + SGTD_TILE_DESCS, cnt);
-  for (int k = tid; k < SGTD_TILE_DESCS * 64; k += 256) (&rows[0][0])[k] = 0;
-  __syncthreads();
-  tile_count_rows(Q, B, slot_of_all + (size_t)q * frame_span, frame_lo, q, d_first, d_last, rows);
-  __syncthreads();
-  if (tid < 64) {
-    u32 tot = 0;
-    for (u32 dd = 0; dd < d_last - d_first; dd++) tot += rows[dd][tid];
-    out[tid] = tot;
-  }
-  if (tid < (int)(d_last - d_first)) {
-    const long long d = (long long)q * Q.stride + d_first + tid;
-    atomicAdd(&q_M[q], B.n_match[d]);
-    atomicAdd(&q_P[q], (unsigned long long)B.n_visit[d]);
+  out[lane] = s_hist[wid][lane];
+  if (lane == 0) {
+    atomicAdd(&q_M[q], total);
+    atomicAdd(&q_P[q], (unsigned long long)visits);
   }
 }
 
-// per query: exclusive scan of tile_count over tiles (in place) per slot, then
+// per query: exclusive scan of blk_count over blocks (in place) per slot, then
 // over slots: pair_off[q][k] (relative to the query's first pair), q_pairs[q]
-__global__ __launch_bounds__(64) void tile_scan_kernel(u32 *tile_count, int tiles_per_query, int cand_num,
-                                                       const int *n_cand, long long *pair_off, u32 *q_pairs,
-                                                       const int *overflow) {
+__global__ __launch_bounds__(64) void block_scan_kernel(u32 *blk_count, int blocks_per_query, int cand_num,
+                                                        const int *n_cand, long long *pair_off, u32 *q_pairs,
+                                                        const int *overflow) {
   __shared__ u32 tot[64];
   if (overflow[0]) return;
   const int q = blockIdx.x, s = threadIdx.x;
-  u32 *tc = tile_count + (size_t)q * tiles_per_query * 64;
+  u32 *tc = blk_count + (size_t)q * blocks_per_query * 64;
   u32 run = 0;
   int t = 0;
-  for (; t + 8 <= tiles_per_query; t += 8) {
+  for (; t + 8 <= blocks_per_query; t += 8) {
     u32 v[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = tc[(size_t)(t + k) * 64 + s];
 #pragma unroll
     for (int k = 0; k < 8; k++) { tc[(size_t)(t + k) * 64 + s] = run; run += v[k]; }
   }
-  for (; t < tiles_per_query; t++) { u32 v = tc[(size_t)t * 64 + s]; tc[(size_t)t * 64 + s] = run; run += v; }
+  for (; t < blocks_per_query; t++) { u32 v = tc[(size_t)t * 64 + s]; tc[(size_t)t * 64 + s] = run; run += v; }
   tot[s] = run;
   __syncthreads();
   if (s == 0) {
@@ -355,69 +441,71 @@ __global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32
   }
 }
 
-// pass 2: every candidate's match_list_ in (i, cell, j) order (:437-449)
-__global__ __launch_bounds__(256) void tile_write_kernel(QueryView Q, ProbeBuffers B,
-                                                         const unsigned char *slot_of_all, u32 frame_span,
-                                                         u32 frame_lo, const u32 *perm, int tiles_per_query,
-                                                         const u32 *tile_excl, int cand_num,
-                                                         const long long *pair_off, const u32 *q_pair_base,
-                                                         u32 *pair_qi, u32 *pair_entry) {
+// pass 2: every candidate's match_list_ in (i, cell, j) order (:437-449);
+// pair = query descriptor index << 32 | insertion index of the table entry
+__global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuffers B,
+                                                          const unsigned char *slot_of_all, u32 frame_span,
+                                                          u32 frame_lo, int blocks_per_query,
+                                                          const u32 *blk_excl, int cand_num,
+                                                          const long long *pair_off, const u32 *q_pair_base,
+                                                          u64 *pairs) {
   constexpr int NW = 256 / SGTD_WAVE;
-  __shared__ u32 rows[SGTD_TILE_DESCS][64];
+  __shared__ u32 s_pre[NW][32];
+  __shared__ u32 s_ptr[NW][32];
+  __shared__ u32 s_cnt[NW][64];
   if (B.overflow[0] || B.overflow[1]) return;
-  const int q = blockIdx.x / tiles_per_query, tile = blockIdx.x % tiles_per_query;
-  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
+  if (!id.valid) return;
+  const int q = id.q;
   const u32 cnt = Q.count[q];
-  const u32 d_first = (u32)tile * SGTD_TILE_DESCS;
+  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (d_first >= cnt) return;
-  const u32 d_last = min(d_first + SGTD_TILE_DESCS, cnt);
   const unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
-  for (int k = tid; k < SGTD_TILE_DESCS * 64; k += 256) (&rows[0][0])[k] = 0;
-  __syncthreads();
-  tile_count_rows(Q, B, slot_of, frame_lo, q, d_first, d_last, rows);
-  __syncthreads();
-  if (tid < 64) {
-    // counts -> absolute first output position of (descriptor, slot)
-    u32 run = 0;
-    if (tid < cand_num)
-      run = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + tid] +
-            tile_excl[((size_t)q * tiles_per_query + tile) * 64 + tid];
-    for (u32 dd = 0; dd < d_last - d_first; dd++) {
-      const u32 c = rows[dd][tid];
-      rows[dd][tid] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  for (u32 i = d_first + wid; i < d_last; i += NW) {
-    const long long d = (long long)q * Q.stride + i;
-    const u32 n = B.n_match[d], p0 = B.list_ptr[d], dd = i - d_first;
-    for (u32 k0 = 0; k0 < n; k0 += SGTD_WAVE) {
-      const u32 k = k0 + lane;
-      unsigned char s = 0xFF;
-      u32 e = 0;
-      if (k < n) {
-        s = slot_of[B.rec_frame[p0 + k] - frame_lo];
-        e = B.rec_entry[p0 + k];
+  // lane s carries the next output position of candidate slot s
+  u32 running = 0;
+  if (lane < cand_num)
+    running = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + lane] +
+              blk_excl[((size_t)q * blocks_per_query + id.blk) * 64 + lane];
+  u32 visits = 0;
+  for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
+    const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
+    for (u32 r0 = 0; r0 < R; r0 += 2 * SGTD_WAVE) {
+      u64 rec[2]; u32 dd[2]; bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const u32 r = r0 + u * SGTD_WAVE + lane;
+        ok[u] = r < R;
+        u32 addr;
+        sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd[u], addr);
+        rec[u] = B.rec[addr];
       }
-      u32 rank, count;
-      wave_group_rank<6>((u32)s & 63u, s != 0xFF, rank, count);
-      u32 base = 0;
-      if (s != 0xFF) base = rows[dd][s];
-      __builtin_amdgcn_wave_barrier();
-      if (s != 0xFF) {
-        const u32 o = base + rank;
-        pair_qi[o] = i;
-        pair_entry[o] = perm[e];
-        if (rank == 0) rows[dd][s] = base + count;
+      unsigned char sl[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        sl[u] = ok[u] ? slot_of[(u32)(rec[u] >> 32) - frame_lo] : (unsigned char)0xFF;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const bool valid = sl[u] != 0xFF;
+        u32 rank, count;
+        wave_group_rank<6>((u32)sl[u] & 63u, valid, rank, count);
+        const u32 base = __shfl(running, (int)(sl[u] & 63u));
+        s_cnt[wid][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+          pairs[base + rank] = ((u64)(d0 + dd[u]) << 32) | (rec[u] & 0xFFFFFFFFull);
+          if (rank == 0) s_cnt[wid][sl[u]] = count;
+        }
+        __builtin_amdgcn_wave_barrier();
+        running += s_cnt[wid][lane];
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
 // diagnostic: the ordered rough-match list of ONE query (reference order i, cell, j)
-__global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuffers B, const u32 *perm, int q,
+__global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuffers B, int q,
                                                            u32 *out_qi, u32 *out_entry, u32 *out_frame,
                                                            unsigned char *out_cell, double *out_dis) {
   __shared__ u32 lds[256 / SGTD_WAVE + 1];
@@ -433,9 +521,10 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
       const u32 p0 = B.list_ptr[d];
       for (u32 k = 0; k < n; k++) {
         const u32 o = carry + ex + k;
+        const u64 r = B.rec[p0 + k];
         out_qi[o] = i;
-        out_entry[o] = perm[B.rec_entry[p0 + k]];
-        out_frame[o] = B.rec_frame[p0 + k];
+        out_entry[o] = (u32)r;
+        out_frame[o] = (u32)(r >> 32);
         if (out_cell) out_cell[o] = B.rec_cell[p0 + k];
         if (out_dis) out_dis[o] = B.rec_dis[p0 + k];
       }

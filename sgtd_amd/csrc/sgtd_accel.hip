@@ -25,13 +25,15 @@ struct DevBuf {
 };
 
 struct DescStore {
-  DevBuf side, angle, center, vertex, label, frame, node_id;
+  DevBuf side, angle, center, vertex, label, frame, node_id, thr2;
   size_t cap = 0;
+  bool with_thr2 = false;   // query descriptors carry their squared match threshold
   DescArrays view() const {
     DescArrays a;
     a.side = side.as<double>(); a.angle = angle.as<double>(); a.center = center.as<double>();
     a.vertex = vertex.as<float>(); a.label = label.as<int>(); a.frame = frame.as<u32>();
     a.node_id = node_id.as<int>();
+    a.thr2 = with_thr2 ? thr2.as<double>() : nullptr;
     return a;
   }
 };
@@ -59,7 +61,7 @@ struct sgtd_engine {
   bool finalized = true;  // empty table is trivially final
 
   // ---- table, probe layout (hot)
-  DevBuf s0, s1, s2, tframe, perm, hash, bucket_start, bucket_key;
+  DevBuf hot, perm, hash, bucket_start, bucket_key;   // hot: HotEntry[E], 32 B per entry
   u32 hash_mask = 0;
   int64_t n_buckets = 0;
   // sort scratch
@@ -84,8 +86,8 @@ struct sgtd_engine {
   std::vector<long long> last_kp_off;
   int last_max_n = 0;
   DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
-  DevBuf q_M, q_P, q_pairs, q_pair_base, tile_count, rec_frame, rec_entry, rec_cell, rec_dis;
-  DevBuf n_cand, cand_frame, cand_votes, pair_off, pair_qi, pair_entry;
+  DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
+  DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
@@ -139,6 +141,7 @@ int ensure_store(sgtd_engine *e, DescStore &s, size_t cap, bool keep = false) {
   CHK(ensure(e, s.label, want * 3 * sizeof(int), keep));
   CHK(ensure(e, s.frame, want * sizeof(u32), keep));
   CHK(ensure(e, s.node_id, want * 3 * sizeof(int), keep));
+  if (s.with_thr2) CHK(ensure(e, s.thr2, want * sizeof(double), keep));
   s.cap = want;
   return SGTD_OK;
 }
@@ -150,7 +153,7 @@ void free_buf(DevBuf &b) {
 }
 void free_store(DescStore &s) {
   free_buf(s.side); free_buf(s.angle); free_buf(s.center); free_buf(s.vertex);
-  free_buf(s.label); free_buf(s.frame); free_buf(s.node_id);
+  free_buf(s.label); free_buf(s.frame); free_buf(s.node_id); free_buf(s.thr2);
   s.cap = 0;
 }
 
@@ -352,17 +355,12 @@ int do_finalize(sgtd_engine *e) {
     std::swap(kin, kout);
     std::swap(vin, vout);
   }
-  // hot arrays
-  CHK(ensure(e, e->s0, (size_t)E * sizeof(double)));
-  CHK(ensure(e, e->s1, (size_t)E * sizeof(double)));
-  CHK(ensure(e, e->s2, (size_t)E * sizeof(double)));
-  CHK(ensure(e, e->tframe, (size_t)E * sizeof(u32)));
+  // probe layout: one 32-B record per entry in sorted order
+  CHK(ensure(e, e->hot, (size_t)E * sizeof(HotEntry)));
   CHK(ensure(e, e->perm, (size_t)E * sizeof(u32)));
   HIPCHK(hipMemcpyAsync(e->perm.p, vin, (size_t)E * sizeof(u32), hipMemcpyDeviceToDevice, e->stream));
   gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->perm.as<u32>(), e->tab.side.as<double>(),
-                                                              e->tab.frame.as<u32>(), e->s0.as<double>(),
-                                                              e->s1.as<double>(), e->s2.as<double>(),
-                                                              e->tframe.as<u32>(), E);
+                                                              e->tab.frame.as<u32>(), e->hot.as<HotEntry>(), E);
   HIPCHK(hipGetLastError());
   // buckets
   CHK(ensure(e, e->flags, (size_t)E * sizeof(u32)));
@@ -397,14 +395,12 @@ int do_finalize(sgtd_engine *e) {
 // the query pipeline on descriptors already in e->qd (strided)
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e) {
-  CHK(ensure(e, e->rec_frame, e->rec_cap * sizeof(u32)));
-  CHK(ensure(e, e->rec_entry, e->rec_cap * sizeof(u32)));
+  CHK(ensure(e, e->rec, e->rec_cap * sizeof(u64)));
   if (e->diag) {
     CHK(ensure(e, e->rec_cell, e->rec_cap));
     CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
   }
-  CHK(ensure(e, e->pair_qi, e->pair_cap * sizeof(u32)));
-  CHK(ensure(e, e->pair_entry, e->pair_cap * sizeof(u32)));
+  CHK(ensure(e, e->pairs, e->pair_cap * sizeof(u64)));
   return SGTD_OK;
 }
 
@@ -413,28 +409,28 @@ struct Views {
   QueryView Q;
   ProbeBuffers B;
   u32 span;
-  int tiles_per_query;
+  int blocks_per_query;
 };
 
 Views make_views(sgtd_engine *e) {
   Views v;
   v.span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   TableView &T = v.T;
-  T.s0 = e->s0.as<double>(); T.s1 = e->s1.as<double>(); T.s2 = e->s2.as<double>();
-  T.frame = e->tframe.as<u32>(); T.perm = e->perm.as<u32>();
+  T.ent = e->hot.as<HotEntry>();
   T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
   T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
   QueryView &Q = v.Q;
-  Q.side = e->qd.side.as<double>(); Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
+  Q.side = e->qd.side.as<double>(); Q.thr2 = e->qd.thr2.as<double>();
+  Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
   Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq;
   ProbeBuffers &B = v.B;
-  B.rec_frame = e->rec_frame.as<u32>(); B.rec_entry = e->rec_entry.as<u32>();
+  B.rec = e->rec.as<u64>();
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
   B.rec_cursor = e->cursors.as<u32>(); B.item_cursor = e->cursors.as<u32>() + 1;
   B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
   B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
-  v.tiles_per_query = (int)((e->q_stride + SGTD_TILE_DESCS - 1) / SGTD_TILE_DESCS);
+  v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   return v;
 }
 
@@ -443,7 +439,7 @@ int launch_select(sgtd_engine *e) {
   const long long n_slots = (long long)nq * e->q_stride;
   const int cn = e->dc.cand_num;
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
-  const int tiles = (int)((e->q_stride + SGTD_TILE_DESCS - 1) / SGTD_TILE_DESCS);
+  const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   CHK(ensure(e, e->cursors, 2 * sizeof(u32)));
   CHK(ensure(e, e->overflow, 2 * sizeof(int)));
   CHK(ensure(e, e->list_ptr, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
@@ -455,7 +451,7 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->q_P, (size_t)nq * sizeof(unsigned long long)));
   CHK(ensure(e, e->q_pairs, (size_t)nq * sizeof(u32)));
   CHK(ensure(e, e->q_pair_base, (size_t)(nq + 1) * sizeof(u32)));
-  CHK(ensure(e, e->tile_count, (size_t)nq * tiles * 64 * sizeof(u32)));
+  CHK(ensure(e, e->blk_count, (size_t)nq * blocks * 64 * sizeof(u32)));
   CHK(ensure(e, e->n_cand, (size_t)nq * sizeof(int)));
   CHK(ensure(e, e->cand_frame, (size_t)nq * cn * sizeof(int)));
   CHK(ensure(e, e->cand_votes, (size_t)nq * cn * sizeof(int)));
@@ -472,8 +468,7 @@ int launch_select(sgtd_engine *e) {
   HIPCHK(hipMemsetAsync(e->q_P.p, 0, (size_t)nq * sizeof(unsigned long long), e->stream));
 
   Views v = make_views(e);
-  const int chunks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
-  const long long n_items = (long long)nq * chunks;
+  const long long n_items = (long long)nq * blocks;
   const int grid = (int)std::max<long long>(1, std::min<long long>(n_items, (long long)e->n_cus * 8));
   const size_t hist_bytes = (size_t)span * sizeof(u32);
   const bool lds_votes = hist_bytes <= 150 * 1024;
@@ -481,17 +476,17 @@ int launch_select(sgtd_engine *e) {
     if (e->diag) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-      probe_kernel<true, true><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+      probe_kernel<true, true><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
     } else {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-      probe_kernel<true, false><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+      probe_kernel<true, false><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
     }
   } else {
     if (e->diag)
-      probe_kernel<false, true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+      probe_kernel<false, true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
     else
-      probe_kernel<false, false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, chunks);
+      probe_kernel<false, false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
   }
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
@@ -500,23 +495,26 @@ int launch_select(sgtd_engine *e) {
                                           e->slot_of.as<unsigned char>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
-  tile_count_kernel<<<nq * tiles, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
-                                                        tiles, e->tile_count.as<u32>(), e->q_M.as<u32>(),
-                                                        e->q_P.as<unsigned long long>());
+  // assemble grid: workgroup b serves query (b/8/groups)*8 + b%8 (XCD affinity, see assemble_block)
+  const int groups = (blocks + 3) / 4;
+  const int agrid = ((nq + 7) / 8) * groups * 8;
+  block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
+                                                    blocks, e->blk_count.as<u32>(), e->q_M.as<u32>(),
+                                                    e->q_P.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
-  tile_scan_kernel<<<nq, 64, 0, e->stream>>>(e->tile_count.as<u32>(), tiles, cn, e->n_cand.as<int>(),
-                                              e->pair_off.as<long long>(), e->q_pairs.as<u32>(),
-                                              e->overflow.as<int>());
+  block_scan_kernel<<<nq, 64, 0, e->stream>>>(e->blk_count.as<u32>(), blocks, cn, e->n_cand.as<int>(),
+                                               e->pair_off.as<long long>(), e->q_pairs.as<u32>(),
+                                               e->overflow.as<int>());
   HIPCHK(hipGetLastError());
   query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
                                                (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
-  tile_write_kernel<<<nq * tiles, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
-                                                        v.T.perm, tiles, e->tile_count.as<u32>(), cn,
-                                                        e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
-                                                        e->pair_qi.as<u32>(), e->pair_entry.as<u32>());
+  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
+                                                    blocks, e->blk_count.as<u32>(), cn,
+                                                    e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
+                                                    e->pairs.as<u64>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
   e->batch_valid = true;
@@ -663,6 +661,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   e->dc.rough = cfg->rough_dis_threshold;
   e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   e->current_frame_id = cfg->first_frame_id;
+  e->qd.with_thr2 = true;
   for (int i = 0; i < EV_COUNT; i++)
     if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
   *out = e;
@@ -674,14 +673,14 @@ int sgtd_destroy(sgtd_handle e) {
   (void)hipSetDevice(e->cfg.device_id);
   (void)hipStreamSynchronize(e->stream);
   free_store(e->tab); free_store(e->tmp); free_store(e->qd);
-  DevBuf *bufs[] = {&e->s0, &e->s1, &e->s2, &e->tframe, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
+  DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
                     &e->tmp_count, &e->q_count, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
-                    &e->tile_count, &e->rec_frame, &e->rec_entry, &e->rec_cell, &e->rec_dis, &e->rough_qi,
+                    &e->blk_count, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
-                    &e->cand_votes, &e->pair_off, &e->pair_qi, &e->pair_entry};
+                    &e->cand_votes, &e->pair_off, &e->pairs};
   for (DevBuf *b : bufs) free_buf(*b);
   for (auto &b : e->scan_lvl) free_buf(b);
   for (int i = 0; i < EV_COUNT; i++)
@@ -829,6 +828,11 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
+  if (nq > 0) {
+    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.thr2.as<double>(), nq,
+                                                           e->dc.rough);
+    HIPCHK(hipGetLastError());
+  }
   u32 cnt = (u32)nq;
   HIPCHK(hipMemcpyAsync(e->q_count.p, &cnt, sizeof(u32), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -890,13 +894,12 @@ int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, i
   *n_pairs = n;
   if (n > capacity) return SGTD_ERR_CAPACITY;
   if (n == 0) return SGTD_OK;
-  std::vector<u32> qi(n), en(n);
-  HIPCHK(hipMemcpyAsync(qi.data(), e->pair_qi.as<u32>() + e->h_pair_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(en.data(), e->pair_entry.as<u32>() + e->h_pair_base[q], n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  std::vector<u64> pr(n);
+  HIPCHK(hipMemcpyAsync(pr.data(), e->pairs.as<u64>() + e->h_pair_base[q], n * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int64_t i = 0; i < n; i++) {
-    if (q_idx) q_idx[i] = (int32_t)qi[i];
-    if (db_entry) db_entry[i] = (int64_t)en[i];
+    if (q_idx) q_idx[i] = (int32_t)(pr[i] >> 32);
+    if (db_entry) db_entry[i] = (int64_t)(pr[i] & 0xFFFFFFFFull);
   }
   return SGTD_OK;
 }
@@ -952,7 +955,7 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
     CHK(ensure(e, e->rough_dis, n * sizeof(double)));
   }
   Views v = make_views(e);
-  rough_gather_kernel<<<1, 256, 0, e->stream>>>(v.Q, v.B, v.T.perm, q, e->rough_qi.as<u32>(), e->rough_entry.as<u32>(),
+  rough_gather_kernel<<<1, 256, 0, e->stream>>>(v.Q, v.B, q, e->rough_qi.as<u32>(), e->rough_entry.as<u32>(),
                                                  e->rough_frame.as<u32>(),
                                                  e->diag ? e->rough_cell.as<unsigned char>() : nullptr,
                                                  e->diag ? e->rough_dis.as<double>() : nullptr);
@@ -1021,7 +1024,7 @@ int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
   e->stats.n_entries = e->n_entries;
   e->stats.n_buckets = e->n_buckets;
   e->stats.n_frames = e->n_add_calls;
-  e->stats.hbm_bytes_table = e->n_entries * 28;
+  e->stats.hbm_bytes_table = e->n_entries * (int64_t)sizeof(HotEntry);
   *out = e->stats;
   return SGTD_OK;
 }

@@ -9,8 +9,8 @@
 //   sort       stable LSD radix sort of (key, g) by key, 8-bit digits, passes
 //              whose digit is constant are skipped; stable => inside a bucket
 //              entries stay in insertion order == the reference's index j
-//   gather     hot probe arrays in sorted order p: side0/1/2 (f64), frame (u32)
-//              = 28 B per entry, plus perm[p] = g
+//   gather     hot probe array in sorted order p: {side0/1/2 f64, frame u32,
+//              g u32} = one 32-B record per entry (28 algorithmic bytes + g)
 //   csr+hash   bucket boundaries -> open-addressing table key -> (start,len)
 #pragma once
 #include "common.hip.h"
@@ -171,14 +171,24 @@ __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
 // gather hot arrays + bucket heads + hash insert
 // ---------------------------------------------------------------------------
 __global__ void gather_hot_kernel(const u32 *perm, const double *side, const u32 *frame,
-                                  double *s0, double *s1, double *s2, u32 *fr, long long n) {
+                                  HotEntry *hot, long long n) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const u32 g = perm[p];
-  s0[p] = side[(size_t)g * 3 + 0];
-  s1[p] = side[(size_t)g * 3 + 1];
-  s2[p] = side[(size_t)g * 3 + 2];
-  fr[p] = frame[g];
+  HotEntry h;
+  h.s0 = side[(size_t)g * 3 + 0];
+  h.s1 = side[(size_t)g * 3 + 1];
+  h.s2 = side[(size_t)g * 3 + 2];
+  h.frame = frame[g];
+  h.g = g;
+  hot[p] = h;
+}
+
+// squared thresholds for caller-provided query descriptors
+__global__ void thr2_kernel(const double *side, double *thr2, long long n, double rough) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  thr2[i] = sq_threshold(norm3(side[i * 3], side[i * 3 + 1], side[i * 3 + 2]) * rough);
 }
 
 __global__ void head_flags_kernel(const u64 *keys, u32 *flags, long long n) {
