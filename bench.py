@@ -174,7 +174,7 @@ def main():
         step()
         mgr.sync()
         s = mgr.stats()
-        for k in ("ms_build", "ms_probe", "ms_topk", "ms_count", "ms_scan", "ms_write", "ms_total"):
+        for k in ("ms_build", "ms_sort", "ms_probe", "ms_votes", "ms_topk", "ms_count", "ms_scan", "ms_write", "ms_total"):
             acc.setdefault(k, []).append(s[k])
     mgr.set_timing(False)
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}

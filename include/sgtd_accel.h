@@ -82,7 +82,7 @@ typedef struct sgtd_stats {
   int64_t hbm_bytes_table; /* bytes of the hot (probed) table arrays           */
   /* per-kernel device time of the last batch, ms (only when timing is enabled
    * with sgtd_set_timing; measured with hipEvents on the handle's stream)     */
-  float ms_build, ms_probe, ms_topk, ms_count, ms_scan, ms_write, ms_total;
+  float ms_build, ms_sort, ms_probe, ms_votes, ms_topk, ms_count, ms_scan, ms_write, ms_total;
   int32_t overflowed;      /* last batch outgrew a work buffer and was re-run  */
 } sgtd_stats;
 

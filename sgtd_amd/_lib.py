@@ -58,7 +58,8 @@ class Stats(C.Structure):
         ("n_entries", C.c_int64), ("n_buckets", C.c_int64), ("n_frames", C.c_int64),
         ("last_queries", C.c_int64), ("last_D", C.c_int64), ("last_P", C.c_int64),
         ("last_M", C.c_int64), ("last_cand_pairs", C.c_int64), ("hbm_bytes_table", C.c_int64),
-        ("ms_build", C.c_float), ("ms_probe", C.c_float), ("ms_topk", C.c_float),
+        ("ms_build", C.c_float), ("ms_sort", C.c_float), ("ms_probe", C.c_float),
+        ("ms_votes", C.c_float), ("ms_topk", C.c_float),
         ("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_write", C.c_float),
         ("ms_total", C.c_float), ("overflowed", C.c_int32),
     ]

@@ -54,6 +54,17 @@ __host__ __device__ __forceinline__ u64 mix64(u64 k) {
   return k;
 }
 
+// bucket hash of a packed table key: two 32-bit multiplies and two xor-shifts
+// (the keys differ in a few low bits of four 16-bit fields; this spreads them
+// well enough for a half-full open-addressing table)
+__host__ __device__ __forceinline__ u32 hash_key(u64 k) {
+  u32 h = (u32)k * 0x9E3779B1u ^ (u32)(k >> 32) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  return h;
+}
+
 // one table entry in the probe layout: 32 bytes, two 16-B loads per lane
 struct __attribute__((aligned(32))) HotEntry {
   double s0, s1, s2;  // side_length_ (scaled)

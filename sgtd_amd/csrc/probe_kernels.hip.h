@@ -63,22 +63,46 @@ struct ProbeBuffers {
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
 
-// resolves the 27 cells of one query descriptor; lane c < 27 returns its
-// bucket (start,len) (len = 0 if gated out / absent) — STDesc.cpp:358-371
-__device__ __forceinline__ void resolve_cells(const TableView &T, double q0, double q1, double q2,
-                                              u32 code, u32 &start, u32 &len) {
-  const int c = lane_id();
-  start = 0; len = 0;
+// ---------------------------------------------------------------------------
+// resolve: STDesc.cpp:358-371 for every (query descriptor, cell) pair, one
+// thread each (32 lanes per descriptor, 27 busy): truncating (int)(side+inc),
+// gate ||side-centre|| < 1.5, hash lookup key -> bucket, then a 32-lane scan
+// gives the descriptor's concatenated visit list.  One 256-B CellRow per
+// descriptor hands the result to the sweep kernel with a single coalesced load.
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(256))) CellRow {
+  u32 off[32];     // [0..26] exclusive offsets of the 27 ranges, [27] = total, rest unused
+  u32 start[32];   // [0..26] first table entry of each range
+};
+
+// Row index = position p; descriptor = order[p] (key-major) or p itself.
+#define SGTD_RESOLVE_THREADS 256
+__global__ __launch_bounds__(SGTD_RESOLVE_THREADS) void resolve_kernel(TableView T, QueryView Q, CellRow *rows,
+                                                                        const u32 *order, const u32 *n_valid_p,
+                                                                        long long n_slots) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long p = t >> 5;
+  const int c = (int)(t & 31);
+  const long long n = order ? (long long)*n_valid_p : n_slots;
+  if (p >= n) return;
+  const long long d = order ? (long long)order[p] : p;
+  if (!order) {
+    const int q = (int)(d / Q.stride);
+    if ((u32)(d - (long long)q * Q.stride) >= Q.count[q]) return;   // uniform over the 32-lane group
+  }
+  u32 start = 0, len = 0;
   if (c < SGTD_NCELL) {
+    const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
+    const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
     const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
     const int x = (int)(q0 + (double)ix), y = (int)(q1 + (double)iy), z = (int)(q2 + (double)iz);
     const double dx = q0 - ((double)x + 0.5), dy = q1 - ((double)y + 0.5), dz = q2 - ((double)z + 0.5);
-    // ||side - centre|| < 1.5 (:366-369): sqrt_rn(y) < 1.5 <=> y < 2.25 exactly
+    // ||side - centre|| < 1.5 (:366-369): sqrt_rn(v) < 1.5 <=> v < 2.25 exactly
     // (sqrt(2.25) = 1.5 and sqrt(pred(2.25)) rounds below 1.5)
     const bool gate = ((dx * dx + dy * dy) + dz * dz) < 2.25;
     if (gate && x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
       const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
-      u32 h = (u32)mix64(key) & T.hash_mask;
+      u32 h = hash_key(key) & T.hash_mask;
       while (true) {
         const HashSlot s = T.hash[h];
         if (s.key == key) { start = s.start; len = s.len; break; }
@@ -87,6 +111,16 @@ __device__ __forceinline__ void resolve_cells(const TableView &T, double q0, dou
       }
     }
   }
+  // inclusive scan over the 32-lane group
+  u32 inc = len;
+#pragma unroll
+  for (int dlt = 1; dlt < 32; dlt <<= 1) {
+    const u32 up = __shfl_up(inc, dlt, 32);
+    if (c >= dlt) inc += up;
+  }
+  CellRow &r = rows[p];
+  r.off[c] = (c < SGTD_NCELL) ? inc - len : inc;   // [27] = total (lanes >= 27 add nothing)
+  r.start[c] = start;
 }
 
 // position `pos` in the concatenation of the 27 ranges -> (cell, entry index)
@@ -104,18 +138,127 @@ __device__ __forceinline__ void locate(const u32 *cell_off /*[32] LDS*/, const u
   entry = cell_start[c] + (pos - cell_off[c]);
 }
 
+// vote sinks of the sweep
+#define SGTD_VOTE_NONE 0    // votes are counted later from the match lists (votes_kernel)
+#define SGTD_VOTE_LDS 1     // LDS histogram of the work item, flushed by the caller
+#define SGTD_VOTE_GLOBAL 2  // one global atomic per match
+
+struct WaveSlab {
+  u32 next, end;   // this wave's private range of match records
+};
+
+// what the sweep needs about one query descriptor; loaded one descriptor ahead
+struct DescFetch {
+  u32 row;              // lane l: word l of the CellRow
+  double q0, q1, q2, thr2;
+  u32 qframe;
+};
+
+__device__ __forceinline__ DescFetch fetch_desc(const QueryView &Q, const CellRow *rows, long long p,
+                                                long long d) {
+  DescFetch f;
+  f.row = reinterpret_cast<const u32 *>(rows + p)[lane_id()];
+  f.q0 = Q.side[d * 3 + 0]; f.q1 = Q.side[d * 3 + 1]; f.q2 = Q.side[d * 3 + 2];
+  f.thr2 = Q.thr2[d];
+  f.qframe = Q.frame[d];
+  return f;
+}
+
+// STDesc.cpp:372-399 for ONE query descriptor d by one wavefront: streams the
+// descriptor's visit list, tests, compacts the matches in (cell, j) order
+template <int VOTE, bool DIAG>
+__device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
+                                                 long long d, const DescFetch &f, u32 *s_off /*[32]*/,
+                                                 u32 *s_start /*[32]*/, WaveSlab &slab, u32 *s_hist, u32 *votes) {
+  const int lane = lane_id();
+  const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
+  const u32 qframe = f.qframe;
+  const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;   // :356-357
+  const u32 total = __shfl(f.row, SGTD_NCELL);
+  if (lane < 32) s_off[lane] = (lane < SGTD_NCELL) ? f.row : 0xFFFFFFFFu;
+  else s_start[lane - 32] = f.row;
+  // records of one descriptor are contiguous: make sure the slab can take
+  // the worst case (every visited entry matches)
+  if (total && slab.next + total > slab.end) {
+    const u32 take = total > SGTD_REC_SLAB ? total : SGTD_REC_SLAB;
+    u32 got = 0;
+    if (lane == 0) got = atomicAdd(B.rec_cursor, take);
+    got = __shfl(got, 0);
+    slab.next = got; slab.end = got + take;
+  }
+  const bool fits = (unsigned long long)slab.next + total <= (unsigned long long)B.rec_cap;
+  if (!fits && lane == 0) B.overflow[0] = 1;
+  __builtin_amdgcn_wave_barrier();
+
+  u32 matches = 0;
+  const u32 n_words = (total + 63u) >> 6;
+  // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
+  // issued before the first use so that several KB per wave are in flight
+  for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
+    double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
+    int cell[SGTD_PROBE_UNROLL];
+    bool valid[SGTD_PROBE_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+      const u32 pos = ((w0 + u) << 6) + lane;
+      valid[u] = pos < total;
+      u32 e;
+      locate(s_off, s_start, valid[u] ? pos : 0u, cell[u], e);
+      if (!valid[u]) e = 0;   // entry 0 always exists when total > 0
+      const double2 *p = reinterpret_cast<const double2 *>(T.ent + e);
+      v01[u] = p[0];          // s0, s1
+      v2x[u] = p[1];          // s2, {frame, g}
+    }
+#pragma unroll
+    for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+      if (w0 + u < n_words) {   // wave-uniform
+        const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
+        const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
+        const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
+        const u32 fr = (u32)fg;
+        // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
+        bool hit;
+        double dis = 0.0;
+        if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
+        else hit = valid[u] && (qframe != fr) && (d2 < thr2);
+        if (hit) {                                                      // :410
+          if (VOTE == SGTD_VOTE_LDS) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
+          if (VOTE == SGTD_VOTE_GLOBAL) atomicAdd(&votes[fr - T.frame_lo], 1u);
+        }
+        const u64 m = __ballot(hit);
+        if (hit && fits) {
+          const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
+          B.rec[o] = (fg << 32) | (fg >> 32);   // frame << 32 | g
+          if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
+        }
+        matches += __popcll(m);
+      }
+    }
+  }
+  if (lane == 0) {
+    B.list_ptr[d] = slab.next;
+    B.n_visit[d] = total;
+    B.n_match[d] = fits ? matches : 0;
+  }
+  if (fits) slab.next += matches;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// sweep, query-major: work item = (query, chunk of 128 of its descriptors),
+// dequeued by persistent workgroups; the votes of the item are privatised in
+// LDS when the histogram fits and flushed with one global atomic per frame
 template <bool LDS_VOTES, bool DIAG>
 __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, QueryView Q,
-                                                                   ProbeBuffers B, double rough,
-                                                                   int chunks_per_query) {
+                                                                   ProbeBuffers B, const CellRow *rows,
+                                                                   double rough, int chunks_per_query) {
   constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
   extern __shared__ u32 s_hist[];  // [frame_span] when LDS_VOTES
   __shared__ u32 s_off[NW][32];    // exclusive offsets, padded to 32 with UINT_MAX
   __shared__ u32 s_start[NW][32];
   __shared__ u32 s_item;
-  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const int tid = threadIdx.x, wid = tid >> 6;
   const u32 n_items = (u32)Q.n_queries * (u32)chunks_per_query;
-  u32 slab_next = 0, slab_end = 0;  // this wave's private record slab
+  WaveSlab slab{0, 0};
 
   while (true) {
     if (tid == 0) s_item = atomicAdd(B.item_cursor, 1u);
@@ -132,92 +275,19 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, 
     }
     __syncthreads();
     u32 *votes = B.votes + (size_t)q * T.frame_span;
-
     // wave w owns the contiguous block [d_first + 32 w, +32): its match lists
     // land back to back in the wave's slab
     const u32 w_first = d_first + (u32)wid * (SGTD_PROBE_CHUNK / NW);
     const u32 w_last = min(w_first + (u32)(SGTD_PROBE_CHUNK / NW), d_last);
-    for (u32 i = w_first; i < w_last; i++) {
-      const long long d = (long long)q * Q.stride + i;
-      const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
-      const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
-      const u32 qframe = Q.frame[d];
-      const double thr2 = Q.thr2[d];                    // squared form of :356-357
-      const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;
-
-      u32 start, len;
-      resolve_cells(T, q0, q1, q2, code, start, len);
-      const u32 inc = wave_incl_scan(len);
-      const u32 total = __shfl(inc, SGTD_WAVE - 1);
-      if (lane < 32) {
-        s_off[wid][lane] = (lane < SGTD_NCELL) ? inc - len : 0xFFFFFFFFu;
-        s_start[wid][lane] = start;
+    if (w_first < w_last) {
+      const long long base = (long long)q * Q.stride;
+      DescFetch nxt = fetch_desc(Q, rows, base + w_first, base + w_first);
+      for (u32 i = w_first; i < w_last; i++) {
+        const DescFetch cur = nxt;
+        if (i + 1 < w_last) nxt = fetch_desc(Q, rows, base + i + 1, base + i + 1);   // in flight during the sweep of i
+        sweep_descriptor<LDS_VOTES ? SGTD_VOTE_LDS : SGTD_VOTE_GLOBAL, DIAG>(
+            T, B, rough, base + i, cur, s_off[wid], s_start[wid], slab, s_hist, votes);
       }
-      // records of one descriptor are contiguous: make sure the slab can take
-      // the worst case (every visited entry matches)
-      if (total && slab_next + total > slab_end) {
-        const u32 take = total > SGTD_REC_SLAB ? total : SGTD_REC_SLAB;
-        u32 got = 0;
-        if (lane == 0) got = atomicAdd(B.rec_cursor, take);
-        got = __shfl(got, 0);
-        slab_next = got; slab_end = got + take;
-      }
-      const bool fits = (unsigned long long)slab_next + total <= (unsigned long long)B.rec_cap;
-      if (!fits && lane == 0) B.overflow[0] = 1;
-      __builtin_amdgcn_wave_barrier();
-
-      u32 matches = 0;
-      const u32 n_words = (total + 63u) >> 6;
-      // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
-      // issued before the first use so that several KB per wave are in flight
-      for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
-        double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
-        int cell[SGTD_PROBE_UNROLL];
-        bool valid[SGTD_PROBE_UNROLL];
-#pragma unroll
-        for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-          const u32 pos = ((w0 + u) << 6) + lane;
-          valid[u] = pos < total;
-          u32 e;
-          locate(s_off[wid], s_start[wid], valid[u] ? pos : 0u, cell[u], e);
-          if (!valid[u]) e = 0;   // entry 0 always exists when total > 0
-          const double2 *p = reinterpret_cast<const double2 *>(T.ent + e);
-          v01[u] = p[0];          // s0, s1
-          v2x[u] = p[1];          // s2, {frame, g}
-        }
-#pragma unroll
-        for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-          if (w0 + u < n_words) {   // wave-uniform
-            const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
-            const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
-            const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
-            const u32 fr = (u32)fg;
-            // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-            bool hit;
-            double dis = 0.0;
-            if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
-            else hit = valid[u] && (qframe != fr) && (d2 < thr2);
-            if (hit) {                                                      // :410
-              if (LDS_VOTES) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
-              else atomicAdd(&votes[fr - T.frame_lo], 1u);
-            }
-            const u64 m = __ballot(hit);
-            if (hit && fits) {
-              const u32 o = slab_next + matches + __popcll(m & lanemask_lt());
-              B.rec[o] = (fg << 32) | (fg >> 32);   // frame << 32 | g
-              if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
-            }
-            matches += __popcll(m);
-          }
-        }
-      }
-      if (lane == 0) {
-        B.list_ptr[d] = slab_next;
-        B.n_visit[d] = total;
-        B.n_match[d] = fits ? matches : 0;
-      }
-      if (fits) slab_next += matches;
-      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     if (LDS_VOTES) {
@@ -228,6 +298,85 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, 
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// sweep, key-major: the batch's descriptors are visited in the order of a
+// locality key (label code, cell x, cell y) and each XCD walks one contiguous
+// eighth of that order, so the buckets a wave needs were just used by its
+// neighbours on the same XCD and come from that XCD's L2 instead of HBM.
+// Results are independent of the order: every descriptor writes its own list.
+// ---------------------------------------------------------------------------
+// 24-bit locality key per descriptor slot (invalid slots sort last)
+__global__ void locality_keys_kernel(QueryView Q, u64 *keys, u32 *vals, long long n_slots, u32 *n_valid) {
+  const long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n_slots) return;
+  const int q = (int)(d / Q.stride);
+  const u32 i = (u32)(d - (long long)q * Q.stride);
+  u64 key = 0xFFFFFFull;
+  if (i < Q.count[q]) {
+    const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
+    const u32 x = (u32)(int)Q.side[d * 3 + 0], y = (u32)(int)Q.side[d * 3 + 1];
+    key = ((u64)code << 12) | ((u64)(x & 63u) << 6) | (u64)(y & 63u);
+    if (key == 0xFFFFFFull) key = 0xFFFFFEull;
+  }
+  keys[d] = key;
+  vals[d] = (u32)d;
+  if (d == 0) {
+    u32 tot = 0;
+    for (int k = 0; k < Q.n_queries; k++) tot += Q.count[k];
+    *n_valid = tot;
+  }
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableView T, QueryView Q,
+                                                                          ProbeBuffers B, const CellRow *rows,
+                                                                          double rough, const u32 *order,
+                                                                          const u32 *n_valid_p,
+                                                                          u32 *xcd_heads /*[8]*/) {
+  constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
+  __shared__ u32 s_off[NW][32];
+  __shared__ u32 s_start[NW][32];
+  __shared__ u32 s_item;
+  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const u32 n_valid = *n_valid_p;
+  const u32 n_chunks = (n_valid + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK;
+  u32 xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  WaveSlab slab{0, 0};
+  // own eighth first, then help the other XCDs (their ranges lose locality but keep the chip busy)
+  for (u32 t = 0; t < 8; t++) {
+    const u32 x = (xcc + t) & 7u;
+    const u32 c_lo = (u32)(((u64)n_chunks * x) >> 3), c_hi = (u32)(((u64)n_chunks * (x + 1)) >> 3);
+    while (true) {
+      if (tid == 0) s_item = atomicAdd(&xcd_heads[x], 1u);
+      __syncthreads();
+      const u32 c = c_lo + s_item;
+      __syncthreads();
+      if (c >= c_hi) break;
+      const u32 p_first = c * SGTD_PROBE_CHUNK + (u32)wid * (SGTD_PROBE_CHUNK / NW);
+      const u32 p_last = min(p_first + (u32)(SGTD_PROBE_CHUNK / NW), n_valid);
+      if (p_first < p_last) {
+        // lane j holds the slot of position p_first + j (32 positions per wave)
+        const u32 ord = (p_first + (u32)lane < p_last) ? order[p_first + lane] : 0u;
+        DescFetch nxt = fetch_desc(Q, rows, (long long)p_first, (long long)__shfl(ord, 0));
+        for (u32 p = p_first; p < p_last; p++) {
+          const DescFetch cur = nxt;
+          const long long d = (long long)__shfl(ord, (int)(p - p_first));
+          if (p + 1 < p_last) nxt = fetch_desc(Q, rows, (long long)p + 1, (long long)__shfl(ord, (int)(p + 1 - p_first)));
+          sweep_descriptor<SGTD_VOTE_NONE, DIAG>(T, B, rough, d, cur, s_off[wid], s_start[wid], slab, nullptr, nullptr);
+        }
+      }
+    }
+  }
+}
+
+// votes (:404-420) from the match lists: one wavefront per 128-descriptor block,
+// the 4 blocks of a workgroup belong to one query and share an LDS histogram
+template <bool LDS_VOTES>
+__global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B, u32 frame_span, u32 frame_lo,
+                                                    int blocks_per_query, u32 *q_M, unsigned long long *q_P);
 
 // top candidate_num frames of one query (:423-433): repeated arg-max of
 // (votes, lowest frame id), requires votes >= 5; marks slot_of[frame] = slot
@@ -333,6 +482,63 @@ __device__ __forceinline__ void sub_locate(const u32 *s_pre, const u32 *s_ptr, u
   addr = s_ptr[c] + (r - s_pre[c]);
 }
 
+template <bool LDS_VOTES>
+__global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B, u32 frame_span, u32 frame_lo,
+                                                    int blocks_per_query, u32 *q_M, unsigned long long *q_P) {
+  constexpr int NW = 256 / SGTD_WAVE;
+  extern __shared__ u32 s_hist[];   // [frame_span] when LDS_VOTES
+  __shared__ u32 s_pre[NW][32];
+  __shared__ u32 s_ptr[NW][32];
+  if (B.overflow[0]) return;
+  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
+  if (id.q >= Q.n_queries) return;   // workgroup-uniform: all 4 waves share the query
+  const int q = id.q;
+  if (LDS_VOTES) {
+    for (u32 f = tid; f < frame_span; f += 256) s_hist[f] = 0;
+    __syncthreads();
+  }
+  u32 *votes = B.votes + (size_t)q * frame_span;
+  const u32 cnt = Q.count[q];
+  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
+  if (id.valid && d_first < cnt) {
+    u32 visits = 0, total = 0;
+    for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
+      const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
+      total += R;
+      for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
+        u32 fr[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const u32 r = r0 + u * SGTD_WAVE + lane;
+          ok[u] = r < R;
+          u32 dd, addr;
+          sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
+          fr[u] = (u32)(B.rec[addr] >> 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (ok[u]) {
+            if (LDS_VOTES) atomicAdd(&s_hist[fr[u] - frame_lo], 1u);
+            else atomicAdd(&votes[fr[u] - frame_lo], 1u);
+          }
+        }
+      }
+    }
+    if (lane == 0) {
+      atomicAdd(&q_M[q], total);
+      atomicAdd(&q_P[q], (unsigned long long)visits);
+    }
+  }
+  if (LDS_VOTES) {
+    __syncthreads();
+    for (u32 f = tid; f < frame_span; f += 256) {
+      const u32 v = s_hist[f];
+      if (v) atomicAdd(&votes[f], v);
+    }
+  }
+}
+
 // pass 1: blk_count[(q*blocks+blk)*64 + s] = matches of the block in slot s;
 // also the per-query sums of visited entries / matches for the statistics
 __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuffers B,
@@ -381,7 +587,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
     }
   }
   out[lane] = s_hist[wid][lane];
-  if (lane == 0) {
+  if (lane == 0 && q_M) {   // statistics (the key-major pipeline takes them in votes_kernel)
     atomicAdd(&q_M[q], total);
     atomicAdd(&q_P[q], (unsigned long long)visits);
   }

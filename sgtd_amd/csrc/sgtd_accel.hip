@@ -38,7 +38,7 @@ struct DescStore {
   }
 };
 
-enum { EV_START = 0, EV_BUILD, EV_PROBE, EV_TOPK, EV_COUNT_T, EV_SCAN, EV_WRITE, EV_COUNT };
+enum { EV_START = 0, EV_BUILD, EV_SORT, EV_PROBE, EV_VOTES, EV_TOPK, EV_COUNT_T, EV_SCAN, EV_WRITE, EV_COUNT };
 
 }  // namespace
 
@@ -91,6 +91,8 @@ struct sgtd_engine {
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
+  bool key_major = false;              // probe in locality-key order (SGTD_PROBE_ORDER=query|key)
+  DevBuf n_valid, xcd_heads, cell_rows;
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
   // host copies after sync
   std::vector<u32> h_count, h_pair_base, h_q_M;
@@ -472,35 +474,92 @@ int launch_select(sgtd_engine *e) {
   const int grid = (int)std::max<long long>(1, std::min<long long>(n_items, (long long)e->n_cus * 8));
   const size_t hist_bytes = (size_t)span * sizeof(u32);
   const bool lds_votes = hist_bytes <= 150 * 1024;
-  if (lds_votes) {
-    if (e->diag) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-      probe_kernel<true, true><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
-    } else {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-      probe_kernel<true, false><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
+  const int groups = (blocks + 3) / 4;
+  const int agrid = ((nq + 7) / 8) * groups * 8;   // workgroup b serves query (b/8/groups)*8 + b%8
+  CHK(ensure(e, e->cell_rows, (size_t)std::max<long long>(n_slots, 1) * sizeof(CellRow)));
+  const CellRow *rows = e->cell_rows.as<CellRow>();
+  if (e->key_major) {
+    // ---- order of the batch's descriptors by locality key: 3 stable 8-bit radix passes
+    CHK(ensure(e, e->keyA, (size_t)n_slots * sizeof(u64)));
+    CHK(ensure(e, e->keyB, (size_t)n_slots * sizeof(u64)));
+    CHK(ensure(e, e->valA, (size_t)n_slots * sizeof(u32)));
+    CHK(ensure(e, e->valB, (size_t)n_slots * sizeof(u32)));
+    CHK(ensure(e, e->n_valid, sizeof(u32)));
+    CHK(ensure(e, e->xcd_heads, 8 * sizeof(u32)));
+    const int nb = (int)((n_slots + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
+    CHK(ensure(e, e->hist, (size_t)256 * nb * sizeof(u32)));
+    u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
+    u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
+    locality_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, kin, vin, n_slots, e->n_valid.as<u32>());
+    HIPCHK(hipGetLastError());
+    for (int pass = 0; pass < 3; pass++) {
+      radix_hist_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, n_slots, pass * 8, e->hist.as<u32>(), nb);
+      HIPCHK(hipGetLastError());
+      CHK(device_scan(e, e->hist.as<u32>(), e->hist.as<u32>(), (long long)256 * nb));
+      radix_scatter_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, n_slots, pass * 8,
+                                                                   e->hist.as<u32>(), nb);
+      HIPCHK(hipGetLastError());
+      std::swap(kin, kout);
+      std::swap(vin, vout);
     }
-  } else {
+    HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * sizeof(u32), e->stream));
+    resolve_kernel<<<grid_for(n_slots * 32, SGTD_RESOLVE_THREADS), SGTD_RESOLVE_THREADS, 0, e->stream>>>(
+        v.T, v.Q, e->cell_rows.as<CellRow>(), vin, e->n_valid.as<u32>(), n_slots);
+    HIPCHK(hipGetLastError());
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
     if (e->diag)
-      probe_kernel<false, true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
+      probe_sorted_kernel<true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
+                                                                             e->n_valid.as<u32>(), e->xcd_heads.as<u32>());
     else
-      probe_kernel<false, false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, e->dc.rough, blocks);
+      probe_sorted_kernel<false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
+                                                                              e->n_valid.as<u32>(), e->xcd_heads.as<u32>());
+    HIPCHK(hipGetLastError());
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
+    if (lds_votes) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+      votes_kernel<true><<<agrid, 256, hist_bytes, e->stream>>>(v.Q, v.B, span, v.T.frame_lo, blocks, e->q_M.as<u32>(),
+                                                                e->q_P.as<unsigned long long>());
+    } else {
+      votes_kernel<false><<<agrid, 256, 0, e->stream>>>(v.Q, v.B, span, v.T.frame_lo, blocks, e->q_M.as<u32>(),
+                                                        e->q_P.as<unsigned long long>());
+    }
+    HIPCHK(hipGetLastError());
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_VOTES], e->stream));
+  } else {
+    resolve_kernel<<<grid_for(n_slots * 32, SGTD_RESOLVE_THREADS), SGTD_RESOLVE_THREADS, 0, e->stream>>>(
+        v.T, v.Q, e->cell_rows.as<CellRow>(), nullptr, nullptr, n_slots);
+    HIPCHK(hipGetLastError());
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
+    if (lds_votes) {
+      if (e->diag) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        probe_kernel<true, true><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
+      } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        probe_kernel<true, false><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
+      }
+    } else {
+      if (e->diag)
+        probe_kernel<false, true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
+      else
+        probe_kernel<false, false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
+    }
+    HIPCHK(hipGetLastError());
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_VOTES], e->stream));
   }
-  HIPCHK(hipGetLastError());
-  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
   topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, v.T.frame_lo, cn, e->n_cand.as<int>(),
                                           e->cand_frame.as<int>(), e->cand_votes.as<int>(),
                                           e->slot_of.as<unsigned char>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
-  // assemble grid: workgroup b serves query (b/8/groups)*8 + b%8 (XCD affinity, see assemble_block)
-  const int groups = (blocks + 3) / 4;
-  const int agrid = ((nq + 7) / 8) * groups * 8;
   block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
-                                                    blocks, e->blk_count.as<u32>(), e->q_M.as<u32>(),
-                                                    e->q_P.as<unsigned long long>());
+                                                    blocks, e->blk_count.as<u32>(),
+                                                    e->key_major ? nullptr : e->q_M.as<u32>(),
+                                                    e->key_major ? nullptr : e->q_P.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
   block_scan_kernel<<<nq, 64, 0, e->stream>>>(e->blk_count.as<u32>(), blocks, cn, e->n_cand.as<int>(),
@@ -581,9 +640,10 @@ int sync_batch(sgtd_engine *e) {
   }
   if (e->timing) {
     auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[b]); return ms; };
-    if (e->last_kind == 1) { s.ms_build = el(EV_START, EV_BUILD); s.ms_probe = el(EV_BUILD, EV_PROBE); }
-    else { s.ms_build = 0; s.ms_probe = el(EV_START, EV_PROBE); }
-    s.ms_topk = el(EV_PROBE, EV_TOPK); s.ms_count = el(EV_TOPK, EV_COUNT_T);
+    if (e->last_kind == 1) { s.ms_build = el(EV_START, EV_BUILD); s.ms_sort = el(EV_BUILD, EV_SORT); }
+    else { s.ms_build = 0; s.ms_sort = el(EV_START, EV_SORT); }
+    s.ms_probe = el(EV_SORT, EV_PROBE); s.ms_votes = el(EV_PROBE, EV_VOTES);
+    s.ms_topk = el(EV_VOTES, EV_TOPK); s.ms_count = el(EV_TOPK, EV_COUNT_T);
     s.ms_scan = el(EV_COUNT_T, EV_SCAN); s.ms_write = el(EV_SCAN, EV_WRITE);
     s.ms_total = el(EV_START, EV_WRITE);
   }
@@ -662,6 +722,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   e->current_frame_id = cfg->first_frame_id;
   e->qd.with_thr2 = true;
+  if (const char *o = getenv("SGTD_PROBE_ORDER")) e->key_major = std::strcmp(o, "key") == 0;
   for (int i = 0; i < EV_COUNT; i++)
     if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
   *out = e;
@@ -676,7 +737,7 @@ int sgtd_destroy(sgtd_handle e) {
   DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->cursors, &e->list_ptr, &e->n_visit,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,

@@ -215,7 +215,7 @@ __global__ void hash_insert_kernel(const u64 *bucket_key, const u32 *bucket_star
   const u64 key = bucket_key[b];
   const u32 start = bucket_start[b];
   const u32 end = (b + 1 < n_buckets) ? bucket_start[b + 1] : n_entries;
-  u32 h = (u32)mix64(key) & mask;
+  u32 h = hash_key(key) & mask;
   while (true) {
     u64 prev = atomicCAS(reinterpret_cast<u64 *>(&table[h].key), SGTD_EMPTY_KEY, key);
     if (prev == SGTD_EMPTY_KEY) {
