@@ -72,6 +72,7 @@ def lib():
         L.orc_destroy.argtypes = [vp]
         L.orc_current_frame_id.restype = C.c_uint32
         L.orc_current_frame_id.argtypes = [vp]
+        L.orc_set_current_frame_id.argtypes = [vp, C.c_uint32]
         L.orc_label_code.restype = C.c_int
         L.orc_label_code.argtypes = [C.c_int] * 3
         L.orc_build.restype = i64
@@ -154,6 +155,9 @@ class OracleManager:
     @property
     def current_frame_id(self):
         return lib().orc_current_frame_id(self._h)
+
+    def set_current_frame_id(self, fid):
+        lib().orc_set_current_frame_id(self._h, int(fid))
 
     def build(self, xyz, label, export=True):
         """BuildSingleScanSTD; returns Descs (or the count if export=False)"""

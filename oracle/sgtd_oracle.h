@@ -59,6 +59,8 @@ orc_manager *orc_create(const orc_config *cfg);
 void orc_destroy(orc_manager *m);
 
 uint32_t orc_current_frame_id(const orc_manager *m);
+/* start value of current_frame_id_ (a table shard of a multi-GPU map starts at its first frame) */
+void orc_set_current_frame_id(orc_manager *m, uint32_t id);
 
 /* Combinatorial_Binary_Encoding — STDesc.cpp:3-16 */
 int orc_label_code(int a, int b, int c);

@@ -56,8 +56,9 @@ def gather_and_merge(local_frames, local_votes, cand_num, group=None):
         return merge_candidates(local_frames[None], local_votes[None], cand_num)
     # one collective: frames and votes travel together
     packed = torch.stack([local_frames, local_votes]).contiguous()
-    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
+    out = torch.empty((world * 2,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)   # concatenation along dim 0 (RCCL and gloo)
+    out = out.view((world, 2) + tuple(packed.shape[1:]))
     return merge_candidates(out[:, 0], out[:, 1], cand_num)
 
 

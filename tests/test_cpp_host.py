@@ -1,0 +1,37 @@
+"""Builds tests/cpp/test_manager.cpp (the C++ host-side mirror of STDescManager
+above the C ABI) with g++ and runs it on the GPU box; the compile itself is
+checked on CPU."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_manager")
+
+
+def _build():
+    from oracle import oracle
+    from sgtd_amd import _lib
+    _lib.build_library()
+    oracle.build_library()
+    src = os.path.join(ROOT, "tests", "cpp", "test_manager.cpp")
+    cmd = ["g++", "-std=c++17", "-O2", "-include", "algorithm", src, "-o", EXE,
+           "-L" + os.path.join(ROOT, "sgtd_amd"), "-lsgtd_accel",
+           "-L" + os.path.join(ROOT, "oracle"), "-lsgtd_oracle",
+           "-Wl,-rpath," + os.path.join(ROOT, "sgtd_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    subprocess.check_call(cmd)
+
+
+def test_cpp_host_mirror_compiles():
+    _build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_matches_oracle():
+    _build()
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "cpp host mirror ok" in out.stdout

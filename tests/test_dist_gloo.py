@@ -1,0 +1,99 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the frame-range sharded map.
+
+Each rank holds a table shard for its frame range (here backed by the CPU
+oracle standing in for the HIP engine — tests may use the oracle as the
+checker/stand-in, the product never does), computes its local top-k, and
+`sgtd_amd.dist.gather_and_merge` must reproduce the single-table candidate
+list bit for bit on every rank.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+N_FRAMES, N_KP, N_Q, CAND = 24, 60, 3, 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_tables(rank, world):
+    """(frames, votes) int32 [N_Q, CAND] of this rank's shard, and the single-table truth"""
+    from oracle.oracle import OracleManager
+    from sgtd_amd import synth
+    from sgtd_amd.dist import shard_range
+    m = synth.make_map(N_FRAMES, N_KP, stream=201)
+    qs = synth.make_queries(m, N_Q, stream=201)
+    lo, hi = shard_range(N_FRAMES, world, rank)
+    shard = OracleManager(candidate_num=CAND)
+    shard.set_current_frame_id(lo)          # sgtd_config.first_frame_id on the HIP engine
+    full = OracleManager(candidate_num=CAND)
+    for f in range(N_FRAMES):
+        full.build(m.xyz[f], m.label[f], export=False)
+        full.add_last()
+        if lo <= f < hi:
+            shard.build(m.xyz[f], m.label[f], export=False)
+            shard.add_last()
+    assert shard.current_frame_id == hi
+    lf = np.full((N_Q, CAND), -1, np.int32)
+    lv = np.zeros((N_Q, CAND), np.int32)
+    truth = []
+    for q in range(N_Q):
+        shard.build(qs.xyz[q], qs.label[q], export=False)
+        r = shard.select()
+        n = len(r["cand_frame"])
+        lf[q, :n], lv[q, :n] = r["cand_frame"], r["cand_votes"]
+        assert np.all((r["cand_frame"] >= lo) & (r["cand_frame"] < hi))
+        full.build(qs.xyz[q], qs.label[q], export=False)
+        t = full.select()
+        truth.append((t["cand_frame"], t["cand_votes"]))
+    return lf, lv, truth
+
+
+def _worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgtd_amd.dist import gather_and_merge
+        lf, lv, truth = _local_tables(rank, world)
+        mf, mv, n = gather_and_merge(torch.from_numpy(lf), torch.from_numpy(lv), CAND)
+        for q in range(N_Q):
+            k = int(n[q])
+            tf, tv = truth[q]
+            assert k == len(tf), (k, len(tf))
+            assert mf[q, :k].tolist() == tf.tolist(), (mf[q].tolist(), tf.tolist())
+            assert mv[q, :k].tolist() == tv.tolist()
+            assert (mf[q, k:] == -1).all() and (mv[q, k:] == 0).all()
+        # every rank holds the same merged list
+        probe = torch.stack([mf, mv]).contiguous()
+        ref = probe.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, probe)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_selection_matches_single_table_gloo():
+    world = 2
+    # a failing assertion in any rank makes mp.spawn raise
+    mp.spawn(_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def test_single_process_merge_matches_oracle_without_process_group():
+    from sgtd_amd.dist import gather_and_merge
+    lf, lv, truth = _local_tables(0, 1)
+    mf, mv, n = gather_and_merge(torch.from_numpy(lf), torch.from_numpy(lv), CAND)
+    for q in range(N_Q):
+        k = int(n[q])
+        assert mf[q, :k].tolist() == truth[q][0].tolist() and mv[q, :k].tolist() == truth[q][1].tolist()

@@ -126,8 +126,12 @@ def _check_query(g, o, res, q, oq_descs, check_rough=True):
     return r
 
 
-def test_select_parity_batch(mods):
+@pytest.mark.parametrize("order", ["query", "key"])
+def test_select_parity_batch(mods, order, monkeypatch):
+    """both sweep orders: query-major (LDS vote histograms) and key-major
+    (locality order over XCD queues, votes from the match lists)"""
     _, _, synth = mods
+    monkeypatch.setenv("SGTD_PROBE_ORDER", order)
     g, o = _pair(mods)
     m = synth.make_map(40, 200, stream=41)
     _fill_both(mods, g, o, m)

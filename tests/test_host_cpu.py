@@ -1,0 +1,100 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol
+the header declares, host-side merge logic, generator determinism."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from sgtd_amd import _lib
+    _lib.build_library()
+    header = open(os.path.join(ROOT, "include", "sgtd_accel.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sgtd_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 25
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+
+
+def test_abi_non_compute_calls_without_gpu():
+    """calls that need no device: defaults, error strings; create must fail loudly
+    (no CPU fallback) when no gfx950 device is present"""
+    import torch
+    from sgtd_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.Config()
+    L.sgtd_default_config(ctypes.byref(cfg))
+    assert (cfg.descriptor_near_num, cfg.candidate_num, cfg.max_frame_n) == (10, 50, 20000)
+    assert (cfg.descriptor_min_len, cfg.descriptor_max_len) == (0.5, 50.0)
+    assert (cfg.std_side_resolution, cfg.rough_dis_threshold) == (1.0, 0.03)
+    assert L.sgtd_strerror(0) == b"ok" and b"gfx950" in L.sgtd_strerror(-2)
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        assert L.sgtd_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
+        from sgtd_amd.manager import STDescManager, SgtdError
+        with pytest.raises(SgtdError):
+            STDescManager()
+    bad = _lib.Config()
+    L.sgtd_default_config(ctypes.byref(bad))
+    bad.descriptor_near_num = 40
+    h = ctypes.c_void_p()
+    assert L.sgtd_create(ctypes.byref(bad), ctypes.byref(h)) == -6
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sgtd_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower()
+
+
+def test_merge_candidates_rule():
+    import torch
+    from sgtd_amd.dist import merge_candidates
+    # two ranks, one query, cand_num 4: votes desc, ties -> lowest frame id, >= 5 votes only
+    f = torch.tensor([[[7, 2, -1, -1]], [[11, 12, 13, -1]]], dtype=torch.int32)
+    v = torch.tensor([[[9, 6, 0, 0]], [[9, 6, 5, 0]]], dtype=torch.int32)
+    mf, mv, n = merge_candidates(f, v, 4)
+    assert mf.tolist() == [[7, 11, 2, 12]] and mv.tolist() == [[9, 9, 6, 6]] and n.tolist() == [4]
+    mf, mv, n = merge_candidates(f[:1], v[:1], 4)
+    assert mf.tolist() == [[7, 2, -1, -1]] and n.tolist() == [2]
+
+
+def test_shard_ranges_cover_and_owner():
+    from sgtd_amd.dist import owner_of, shard_range
+    for n, w in ((10, 3), (1000, 8), (7, 8), (100000, 8)):
+        ranges = [shard_range(n, w, r) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
+        for f in (0, n // 2, n - 1):
+            lo, hi = ranges[owner_of(f, n, w)]
+            assert lo <= f < hi
+
+
+def test_generator_is_deterministic_and_tie_free_checker():
+    from sgtd_amd import synth
+    a = synth.make_map(5, 40, stream=77)
+    b = synth.make_map(5, 40, stream=77)
+    np.testing.assert_array_equal(a.xyz, b.xyz)
+    np.testing.assert_array_equal(a.label, b.label)
+    assert a.xyz.dtype == np.float32 and a.label.dtype == np.uint32
+    assert a.label.min() >= 3 and a.label.max() <= 11
+    qa = synth.make_queries(a, 3, stream=77)
+    qb = synth.make_queries(b, 3, stream=77)
+    np.testing.assert_array_equal(qa.xyz, qb.xyz)
+    grid = np.zeros((16, 3), np.float32)
+    grid[:, 0] = np.arange(16) % 4
+    grid[:, 1] = np.arange(16) // 4
+    assert synth.has_knn_ties(grid, 5)
+    assert not synth.has_knn_ties(a.xyz[0], 10)
