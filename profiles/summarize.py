@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of profiles/collect.sh into the small files that
+are committed under profiles/: per-kernel duration stats, per-kernel PMC means,
+and probe_traffic.json (HBM bytes per probe launch, read by bench.py).
+
+HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md §HBM:
+FETCH_SIZE (KB) counts 128-B requests as 64 B for wide coalesced reads (the
+sweep reads 16 B per lane), so the read side is doubled; WRITE_SIZE is exact.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def pmc_means(pattern):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(pattern):
+        for r in csv.DictReader(open(path)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    here = os.path.dirname(os.path.abspath(__file__))
+    stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(here, "%s_kernel_stats.csv" % tag))
+    b = os.path.join(src, "bench_under_stats.json")
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(here, "%s_bench_under_rocprof.json" % tag))
+    pmc = {}
+    for name in ("fetch", "write", "tcc"):
+        for k, cs in pmc_means(os.path.join(src, name, "*", "*_counter_collection.csv")).items():
+            pmc.setdefault(k, {}).update(cs)
+    keep = {k: v for k, v in pmc.items() if any(s in k for s in
+            ("probe", "resolve", "block_", "votes", "topk", "build_frames", "locality", "radix", "query_base"))}
+    json.dump(keep, open(os.path.join(here, "%s_pmc_means.json" % tag), "w"), indent=1, sort_keys=True)
+    probe = [v for k, v in keep.items() if k.startswith("probe_kernel") or k.startswith("probe_sorted_kernel")]
+    if probe and os.path.exists(b):
+        cfg = json.loads(open(b).read().strip().splitlines()[-1])["config"]
+        p = probe[0]
+        fetch_kb, write_kb = p.get("FETCH_SIZE", 0.0), p.get("WRITE_SIZE", 0.0)
+        traffic = {"frames": cfg["map_frames"], "queries": cfg["queries_per_step"], "keypoints": cfg["keypoints_per_frame"],
+                   "gpus": 1, "kernel": "probe_kernel", "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+                   "correction": "read bytes = 2 * FETCH_SIZE (gfx950 wide-load undercount), write bytes = WRITE_SIZE",
+                   "bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+                   "TCC_HIT_sum": p.get("TCC_HIT_sum"), "TCC_MISS_sum": p.get("TCC_MISS_sum")}
+        json.dump(traffic, open(os.path.join(here, "probe_traffic.json"), "w"), indent=1, sort_keys=True)
+        print(json.dumps(traffic))
+
+
+if __name__ == "__main__":
+    main()
