@@ -107,10 +107,18 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # SGTD_BENCH_BACKEND=gloo + SGTD_BENCH_SHARE_GPU=1 let the N>1 code path be exercised on a
+    # 1-GPU box (all ranks on cuda:0, collectives over gloo); never used for reported numbers
+    backend = os.environ.get("SGTD_BENCH_BACKEND", "nccl")
+    if os.environ.get("SGTD_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     F, N, Q = args.frames, args.keypoints, args.queries
     smap = synth.make_map(F, N, stream=1)
