@@ -564,28 +564,25 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
     const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
     total += R;
-    for (u32 r0 = 0; r0 < R; r0 += 2 * SGTD_WAVE) {
-      u32 fr[2]; bool ok[2];
+    for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
+      u32 fr[4]; bool ok[4];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < 4; u++) {
         const u32 r = r0 + u * SGTD_WAVE + lane;
         ok[u] = r < R;
         u32 dd, addr;
         sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
         fr[u] = (u32)(B.rec[addr] >> 32);
       }
-      unsigned char sl[2];
+      unsigned char sl[4];
 #pragma unroll
-      for (int u = 0; u < 2; u++) sl[u] = ok[u] ? slot_of[fr[u] - frame_lo] : (unsigned char)0xFF;
+      for (int u = 0; u < 4; u++) sl[u] = ok[u] ? slot_of[fr[u] - frame_lo] : (unsigned char)0xFF;
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        u32 rank, count;
-        wave_group_rank<6>((u32)sl[u] & 63u, sl[u] != 0xFF, rank, count);
-        if (sl[u] != 0xFF && rank == 0) s_hist[wid][sl[u]] += count;
-        __builtin_amdgcn_wave_barrier();
-      }
+      for (int u = 0; u < 4; u++)
+        if (sl[u] != 0xFF) atomicAdd(&s_hist[wid][sl[u]], 1u);   // counting needs no order
     }
   }
+  __builtin_amdgcn_wave_barrier();
   out[lane] = s_hist[wid][lane];
   if (lane == 0 && q_M) {   // statistics (the key-major pipeline takes them in votes_kernel)
     atomicAdd(&q_M[q], total);
@@ -656,9 +653,11 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
                                                           const long long *pair_off, const u32 *q_pair_base,
                                                           u64 *pairs) {
   constexpr int NW = 256 / SGTD_WAVE;
+  constexpr int CAP = 16;   // staged pairs per slot = one 128-B line
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
   __shared__ u32 s_cnt[NW][64];
+  __shared__ u64 s_stage[NW][64][CAP];   // per wave and slot: pairs waiting for a full-line store
   if (B.overflow[0] || B.overflow[1]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
@@ -668,11 +667,24 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (d_first >= cnt) return;
   const unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
-  // lane s carries the next output position of candidate slot s
-  u32 running = 0;
+  // lane s carries, for candidate slot s, the output position of its first staged
+  // pair (`running`) and the number of staged pairs (`fill`)
+  u32 running = 0, fill = 0;
   if (lane < cand_num)
     running = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + lane] +
               blk_excl[((size_t)q * blocks_per_query + id.blk) * 64 + lane];
+  // all staged pairs go out as 16-lane groups, 4 slots per store instruction
+  auto flush = [&]() {
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+      const int s = it * 4 + (lane >> 4), k = lane & 15;
+      const u32 f = __shfl(fill, s), base = __shfl(running, s);
+      if ((u32)k < f) pairs[base + k] = s_stage[wid][s][k];
+    }
+    running += fill;
+    fill = 0;
+    __builtin_amdgcn_wave_barrier();
+  };
   u32 visits = 0;
   for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
     const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
@@ -693,21 +705,32 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const bool valid = sl[u] != 0xFF;
+        const int s = (int)(sl[u] & 63u);
         u32 rank, count;
-        wave_group_rank<6>((u32)sl[u] & 63u, valid, rank, count);
-        const u32 base = __shfl(running, (int)(sl[u] & 63u));
+        wave_group_rank<6>((u32)s, valid, rank, count);
+        u32 have = __shfl(fill, s);
+        if (__ballot(valid && have + count > (u32)CAP)) {   // some slot would overflow its line: drain all
+          flush();
+          have = 0;
+        }
+        const u32 base = __shfl(running, s);
+        const bool direct = count > (u32)CAP;               // a group larger than a line bypasses the stage
+        const u64 pair = ((u64)(d0 + dd[u]) << 32) | (rec[u] & 0xFFFFFFFFull);
         s_cnt[wid][lane] = 0;
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-          pairs[base + rank] = ((u64)(d0 + dd[u]) << 32) | (rec[u] & 0xFFFFFFFFull);
-          if (rank == 0) s_cnt[wid][sl[u]] = count;
+          if (direct) pairs[base + rank] = pair;            // its stage is empty here (just drained)
+          else s_stage[wid][s][have + rank] = pair;
+          if (rank == 0) s_cnt[wid][s] = direct ? (count | 0x80000000u) : count;
         }
         __builtin_amdgcn_wave_barrier();
-        running += s_cnt[wid][lane];
+        const u32 c = s_cnt[wid][lane];
+        if (c & 0x80000000u) running += c & 0x7FFFFFFFu; else fill += c;
         __builtin_amdgcn_wave_barrier();
       }
     }
   }
+  flush();
 }
 
 // diagnostic: the ordered rough-match list of ONE query (reference order i, cell, j)
