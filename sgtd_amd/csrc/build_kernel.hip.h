@@ -23,7 +23,7 @@ struct DescArrays {
   double *thr2;                   // [cap] squared match threshold (query descriptors only; may be null)
 };
 
-#define SGTD_BUILD_THREADS 256
+#define SGTD_BUILD_THREADS 1024
 #define SGTD_TRI_INVALID 0xFFFFFFFFFFFFFFFFull
 #define SGTD_SLOT_EMPTY 0xFFFFFFFFu
 
@@ -150,20 +150,20 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     for (int w = tid; w < nwords; w += SGTD_BUILD_THREADS) winbits[w] = 0;
     __syncthreads();
 
-    // ---- stage 1: k-NN, one thread per keypoint, sorted insertion network
-    for (int i = tid; i < n; i += SGTD_BUILD_THREADS) {
+    // ---- stage 1: k-NN by sorted insertion networks in registers.  Four threads
+    // share a keypoint: each scans a quarter of the candidates (ascending index),
+    // parts 1..3 park their K best in the (not yet live) dedup-key area and part 0
+    // inserts them in part order — the same sequence of insertions as one thread
+    // scanning all candidates in index order, so ties still go to the lower index.
+    const int parts = (3 * K <= tpi) ? 4 : 1;   // the parking area is T*8 bytes = n*tpi*8
+    const int per_pass = SGTD_BUILD_THREADS / parts;
+    for (int i0 = 0; i0 < n; i0 += per_pass) {
+      const int i = i0 + tid / parts, part = tid % parts;
       float bd[SGTD_MAX_K];
       int bi[SGTD_MAX_K];
 #pragma unroll
       for (int k = 0; k < SGTD_MAX_K; k++) { bd[k] = __builtin_inff(); bi[k] = 0; }
-      const float4 q = pts[i];
-      for (int j = 0; j < n; j++) {
-        const float4 p = pts[j];
-        float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-        float d = dx * dx;   // FLANN L2_Simple accumulation order
-        d += dy * dy;
-        d += dz * dz;
-        float cd = d; int cj = j;
+      auto insert = [&](float cd, int cj) {
         bool lt = false;
 #pragma unroll
         for (int k = 0; k < SGTD_MAX_K; k++) {
@@ -174,10 +174,40 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
           bd[k] = lt ? cd : bd[k]; bi[k] = lt ? cj : bi[k];
           cd = td; cj = tj;
         }
-      }
+      };
+      if (i < n) {
+        const float4 q = pts[i];
+        const int j_lo = (int)((long long)n * part / parts), j_hi = (int)((long long)n * (part + 1) / parts);
+        for (int j = j_lo; j < j_hi; j++) {
+          const float4 p = pts[j];
+          float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+          float d = dx * dx;   // FLANN L2_Simple accumulation order
+          d += dy * dy;
+          d += dz * dz;
+          insert(d, j);
+        }
+        if (part > 0) {
 #pragma unroll
-      for (int k = 0; k < SGTD_MAX_K; k++)
-        if (k < K) knn[i * K + k] = (unsigned short)bi[k];
+          for (int k = 0; k < SGTD_MAX_K; k++)
+            if (k < K) keys[((size_t)i * 3 + (part - 1)) * K + k] = ((u64)__float_as_uint(bd[k]) << 32) | (u32)bi[k];
+        }
+      }
+      if (parts > 1) {
+        if (!LDS_DEDUP) __threadfence_block();
+        __syncthreads();
+        if (i < n && part == 0) {
+          for (int pk = 0; pk < 3 * K; pk++) {   // part 1, 2, 3, each in its own sorted order
+            const u64 v = keys[(size_t)i * 3 * K + pk];
+            insert(__uint_as_float((u32)(v >> 32)), (int)(u32)v);
+          }
+        }
+      }
+      if (i < n && part == 0) {
+#pragma unroll
+        for (int k = 0; k < SGTD_MAX_K; k++)
+          if (k < K) knn[i * K + k] = (unsigned short)bi[k];
+      }
+      if (parts > 1) __syncthreads();   // the parking area is reused by the next pass
     }
     __syncthreads();
 
