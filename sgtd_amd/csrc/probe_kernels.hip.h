@@ -378,18 +378,97 @@ template <bool LDS_VOTES>
 __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B, u32 frame_span, u32 frame_lo,
                                                     int blocks_per_query, u32 *q_M, unsigned long long *q_P);
 
-// top candidate_num frames of one query (:423-433): repeated arg-max of
-// (votes, lowest frame id), requires votes >= 5; marks slot_of[frame] = slot
+// top candidate_num frames of one query (:423-433): arg-max rounds over
+// (votes, lowest frame id), requires votes >= 5; marks slot_of[frame] = slot.
+// Fast path: a vote-value histogram gives the threshold below which no frame can
+// make the list; the <= 1024 frames at or above it are pooled and one wavefront
+// runs the reference's rounds on the pool held in registers.  If more frames tie
+// at the threshold than the pool holds, the rounds run over all frames.
+#define SGTD_TOPK_BINS 8192
+#define SGTD_TOPK_POOL 1024
 __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 frame_span, u32 frame_lo,
                                                    int cand_num, int *n_cand, int *cand_frame,
                                                    int *cand_votes, unsigned char *slot_of_all) {
   __shared__ u64 red[256 / SGTD_WAVE];
   __shared__ int n_picked;
+  __shared__ u32 s_hist[SGTD_TOPK_BINS];
+  __shared__ u64 s_pool[SGTD_TOPK_POOL];
+  __shared__ u32 s_thr, s_n_ge, s_npool;
   const int q = blockIdx.x;
+  const int tid = threadIdx.x, lane = lane_id();
   const u32 *votes = votes_all + (size_t)q * frame_span;
   unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
-  if (threadIdx.x == 0) n_picked = 0;
+  for (int b = tid; b < SGTD_TOPK_BINS; b += 256) s_hist[b] = 0;
+  if (tid == 0) { n_picked = 0; s_npool = 0; }
   __syncthreads();
+  for (u32 f = tid; f < frame_span; f += 256) {
+    const u32 v = votes[f];
+    if (v >= 5) atomicAdd(&s_hist[min(v, (u32)SGTD_TOPK_BINS - 1u)], 1u);
+  }
+  __syncthreads();
+  if (tid < SGTD_WAVE) {
+    // largest t with count(votes >= t) >= cand_num (t = 5 if fewer frames qualify at all)
+    constexpr int PER = SGTD_TOPK_BINS / SGTD_WAVE;
+    u32 mine = 0;
+    for (int b = 0; b < PER; b++) mine += s_hist[lane * PER + b];
+    u32 suffix = mine;   // inclusive suffix sum over lanes >= lane
+#pragma unroll
+    for (int d = 1; d < SGTD_WAVE; d <<= 1) {
+      const u32 o = __shfl_down(suffix, d);
+      if (lane + d < SGTD_WAVE) suffix += o;
+    }
+    const u64 okmask = __ballot(suffix >= (u32)cand_num);
+    u32 thr = 5, n_ge = __shfl(suffix, 0);
+    if (okmask) {
+      const int L = 63 - __builtin_clzll(okmask);
+      if (lane == L) {
+        u32 acc = suffix - mine;
+        int b = L * PER + PER - 1;
+        for (; b >= L * PER; b--) { acc += s_hist[b]; if (acc >= (u32)cand_num) break; }
+        s_thr = (u32)max(b, 5); s_n_ge = acc;
+      }
+    } else if (lane == 0) { s_thr = thr; s_n_ge = n_ge; }
+  }
+  __syncthreads();
+  const u32 thr = s_thr;
+  if (s_n_ge <= (u32)SGTD_TOPK_POOL) {
+    for (u32 f = tid; f < frame_span; f += 256) {
+      const u32 v = votes[f];
+      if (v >= thr) s_pool[atomicAdd(&s_npool, 1u)] = ((u64)v << 32) | (u64)(0xFFFFFFFFu - f);
+    }
+    __syncthreads();
+    if (tid < SGTD_WAVE) {
+      constexpr int PER = SGTD_TOPK_POOL / SGTD_WAVE;
+      const u32 np = s_npool;
+      u64 a[PER];
+#pragma unroll
+      for (int k = 0; k < PER; k++) a[k] = ((u32)(k * SGTD_WAVE + lane) < np) ? s_pool[k * SGTD_WAVE + lane] : 0ull;
+      int picked = 0;
+      for (int round = 0; round < cand_num; round++) {
+        u64 best = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) best = a[k] > best ? a[k] : best;
+#pragma unroll
+        for (int dlt = SGTD_WAVE / 2; dlt > 0; dlt >>= 1) {
+          const u64 o = __shfl_xor(best, dlt);
+          best = o > best ? o : best;
+        }
+        if ((u32)(best >> 32) < 5u) break;   // max_vote > 1 && max_vote >= 5 (:427,433)
+#pragma unroll
+        for (int k = 0; k < PER; k++) a[k] = (a[k] == best) ? 0ull : a[k];   // match_array[...] = 0 (:435)
+        if (lane == 0) {
+          const u32 f = 0xFFFFFFFFu - (u32)(best & 0xFFFFFFFFu);
+          slot_of[f] = (unsigned char)picked;
+          cand_frame[q * cand_num + picked] = (int)(f + frame_lo);
+          cand_votes[q * cand_num + picked] = (int)(u32)(best >> 32);
+        }
+        picked++;
+      }
+      if (lane == 0) n_cand[q] = picked;
+    }
+    return;
+  }
+  // ---- general path: more ties at the threshold than the pool holds
   for (int round = 0; round < cand_num; round++) {
     // key = votes << 32 | ~local frame : max key = most votes, then lowest frame
     u64 best = 0;
