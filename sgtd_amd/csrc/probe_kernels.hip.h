@@ -59,6 +59,9 @@ struct ProbeBuffers {
 
 #define SGTD_PROBE_THREADS 256
 #define SGTD_PROBE_CHUNK 128    // query descriptors per work item = per assemble block
+#ifndef SGTD_SORTED_CHUNK
+#define SGTD_SORTED_CHUNK 4     // descriptors per wave ticket of the key-major sweep (<= 64)
+#endif
 #define SGTD_REC_SLAB 2048u     // match records a wave takes from the global cursor at once
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
@@ -174,9 +177,10 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
   const u32 qframe = f.qframe;
   const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;   // :356-357
-  const u32 total = __shfl(f.row, SGTD_NCELL);
-  if (lane < 32) s_off[lane] = (lane < SGTD_NCELL) ? f.row : 0xFFFFFFFFu;
-  else s_start[lane - 32] = f.row;
+  // lane c < 27 holds off[c] (lane 27: total = the sentinel off[27]); dl[c] = start[c] - off[c]
+  const u32 total = (u32)__builtin_amdgcn_readlane((int)f.row, SGTD_NCELL);
+  const u32 dl = (u32)__shfl((int)f.row, (lane + 32) & 63) - f.row;
+  (void)s_off; (void)s_start;
   // records of one descriptor are contiguous: make sure the slab can take
   // the worst case (every visited entry matches)
   if (total && slab.next + total > slab.end) {
@@ -192,6 +196,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
 
   u32 matches = 0;
   const u32 n_words = (total + 63u) >> 6;
+  int c_cur = 0;   // wave-uniform cursor: cell that holds the first position of the current word
   // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
   // issued before the first use so that several KB per wave are in flight
   for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
@@ -200,11 +205,27 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
     bool valid[SGTD_PROBE_UNROLL];
 #pragma unroll
     for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-      const u32 pos = ((w0 + u) << 6) + lane;
+      const u32 pos0 = (w0 + u) << 6, pos = pos0 + lane;
       valid[u] = pos < total;
-      u32 e;
-      locate(s_off, s_start, valid[u] ? pos : 0u, cell[u], e);
-      if (!valid[u]) e = 0;   // entry 0 always exists when total > 0
+      u32 e = 0;   // entry 0 always exists when total > 0
+      cell[u] = 0;
+      if (pos0 < total) {   // wave-uniform
+        // position -> (cell, entry) with scalar cursors instead of a per-lane search: a word
+        // of 64 consecutive positions spans the cells c_lo..c_hi, usually one or two
+        const u32 pos_last = min(pos0 + 63u, total - 1u);
+        while ((u32)__builtin_amdgcn_readlane((int)f.row, c_cur + 1) <= pos0) c_cur++;
+        int c_hi = c_cur;
+        while ((u32)__builtin_amdgcn_readlane((int)f.row, c_hi + 1) <= pos_last) c_hi++;
+        u32 delta = (u32)__builtin_amdgcn_readlane((int)dl, c_cur);
+        int cl = c_cur;
+        for (int c = c_cur + 1; c <= c_hi; c++) {   // the last cell with off[c] <= pos wins (skips empty cells)
+          const bool ge = pos >= (u32)__builtin_amdgcn_readlane((int)f.row, c);
+          delta = ge ? (u32)__builtin_amdgcn_readlane((int)dl, c) : delta;
+          cl = ge ? c : cl;
+        }
+        cell[u] = cl;
+        if (valid[u]) e = pos + delta;
+      }
       const double2 *p = reinterpret_cast<const double2 *>(T.ent + e);
       v01[u] = p[0];          // s0, s1
       v2x[u] = p[1];          // s2, {frame, g}
@@ -333,14 +354,15 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableV
                                                                           ProbeBuffers B, const CellRow *rows,
                                                                           double rough, const u32 *order,
                                                                           const u32 *n_valid_p,
-                                                                          u32 *xcd_heads /*[8]*/) {
-  constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
-  __shared__ u32 s_off[NW][32];
-  __shared__ u32 s_start[NW][32];
-  __shared__ u32 s_item;
-  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+                                                                          u32 *xcd_heads /*[8 * 1024]: one head per XCD, 4 KB apart (own L2 channel)*/,
+                                                                          u32 chunk /* 1..64 */) {
+  const int lane = lane_id();
   const u32 n_valid = *n_valid_p;
-  const u32 n_chunks = (n_valid + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK;
+  // Every WAVE dequeues `chunk` consecutive positions at a time (no workgroup barrier;
+  // the next ticket is fetched while the current chunk is swept).  Small chunks keep
+  // the descriptors in flight on one XCD — and with them the buckets it is reading —
+  // within that XCD's 4 MB L2; the host sizes a ticket to about 2k entry visits.
+  const u32 n_chunks = (n_valid + chunk - 1) / chunk;
   u32 xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
@@ -349,25 +371,23 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableV
   for (u32 t = 0; t < 8; t++) {
     const u32 x = (xcc + t) & 7u;
     const u32 c_lo = (u32)(((u64)n_chunks * x) >> 3), c_hi = (u32)(((u64)n_chunks * (x + 1)) >> 3);
-    while (true) {
-      if (tid == 0) s_item = atomicAdd(&xcd_heads[x], 1u);
-      __syncthreads();
-      const u32 c = c_lo + s_item;
-      __syncthreads();
-      if (c >= c_hi) break;
-      const u32 p_first = c * SGTD_PROBE_CHUNK + (u32)wid * (SGTD_PROBE_CHUNK / NW);
-      const u32 p_last = min(p_first + (u32)(SGTD_PROBE_CHUNK / NW), n_valid);
-      if (p_first < p_last) {
-        // lane j holds the slot of position p_first + j (32 positions per wave)
-        const u32 ord = (p_first + (u32)lane < p_last) ? order[p_first + lane] : 0u;
-        DescFetch nxt = fetch_desc(Q, rows, (long long)p_first, (long long)__shfl(ord, 0));
-        for (u32 p = p_first; p < p_last; p++) {
-          const DescFetch cur = nxt;
-          const long long d = (long long)__shfl(ord, (int)(p - p_first));
-          if (p + 1 < p_last) nxt = fetch_desc(Q, rows, (long long)p + 1, (long long)__shfl(ord, (int)(p + 1 - p_first)));
-          sweep_descriptor<SGTD_VOTE_NONE, DIAG>(T, B, rough, d, cur, s_off[wid], s_start[wid], slab, nullptr, nullptr);
-        }
+    u32 ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&xcd_heads[x * 1024u], 1u);
+    u32 cur_c = c_lo + (u32)__builtin_amdgcn_readfirstlane((int)ticket);
+    while (cur_c < c_hi) {
+      if (lane == 0) ticket = atomicAdd(&xcd_heads[x * 1024u], 1u);   // in flight during this chunk
+      const u32 p_first = cur_c * chunk;
+      const u32 p_last = min(p_first + chunk, n_valid);
+      // lane j holds the slot of position p_first + j
+      const u32 ord = (p_first + (u32)lane < p_last) ? order[p_first + lane] : 0u;
+      DescFetch nxt = fetch_desc(Q, rows, (long long)p_first, (long long)__shfl(ord, 0));
+      for (u32 p = p_first; p < p_last; p++) {
+        const DescFetch cur = nxt;
+        const long long d = (long long)__shfl(ord, (int)(p - p_first));
+        if (p + 1 < p_last) nxt = fetch_desc(Q, rows, (long long)p + 1, (long long)__shfl(ord, (int)(p + 1 - p_first)));
+        sweep_descriptor<SGTD_VOTE_NONE, DIAG>(T, B, rough, d, cur, nullptr, nullptr, slab, nullptr, nullptr);
       }
+      cur_c = c_lo + (u32)__builtin_amdgcn_readfirstlane((int)ticket);
     }
   }
 }

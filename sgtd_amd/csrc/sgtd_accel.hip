@@ -91,8 +91,9 @@ struct sgtd_engine {
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
-  bool key_major = false;              // probe in locality-key order (SGTD_PROBE_ORDER=query|key)
+  bool key_major = true;               // sweep in locality-key order (SGTD_PROBE_ORDER=query|key)
   DevBuf n_valid, xcd_heads, cell_rows;
+  int sorted_chunk = 0;                // > 0: fixed descriptors per ticket (SGTD_SORTED_CHUNK), else adaptive
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
   // host copies after sync
   std::vector<u32> h_count, h_pair_base, h_q_M;
@@ -485,7 +486,7 @@ int launch_select(sgtd_engine *e) {
     CHK(ensure(e, e->valA, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->valB, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->n_valid, sizeof(u32)));
-    CHK(ensure(e, e->xcd_heads, 8 * sizeof(u32)));
+    CHK(ensure(e, e->xcd_heads, 8 * 1024 * sizeof(u32)));
     const int nb = (int)((n_slots + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
     CHK(ensure(e, e->hist, (size_t)256 * nb * sizeof(u32)));
     u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
@@ -502,17 +503,27 @@ int launch_select(sgtd_engine *e) {
       std::swap(kin, kout);
       std::swap(vin, vout);
     }
-    HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * sizeof(u32), e->stream));
+    HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * 1024 * sizeof(u32), e->stream));
     resolve_kernel<<<grid_for(n_slots * 32, SGTD_RESOLVE_THREADS), SGTD_RESOLVE_THREADS, 0, e->stream>>>(
         v.T, v.Q, e->cell_rows.as<CellRow>(), vin, e->n_valid.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
+    // descriptors per wave ticket: about 2k entry visits, from the visits per descriptor the
+    // previous batch measured (4 until there is one); SGTD_SORTED_CHUNK overrides
+    u32 chunk = 4;
+    if (e->stats.last_D > 0 && e->stats.last_P > 0) {
+      const double per_desc = (double)e->stats.last_P / (double)e->stats.last_D;
+      chunk = (u32)std::min(8.0, std::max(1.0, std::floor(2048.0 / per_desc + 0.5)));
+    }
+    if (e->sorted_chunk > 0) chunk = (u32)std::min(64, e->sorted_chunk);
+    // the grid is sized by resident waves, not by work items: every wave pulls tickets
+    const int sgrid = e->n_cus * 8;
     if (e->diag)
-      probe_sorted_kernel<true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
-                                                                             e->n_valid.as<u32>(), e->xcd_heads.as<u32>());
+      probe_sorted_kernel<true><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
+                                                                              e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk);
     else
-      probe_sorted_kernel<false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
-                                                                              e->n_valid.as<u32>(), e->xcd_heads.as<u32>());
+      probe_sorted_kernel<false><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
+                                                                               e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk);
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
     if (lds_votes) {
@@ -723,6 +734,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   e->current_frame_id = cfg->first_frame_id;
   e->qd.with_thr2 = true;
   if (const char *o = getenv("SGTD_PROBE_ORDER")) e->key_major = std::strcmp(o, "key") == 0;
+  if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
   for (int i = 0; i < EV_COUNT; i++)
     if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
   *out = e;
