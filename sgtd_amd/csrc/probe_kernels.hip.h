@@ -196,7 +196,11 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
 
   u32 matches = 0;
   const u32 n_words = (total + 63u) >> 6;
-  int c_cur = 0;   // wave-uniform cursor: cell that holds the first position of the current word
+  // per-lane cursor: a lane's positions grow by 64 per word, so the cell that holds its
+  // position only moves forward; off[cl+1] and dl[cl] come from the row registers by
+  // ds_bpermute (no memory, no scalar loop)
+  int cl = 0;
+  u32 nxt_off = (u32)__shfl((int)f.row, 1);
   // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
   // issued before the first use so that several KB per wave are in flight
   for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
@@ -205,27 +209,16 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
     bool valid[SGTD_PROBE_UNROLL];
 #pragma unroll
     for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-      const u32 pos0 = (w0 + u) << 6, pos = pos0 + lane;
+      const u32 pos = ((w0 + u) << 6) + lane;
       valid[u] = pos < total;
-      u32 e = 0;   // entry 0 always exists when total > 0
-      cell[u] = 0;
-      if (pos0 < total) {   // wave-uniform
-        // position -> (cell, entry) with scalar cursors instead of a per-lane search: a word
-        // of 64 consecutive positions spans the cells c_lo..c_hi, usually one or two
-        const u32 pos_last = min(pos0 + 63u, total - 1u);
-        while ((u32)__builtin_amdgcn_readlane((int)f.row, c_cur + 1) <= pos0) c_cur++;
-        int c_hi = c_cur;
-        while ((u32)__builtin_amdgcn_readlane((int)f.row, c_hi + 1) <= pos_last) c_hi++;
-        u32 delta = (u32)__builtin_amdgcn_readlane((int)dl, c_cur);
-        int cl = c_cur;
-        for (int c = c_cur + 1; c <= c_hi; c++) {   // the last cell with off[c] <= pos wins (skips empty cells)
-          const bool ge = pos >= (u32)__builtin_amdgcn_readlane((int)f.row, c);
-          delta = ge ? (u32)__builtin_amdgcn_readlane((int)dl, c) : delta;
-          cl = ge ? c : cl;
-        }
-        cell[u] = cl;
-        if (valid[u]) e = pos + delta;
+      // the last cell with off[c] <= pos (empty cells are stepped over); off[27] = total stops it
+      while (__ballot(valid[u] && pos >= nxt_off)) {
+        if (valid[u] && pos >= nxt_off) cl++;
+        nxt_off = (u32)__shfl((int)f.row, cl + 1);
       }
+      cell[u] = cl;
+      const u32 dsel = (u32)__shfl((int)dl, cl);     // all lanes execute the permute (sources must be active)
+      const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
       const double2 *p = reinterpret_cast<const double2 *>(T.ent + e);
       v01[u] = p[0];          // s0, s1
       v2x[u] = p[1];          // s2, {frame, g}

@@ -58,7 +58,7 @@ struct sgtd_engine {
   int64_t n_add_calls = 0;
   bool have_frames = false;
   u32 frame_lo = 0, frame_hi = 0;
-  bool finalized = true;  // empty table is trivially final
+  bool finalized = false;  // the first query builds the (possibly empty) bucket directory
 
   // ---- table, probe layout (hot)
   DevBuf hot, perm, hash, bucket_start, bucket_key;   // hot: HotEntry[E], 32 B per entry

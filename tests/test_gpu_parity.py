@@ -255,3 +255,88 @@ def test_roundtrip_properties_medium_map(mods):
         ent = g.fetch_entries(de[lo:hi][:256])
         assert np.all(ent.frame == f)
         assert np.all(np.diff(res.cand_votes[q, :res.n_cand[q]]) <= 0)
+
+
+def test_query_against_empty_table(mods):
+    _, manager, synth = mods
+    g = manager.STDescManager()
+    m = synth.make_map(2, 60, stream=91)
+    res = g.query_frames(m.xyz, m.label)
+    assert res.n_cand.tolist() == [0, 0]
+    assert g.stats()["last_M"] == 0 and g.stats()["last_P"] == 0
+    d = g.BuildSingleScanSTD(m.xyz[0], m.label[0])
+    assert g.candidate_selector(d) == []
+    empty = manager.Descs(0)
+    assert g.candidate_selector(empty) == []
+
+
+@pytest.mark.parametrize("n_kp", [420, 900])
+def test_large_frames_use_the_global_dedup_path(mods, n_kp):
+    """frames whose dedup tables do not fit LDS (N > ~380) take the global-memory variant"""
+    _, _, synth = mods
+    g, o = _pair(mods)
+    m = synth.make_map(3, n_kp, stream=95)
+    for f in range(3):
+        assert_descs_equal(g.BuildSingleScanSTD(m.xyz[f], m.label[f]), o.build(m.xyz[f], m.label[f]))
+    g.add_frames(m.xyz[:2], m.label[:2])
+    for f in range(2):
+        o.build(m.xyz[f], m.label[f]); o.add_last()
+    res = g.query_frames(m.xyz[2:3], m.label[2:3])
+    od = o.build(m.xyz[2], m.label[2])
+    _check_query(g, o, res, 0, od)
+
+
+@pytest.mark.parametrize("order", ["query", "key"])
+def test_skewed_labels_and_max_candidates(mods, order, monkeypatch):
+    """one dominant class (few label codes, long buckets), candidate_num = 64, K = 16"""
+    _, _, synth = mods
+    monkeypatch.setenv("SGTD_PROBE_ORDER", order)
+    cfg = dict(candidate_num=64, descriptor_near_num=16, rough_dis_threshold=0.02)
+    g, o = _pair(mods, **cfg)
+    m = synth.make_map(70, 40, stream=97, label_lo=5, label_hi=6)
+    _fill_both(mods, g, o, m)
+    qs = synth.make_queries(m, 2, stream=97)
+    res = g.query_frames(qs.xyz, qs.label)
+    for q in range(2):
+        od = o.build(qs.xyz[q], qs.label[q])
+        r = _check_query(g, o, res, q, od)
+        assert len(r["cand_frame"]) == 64
+
+
+def test_vote_counts_beyond_the_topk_histogram_range(mods):
+    """more than 8191 votes for one frame (clipped histogram bin) and heavy ties at the
+    threshold (general top-k path): 9000 identical table entries per frame"""
+    oracle, manager, _ = mods
+    g = manager.STDescManager(candidate_num=3)
+    o = oracle.OracleManager(candidate_num=3)
+    for fid, n in ((0, 9000), (1, 9000), (2, 8500), (3, 9000)):
+        for mk in (manager.Descs, oracle.Descs):
+            d = mk(n)
+            d.side[:] = (5.1, 6.2, 7.3); d.label[:] = (3, 4, 5); d.frame[:] = fid
+            (g if mk is manager.Descs else o).__getattribute__("AddSTDescs" if mk is manager.Descs else "add")(d)
+    q = manager.Descs(1); q.side[0] = (5.1, 6.2, 7.3); q.label[0] = (3, 4, 5); q.frame[0] = 9
+    oq = oracle.Descs(1); oq.side[0] = (5.1, 6.2, 7.3); oq.label[0] = (3, 4, 5); oq.frame[0] = 9
+    lists = g.candidate_selector(q)
+    r = o.select(oq)
+    assert [l.match_id_[1] for l in lists] == list(r["cand_frame"]) == [0, 1, 3]
+    assert [l.votes for l in lists] == list(r["cand_votes"]) == [9000, 9000, 9000]
+    np.testing.assert_array_equal(np.concatenate([l.db_entry for l in lists]), r["db_entry"])
+
+
+def test_many_tied_frames_take_the_general_topk_path(mods):
+    """1500 frames with exactly 6 votes each: more ties at the threshold than the pool holds"""
+    oracle, manager, _ = mods
+    g = manager.STDescManager(candidate_num=50, max_frame_n=4000)
+    o = oracle.OracleManager(candidate_num=50, max_frame_n=4000)
+    n_f = 1500
+    dg, do = manager.Descs(6 * n_f), oracle.Descs(6 * n_f)
+    for d in (dg, do):
+        d.side[:] = (5.1, 6.2, 7.3); d.label[:] = (3, 4, 5)
+        d.frame[:] = np.repeat(np.arange(n_f), 6)
+    g.AddSTDescs(dg); o.add(do)
+    q = manager.Descs(1); q.side[0] = (5.1, 6.2, 7.3); q.label[0] = (3, 4, 5); q.frame[0] = 3999
+    oq = oracle.Descs(1); oq.side[0] = (5.1, 6.2, 7.3); oq.label[0] = (3, 4, 5); oq.frame[0] = 3999
+    lists = g.candidate_selector(q)
+    r = o.select(oq)
+    assert [l.match_id_[1] for l in lists] == list(r["cand_frame"]) == list(range(50))
+    assert all(l.votes == 6 for l in lists)
