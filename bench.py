@@ -7,10 +7,14 @@ then candidate_selector (probe, votes, top-50, ordered match lists) against an
 F-frame map table — all on the GPU through the C ABI.  Default workload =
 BASELINE.json configs[1]: 200 keypoints/frame, 1k-frame map.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME map is
-sharded by frame range over the ranks (strong scaling), every rank probes its
-shard with all Q queries, local top-50 tables are all-gathered with RCCL and
-merged (sgtd_amd/dist.py).
+N > 1 (launched by torch.distributed.run, one rank per GPU; total work fixed =
+strong scaling), two modes (--shard):
+  table  the map's hash table is sharded by frame range over the ranks, every
+         rank sweeps its shard with all Q queries, local top-50 tables are
+         all-gathered with RCCL and merged (sgtd_amd/dist.py::ShardedMap);
+  query  the table is replicated and every rank serves Q/N queries of the batch,
+         result tables are all-gathered with RCCL (ReplicatedMap);
+  auto   query when the whole table needs < 1/8 of one GPU's HBM, else table.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,19 +30,22 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_BYTES = 288e9
+KERNEL_KEYS = ("ms_build", "ms_sort", "ms_probe", "ms_votes", "ms_topk", "ms_count", "ms_scan", "ms_write", "ms_total")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="map size F")
     ap.add_argument("--keypoints", type=int, default=200, help="keypoints per frame N")
-    ap.add_argument("--queries", type=int, default=256, help="query frames per step")
+    ap.add_argument("--queries", type=int, default=1024, help="query frames per step (whole job)")
+    ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the timed sample")
-    ap.add_argument("--profile-steps", type=int, default=5, help="steps timed per kernel for the roofline")
+    ap.add_argument("--profile-steps", type=int, default=3, help="steps timed per kernel for the roofline")
     return ap.parse_args()
 
 
@@ -98,7 +105,7 @@ def main():
     import torch
     import torch.distributed as dist
     from sgtd_amd import synth
-    from sgtd_amd.dist import ShardedMap, shard_range
+    from sgtd_amd.dist import ReplicatedMap, ShardedMap, query_slice, shard_range
     from sgtd_amd.manager import STDescManager
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,31 +130,50 @@ def main():
     F, N, Q = args.frames, args.keypoints, args.queries
     smap = synth.make_map(F, N, stream=1)
     queries = synth.make_queries(smap, Q, stream=1)
-    d_qxyz = torch.from_numpy(queries.xyz).to(dev).contiguous()
-    d_qlab = torch.from_numpy(queries.label.astype(np.int64)).to(dev).to(torch.int32).contiguous()
+
+    def to_dev(xyz, label):
+        return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
+                torch.from_numpy(np.ascontiguousarray(label).astype(np.int64)).to(dev).to(torch.int32).contiguous())
+
+    # cold + probe layout of the whole table: ~170 B per descriptor, <= 36*N per frame
+    table_bytes = 170.0 * 36 * N * F
+    mode = "single"
+    if world > 1:
+        mode = args.shard if args.shard != "auto" else ("query" if table_bytes < HBM_BYTES / 8 else "table")
 
     stream = torch.cuda.current_stream()
-    if world == 1:
+    merged = {}
+    if mode == "single":
         mgr = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 1))
         mgr.set_stream(stream.cuda_stream)
-        mgr.add_frames(torch.from_numpy(smap.xyz).to(dev).contiguous(),
-                       torch.from_numpy(smap.label.astype(np.int64)).to(dev).to(torch.int32).contiguous())
+        mgr.add_frames(*to_dev(smap.xyz, smap.label))
         mgr.finalize()
-        sm = None
+        d_qxyz, d_qlab = to_dev(queries.xyz, queries.label)
+        q_lo, q_hi = 0, Q
 
         def step():
             mgr.query_frames(d_qxyz, d_qlab, fetch=False)
-    else:
+    elif mode == "table":
         sm = ShardedMap(F, rank, world, device_id=local_rank)
         mgr = sm.mgr
         mgr.set_stream(stream.cuda_stream)
         lo, hi = shard_range(F, world, rank)
-        sm.add_shard_frames(torch.from_numpy(smap.xyz[lo:hi]).to(dev).contiguous(),
-                            torch.from_numpy(smap.label[lo:hi].astype(np.int64)).to(dev).to(torch.int32).contiguous())
-        merged = {}
+        sm.add_shard_frames(*to_dev(smap.xyz[lo:hi], smap.label[lo:hi]))
+        d_qxyz, d_qlab = to_dev(queries.xyz, queries.label)
+        q_lo, q_hi = 0, Q
 
         def step():
-            merged["out"] = sm.query(d_qxyz, d_qlab)
+            merged["out"] = sm.query(d_qxyz, d_qlab)[:2]
+    else:
+        rm = ReplicatedMap(F, rank, world, device_id=local_rank)
+        mgr = rm.mgr
+        mgr.set_stream(stream.cuda_stream)
+        rm.add_frames(*to_dev(smap.xyz, smap.label))
+        q_lo, q_hi = query_slice(Q, world, rank)
+        d_qxyz, d_qlab = to_dev(queries.xyz[q_lo:q_hi], queries.label[q_lo:q_hi])
+
+        def step():
+            merged["out"] = rm.query(d_qxyz, d_qlab, Q)
 
     def barrier():
         if world > 1:
@@ -182,13 +208,13 @@ def main():
         step()
         mgr.sync()
         s = mgr.stats()
-        for k in ("ms_build", "ms_sort", "ms_probe", "ms_votes", "ms_topk", "ms_count", "ms_scan", "ms_write", "ms_total"):
+        for k in KERNEL_KEYS:
             acc.setdefault(k, []).append(s[k])
     mgr.set_timing(False)
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
     st = mgr.stats()
     P, M, D = st["last_P"], st["last_M"], st["last_D"]
-    probe_bytes = 28 * P + 64 * D + 8 * M     # algorithmic bytes of one probe launch
+    probe_bytes = 28 * P + 64 * D + 8 * M     # algorithmic bytes of one sweep launch
     achieved = probe_bytes / (kern_ms["ms_probe"] * 1e-3) / 1e9 if kern_ms["ms_probe"] > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "probe_traffic.json")
@@ -201,10 +227,12 @@ def main():
             traffic = None
 
     res = mgr.results()
-    top1 = res.top1()
     out = None
     if rank == 0:
         value = Q * args.steps / elapsed
+        sharding = {"single": "none",
+                    "table": "map frames range-sharded over %d GPUs, every rank sweeps all queries, RCCL all_gather + merge of top-50" % world,
+                    "query": "map replicated on %d GPUs, queries sharded, RCCL all_gather of the result tables" % world}[mode]
         out = {
             "metric": "query frames/sec vs map size (descriptor build + candidate selection)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -213,20 +241,21 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic %d keypoints/frame, %d-frame map, descriptor build+match" % (N, F),
                        "map_frames": F, "keypoints_per_frame": N, "queries_per_step": Q,
-                       "sharding": "none" if world == 1 else "map frames range-sharded over %d GPUs, RCCL all_gather of top-50" % world,
+                       "sharding": sharding, "queries_this_rank": q_hi - q_lo,
                        "table_entries_this_rank": st["n_entries"], "table_buckets_this_rank": st["n_buckets"]},
-            "roofline": {"bound": "hbm", "kernel": "probe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "probe_sorted_kernel (sweep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": probe_bytes,
-                         "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"], "kernel_ms": kern_ms},
+                         "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
+                         "kernel_ms": kern_ms},
         }
-        if world == 1:
-            out["recall"] = recall(smap, queries, top1)
+        if mode == "single":
+            out["recall"] = recall(smap, queries, res.top1())
         else:
-            f, v, n = merged["out"]
+            f, v = merged["out"]
             out["recall"] = recall(smap, queries, f[:, 0].cpu().numpy())
         want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and F <= 2000)
-        if world == 1 and want_cpu:
+        if mode == "single" and want_cpu:
             cb, par = cpu_baseline(smap, queries, res, mgr, args.cpu_seconds)
             out["cpu_baseline"] = cb
             out["parity"] = par

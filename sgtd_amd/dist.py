@@ -1,5 +1,10 @@
-"""Multi-GPU form of candidate_selector: the map's hash table is sharded by
-frame range, one process per GPU, candidates gathered with RCCL.
+"""Multi-GPU forms of candidate_selector, one process per GPU, RCCL collectives.
+
+Two modes (bench.py --shard auto|table|query):
+* table-sharded (below): the map's hash table is sharded by frame range — for maps
+  that do not fit, or should not be replicated on, one GPU;
+* query-sharded (`ReplicatedMap`): the table is replicated and every rank serves a
+  slice of each query batch — the throughput mode for maps that fit one GPU.
 
 Sharding: rank r owns map frames [lo_r, hi_r) and holds a
 complete table for them, so every vote of a frame is counted on exactly one
@@ -90,3 +95,62 @@ class ShardedMap:
                           torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev))
         self.mgr.export_candidates(*self._bufs)
         return gather_and_merge(self._bufs[0], self._bufs[1], self.cand_num)
+
+
+def query_slice(n_queries, world, rank):
+    """contiguous slice [lo, hi) of a query batch that `rank` serves when the MAP is
+    replicated and the QUERIES are sharded"""
+    return rank * n_queries // world, (rank + 1) * n_queries // world
+
+
+def gather_query_slices(local_frames, local_votes, n_queries, group=None):
+    """query-sharded mode: every rank computed the candidate tables [q_hi-q_lo, cn] of its
+    query slice against a full replica of the map; one all_gather gives every rank the
+    tables of the whole batch.  Slices may differ by one row: they travel padded."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_frames, local_votes
+    rows = (n_queries + world - 1) // world
+    cn = local_frames.shape[1]
+    packed = torch.full((2, rows, cn), -1, dtype=torch.int32, device=local_frames.device)
+    packed[0, :local_frames.shape[0]] = local_frames
+    packed[1, :local_votes.shape[0]] = local_votes
+    out = torch.empty((world * 2, rows, cn), dtype=torch.int32, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    out = out.view(world, 2, rows, cn)
+    frames, votes = [], []
+    for r in range(world):
+        lo, hi = query_slice(n_queries, world, r)
+        frames.append(out[r, 0, :hi - lo])
+        votes.append(out[r, 1, :hi - lo])
+    return torch.cat(frames), torch.cat(votes)
+
+
+class ReplicatedMap:
+    """multi-GPU mode for maps that fit one GPU: every rank holds the whole table and
+    serves its slice of each query batch (no collective on the data path but the
+    gather of the results)"""
+
+    def __init__(self, n_frames_total, rank, world, device_id=0, **cfg):
+        from .manager import STDescManager
+        self.rank, self.world = rank, world
+        cfg.setdefault("max_frame_n", max(20000, n_frames_total + 1))
+        self.mgr = STDescManager(device_id=device_id, **cfg)
+        self.cand_num = self.mgr.config_setting_["candidate_num"]
+        self._bufs = None
+
+    def add_frames(self, xyz, label, kp_off=None):
+        self.mgr.add_frames(xyz, label, kp_off)
+        self.mgr.finalize()
+
+    def query(self, xyz_slice, label_slice, n_queries_total):
+        """xyz_slice/label_slice: THIS rank's slice of the batch (uniform frames [n, N, 3]);
+        returns (frames, votes) [n_queries_total, cn] on every rank"""
+        self.mgr.query_frames(xyz_slice, label_slice, fetch=False)
+        nq = self.mgr._nq
+        dev = torch.device("cuda", self.mgr.config_setting_["device_id"])
+        if self._bufs is None or self._bufs[0].shape[0] != nq:
+            self._bufs = (torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev),
+                          torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev))
+        self.mgr.export_candidates(*self._bufs)
+        return gather_query_slices(self._bufs[0], self._bufs[1], n_queries_total)

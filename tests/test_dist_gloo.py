@@ -79,6 +79,19 @@ def _worker(rank, world, port):
         ref = probe.clone()
         dist.broadcast(ref, src=0)
         assert torch.equal(ref, probe)
+        # query-sharded mode: every rank serves a slice of the batch against the full table
+        from sgtd_amd.dist import gather_query_slices, query_slice
+        full_f = np.full((N_Q, CAND), -1, np.int32)
+        full_v = np.zeros((N_Q, CAND), np.int32)
+        for q in range(N_Q):
+            tf, tv = truth[q]
+            full_f[q, :len(tf)], full_v[q, :len(tv)] = tf, tv
+        lo, hi = query_slice(N_Q, world, rank)
+        gf, gv = gather_query_slices(torch.from_numpy(full_f[lo:hi].copy()), torch.from_numpy(full_v[lo:hi].copy()), N_Q)
+        assert gf.shape == (N_Q, CAND)
+        assert np.array_equal(gf.numpy(), full_f)
+        valid = full_f >= 0
+        assert np.array_equal(gv.numpy()[valid], full_v[valid])
     finally:
         dist.destroy_process_group()
 

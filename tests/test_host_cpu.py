@@ -55,8 +55,9 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
-    for f in os.listdir(os.path.join(ROOT, "include")):
-        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "oracle" not in open(os.path.join(dirpath, f)).read().lower(), os.path.join(dirpath, f)
 
 
 def test_merge_candidates_rule():
