@@ -21,6 +21,7 @@ struct DescArrays {
   u32 *frame;                     // [cap]
   int *node_id;                   // [cap*3]
   double *thr2;                   // [cap] squared match threshold (query descriptors only; may be null)
+  u32 *gate;                      // [cap] 27-bit gate mask of the probe cells (with thr2)
 };
 
 #define SGTD_BUILD_THREADS 1024
@@ -287,8 +288,10 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
       out.label[o * 3 + 1] = (int)(double)__float_as_uint(B.w);
       out.label[o * 3 + 2] = (int)(double)__float_as_uint(C.w);
       out.frame[o] = frame_id;
-      if (out.thr2)   // dis_threshold of :356-357 in squared, comparison-exact form
+      if (out.thr2) {   // dis_threshold of :356-357 in squared, comparison-exact form; cell gate :366-369
         out.thr2[o] = sq_threshold(norm3(cfg.scale * a, cfg.scale * b, cfg.scale * c) * cfg.rough);
+        out.gate[o] = gate_mask(cfg.scale * a, cfg.scale * b, cfg.scale * c);
+      }
       out.node_id[o * 3 + 0] = i; out.node_id[o * 3 + 1] = m; out.node_id[o * 3 + 2] = nn;
     }
   }

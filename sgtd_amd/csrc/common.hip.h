@@ -88,6 +88,25 @@ __device__ __forceinline__ double sq_threshold(double thr) {
   }
 }
 
+// 27-bit mask of the probe cells that pass the gate ||side - centre|| < 1.5
+// (STDesc.cpp:366-369); bit c = voxel_round index (x outer .. z inner, :327-333).
+// sqrt_rn(v) < 1.5 <=> v < 2.25 exactly (sqrt(2.25) = 1.5, sqrt(pred(2.25)) rounds below 1.5).
+__device__ __forceinline__ u32 gate_mask(double q0, double q1, double q2) {
+  double ex[3], ey[3], ez[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double dx = q0 - ((double)(int)(q0 + (double)(k - 1)) + 0.5);
+    const double dy = q1 - ((double)(int)(q1 + (double)(k - 1)) + 0.5);
+    const double dz = q2 - ((double)(int)(q2 + (double)(k - 1)) + 0.5);
+    ex[k] = dx * dx; ey[k] = dy * dy; ez[k] = dz * dz;
+  }
+  u32 m = 0;
+#pragma unroll
+  for (int c = 0; c < 27; c++)
+    if (((ex[c / 9] + ey[(c / 3) % 3]) + ez[c % 3]) < 2.25) m |= 1u << c;
+  return m;
+}
+
 struct HashSlot {  // 16 bytes
   u64 key;
   u32 start;

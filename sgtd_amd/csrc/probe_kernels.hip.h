@@ -1,17 +1,23 @@
 // probe_kernels.hip.h — candidate_selector (src/sgtd/src/STDesc.cpp:318-460)
 //
-//   probe     (:351-400) work item = (query, chunk of 128 query descriptors),
-//             dequeued by persistent workgroups; one wavefront per descriptor:
-//             27 lanes resolve the 27 cells (truncating (int)(side+inc), gate
-//             ||side-centre|| < 1.5, hash lookup key -> bucket), then all 64
-//             lanes stream the concatenated bucket ranges from the 32-B/entry
-//             probe layout (two 16-B loads per lane, 4 x 64 entries in flight).
-//             The distance test runs on squared values against the exact
-//             squared threshold (common.hip.h sq_threshold) — no per-entry sqrt.
-//             Matches are compacted in (cell, j) order by __ballot/popcount
-//             prefix into a per-descriptor list of (frame, entry) records;
-//             votes (:404-420) go to an LDS histogram per work item that is
-//             flushed with one global atomic per touched frame.
+//   probe     (:351-400) one wavefront per query descriptor: its 27 cells
+//             (truncating (int)(side+inc), gate ||side-centre|| < 1.5, hash
+//             lookup key -> bucket) become one concatenated visit list that all
+//             64 lanes stream from the 32-B/entry probe layout (two 16-B loads
+//             per lane, 4 x 64 entries in flight).  The distance test runs on
+//             squared values against the exact squared threshold (common.hip.h
+//             sq_threshold) — no per-entry sqrt.  Matches are compacted in
+//             (cell, j) order by __ballot/popcount prefix into a per-descriptor
+//             list of (frame, entry) records.  Two schedules of the same sweep:
+//             * query-major (probe_kernel): work item = (query, 128 descriptors),
+//               resolve_kernel writes one CellRow per descriptor, votes (:404-420)
+//               go to an LDS histogram per work item;
+//             * key-major (probe_sorted_kernel, the default): the batch's
+//               descriptors are radix-sorted by home cell, descriptors of one home
+//               cell share ONE set of 27 bucket lookups (GroupRow), per-XCD ticket
+//               queues hand neighbouring cells to waves of one XCD so that the
+//               buckets stay in that XCD's L2; votes_kernel counts votes from the
+//               lists afterwards.
 //   topk      (:423-433) candidate_num rounds of arg-max over the votes:
 //             votes desc, frame id asc, stop below 5 votes
 //   assemble  (:434-449) one wavefront per 128-descriptor block walks the
@@ -36,6 +42,7 @@ struct TableView {
 struct QueryView {
   const double *side;   // [n_slots*3]
   const double *thr2;   // [n_slots] exact squared threshold of the descriptor
+  const u32 *gate;      // [n_slots] 27-bit mask of the cells that pass the 1.5 gate
   const int *label;     // [n_slots*3]
   const u32 *frame;     // [n_slots]
   const u32 *count;     // [n_queries] descriptors per query
@@ -59,9 +66,6 @@ struct ProbeBuffers {
 
 #define SGTD_PROBE_THREADS 256
 #define SGTD_PROBE_CHUNK 128    // query descriptors per work item = per assemble block
-#ifndef SGTD_SORTED_CHUNK
-#define SGTD_SORTED_CHUNK 4     // descriptors per wave ticket of the key-major sweep (<= 64)
-#endif
 #define SGTD_REC_SLAB 2048u     // match records a wave takes from the global cursor at once
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
@@ -126,21 +130,6 @@ __global__ __launch_bounds__(SGTD_RESOLVE_THREADS) void resolve_kernel(TableView
   r.start[c] = start;
 }
 
-// position `pos` in the concatenation of the 27 ranges -> (cell, entry index)
-__device__ __forceinline__ void locate(const u32 *cell_off /*[32] LDS*/, const u32 *cell_start,
-                                       u32 pos, int &cell, u32 &entry) {
-  // branch-free binary search for the last cell with off <= pos (offsets ascending,
-  // entries 27..31 are UINT_MAX)
-  int c = 0;
-  if (cell_off[c + 16] <= pos) c += 16;
-  if (cell_off[c + 8] <= pos) c += 8;
-  if (cell_off[c + 4] <= pos) c += 4;
-  if (cell_off[c + 2] <= pos) c += 2;
-  if (cell_off[c + 1] <= pos) c += 1;
-  cell = c;
-  entry = cell_start[c] + (pos - cell_off[c]);
-}
-
 // vote sinks of the sweep
 #define SGTD_VOTE_NONE 0    // votes are counted later from the match lists (votes_kernel)
 #define SGTD_VOTE_LDS 1     // LDS histogram of the work item, flushed by the caller
@@ -150,11 +139,13 @@ struct WaveSlab {
   u32 next, end;   // this wave's private range of match records
 };
 
-// what the sweep needs about one query descriptor; loaded one descriptor ahead
+// what the sweep needs about one query descriptor; the loads are issued one descriptor
+// ahead (DescFetch), the per-lane plan is derived right before the sweep (plan_*)
 struct DescFetch {
-  u32 row;              // lane l: word l of the CellRow
+  u32 row;              // lane l: word l of the descriptor's CellRow / of its group's GroupRow
   double q0, q1, q2, thr2;
   u32 qframe;
+  u32 gate;             // key-major path: the descriptor's 27-bit gate mask
 };
 
 __device__ __forceinline__ DescFetch fetch_desc(const QueryView &Q, const CellRow *rows, long long p,
@@ -167,20 +158,33 @@ __device__ __forceinline__ DescFetch fetch_desc(const QueryView &Q, const CellRo
   return f;
 }
 
+// the visit list of a descriptor as the sweep walks it: lane c < 27 holds the exclusive
+// offset off[c] of cell c (lane 27: the total = sentinel off[27]) and dl[c] = start[c] - off[c]
+struct DescPlan {
+  u32 off, dl;
+};
+
+// CellRow (resolve_kernel did gate + scan): off in lanes 0..27, start in lanes 32..58
+__device__ __forceinline__ DescPlan plan_from_cell_row(const DescFetch &f) {
+  DescPlan pl;
+  pl.off = f.row;
+  pl.dl = (u32)__shfl((int)f.row, (lane_id() + 32) & 63) - f.row;
+  return pl;
+}
+
 // STDesc.cpp:372-399 for ONE query descriptor d by one wavefront: streams the
 // descriptor's visit list, tests, compacts the matches in (cell, j) order
 template <int VOTE, bool DIAG>
 __device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
-                                                 long long d, const DescFetch &f, u32 *s_off /*[32]*/,
-                                                 u32 *s_start /*[32]*/, WaveSlab &slab, u32 *s_hist, u32 *votes) {
+                                                 long long d, const DescFetch &f, const DescPlan &pl,
+                                                 WaveSlab &slab, u32 *s_hist, u32 *votes) {
   const int lane = lane_id();
   const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
   const u32 qframe = f.qframe;
   const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;   // :356-357
   // lane c < 27 holds off[c] (lane 27: total = the sentinel off[27]); dl[c] = start[c] - off[c]
-  const u32 total = (u32)__builtin_amdgcn_readlane((int)f.row, SGTD_NCELL);
-  const u32 dl = (u32)__shfl((int)f.row, (lane + 32) & 63) - f.row;
-  (void)s_off; (void)s_start;
+  const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_NCELL);
+  const u32 dl = pl.dl;
   // records of one descriptor are contiguous: make sure the slab can take
   // the worst case (every visited entry matches)
   if (total && slab.next + total > slab.end) {
@@ -200,7 +204,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   // position only moves forward; off[cl+1] and dl[cl] come from the row registers by
   // ds_bpermute (no memory, no scalar loop)
   int cl = 0;
-  u32 nxt_off = (u32)__shfl((int)f.row, 1);
+  u32 nxt_off = (u32)__shfl((int)pl.off, 1);
   // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
   // issued before the first use so that several KB per wave are in flight
   for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
@@ -214,7 +218,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
       // the last cell with off[c] <= pos (empty cells are stepped over); off[27] = total stops it
       while (__ballot(valid[u] && pos >= nxt_off)) {
         if (valid[u] && pos >= nxt_off) cl++;
-        nxt_off = (u32)__shfl((int)f.row, cl + 1);
+        nxt_off = (u32)__shfl((int)pl.off, cl + 1);
       }
       cell[u] = cl;
       const u32 dsel = (u32)__shfl((int)dl, cl);     // all lanes execute the permute (sources must be active)
@@ -267,8 +271,6 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, 
                                                                    double rough, int chunks_per_query) {
   constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
   extern __shared__ u32 s_hist[];  // [frame_span] when LDS_VOTES
-  __shared__ u32 s_off[NW][32];    // exclusive offsets, padded to 32 with UINT_MAX
-  __shared__ u32 s_start[NW][32];
   __shared__ u32 s_item;
   const int tid = threadIdx.x, wid = tid >> 6;
   const u32 n_items = (u32)Q.n_queries * (u32)chunks_per_query;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, 
         const DescFetch cur = nxt;
         if (i + 1 < w_last) nxt = fetch_desc(Q, rows, base + i + 1, base + i + 1);   // in flight during the sweep of i
         sweep_descriptor<LDS_VOTES ? SGTD_VOTE_LDS : SGTD_VOTE_GLOBAL, DIAG>(
-            T, B, rough, base + i, cur, s_off[wid], s_start[wid], slab, s_hist, votes);
+            T, B, rough, base + i, cur, plan_from_cell_row(cur), slab, s_hist, votes);
       }
     }
     __syncthreads();
@@ -320,31 +322,136 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, 
 // neighbours on the same XCD and come from that XCD's L2 instead of HBM.
 // Results are independent of the order: every descriptor writes its own list.
 // ---------------------------------------------------------------------------
-// 24-bit locality key per descriptor slot (invalid slots sort last)
-__global__ void locality_keys_kernel(QueryView Q, u64 *keys, u32 *vals, long long n_slots, u32 *n_valid) {
+// Home key of a descriptor slot = (label code, (int)side0, (int)side1, (int)side2) packed
+// with `cbits` bits per cell coordinate; invalid slots sort last.  The 27 probed cells
+// (int)(side+inc) are a function of the home cell alone (per axis n = (int)s gives
+// {n ? n-1 : 0, n, n+1}), so all descriptors of the batch with equal home key share ONE set
+// of bucket lookups (a GroupRow); only the gate is per descriptor.
+// exclusive prefix of the per-query descriptor counts and their total (one workgroup)
+__global__ __launch_bounds__(256) void query_prefix_kernel(const u32 *count, u32 *q_prefix, int n_queries,
+                                                           u32 *n_valid) {
+  __shared__ u32 lds[256 / SGTD_WAVE + 1];
+  u32 carry = 0;
+  for (int q0 = 0; q0 < n_queries; q0 += 256) {
+    const int q = q0 + threadIdx.x;
+    const u32 v = (q < n_queries) ? count[q] : 0;
+    u32 tot;
+    const u32 ex = block_excl_scan(v, lds, tot);
+    if (q < n_queries) q_prefix[q] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *n_valid = carry;
+}
+
+// keys/vals are compact: the descriptor (q, i) goes to index q_prefix[q] + i
+__global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, u64 *keys, u32 *vals, long long n_slots,
+                                 int cbits) {
   const long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n_slots) return;
   const int q = (int)(d / Q.stride);
   const u32 i = (u32)(d - (long long)q * Q.stride);
-  u64 key = 0xFFFFFFull;
-  if (i < Q.count[q]) {
-    const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
-    const u32 x = (u32)(int)Q.side[d * 3 + 0], y = (u32)(int)Q.side[d * 3 + 1];
-    key = ((u64)code << 12) | ((u64)(x & 63u) << 6) | (u64)(y & 63u);
-    if (key == 0xFFFFFFull) key = 0xFFFFFEull;
+  if (i >= Q.count[q]) return;
+  const u64 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
+  const u64 cmask = (1ull << cbits) - 1ull;
+  // a coordinate that does not fit cbits-1 bits becomes the all-ones marker: such a
+  // descriptor never shares a group (group_heads_kernel), so aliasing cannot merge cells
+  const u64 x = min((u64)(u32)(int)Q.side[d * 3 + 0], cmask), y = min((u64)(u32)(int)Q.side[d * 3 + 1], cmask),
+            z = min((u64)(u32)(int)Q.side[d * 3 + 2], cmask);
+  const u32 idx = q_prefix[q] + i;
+  keys[idx] = (((code << cbits | x) << cbits | y) << cbits) | z;
+  vals[idx] = (u32)d;
+}
+
+// group id of every sorted position from the SORTED home keys: flags[p] = 1 where the key
+// changes or where the next key carries an overflow marker (such a descriptor is a group of
+// its own: its key does not name its cell).  flags[p] says whether position p+1 starts a new
+// group, so the EXCLUSIVE scan of the flags is the group id of p (position 0 is group 0).
+__global__ void group_heads_kernel(const u64 *keys, const u32 *n_valid_p, u32 *flags, long long n, int cbits) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  u32 head = 0;
+  if (p + 1 < (long long)*n_valid_p) {
+    const u64 a = keys[p + 1], b = keys[p];
+    const u64 cmask = (1ull << cbits) - 1ull;
+    head = (a != b) || ((a & cmask) == cmask) || (((a >> cbits) & cmask) == cmask) ||
+           (((a >> (2 * cbits)) & cmask) == cmask);
   }
-  keys[d] = key;
-  vals[d] = (u32)d;
-  if (d == 0) {
-    u32 tot = 0;
-    for (int k = 0; k < Q.n_queries; k++) tot += Q.count[k];
-    *n_valid = tot;
+  flags[p] = head;
+}
+
+// first sorted position of every group and the number of groups
+__global__ void group_first_kernel(const u32 *gid, const u32 *n_valid_p, u32 *group_first, u32 *n_groups,
+                                   long long n) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nv = (long long)*n_valid_p;
+  if (p >= n || p >= nv) return;
+  const u32 g = gid[p];
+  if (p == 0 || gid[p - 1] != g) group_first[g] = (u32)p;
+  if (p == nv - 1) *n_groups = g + 1;
+}
+
+// One GroupRow per home cell of the batch: the 27 ungated bucket lookups (STDesc.cpp:358-371
+// minus the gate): words 0..31 = start[c], words 32..63 = len[c].  32 lanes per group, grid-stride.
+__global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryView Q, const u32 *order,
+                                                            const u32 *group_first, const u32 *n_groups_p,
+                                                            const u32 *n_valid_p, CellRow *rows) {
+  const int c = (int)(threadIdx.x & 31);
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 5;
+  const long long n_groups = (*n_valid_p) ? (long long)*n_groups_p : 0;
+  for (long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; g < n_groups; g += stride) {
+    const long long d = (long long)order[group_first[g]];
+    u32 start = 0, len = 0;
+    if (c < SGTD_NCELL) {
+      const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
+      const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
+      const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
+      const int x = (int)(q0 + (double)ix), y = (int)(q1 + (double)iy), z = (int)(q2 + (double)iz);
+      if (x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
+        const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
+        u32 h = hash_key(key) & T.hash_mask;
+        while (true) {
+          const HashSlot s = T.hash[h];
+          if (s.key == key) { start = s.start; len = s.len; break; }
+          if (s.key == SGTD_EMPTY_KEY) break;
+          h = (h + 1) & T.hash_mask;
+        }
+      }
+    }
+    CellRow &r = rows[g];
+    r.off[c] = start;     // GroupRow layout: words 0..31 = start, words 32..63 = len
+    r.start[c] = len;
   }
+}
+
+// loads for the descriptor at sorted position p (slot d): its group's GroupRow (lane l = word l:
+// start[0..31], len[0..31]), its gate mask, its sides.
+__device__ __forceinline__ DescFetch fetch_desc_group(const QueryView &Q, const CellRow *group_rows,
+                                                      const u32 *gid, long long p, long long d) {
+  DescFetch f;
+  f.row = reinterpret_cast<const u32 *>(group_rows + gid[p])[lane_id()];
+  f.q0 = Q.side[d * 3 + 0]; f.q1 = Q.side[d * 3 + 1]; f.q2 = Q.side[d * 3 + 2];
+  f.thr2 = Q.thr2[d];
+  f.qframe = Q.frame[d];
+  f.gate = Q.gate[d];
+  return f;
+}
+
+// GroupRow + the descriptor's gate mask (:366-369): gated lengths, their exclusive scan
+__device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
+  const int c = lane_id();
+  u32 len = (u32)__shfl((int)f.row, (c + 32) & 63);
+  len = (c < SGTD_NCELL && ((f.gate >> c) & 1u)) ? len : 0u;
+  const u32 inc = wave_incl_scan(len);
+  DescPlan pl;
+  pl.off = inc - len;          // lanes >= 27 add nothing: lane 27 holds the total
+  pl.dl = f.row - pl.off;      // lanes < 27: start[c] - off[c]
+  return pl;
 }
 
 template <bool DIAG>
 __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableView T, QueryView Q,
                                                                           ProbeBuffers B, const CellRow *rows,
+                                                                          const u32 *gid,
                                                                           double rough, const u32 *order,
                                                                           const u32 *n_valid_p,
                                                                           u32 *xcd_heads /*[8 * 1024]: one head per XCD, 4 KB apart (own L2 channel)*/,
@@ -373,12 +480,13 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableV
       const u32 p_last = min(p_first + chunk, n_valid);
       // lane j holds the slot of position p_first + j
       const u32 ord = (p_first + (u32)lane < p_last) ? order[p_first + lane] : 0u;
-      DescFetch nxt = fetch_desc(Q, rows, (long long)p_first, (long long)__shfl(ord, 0));
+      DescFetch nxt = fetch_desc_group(Q, rows, gid, (long long)p_first, (long long)__shfl(ord, 0));
       for (u32 p = p_first; p < p_last; p++) {
         const DescFetch cur = nxt;
         const long long d = (long long)__shfl(ord, (int)(p - p_first));
-        if (p + 1 < p_last) nxt = fetch_desc(Q, rows, (long long)p + 1, (long long)__shfl(ord, (int)(p + 1 - p_first)));
-        sweep_descriptor<SGTD_VOTE_NONE, DIAG>(T, B, rough, d, cur, nullptr, nullptr, slab, nullptr, nullptr);
+        if (p + 1 < p_last)   // the next descriptor's loads are in flight during this sweep
+          nxt = fetch_desc_group(Q, rows, gid, (long long)p + 1, (long long)__shfl(ord, (int)(p + 1 - p_first)));
+        sweep_descriptor<SGTD_VOTE_NONE, DIAG>(T, B, rough, d, cur, plan_from_group_row(cur), slab, nullptr, nullptr);
       }
       cur_c = c_lo + (u32)__builtin_amdgcn_readfirstlane((int)ticket);
     }

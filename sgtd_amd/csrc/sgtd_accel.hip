@@ -25,7 +25,7 @@ struct DevBuf {
 };
 
 struct DescStore {
-  DevBuf side, angle, center, vertex, label, frame, node_id, thr2;
+  DevBuf side, angle, center, vertex, label, frame, node_id, thr2, gate;
   size_t cap = 0;
   bool with_thr2 = false;   // query descriptors carry their squared match threshold
   DescArrays view() const {
@@ -34,6 +34,7 @@ struct DescStore {
     a.vertex = vertex.as<float>(); a.label = label.as<int>(); a.frame = frame.as<u32>();
     a.node_id = node_id.as<int>();
     a.thr2 = with_thr2 ? thr2.as<double>() : nullptr;
+    a.gate = with_thr2 ? gate.as<u32>() : nullptr;
     return a;
   }
 };
@@ -92,7 +93,7 @@ struct sgtd_engine {
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
   bool key_major = true;               // sweep in locality-key order (SGTD_PROBE_ORDER=query|key)
-  DevBuf n_valid, xcd_heads, cell_rows;
+  DevBuf n_valid, xcd_heads, cell_rows, gid, q_prefix, group_first, n_groups;
   int sorted_chunk = 0;                // > 0: fixed descriptors per ticket (SGTD_SORTED_CHUNK), else adaptive
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
   // host copies after sync
@@ -145,6 +146,7 @@ int ensure_store(sgtd_engine *e, DescStore &s, size_t cap, bool keep = false) {
   CHK(ensure(e, s.frame, want * sizeof(u32), keep));
   CHK(ensure(e, s.node_id, want * 3 * sizeof(int), keep));
   if (s.with_thr2) CHK(ensure(e, s.thr2, want * sizeof(double), keep));
+  if (s.with_thr2) CHK(ensure(e, s.gate, want * sizeof(u32), keep));
   s.cap = want;
   return SGTD_OK;
 }
@@ -156,7 +158,7 @@ void free_buf(DevBuf &b) {
 }
 void free_store(DescStore &s) {
   free_buf(s.side); free_buf(s.angle); free_buf(s.center); free_buf(s.vertex);
-  free_buf(s.label); free_buf(s.frame); free_buf(s.node_id); free_buf(s.thr2);
+  free_buf(s.label); free_buf(s.frame); free_buf(s.node_id); free_buf(s.thr2); free_buf(s.gate);
   s.cap = 0;
 }
 
@@ -423,7 +425,7 @@ Views make_views(sgtd_engine *e) {
   T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
   T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
   QueryView &Q = v.Q;
-  Q.side = e->qd.side.as<double>(); Q.thr2 = e->qd.thr2.as<double>();
+  Q.side = e->qd.side.as<double>(); Q.thr2 = e->qd.thr2.as<double>(); Q.gate = e->qd.gate.as<u32>();
   Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
   Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq;
   ProbeBuffers &B = v.B;
@@ -480,32 +482,51 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->cell_rows, (size_t)std::max<long long>(n_slots, 1) * sizeof(CellRow)));
   const CellRow *rows = e->cell_rows.as<CellRow>();
   if (e->key_major) {
-    // ---- order of the batch's descriptors by locality key: 3 stable 8-bit radix passes
+    // ---- order of the batch's descriptors by home key (label code + truncated cell):
+    // stable 8-bit radix passes over 12 + 3*cbits key bits, then one GroupRow of bucket
+    // lookups per distinct home cell
     CHK(ensure(e, e->keyA, (size_t)n_slots * sizeof(u64)));
     CHK(ensure(e, e->keyB, (size_t)n_slots * sizeof(u64)));
     CHK(ensure(e, e->valA, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->valB, (size_t)n_slots * sizeof(u32)));
+    CHK(ensure(e, e->gid, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->n_valid, sizeof(u32)));
     CHK(ensure(e, e->xcd_heads, 8 * 1024 * sizeof(u32)));
     const int nb = (int)((n_slots + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
     CHK(ensure(e, e->hist, (size_t)256 * nb * sizeof(u32)));
     u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
     u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
-    locality_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, kin, vin, n_slots, e->n_valid.as<u32>());
+    // bits per cell coordinate of the sort key: the largest cell a built descriptor can have
+    int cbits = 1;
+    while ((1ll << cbits) < (long long)(e->dc.max_len * e->dc.scale) + 3 && cbits < 16) cbits++;
+    const int key_bits = 12 + 3 * cbits;
+    CHK(ensure(e, e->q_prefix, (size_t)nq * sizeof(u32)));
+    CHK(ensure(e, e->group_first, (size_t)n_slots * sizeof(u32)));
+    CHK(ensure(e, e->n_groups, sizeof(u32)));
+    const u32 *nv = e->n_valid.as<u32>();
+    query_prefix_kernel<<<1, 256, 0, e->stream>>>(e->q_count.as<u32>(), e->q_prefix.as<u32>(), nq, e->n_valid.as<u32>());
     HIPCHK(hipGetLastError());
-    for (int pass = 0; pass < 3; pass++) {
-      radix_hist_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, n_slots, pass * 8, e->hist.as<u32>(), nb);
+    home_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), kin, vin, n_slots, cbits);
+    HIPCHK(hipGetLastError());
+    for (int shift = 0; shift < key_bits; shift += 8) {   // only the n_valid compact elements are live
+      radix_hist_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, n_slots, shift, e->hist.as<u32>(), nb, nv);
       HIPCHK(hipGetLastError());
       CHK(device_scan(e, e->hist.as<u32>(), e->hist.as<u32>(), (long long)256 * nb));
-      radix_scatter_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, n_slots, pass * 8,
-                                                                   e->hist.as<u32>(), nb);
+      radix_scatter_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, n_slots, shift,
+                                                                   e->hist.as<u32>(), nb, nv);
       HIPCHK(hipGetLastError());
       std::swap(kin, kout);
       std::swap(vin, vout);
     }
     HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * 1024 * sizeof(u32), e->stream));
-    resolve_kernel<<<grid_for(n_slots * 32, SGTD_RESOLVE_THREADS), SGTD_RESOLVE_THREADS, 0, e->stream>>>(
-        v.T, v.Q, e->cell_rows.as<CellRow>(), vin, e->n_valid.as<u32>(), n_slots);
+    group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits);
+    HIPCHK(hipGetLastError());
+    CHK(device_scan(e, e->gid.as<u32>(), e->gid.as<u32>(), n_slots));
+    group_first_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), nv, e->group_first.as<u32>(),
+                                                                        e->n_groups.as<u32>(), n_slots);
+    HIPCHK(hipGetLastError());
+    group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(v.T, v.Q, vin, e->group_first.as<u32>(),
+                                                                e->n_groups.as<u32>(), nv, e->cell_rows.as<CellRow>());
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
     // descriptors per wave ticket: about 2k entry visits, from the visits per descriptor the
@@ -519,10 +540,10 @@ int launch_select(sgtd_engine *e) {
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
     const int sgrid = e->n_cus * 8;
     if (e->diag)
-      probe_sorted_kernel<true><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
+      probe_sorted_kernel<true><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->gid.as<u32>(), e->dc.rough, vin,
                                                                               e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk);
     else
-      probe_sorted_kernel<false><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, vin,
+      probe_sorted_kernel<false><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->gid.as<u32>(), e->dc.rough, vin,
                                                                                e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk);
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
@@ -749,7 +770,7 @@ int sgtd_destroy(sgtd_handle e) {
   DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->cursors, &e->list_ptr, &e->n_visit,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
@@ -902,7 +923,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
   if (nq > 0) {
-    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.thr2.as<double>(), nq,
+    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.thr2.as<double>(), e->qd.gate.as<u32>(), nq,
                                                            e->dc.rough);
     HIPCHK(hipGetLastError());
   }

@@ -102,8 +102,10 @@ __global__ void make_keys_kernel(const double *side, const int *label, u64 *keys
 
 // hist[digit * nblocks + block]
 __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_hist_kernel(const u64 *keys, long long n, int shift,
-                                                                      u32 *hist, int nblocks) {
+                                                                      u32 *hist, int nblocks,
+                                                                      const u32 *n_dev = nullptr) {
   __shared__ u32 h[256];
+  if (n_dev) n = min(n, (long long)*n_dev);   // element count known only on the device
   h[threadIdx.x] = 0;
   __syncthreads();
   long long base = (long long)blockIdx.x * SGTD_RS_TILE;
@@ -130,11 +132,13 @@ __global__ void radix_digit_totals_kernel(const u32 *hist, int nblocks, u32 *tot
 // stable scatter: hist now holds the exclusive scan (global base per digit,block)
 __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
     const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out, long long n,
-    int shift, const u32 *hist_scanned, int nblocks) {
+    int shift, const u32 *hist_scanned, int nblocks, const u32 *n_dev = nullptr) {
   constexpr int NW = SGTD_RS_THREADS / SGTD_WAVE;
   __shared__ u32 run[256];          // next free position per digit for this block
   __shared__ u32 wcount[NW][256];   // per-wave digit counts of the current round
   const int tid = threadIdx.x, wid = tid >> 6;
+  if (n_dev) n = min(n, (long long)*n_dev);
+  if ((long long)blockIdx.x * SGTD_RS_TILE >= n) return;   // uniform: nothing of this tile is live
   run[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x];
   long long base = (long long)blockIdx.x * SGTD_RS_TILE;
   for (int r = 0; r < SGTD_RS_ROUNDS; r++) {
@@ -185,10 +189,11 @@ __global__ void gather_hot_kernel(const u32 *perm, const double *side, const u32
 }
 
 // squared thresholds for caller-provided query descriptors
-__global__ void thr2_kernel(const double *side, double *thr2, long long n, double rough) {
+__global__ void thr2_kernel(const double *side, double *thr2, u32 *gate, long long n, double rough) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   thr2[i] = sq_threshold(norm3(side[i * 3], side[i * 3 + 1], side[i * 3 + 2]) * rough);
+  gate[i] = gate_mask(side[i * 3], side[i * 3 + 1], side[i * 3 + 2]);
 }
 
 __global__ void head_flags_kernel(const u64 *keys, u32 *flags, long long n) {
