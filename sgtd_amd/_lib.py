@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgtd_accel.so")
+# SGTD_ACCEL_LIB points at another build of the same ABI (kernel variants under test)
+LIB_PATH = os.environ.get("SGTD_ACCEL_LIB") or os.path.join(_HERE, "libsgtd_accel.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SGTD_OK = 0

@@ -65,12 +65,18 @@ __host__ __device__ __forceinline__ u32 hash_key(u64 k) {
   return h;
 }
 
-// one table entry in the probe layout: 32 bytes, two 16-B loads per lane
-struct __attribute__((aligned(32))) HotEntry {
-  double s0, s1, s2;  // side_length_ (scaled)
+// one table entry in the probe layout: 32 bytes in two 16-B halves kept in two arrays
+// (head[E], tail[E]) so that each 16-B-per-lane load of a wavefront covers 1 KB of
+// consecutive memory (8 full lines) instead of half of 16 lines
+struct __attribute__((aligned(16))) HotHead {
+  double s0, s1;      // side_length_ (scaled)
+};
+struct __attribute__((aligned(16))) HotTail {
+  double s2;
   u32 frame;          // frame_id_
   u32 g;              // insertion index (bucket order == ascending g)
 };
+#define SGTD_HOT_BYTES 32   // per entry, both halves
 
 // smallest y with sqrt_rn(y) >= thr:  (sqrt_rn(d2) < thr)  <=>  (d2 < y), because the
 // correctly rounded sqrt is monotone.  Lets the per-entry test of STDesc.cpp:374-378
@@ -114,14 +120,19 @@ struct HashSlot {  // 16 bytes
 };
 #define SGTD_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
-// inclusive wave scan (64 lanes) by shuffles
+// inclusive wave scan (64 lanes), six DPP adds: row_shr 1/2/4/8 scan each 16-lane row,
+// row_bcast:15 carries rows 0->1 and 2->3, row_bcast:31 carries the lower half into rows
+// 2 and 3.  Lanes without a source read 0 (old = 0, bound_ctrl off).  All 64 lanes must
+// be active.
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
-#pragma unroll
-  for (int d = 1; d < SGTD_WAVE; d <<= 1) {
-    u32 t = __shfl_up(v, d);
-    if (lane_id() >= d) v += t;
-  }
-  return v;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (u32)x;
 }
 
 __device__ __forceinline__ u32 wave_sum(u32 v) {

@@ -29,9 +29,11 @@
 //             lane registers
 #pragma once
 #include "common.hip.h"
+#include <type_traits>
 
 struct TableView {
-  const HotEntry *ent;         // [E] sorted by key, insertion order inside a bucket
+  const HotHead *head;         // [E] sorted by key, insertion order inside a bucket
+  const HotTail *tail;         // [E] same order
   const HashSlot *hash;
   u32 hash_mask;
   u32 n_entries;
@@ -68,7 +70,12 @@ struct ProbeBuffers {
 #define SGTD_PROBE_CHUNK 128    // query descriptors per work item = per assemble block
 #define SGTD_REC_SLAB 2048u     // match records a wave takes from the global cursor at once
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
+#ifndef SGTD_PROBE_UNROLL
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
+#endif
+#ifndef SGTD_BSEARCH_BELOW
+#define SGTD_BSEARCH_BELOW 1024u  // visit lists shorter than this locate cells by binary search
+#endif
 
 // ---------------------------------------------------------------------------
 // resolve: STDesc.cpp:358-371 for every (query descriptor, cell) pair, one
@@ -174,7 +181,10 @@ __device__ __forceinline__ DescPlan plan_from_cell_row(const DescFetch &f) {
 
 // STDesc.cpp:372-399 for ONE query descriptor d by one wavefront: streams the
 // descriptor's visit list, tests, compacts the matches in (cell, j) order
-template <int VOTE, bool DIAG>
+// WIDE = false: the probe layout and the record buffer are each below 4 GB, so entry and
+// record addresses are a uniform base + a 32-bit byte offset (no quarter-rate 64-bit VALU
+// address arithmetic per entry); the host picks the variant from the buffer sizes
+template <int VOTE, bool DIAG, bool WIDE = true>
 __device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
                                                  long long d, const DescFetch &f, const DescPlan &pl,
                                                  WaveSlab &slab, u32 *s_hist, u32 *votes) {
@@ -200,59 +210,96 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
 
   u32 matches = 0;
   const u32 n_words = (total + 63u) >> 6;
-  // per-lane cursor: a lane's positions grow by 64 per word, so the cell that holds its
-  // position only moves forward; off[cl+1] and dl[cl] come from the row registers by
-  // ds_bpermute (no memory, no scalar loop)
-  int cl = 0;
-  u32 nxt_off = (u32)__shfl((int)pl.off, 1);
+  // position -> cell, the last c with off[c] <= pos (empty cells share their successor's
+  // offset and are stepped over), read from the row registers by ds_bpermute — no memory.
+  // Two forms, chosen per descriptor (wave-uniform):
+  //  * short lists (many cell boundaries per 64-entry word): branch-free binary search over
+  //    the 32 offsets in lanes 0..31 (off[27..31] = total), five permutes per word;
+  //  * long lists (about one boundary per word): a per-lane cursor that only moves forward,
+  //    one permute per boundary crossed.
+  // All lanes execute the permutes (sources must be active).
   // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
   // issued before the first use so that several KB per wave are in flight
-  for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
-    double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
-    int cell[SGTD_PROBE_UNROLL];
-    bool valid[SGTD_PROBE_UNROLL];
+  auto run = [&](auto bsearch_tag) {
+    constexpr bool BSEARCH = decltype(bsearch_tag)::value;
+    u32 cur4 = 0;   // cursor form: 4 * cell = ds_bpermute byte address
+    u32 nxt_off = BSEARCH ? 0u : (u32)__builtin_amdgcn_ds_bpermute(4, (int)pl.off);
+    for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
+      double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
+      int cell[SGTD_PROBE_UNROLL];
+      bool valid[SGTD_PROBE_UNROLL];
 #pragma unroll
-    for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-      const u32 pos = ((w0 + u) << 6) + lane;
-      valid[u] = pos < total;
-      // the last cell with off[c] <= pos (empty cells are stepped over); off[27] = total stops it
-      while (__ballot(valid[u] && pos >= nxt_off)) {
-        if (valid[u] && pos >= nxt_off) cl++;
-        nxt_off = (u32)__shfl((int)pl.off, cl + 1);
-      }
-      cell[u] = cl;
-      const u32 dsel = (u32)__shfl((int)dl, cl);     // all lanes execute the permute (sources must be active)
-      const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
-      const double2 *p = reinterpret_cast<const double2 *>(T.ent + e);
-      v01[u] = p[0];          // s0, s1
-      v2x[u] = p[1];          // s2, {frame, g}
-    }
+      for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+        const u32 pos = ((w0 + u) << 6) + lane;
+        valid[u] = pos < total;
+        u32 c4;
+        if constexpr (BSEARCH) {
+          c4 = 0;
 #pragma unroll
-    for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-      if (w0 + u < n_words) {   // wave-uniform
-        const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
-        const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
-        const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
-        const u32 fr = (u32)fg;
-        // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-        bool hit;
-        double dis = 0.0;
-        if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
-        else hit = valid[u] && (qframe != fr) && (d2 < thr2);
-        if (hit) {                                                      // :410
-          if (VOTE == SGTD_VOTE_LDS) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
-          if (VOTE == SGTD_VOTE_GLOBAL) atomicAdd(&votes[fr - T.frame_lo], 1u);
+          for (int s = 64; s >= 4; s >>= 1) {
+            const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)s), (int)pl.off);
+            c4 += (t <= pos) ? (u32)s : 0u;
+          }
+        } else {
+          while (__ballot(valid[u] && pos >= nxt_off)) {   // off[27] = total stops it
+            cur4 += (valid[u] && pos >= nxt_off) ? 4u : 0u;
+            nxt_off = (u32)__builtin_amdgcn_ds_bpermute((int)(cur4 + 4u), (int)pl.off);
+          }
+          c4 = cur4;
         }
-        const u64 m = __ballot(hit);
-        if (hit && fits) {
-          const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
-          B.rec[o] = (fg << 32) | (fg >> 32);   // frame << 32 | g
-          if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
+        cell[u] = (int)(c4 >> 2);
+        const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
+#ifdef SGTD_EXP_MASK
+        const u32 e = valid[u] ? ((pos + dsel) & SGTD_EXP_MASK) : 0u;
+#else
+        const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
+#endif
+        const double2 *pa = WIDE ? reinterpret_cast<const double2 *>(T.head + e)
+                                 : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.head) + (e << 4));
+        const double2 *pb = WIDE ? reinterpret_cast<const double2 *>(T.tail + e)
+                                 : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.tail) + (e << 4));
+#ifdef SGTD_EXP_NOLOAD
+        v01[u] = make_double2((double)e, q1); v2x[u] = make_double2(q2, __longlong_as_double((long long)e << 32 | (e & 1023)));
+        (void)pa; (void)pb;
+#else
+        v01[u] = *pa;           // s0, s1
+        v2x[u] = *pb;           // s2, {frame, g}
+#endif
+      }
+#pragma unroll
+      for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+        if (w0 + u < n_words) {   // wave-uniform
+          const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
+          const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
+          const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
+          const u32 fr = (u32)fg;
+          // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
+          bool hit;
+          double dis = 0.0;
+          if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
+          else hit = valid[u] && (qframe != fr) && (d2 < thr2);
+          if (hit) {                                                      // :410
+            if (VOTE == SGTD_VOTE_LDS) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
+            if (VOTE == SGTD_VOTE_GLOBAL) atomicAdd(&votes[fr - T.frame_lo], 1u);
+          }
+          const u64 m = __ballot(hit);
+          if (hit && fits) {
+            const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
+#ifndef SGTD_EXP_NOSTORE
+            u64 *dst = WIDE ? B.rec + o : reinterpret_cast<u64 *>(reinterpret_cast<char *>(B.rec) + (o << 3));
+            *dst = (fg << 32) | (fg >> 32);   // frame << 32 | g
+#else
+            if (o == 0xFFFFFFFFu) B.rec[o] = fg;
+#endif
+            if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
+          }
+          matches += __popcll(m);
         }
-        matches += __popcll(m);
       }
     }
-  }
+  };
+  if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
+  else run(std::false_type{});
   if (lane == 0) {
     B.list_ptr[d] = slab.next;
     B.n_visit[d] = total;
@@ -448,8 +495,11 @@ __device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
   return pl;
 }
 
-template <bool DIAG>
-__global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableView T, QueryView Q,
+#ifndef SGTD_SWEEP_OCC
+#define SGTD_SWEEP_OCC
+#endif
+template <bool DIAG, bool WIDE>
+__global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorted_kernel(TableView T, QueryView Q,
                                                                           ProbeBuffers B, const CellRow *rows,
                                                                           const u32 *gid,
                                                                           double rough, const u32 *order,
@@ -467,8 +517,15 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableV
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
   WaveSlab slab{0, 0};
+#ifdef SGTD_EXP_TRACE
+  const u64 tr_t0 = wall_clock64();
+  u64 tr_own = 0; u32 tr_n_own = 0, tr_n_st = 0;
+#endif
   // own eighth first, then help the other XCDs (their ranges lose locality but keep the chip busy)
   for (u32 t = 0; t < 8; t++) {
+#ifdef SGTD_EXP_TRACE
+    if (t == 1) tr_own = wall_clock64();
+#endif
     const u32 x = (xcc + t) & 7u;
     const u32 c_lo = (u32)(((u64)n_chunks * x) >> 3), c_hi = (u32)(((u64)n_chunks * (x + 1)) >> 3);
     u32 ticket = 0;
@@ -478,6 +535,9 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableV
       if (lane == 0) ticket = atomicAdd(&xcd_heads[x * 1024u], 1u);   // in flight during this chunk
       const u32 p_first = cur_c * chunk;
       const u32 p_last = min(p_first + chunk, n_valid);
+#ifdef SGTD_EXP_TRACE
+      if (t == 0) tr_n_own += p_last - p_first; else tr_n_st += p_last - p_first;
+#endif
       // lane j holds the slot of position p_first + j
       const u32 ord = (p_first + (u32)lane < p_last) ? order[p_first + lane] : 0u;
       DescFetch nxt = fetch_desc_group(Q, rows, gid, (long long)p_first, (long long)__shfl(ord, 0));
@@ -486,11 +546,18 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(TableV
         const long long d = (long long)__shfl(ord, (int)(p - p_first));
         if (p + 1 < p_last)   // the next descriptor's loads are in flight during this sweep
           nxt = fetch_desc_group(Q, rows, gid, (long long)p + 1, (long long)__shfl(ord, (int)(p + 1 - p_first)));
-        sweep_descriptor<SGTD_VOTE_NONE, DIAG>(T, B, rough, d, cur, plan_from_group_row(cur), slab, nullptr, nullptr);
+        sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, cur, plan_from_group_row(cur), slab, nullptr, nullptr);
       }
       cur_c = c_lo + (u32)__builtin_amdgcn_readfirstlane((int)ticket);
     }
   }
+#ifdef SGTD_EXP_TRACE
+  if (lane == 0) {
+    u64 *tr = reinterpret_cast<u64 *>(xcd_heads + 8 * 1024) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    tr[0] = tr_t0; tr[1] = tr_own; tr[2] = wall_clock64();
+    tr[3] = ((u64)xcc << 56) | ((u64)tr_n_own << 28) | (u64)tr_n_st;
+  }
+#endif
 }
 
 // votes (:404-420) from the match lists: one wavefront per 128-descriptor block,
@@ -682,6 +749,36 @@ __device__ __forceinline__ void sub_locate(const u32 *s_pre, const u32 *s_ptr, u
   addr = s_ptr[c] + (r - s_pre[c]);
 }
 
+// frame -> candidate slot of one query as an LDS open-addressing table (cand_num <= 64
+// frames in 256 slots): the assemble kernels look every match record up here instead of in
+// the per-frame slot_of array in global memory — no dependent global load per record, and
+// the LDS footprint does not grow with the number of map frames.  Entry = frame << 8 | slot.
+#define SGTD_CAND_HASH 256
+#define SGTD_CAND_EMPTY 0xFFFFFFFFFFFFFFFFull
+// all 256 threads of the workgroup (blockDim.x == SGTD_CAND_HASH)
+__device__ __forceinline__ void cand_hash_build(u64 *s_tab, const int *n_cand, const int *cand_frame, int q,
+                                                int n_queries, int cand_num) {
+  s_tab[threadIdx.x] = SGTD_CAND_EMPTY;
+  __syncthreads();
+  const int s = (int)threadIdx.x;
+  if (q < n_queries && s < cand_num && s < n_cand[q]) {
+    const u32 f = (u32)cand_frame[(size_t)q * cand_num + s];
+    u32 h = (f * 0x9E3779B1u) >> 24;
+    while (atomicCAS(&s_tab[h], SGTD_CAND_EMPTY, ((u64)f << 8) | (u64)s) != SGTD_CAND_EMPTY) h = (h + 1) & (SGTD_CAND_HASH - 1);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ u32 cand_slot(const u64 *s_tab, u32 frame) {
+  u32 h = (frame * 0x9E3779B1u) >> 24;
+  while (true) {
+    const u64 e = s_tab[h];
+    if (e == SGTD_CAND_EMPTY) return 0xFFu;
+    if ((u32)(e >> 8) == frame) return (u32)e & 0xFFu;
+    h = (h + 1) & (SGTD_CAND_HASH - 1);
+  }
+}
+
 template <bool LDS_VOTES>
 __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B, u32 frame_span, u32 frame_lo,
                                                     int blocks_per_query, u32 *q_M, unsigned long long *q_P) {
@@ -741,24 +838,25 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
 
 // pass 1: blk_count[(q*blocks+blk)*64 + s] = matches of the block in slot s;
 // also the per-query sums of visited entries / matches for the statistics
-__global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuffers B,
-                                                          const unsigned char *slot_of_all, u32 frame_span,
-                                                          u32 frame_lo, int blocks_per_query, u32 *blk_count,
+__global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
+                                                          const int *cand_frame, int cand_num,
+                                                          int blocks_per_query, u32 *blk_count,
                                                           u32 *q_M, unsigned long long *q_P) {
   constexpr int NW = 256 / SGTD_WAVE;
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
   __shared__ u32 s_hist[NW][64];
+  __shared__ u64 s_cand[SGTD_CAND_HASH];
   if (B.overflow[0]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
-  if (!id.valid) return;
   const int q = id.q;
+  cand_hash_build(s_cand, n_cand, cand_frame, q, Q.n_queries, cand_num);
+  if (!id.valid) return;
   const u32 cnt = Q.count[q];
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   u32 *out = blk_count + ((size_t)q * blocks_per_query + id.blk) * 64;
   if (d_first >= cnt) { out[lane] = 0; return; }
-  const unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
   s_hist[wid][lane] = 0;
   u32 visits = 0, total = 0;
   for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
@@ -774,12 +872,11 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
         sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
         fr[u] = (u32)(B.rec[addr] >> 32);
       }
-      unsigned char sl[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) sl[u] = ok[u] ? slot_of[fr[u] - frame_lo] : (unsigned char)0xFF;
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (sl[u] != 0xFF) atomicAdd(&s_hist[wid][sl[u]], 1u);   // counting needs no order
+      for (int u = 0; u < 4; u++) {
+        const u32 sl = ok[u] ? cand_slot(s_cand, fr[u]) : 0xFFu;
+        if (sl != 0xFFu) atomicAdd(&s_hist[wid][sl], 1u);   // counting needs no order
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -846,9 +943,8 @@ __global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32
 
 // pass 2: every candidate's match_list_ in (i, cell, j) order (:437-449);
 // pair = query descriptor index << 32 | insertion index of the table entry
-__global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuffers B,
-                                                          const unsigned char *slot_of_all, u32 frame_span,
-                                                          u32 frame_lo, int blocks_per_query,
+__global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
+                                                          const int *cand_frame, int blocks_per_query,
                                                           const u32 *blk_excl, int cand_num,
                                                           const long long *pair_off, const u32 *q_pair_base,
                                                           u64 *pairs) {
@@ -857,16 +953,17 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
   __shared__ u32 s_cnt[NW][64];
+  __shared__ u64 s_cand[SGTD_CAND_HASH];
   __shared__ u64 s_stage[NW][64][CAP];   // per wave and slot: pairs waiting for a full-line store
   if (B.overflow[0] || B.overflow[1]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
-  if (!id.valid) return;
   const int q = id.q;
+  cand_hash_build(s_cand, n_cand, cand_frame, q, Q.n_queries, cand_num);
+  if (!id.valid) return;
   const u32 cnt = Q.count[q];
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (d_first >= cnt) return;
-  const unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
   // lane s carries, for candidate slot s, the output position of its first staged
   // pair (`running`) and the number of staged pairs (`fill`)
   u32 running = 0, fill = 0;
@@ -888,24 +985,29 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   u32 visits = 0;
   for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
     const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
-    for (u32 r0 = 0; r0 < R; r0 += 2 * SGTD_WAVE) {
-      u64 rec[2]; u32 dd[2]; bool ok[2];
+    // the records of the next two words are loaded while the current two are split
+    u64 nrec[2]; u32 ndd[2];
+    auto load2 = [&](u32 r0) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const u32 r = r0 + u * SGTD_WAVE + lane;
-        ok[u] = r < R;
         u32 addr;
-        sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd[u], addr);
-        rec[u] = B.rec[addr];
+        sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, ndd[u], addr);
+        nrec[u] = B.rec[addr];
       }
-      unsigned char sl[2];
+    };
+    if (R) load2(0);
+    for (u32 r0 = 0; r0 < R; r0 += 2 * SGTD_WAVE) {
+      u64 rec[2]; u32 dd[2];
 #pragma unroll
-      for (int u = 0; u < 2; u++)
-        sl[u] = ok[u] ? slot_of[(u32)(rec[u] >> 32) - frame_lo] : (unsigned char)0xFF;
+      for (int u = 0; u < 2; u++) { rec[u] = nrec[u]; dd[u] = ndd[u]; }
+      if (r0 + 2 * SGTD_WAVE < R) load2(r0 + 2 * SGTD_WAVE);
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const bool valid = sl[u] != 0xFF;
-        const int s = (int)(sl[u] & 63u);
+        const bool ok = r0 + u * SGTD_WAVE + lane < R;
+        const u32 sl = ok ? cand_slot(s_cand, (u32)(rec[u] >> 32)) : 0xFFu;
+        const bool valid = sl != 0xFFu;
+        const int s = (int)(sl & 63u);
         u32 rank, count;
         wave_group_rank<6>((u32)s, valid, rank, count);
         u32 have = __shfl(fill, s);

@@ -62,7 +62,7 @@ struct sgtd_engine {
   bool finalized = false;  // the first query builds the (possibly empty) bucket directory
 
   // ---- table, probe layout (hot)
-  DevBuf hot, perm, hash, bucket_start, bucket_key;   // hot: HotEntry[E], 32 B per entry
+  DevBuf hot, perm, hash, bucket_start, bucket_key;   // hot: HotHead[E] then HotTail[E], 32 B per entry
   u32 hash_mask = 0;
   int64_t n_buckets = 0;
   // sort scratch
@@ -361,11 +361,12 @@ int do_finalize(sgtd_engine *e) {
     std::swap(vin, vout);
   }
   // probe layout: one 32-B record per entry in sorted order
-  CHK(ensure(e, e->hot, (size_t)E * sizeof(HotEntry)));
+  CHK(ensure(e, e->hot, (size_t)E * SGTD_HOT_BYTES));
   CHK(ensure(e, e->perm, (size_t)E * sizeof(u32)));
   HIPCHK(hipMemcpyAsync(e->perm.p, vin, (size_t)E * sizeof(u32), hipMemcpyDeviceToDevice, e->stream));
   gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->perm.as<u32>(), e->tab.side.as<double>(),
-                                                              e->tab.frame.as<u32>(), e->hot.as<HotEntry>(), E);
+                                                              e->tab.frame.as<u32>(), e->hot.as<HotHead>(),
+                                                              reinterpret_cast<HotTail *>(e->hot.as<HotHead>() + E), E);
   HIPCHK(hipGetLastError());
   // buckets
   CHK(ensure(e, e->flags, (size_t)E * sizeof(u32)));
@@ -421,7 +422,8 @@ Views make_views(sgtd_engine *e) {
   Views v;
   v.span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   TableView &T = v.T;
-  T.ent = e->hot.as<HotEntry>();
+  T.head = e->hot.as<HotHead>();
+  T.tail = reinterpret_cast<const HotTail *>(T.head + e->n_entries);
   T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
   T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
   QueryView &Q = v.Q;
@@ -491,7 +493,11 @@ int launch_select(sgtd_engine *e) {
     CHK(ensure(e, e->valB, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->gid, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->n_valid, sizeof(u32)));
+#ifdef SGTD_EXP_TRACE
+    CHK(ensure(e, e->xcd_heads, 8 * 1024 * sizeof(u32) + (size_t)e->n_cus * 8 * 4 * 32));
+#else
     CHK(ensure(e, e->xcd_heads, 8 * 1024 * sizeof(u32)));
+#endif
     const int nb = (int)((n_slots + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
     CHK(ensure(e, e->hist, (size_t)256 * nb * sizeof(u32)));
     u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
@@ -539,12 +545,47 @@ int launch_select(sgtd_engine *e) {
     if (e->sorted_chunk > 0) chunk = (u32)std::min(64, e->sorted_chunk);
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
     const int sgrid = e->n_cus * 8;
-    if (e->diag)
-      probe_sorted_kernel<true><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->gid.as<u32>(), e->dc.rough, vin,
-                                                                              e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk);
-    else
-      probe_sorted_kernel<false><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->gid.as<u32>(), e->dc.rough, vin,
-                                                                               e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk);
+    // 32-bit byte offsets when both the probe layout and the record buffer stay below 4 GB
+    const bool narrow = (unsigned long long)v.T.n_entries * sizeof(HotHead) < (1ull << 32) &&
+                        (unsigned long long)v.B.rec_cap * sizeof(u64) < (1ull << 32);
+#define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
+  probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
+      v.T, v.Q, v.B, rows, e->gid.as<u32>(), e->dc.rough, vin, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
+    if (e->diag) SGTD_LAUNCH_SORTED(true, true);
+    else if (narrow) SGTD_LAUNCH_SORTED(false, false);
+    else SGTD_LAUNCH_SORTED(false, true);
+#undef SGTD_LAUNCH_SORTED
+#ifdef SGTD_EXP_TRACE
+    {
+      static int calls = 0;
+      if (++calls == 3) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const size_t nw = (size_t)sgrid * 4;
+        std::vector<u64> tr(nw * 4);
+        HIPCHK(hipMemcpy(tr.data(), (char *)e->xcd_heads.p + 8 * 1024 * sizeof(u32), nw * 32, hipMemcpyDeviceToHost));
+        u64 t0 = ~0ull, t1 = 0;
+        for (size_t w = 0; w < nw; w++) { t0 = std::min(t0, tr[w * 4]); t1 = std::max(t1, tr[w * 4 + 2]); }
+        fprintf(stderr, "TRACE kernel span %.1f us (100 MHz ticks), chunk %u\n", (t1 - t0) / 100.0, chunk);
+        for (int x = 0; x < 8; x++) {
+          double own_max = 0, own_min = 1e30, end_max = 0, end_min = 1e30, start_max = 0; u64 n_own = 0, n_st = 0; int cnt = 0, late = 0;
+          double busy = 0;
+          for (size_t w = 0; w < nw; w++) {
+            if ((int)(tr[w * 4 + 3] >> 56) != x) continue;
+            cnt++;
+            const double s = (tr[w * 4] - t0) / 100.0, o = (tr[w * 4 + 1] - t0) / 100.0, en = (tr[w * 4 + 2] - t0) / 100.0;
+            if (s > 100.0) late++;
+            start_max = std::max(start_max, s);
+            if (s <= 100.0) { own_max = std::max(own_max, o); own_min = std::min(own_min, o); }
+            end_max = std::max(end_max, en); end_min = std::min(end_min, en);
+            n_own += (tr[w * 4 + 3] >> 28) & 0xFFFFFFF; n_st += tr[w * 4 + 3] & 0xFFFFFFF;
+            busy += en - s;
+          }
+          fprintf(stderr, "  xcd %d: waves %d (late %d, last start %.0f us) own-queue done %.0f..%.0f us, end %.0f..%.0f us, descs own %llu stolen %llu, mean wave life %.0f us\n",
+                  x, cnt, late, start_max, own_min, own_max, end_min, end_max, (unsigned long long)n_own, (unsigned long long)n_st, busy / std::max(cnt, 1));
+        }
+      }
+    }
+#endif
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
     if (lds_votes) {
@@ -588,7 +629,7 @@ int launch_select(sgtd_engine *e) {
                                           e->slot_of.as<unsigned char>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
-  block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
+  block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
                                                     blocks, e->blk_count.as<u32>(),
                                                     e->key_major ? nullptr : e->q_M.as<u32>(),
                                                     e->key_major ? nullptr : e->q_P.as<unsigned long long>());
@@ -602,7 +643,7 @@ int launch_select(sgtd_engine *e) {
                                                (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
-  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->slot_of.as<unsigned char>(), span, v.T.frame_lo,
+  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(),
                                                     blocks, e->blk_count.as<u32>(), cn,
                                                     e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
                                                     e->pairs.as<u64>());
@@ -1118,7 +1159,7 @@ int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
   e->stats.n_entries = e->n_entries;
   e->stats.n_buckets = e->n_buckets;
   e->stats.n_frames = e->n_add_calls;
-  e->stats.hbm_bytes_table = e->n_entries * (int64_t)sizeof(HotEntry);
+  e->stats.hbm_bytes_table = e->n_entries * (int64_t)SGTD_HOT_BYTES;
   *out = e->stats;
   return SGTD_OK;
 }

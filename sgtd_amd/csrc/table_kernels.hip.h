@@ -175,17 +175,19 @@ __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
 // gather hot arrays + bucket heads + hash insert
 // ---------------------------------------------------------------------------
 __global__ void gather_hot_kernel(const u32 *perm, const double *side, const u32 *frame,
-                                  HotEntry *hot, long long n) {
+                                  HotHead *head, HotTail *tail, long long n) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const u32 g = perm[p];
-  HotEntry h;
+  HotHead h;
+  HotTail t;
   h.s0 = side[(size_t)g * 3 + 0];
   h.s1 = side[(size_t)g * 3 + 1];
-  h.s2 = side[(size_t)g * 3 + 2];
-  h.frame = frame[g];
-  h.g = g;
-  hot[p] = h;
+  t.s2 = side[(size_t)g * 3 + 2];
+  t.frame = frame[g];
+  t.g = g;
+  head[p] = h;
+  tail[p] = t;
 }
 
 // squared thresholds for caller-provided query descriptors
