@@ -426,15 +426,30 @@ __global__ void group_heads_kernel(const u64 *keys, const u32 *n_valid_p, u32 *f
   flags[p] = head;
 }
 
-// first sorted position of every group and the number of groups
-__global__ void group_first_kernel(const u32 *gid, const u32 *n_valid_p, u32 *group_first, u32 *n_groups,
-                                   long long n) {
+// What the sweep needs about the descriptor at sorted position p, gathered into one 64-B
+// record so that a wavefront loads a whole ticket of descriptors with ONE 16-B-per-lane load
+// (lane j = quarter j & 3 of descriptor j >> 2) and reads the fields out with v_readlane:
+//   quarter 0: q0, q1   quarter 1: q2, thr2   quarter 2: frame, gate mask, group id, slot d
+struct __attribute__((aligned(64))) SortedDesc {
+  double q0, q1, q2, thr2;
+  u32 qframe, gate, gid, d;
+  u32 pad[4];
+};
+
+// sorted records + first sorted position of every group + the number of groups
+__global__ void sorted_desc_kernel(QueryView Q, const u32 *order, const u32 *gid, const u32 *n_valid_p,
+                                   SortedDesc *out, u32 *group_first, u32 *n_groups, long long n) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long nv = (long long)*n_valid_p;
   if (p >= n || p >= nv) return;
   const u32 g = gid[p];
   if (p == 0 || gid[p - 1] != g) group_first[g] = (u32)p;
   if (p == nv - 1) *n_groups = g + 1;
+  const long long d = (long long)order[p];
+  double2 *o = reinterpret_cast<double2 *>(out + p);
+  o[0] = make_double2(Q.side[d * 3 + 0], Q.side[d * 3 + 1]);
+  o[1] = make_double2(Q.side[d * 3 + 2], Q.thr2[d]);
+  reinterpret_cast<uint4 *>(o)[2] = make_uint4(Q.frame[d], Q.gate[d], g, (u32)d);
 }
 
 // One GroupRow per home cell of the batch: the 27 ungated bucket lookups (STDesc.cpp:358-371
@@ -470,19 +485,6 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
   }
 }
 
-// loads for the descriptor at sorted position p (slot d): its group's GroupRow (lane l = word l:
-// start[0..31], len[0..31]), its gate mask, its sides.
-__device__ __forceinline__ DescFetch fetch_desc_group(const QueryView &Q, const CellRow *group_rows,
-                                                      const u32 *gid, long long p, long long d) {
-  DescFetch f;
-  f.row = reinterpret_cast<const u32 *>(group_rows + gid[p])[lane_id()];
-  f.q0 = Q.side[d * 3 + 0]; f.q1 = Q.side[d * 3 + 1]; f.q2 = Q.side[d * 3 + 2];
-  f.thr2 = Q.thr2[d];
-  f.qframe = Q.frame[d];
-  f.gate = Q.gate[d];
-  return f;
-}
-
 // GroupRow + the descriptor's gate mask (:366-369): gated lengths, their exclusive scan
 __device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
   const int c = lane_id();
@@ -498,64 +500,114 @@ __device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
 #ifndef SGTD_SWEEP_OCC
 #define SGTD_SWEEP_OCC
 #endif
+#define SGTD_TICKET_MAX 16   // descriptors per ticket: 4 lanes each in one 64-lane load
+#define SGTD_NO_CHUNK 0xFFFFFFFFu
+
+// The per-XCD ticket queues of the key-major sweep: chunk ids [c_lo, c_hi) of queue x belong
+// to XCD x; a wave drains its own XCD's queue first, then helps the others (their ranges
+// lose locality but keep the chip busy).  Heads are 4 KB apart (own L2 channel each).
+struct TicketQueue {
+  u32 *heads;
+  u32 n_chunks, xcc;
+  u32 t, c_lo, c_hi;     // current queue = (xcc + t) & 7
+  __device__ __forceinline__ void select(u32 t_) {
+    t = t_;
+    const u32 x = (xcc + t) & 7u;
+    c_lo = (u32)(((u64)n_chunks * x) >> 3);
+    c_hi = (u32)(((u64)n_chunks * (x + 1)) >> 3);
+  }
+  // one ticket of the current queue, not waited for (lane 0 holds it)
+  __device__ __forceinline__ u32 issue() const {
+    u32 tk = 0;
+    if (t < 8 && lane_id() == 0) tk = atomicAdd(&heads[((xcc + t) & 7u) * 1024u], 1u);
+    return tk;
+  }
+  // ticket -> chunk id; moves on to the next queues (blocking) when this one is drained
+  __device__ __forceinline__ u32 resolve(u32 tk) {
+    while (t < 8) {
+      const u32 c = c_lo + (u32)__builtin_amdgcn_readfirstlane((int)tk);
+      if (c < c_hi) return c;
+      select(t + 1);
+      tk = issue();
+    }
+    return SGTD_NO_CHUNK;
+  }
+};
+
 template <bool DIAG, bool WIDE>
-__global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorted_kernel(TableView T, QueryView Q,
-                                                                          ProbeBuffers B, const CellRow *rows,
-                                                                          const u32 *gid,
-                                                                          double rough, const u32 *order,
-                                                                          const u32 *n_valid_p,
-                                                                          u32 *xcd_heads /*[8 * 1024]: one head per XCD, 4 KB apart (own L2 channel)*/,
-                                                                          u32 chunk /* 1..64 */) {
+__global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorted_kernel(
+    TableView T, ProbeBuffers B, const CellRow *rows, const SortedDesc *sorted, double rough,
+    const u32 *n_valid_p, u32 *xcd_heads /*[8 * 1024]*/, u32 chunk /* 1..SGTD_TICKET_MAX */) {
   const int lane = lane_id();
   const u32 n_valid = *n_valid_p;
-  // Every WAVE dequeues `chunk` consecutive positions at a time (no workgroup barrier;
-  // the next ticket is fetched while the current chunk is swept).  Small chunks keep
-  // the descriptors in flight on one XCD — and with them the buckets it is reading —
-  // within that XCD's 4 MB L2; the host sizes a ticket to about 2k entry visits.
-  const u32 n_chunks = (n_valid + chunk - 1) / chunk;
+  // Every WAVE dequeues `chunk` consecutive sorted positions at a time (no workgroup
+  // barrier).  Small chunks keep the descriptors in flight on one XCD — and with them the
+  // buckets it is reading — within that XCD's 4 MB L2; the host sizes a ticket to about 2k
+  // entry visits.  Software pipeline per wave: the ticket after next is in flight, the next
+  // ticket's descriptor records are in flight, the next descriptor's GroupRow is in flight
+  // while the current descriptor is swept.
+  TicketQueue tq;
+  tq.heads = xcd_heads;
+  tq.n_chunks = (n_valid + chunk - 1) / chunk;
   u32 xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  xcc &= 7u;
+  tq.xcc = xcc & 7u;
+  tq.select(0);
   WaveSlab slab{0, 0};
 #ifdef SGTD_EXP_TRACE
   const u64 tr_t0 = wall_clock64();
   u64 tr_own = 0; u32 tr_n_own = 0, tr_n_st = 0;
 #endif
-  // own eighth first, then help the other XCDs (their ranges lose locality but keep the chip busy)
-  for (u32 t = 0; t < 8; t++) {
+  // lane j loads quarter j & 3 of descriptor j >> 2 of the chunk
+  auto load_chunk = [&](u32 c) {
+    const u32 p = c * chunk + ((u32)lane >> 2);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (c != SGTD_NO_CHUNK && ((u32)lane >> 2) < chunk && p < n_valid)
+      r = reinterpret_cast<const uint4 *>(sorted + p)[lane & 3];
+    return r;
+  };
+  auto load_row = [&](u32 g) { return reinterpret_cast<const u32 *>(rows + g)[lane]; };
+
+  u32 cur_c = tq.resolve(tq.issue());
+  uint4 rec = load_chunk(cur_c);
+  u32 tk_next = tq.issue();
+  while (cur_c != SGTD_NO_CHUNK) {
+    const u32 nxt_c = tq.resolve(tk_next);        // requested one whole chunk ago
+    tk_next = tq.issue();                         // in flight during this chunk
+    const uint4 rec_next = load_chunk(nxt_c);     // in flight during this chunk
+    const u32 p_first = cur_c * chunk;
+    const u32 n = min(chunk, n_valid - p_first);
 #ifdef SGTD_EXP_TRACE
-    if (t == 1) tr_own = wall_clock64();
+    if (tq.t == 0) tr_n_own += n; else { if (!tr_own) tr_own = wall_clock64(); tr_n_st += n; }
 #endif
-    const u32 x = (xcc + t) & 7u;
-    const u32 c_lo = (u32)(((u64)n_chunks * x) >> 3), c_hi = (u32)(((u64)n_chunks * (x + 1)) >> 3);
-    u32 ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&xcd_heads[x * 1024u], 1u);
-    u32 cur_c = c_lo + (u32)__builtin_amdgcn_readfirstlane((int)ticket);
-    while (cur_c < c_hi) {
-      if (lane == 0) ticket = atomicAdd(&xcd_heads[x * 1024u], 1u);   // in flight during this chunk
-      const u32 p_first = cur_c * chunk;
-      const u32 p_last = min(p_first + chunk, n_valid);
-#ifdef SGTD_EXP_TRACE
-      if (t == 0) tr_n_own += p_last - p_first; else tr_n_st += p_last - p_first;
-#endif
-      // lane j holds the slot of position p_first + j
-      const u32 ord = (p_first + (u32)lane < p_last) ? order[p_first + lane] : 0u;
-      DescFetch nxt = fetch_desc_group(Q, rows, gid, (long long)p_first, (long long)__shfl(ord, 0));
-      for (u32 p = p_first; p < p_last; p++) {
-        const DescFetch cur = nxt;
-        const long long d = (long long)__shfl(ord, (int)(p - p_first));
-        if (p + 1 < p_last)   // the next descriptor's loads are in flight during this sweep
-          nxt = fetch_desc_group(Q, rows, gid, (long long)p + 1, (long long)__shfl(ord, (int)(p + 1 - p_first)));
-        sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, cur, plan_from_group_row(cur), slab, nullptr, nullptr);
+    u32 g_cur = (u32)__builtin_amdgcn_readlane((int)rec.z, 2);
+    u32 row_next = load_row(g_cur);
+    for (u32 i = 0; i < n; i++) {
+      DescFetch f;
+      f.row = row_next;
+      if (i + 1 < n) {   // the next descriptor's GroupRow (often the same one)
+        const u32 g1 = (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * i + 6));
+        if (g1 != g_cur) row_next = load_row(g1);
+        g_cur = g1;
       }
-      cur_c = c_lo + (u32)__builtin_amdgcn_readfirstlane((int)ticket);
+      const int l0 = (int)(4 * i);
+      f.q0 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0), __builtin_amdgcn_readlane((int)rec.x, l0));
+      f.q1 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0), __builtin_amdgcn_readlane((int)rec.z, l0));
+      f.q2 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0 + 1), __builtin_amdgcn_readlane((int)rec.x, l0 + 1));
+      f.thr2 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0 + 1), __builtin_amdgcn_readlane((int)rec.z, l0 + 1));
+      f.qframe = (u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 2);
+      f.gate = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
+      const long long d = (long long)(u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
+      sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, f, plan_from_group_row(f), slab, nullptr, nullptr);
     }
+    cur_c = nxt_c;
+    rec = rec_next;
   }
 #ifdef SGTD_EXP_TRACE
   if (lane == 0) {
     u64 *tr = reinterpret_cast<u64 *>(xcd_heads + 8 * 1024) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     tr[0] = tr_t0; tr[1] = tr_own; tr[2] = wall_clock64();
-    tr[3] = ((u64)xcc << 56) | ((u64)tr_n_own << 28) | (u64)tr_n_st;
+    tr[3] = ((u64)tq.xcc << 56) | ((u64)tr_n_own << 28) | (u64)tr_n_st;
   }
 #endif
 }

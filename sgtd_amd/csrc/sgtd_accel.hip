@@ -93,7 +93,7 @@ struct sgtd_engine {
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
   bool key_major = true;               // sweep in locality-key order (SGTD_PROBE_ORDER=query|key)
-  DevBuf n_valid, xcd_heads, cell_rows, gid, q_prefix, group_first, n_groups;
+  DevBuf n_valid, xcd_heads, cell_rows, gid, q_prefix, group_first, n_groups, sdesc;
   int sorted_chunk = 0;                // > 0: fixed descriptors per ticket (SGTD_SORTED_CHUNK), else adaptive
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
   // host copies after sync
@@ -528,8 +528,9 @@ int launch_select(sgtd_engine *e) {
     group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits);
     HIPCHK(hipGetLastError());
     CHK(device_scan(e, e->gid.as<u32>(), e->gid.as<u32>(), n_slots));
-    group_first_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), nv, e->group_first.as<u32>(),
-                                                                        e->n_groups.as<u32>(), n_slots);
+    CHK(ensure(e, e->sdesc, (size_t)n_slots * sizeof(SortedDesc)));
+    sorted_desc_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, vin, e->gid.as<u32>(), nv, e->sdesc.as<SortedDesc>(),
+                                                                        e->group_first.as<u32>(), e->n_groups.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
     group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(v.T, v.Q, vin, e->group_first.as<u32>(),
                                                                 e->n_groups.as<u32>(), nv, e->cell_rows.as<CellRow>());
@@ -542,7 +543,7 @@ int launch_select(sgtd_engine *e) {
       const double per_desc = (double)e->stats.last_P / (double)e->stats.last_D;
       chunk = (u32)std::min(8.0, std::max(1.0, std::floor(2048.0 / per_desc + 0.5)));
     }
-    if (e->sorted_chunk > 0) chunk = (u32)std::min(64, e->sorted_chunk);
+    if (e->sorted_chunk > 0) chunk = (u32)std::min(SGTD_TICKET_MAX, e->sorted_chunk);
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
     const int sgrid = e->n_cus * 8;
     // 32-bit byte offsets when both the probe layout and the record buffer stay below 4 GB
@@ -550,7 +551,7 @@ int launch_select(sgtd_engine *e) {
                         (unsigned long long)v.B.rec_cap * sizeof(u64) < (1ull << 32);
 #define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
   probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
-      v.T, v.Q, v.B, rows, e->gid.as<u32>(), e->dc.rough, vin, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
+      v.T, v.B, rows, e->sdesc.as<SortedDesc>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
     if (e->diag) SGTD_LAUNCH_SORTED(true, true);
     else if (narrow) SGTD_LAUNCH_SORTED(false, false);
     else SGTD_LAUNCH_SORTED(false, true);
@@ -811,7 +812,7 @@ int sgtd_destroy(sgtd_handle e) {
   DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->cursors, &e->list_ptr, &e->n_visit,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
