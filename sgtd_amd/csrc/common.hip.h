@@ -78,6 +78,20 @@ struct __attribute__((aligned(16))) HotTail {
 };
 #define SGTD_HOT_BYTES 32   // per entry, both halves
 
+// What the sweep needs about ONE query descriptor, 64 B: written per descriptor slot by the
+// build kernel (gid, d unset), and per sorted position by sorted_desc_kernel.  A wavefront
+// loads 16 of them with one 16-B-per-lane load (lane j = quarter j & 3 of record j >> 2):
+//   quarter 0: q0, q1   quarter 1: q2, thr2   quarter 2: frame, gate mask, group id, slot d
+struct __attribute__((aligned(64))) QueryRec {
+  double q0, q1, q2;  // side_length_ (scaled)
+  double thr2;        // exact squared match threshold (sq_threshold)
+  u32 qframe;         // frame_id_
+  u32 gate;           // 27-bit mask of the probe cells that pass the 1.5 gate (gate_mask)
+  u32 gid;            // key-major: group (home cell) of the descriptor
+  u32 d;              // key-major: descriptor slot
+  u32 pad[4];
+};
+
 // smallest y with sqrt_rn(y) >= thr:  (sqrt_rn(d2) < thr)  <=>  (d2 < y), because the
 // correctly rounded sqrt is monotone.  Lets the per-entry test of STDesc.cpp:374-378
 // compare squared distances bit-exactly, without a per-entry sqrt.

@@ -43,8 +43,7 @@ struct TableView {
 
 struct QueryView {
   const double *side;   // [n_slots*3]
-  const double *thr2;   // [n_slots] exact squared threshold of the descriptor
-  const u32 *gate;      // [n_slots] 27-bit mask of the cells that pass the 1.5 gate
+  const QueryRec *qrec; // [n_slots] sweep record of the descriptor (threshold, gate mask)
   const int *label;     // [n_slots*3]
   const u32 *frame;     // [n_slots]
   const u32 *count;     // [n_queries] descriptors per query
@@ -160,7 +159,7 @@ __device__ __forceinline__ DescFetch fetch_desc(const QueryView &Q, const CellRo
   DescFetch f;
   f.row = reinterpret_cast<const u32 *>(rows + p)[lane_id()];
   f.q0 = Q.side[d * 3 + 0]; f.q1 = Q.side[d * 3 + 1]; f.q2 = Q.side[d * 3 + 2];
-  f.thr2 = Q.thr2[d];
+  f.thr2 = Q.qrec[d].thr2;
   f.qframe = Q.frame[d];
   return f;
 }
@@ -426,30 +425,24 @@ __global__ void group_heads_kernel(const u64 *keys, const u32 *n_valid_p, u32 *f
   flags[p] = head;
 }
 
-// What the sweep needs about the descriptor at sorted position p, gathered into one 64-B
-// record so that a wavefront loads a whole ticket of descriptors with ONE 16-B-per-lane load
-// (lane j = quarter j & 3 of descriptor j >> 2) and reads the fields out with v_readlane:
-//   quarter 0: q0, q1   quarter 1: q2, thr2   quarter 2: frame, gate mask, group id, slot d
-struct __attribute__((aligned(64))) SortedDesc {
-  double q0, q1, q2, thr2;
-  u32 qframe, gate, gid, d;
-  u32 pad[4];
-};
-
-// sorted records + first sorted position of every group + the number of groups
+// sorted records + first sorted position of every group + the number of groups; four
+// threads per position, one 16-B quarter of the record each (coalesced 64-B reads, 1-KB writes)
 __global__ void sorted_desc_kernel(QueryView Q, const u32 *order, const u32 *gid, const u32 *n_valid_p,
-                                   SortedDesc *out, u32 *group_first, u32 *n_groups, long long n) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                   QueryRec *out, u32 *group_first, u32 *n_groups, long long n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long p = t >> 2;
+  const int qtr = (int)(t & 3);
   const long long nv = (long long)*n_valid_p;
   if (p >= n || p >= nv) return;
   const u32 g = gid[p];
-  if (p == 0 || gid[p - 1] != g) group_first[g] = (u32)p;
-  if (p == nv - 1) *n_groups = g + 1;
-  const long long d = (long long)order[p];
-  double2 *o = reinterpret_cast<double2 *>(out + p);
-  o[0] = make_double2(Q.side[d * 3 + 0], Q.side[d * 3 + 1]);
-  o[1] = make_double2(Q.side[d * 3 + 2], Q.thr2[d]);
-  reinterpret_cast<uint4 *>(o)[2] = make_uint4(Q.frame[d], Q.gate[d], g, (u32)d);
+  const u32 d = order[p];
+  uint4 v = reinterpret_cast<const uint4 *>(Q.qrec + d)[qtr];
+  if (qtr == 2) {
+    v.z = g; v.w = d;
+    if (p == 0 || gid[p - 1] != g) group_first[g] = (u32)p;
+    if (p == nv - 1) *n_groups = g + 1;
+  }
+  reinterpret_cast<uint4 *>(out + p)[qtr] = v;
 }
 
 // One GroupRow per home cell of the batch: the 27 ungated bucket lookups (STDesc.cpp:358-371
@@ -536,7 +529,7 @@ struct TicketQueue {
 
 template <bool DIAG, bool WIDE>
 __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorted_kernel(
-    TableView T, ProbeBuffers B, const CellRow *rows, const SortedDesc *sorted, double rough,
+    TableView T, ProbeBuffers B, const CellRow *rows, const QueryRec *sorted, double rough,
     const u32 *n_valid_p, u32 *xcd_heads /*[8 * 1024]*/, u32 chunk /* 1..SGTD_TICKET_MAX */) {
   const int lane = lane_id();
   const u32 n_valid = *n_valid_p;

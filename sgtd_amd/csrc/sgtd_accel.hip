@@ -25,7 +25,7 @@ struct DevBuf {
 };
 
 struct DescStore {
-  DevBuf side, angle, center, vertex, label, frame, node_id, thr2, gate;
+  DevBuf side, angle, center, vertex, label, frame, node_id, qrec;
   size_t cap = 0;
   bool with_thr2 = false;   // query descriptors carry their squared match threshold
   DescArrays view() const {
@@ -33,8 +33,7 @@ struct DescStore {
     a.side = side.as<double>(); a.angle = angle.as<double>(); a.center = center.as<double>();
     a.vertex = vertex.as<float>(); a.label = label.as<int>(); a.frame = frame.as<u32>();
     a.node_id = node_id.as<int>();
-    a.thr2 = with_thr2 ? thr2.as<double>() : nullptr;
-    a.gate = with_thr2 ? gate.as<u32>() : nullptr;
+    a.qrec = with_thr2 ? qrec.as<QueryRec>() : nullptr;
     return a;
   }
 };
@@ -145,8 +144,7 @@ int ensure_store(sgtd_engine *e, DescStore &s, size_t cap, bool keep = false) {
   CHK(ensure(e, s.label, want * 3 * sizeof(int), keep));
   CHK(ensure(e, s.frame, want * sizeof(u32), keep));
   CHK(ensure(e, s.node_id, want * 3 * sizeof(int), keep));
-  if (s.with_thr2) CHK(ensure(e, s.thr2, want * sizeof(double), keep));
-  if (s.with_thr2) CHK(ensure(e, s.gate, want * sizeof(u32), keep));
+  if (s.with_thr2) CHK(ensure(e, s.qrec, want * sizeof(QueryRec), keep));
   s.cap = want;
   return SGTD_OK;
 }
@@ -158,7 +156,7 @@ void free_buf(DevBuf &b) {
 }
 void free_store(DescStore &s) {
   free_buf(s.side); free_buf(s.angle); free_buf(s.center); free_buf(s.vertex);
-  free_buf(s.label); free_buf(s.frame); free_buf(s.node_id); free_buf(s.thr2); free_buf(s.gate);
+  free_buf(s.label); free_buf(s.frame); free_buf(s.node_id); free_buf(s.qrec);
   s.cap = 0;
 }
 
@@ -427,7 +425,7 @@ Views make_views(sgtd_engine *e) {
   T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
   T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
   QueryView &Q = v.Q;
-  Q.side = e->qd.side.as<double>(); Q.thr2 = e->qd.thr2.as<double>(); Q.gate = e->qd.gate.as<u32>();
+  Q.side = e->qd.side.as<double>(); Q.qrec = e->qd.qrec.as<QueryRec>();
   Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
   Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq;
   ProbeBuffers &B = v.B;
@@ -528,8 +526,8 @@ int launch_select(sgtd_engine *e) {
     group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits);
     HIPCHK(hipGetLastError());
     CHK(device_scan(e, e->gid.as<u32>(), e->gid.as<u32>(), n_slots));
-    CHK(ensure(e, e->sdesc, (size_t)n_slots * sizeof(SortedDesc)));
-    sorted_desc_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, vin, e->gid.as<u32>(), nv, e->sdesc.as<SortedDesc>(),
+    CHK(ensure(e, e->sdesc, (size_t)n_slots * sizeof(QueryRec)));
+    sorted_desc_kernel<<<grid_for(n_slots * 4, 256), 256, 0, e->stream>>>(v.Q, vin, e->gid.as<u32>(), nv, e->sdesc.as<QueryRec>(),
                                                                         e->group_first.as<u32>(), e->n_groups.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
     group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(v.T, v.Q, vin, e->group_first.as<u32>(),
@@ -551,7 +549,7 @@ int launch_select(sgtd_engine *e) {
                         (unsigned long long)v.B.rec_cap * sizeof(u64) < (1ull << 32);
 #define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
   probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
-      v.T, v.B, rows, e->sdesc.as<SortedDesc>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
+      v.T, v.B, rows, e->sdesc.as<QueryRec>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
     if (e->diag) SGTD_LAUNCH_SORTED(true, true);
     else if (narrow) SGTD_LAUNCH_SORTED(false, false);
     else SGTD_LAUNCH_SORTED(false, true);
@@ -965,7 +963,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
   if (nq > 0) {
-    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.thr2.as<double>(), e->qd.gate.as<u32>(), nq,
+    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.frame.as<u32>(), e->qd.qrec.as<QueryRec>(), nq,
                                                            e->dc.rough);
     HIPCHK(hipGetLastError());
   }

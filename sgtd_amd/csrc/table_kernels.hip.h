@@ -191,11 +191,14 @@ __global__ void gather_hot_kernel(const u32 *perm, const double *side, const u32
 }
 
 // squared thresholds for caller-provided query descriptors
-__global__ void thr2_kernel(const double *side, double *thr2, u32 *gate, long long n, double rough) {
+__global__ void thr2_kernel(const double *side, const u32 *frame, QueryRec *qrec, long long n, double rough) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  thr2[i] = sq_threshold(norm3(side[i * 3], side[i * 3 + 1], side[i * 3 + 2]) * rough);
-  gate[i] = gate_mask(side[i * 3], side[i * 3 + 1], side[i * 3 + 2]);
+  const double s0 = side[i * 3], s1 = side[i * 3 + 1], s2 = side[i * 3 + 2];
+  double2 *qr = reinterpret_cast<double2 *>(qrec + i);
+  qr[0] = make_double2(s0, s1);
+  qr[1] = make_double2(s2, sq_threshold(norm3(s0, s1, s2) * rough));
+  reinterpret_cast<uint4 *>(qr)[2] = make_uint4(frame[i], gate_mask(s0, s1, s2), 0u, 0u);
 }
 
 __global__ void head_flags_kernel(const u64 *keys, u32 *flags, long long n) {
