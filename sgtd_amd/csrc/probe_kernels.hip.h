@@ -52,7 +52,8 @@ struct QueryView {
 };
 
 struct ProbeBuffers {
-  u64 *rec;             // [rec_cap] match record: frame << 32 | insertion index
+  u32 *rec_frame;       // [rec_cap] match record, frame id (votes and counting read only this half)
+  u32 *rec_g;           // [rec_cap] match record, insertion index of the entry
   unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
@@ -285,10 +286,12 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
           if (hit && fits) {
             const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
 #ifndef SGTD_EXP_NOSTORE
-            u64 *dst = WIDE ? B.rec + o : reinterpret_cast<u64 *>(reinterpret_cast<char *>(B.rec) + (o << 3));
-            *dst = (fg << 32) | (fg >> 32);   // frame << 32 | g
+            u32 *df = WIDE ? B.rec_frame + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_frame) + (o << 2));
+            u32 *dg = WIDE ? B.rec_g + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_g) + (o << 2));
+            *df = fr;
+            *dg = (u32)(fg >> 32);
 #else
-            if (o == 0xFFFFFFFFu) B.rec[o] = fg;
+            if (o == 0xFFFFFFFFu) B.rec_g[o] = fr;
 #endif
             if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
           }
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
           ok[u] = r < R;
           u32 dd, addr;
           sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
-          fr[u] = (u32)(B.rec[addr] >> 32);
+          fr[u] = B.rec_frame[addr];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
         ok[u] = r < R;
         u32 dd, addr;
         sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
-        fr[u] = (u32)(B.rec[addr] >> 32);
+        fr[u] = B.rec_frame[addr];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
         const u32 r = r0 + u * SGTD_WAVE + lane;
         u32 addr;
         sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, ndd[u], addr);
-        nrec[u] = B.rec[addr];
+        nrec[u] = ((u64)B.rec_frame[addr] << 32) | (u64)B.rec_g[addr];
       }
     };
     if (R) load2(0);
@@ -1097,10 +1100,9 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
       const u32 p0 = B.list_ptr[d];
       for (u32 k = 0; k < n; k++) {
         const u32 o = carry + ex + k;
-        const u64 r = B.rec[p0 + k];
         out_qi[o] = i;
-        out_entry[o] = (u32)r;
-        out_frame[o] = (u32)(r >> 32);
+        out_entry[o] = B.rec_g[p0 + k];
+        out_frame[o] = B.rec_frame[p0 + k];
         if (out_cell) out_cell[o] = B.rec_cell[p0 + k];
         if (out_dis) out_dis[o] = B.rec_dis[p0 + k];
       }

@@ -429,9 +429,9 @@ Views make_views(sgtd_engine *e) {
   Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
   Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq;
   ProbeBuffers &B = v.B;
-  B.rec = e->rec.as<u64>();
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
+  B.rec_frame = e->rec.as<u32>(); B.rec_g = e->rec.as<u32>() + e->rec_cap;   // two halves of one allocation
   B.rec_cursor = e->cursors.as<u32>(); B.item_cursor = e->cursors.as<u32>() + 1;
   B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
   B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
@@ -546,7 +546,7 @@ int launch_select(sgtd_engine *e) {
     const int sgrid = e->n_cus * 8;
     // 32-bit byte offsets when both the probe layout and the record buffer stay below 4 GB
     const bool narrow = (unsigned long long)v.T.n_entries * sizeof(HotHead) < (1ull << 32) &&
-                        (unsigned long long)v.B.rec_cap * sizeof(u64) < (1ull << 32);
+                        (unsigned long long)v.B.rec_cap * sizeof(u32) < (1ull << 32);
 #define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
   probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
       v.T, v.B, rows, e->sdesc.as<QueryRec>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
