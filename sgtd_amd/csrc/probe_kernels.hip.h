@@ -68,7 +68,7 @@ struct ProbeBuffers {
 
 #define SGTD_PROBE_THREADS 256
 #define SGTD_PROBE_CHUNK 128    // query descriptors per work item = per assemble block
-#define SGTD_REC_SLAB 2048u     // match records a wave takes from the global cursor at once
+#define SGTD_REC_SLAB 8192u     // match records a wave takes from the global cursor at once
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
 #ifndef SGTD_PROBE_UNROLL
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
@@ -144,7 +144,18 @@ __global__ __launch_bounds__(SGTD_RESOLVE_THREADS) void resolve_kernel(TableView
 
 struct WaveSlab {
   u32 next, end;   // this wave's private range of match records
+#ifdef SGTD_EXP_PHASE
+  u64 ph[8];
+#endif
 };
+#ifdef SGTD_EXP_PHASE
+__device__ unsigned long long g_phase[8];
+#define PH_T() __builtin_readcyclecounter()
+#define PH_ADD(i, t0) do { const u64 _n = PH_T(); slab.ph[i] += _n - (t0); (t0) = _n; } while (0)
+#else
+#define PH_T() 0ull
+#define PH_ADD(i, t0) do { } while (0)
+#endif
 
 // what the sweep needs about one query descriptor; the loads are issued one descriptor
 // ahead (DescFetch), the per-lane plan is derived right before the sweep (plan_*)
@@ -195,6 +206,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   // lane c < 27 holds off[c] (lane 27: total = the sentinel off[27]); dl[c] = start[c] - off[c]
   const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_NCELL);
   const u32 dl = pl.dl;
+  u64 ph_t = PH_T(); (void)ph_t;
   // records of one descriptor are contiguous: make sure the slab can take
   // the worst case (every visited entry matches)
   if (total && slab.next + total > slab.end) {
@@ -207,6 +219,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   const bool fits = (unsigned long long)slab.next + total <= (unsigned long long)B.rec_cap;
   if (!fits && lane == 0) B.overflow[0] = 1;
   __builtin_amdgcn_wave_barrier();
+  PH_ADD(0, ph_t);
 
   u32 matches = 0;
   const u32 n_words = (total + 63u) >> 6;
@@ -228,6 +241,9 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
       double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
       int cell[SGTD_PROBE_UNROLL];
       bool valid[SGTD_PROBE_UNROLL];
+#ifdef SGTD_EXP_PHASE
+      u32 ee[SGTD_PROBE_UNROLL];
+#endif
 #pragma unroll
       for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
         const u32 pos = ((w0 + u) << 6) + lane;
@@ -249,23 +265,27 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
         }
         cell[u] = (int)(c4 >> 2);
         const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
-#ifdef SGTD_EXP_MASK
-        const u32 e = valid[u] ? ((pos + dsel) & SGTD_EXP_MASK) : 0u;
-#else
         const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
+#ifdef SGTD_EXP_PHASE
+        ee[u] = e;
+      }
+      PH_ADD(5, ph_t);
+#pragma unroll
+      for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+        const u32 e = ee[u];
 #endif
         const double2 *pa = WIDE ? reinterpret_cast<const double2 *>(T.head + e)
                                  : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.head) + (e << 4));
         const double2 *pb = WIDE ? reinterpret_cast<const double2 *>(T.tail + e)
                                  : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.tail) + (e << 4));
-#ifdef SGTD_EXP_NOLOAD
-        v01[u] = make_double2((double)e, q1); v2x[u] = make_double2(q2, __longlong_as_double((long long)e << 32 | (e & 1023)));
-        (void)pa; (void)pb;
-#else
         v01[u] = *pa;           // s0, s1
         v2x[u] = *pb;           // s2, {frame, g}
-#endif
       }
+#ifdef SGTD_EXP_PHASE
+      PH_ADD(1, ph_t);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+      PH_ADD(2, ph_t);
+#endif
 #pragma unroll
       for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
         if (w0 + u < n_words) {   // wave-uniform
@@ -285,19 +305,16 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
           const u64 m = __ballot(hit);
           if (hit && fits) {
             const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
-#ifndef SGTD_EXP_NOSTORE
             u32 *df = WIDE ? B.rec_frame + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_frame) + (o << 2));
             u32 *dg = WIDE ? B.rec_g + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_g) + (o << 2));
             *df = fr;
             *dg = (u32)(fg >> 32);
-#else
-            if (o == 0xFFFFFFFFu) B.rec_g[o] = fr;
-#endif
             if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
           }
           matches += __popcll(m);
         }
       }
+      PH_ADD(3, ph_t);
     }
   };
   if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
@@ -309,6 +326,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   }
   if (fits) slab.next += matches;
   __builtin_amdgcn_wave_barrier();
+  PH_ADD(4, ph_t);
 }
 
 // sweep, query-major: work item = (query, chunk of 128 of its descriptors),
@@ -550,6 +568,10 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
   tq.xcc = xcc & 7u;
   tq.select(0);
   WaveSlab slab{0, 0};
+#ifdef SGTD_EXP_PHASE
+  for (int i = 0; i < 8; i++) slab.ph[i] = 0;
+  const u64 ph_start = PH_T();
+#endif
 #ifdef SGTD_EXP_TRACE
   const u64 tr_t0 = wall_clock64();
   u64 tr_own = 0; u32 tr_n_own = 0, tr_n_st = 0;
@@ -599,6 +621,13 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
     cur_c = nxt_c;
     rec = rec_next;
   }
+#ifdef SGTD_EXP_PHASE
+  if (lane == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(&g_phase[i], slab.ph[i]);
+    atomicAdd(&g_phase[7], PH_T() - ph_start);
+    atomicAdd(&g_phase[6], 1ull);
+  }
+#endif
 #ifdef SGTD_EXP_TRACE
   if (lane == 0) {
     u64 *tr = reinterpret_cast<u64 *>(xcd_heads + 8 * 1024) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;

@@ -554,6 +554,20 @@ int launch_select(sgtd_engine *e) {
     else if (narrow) SGTD_LAUNCH_SORTED(false, false);
     else SGTD_LAUNCH_SORTED(false, true);
 #undef SGTD_LAUNCH_SORTED
+#ifdef SGTD_EXP_PHASE
+    {
+      static int pcalls = 0;
+      if (++pcalls == 6) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        unsigned long long ph[8];
+        HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)));
+        const double tot = (double)ph[7];
+        fprintf(stderr, "PHASE: slab %.3f locate %.3f issue %.3f wait %.3f compute %.3f tail %.3f outer %.3f (fractions of wave life)\n",
+                ph[0] / tot, ph[5] / tot, ph[1] / tot, ph[2] / tot, ph[3] / tot, ph[4] / tot,
+                (tot - ph[0] - ph[1] - ph[2] - ph[3] - ph[4] - ph[5]) / tot);
+      }
+    }
+#endif
 #ifdef SGTD_EXP_TRACE
     {
       static int calls = 0;
