@@ -245,6 +245,7 @@ def main():
                        "table_entries_this_rank": st["n_entries"], "table_buckets_this_rank": st["n_buckets"]},
             "roofline": {"bound": "hbm", "kernel": "probe_sorted_kernel (sweep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_GBps": (traffic / (kern_ms["ms_probe"] * 1e-3) / 1e9) if traffic and kern_ms["ms_probe"] > 0 else None,
                          "algorithmic_bytes_per_launch": probe_bytes,
                          "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
                          "kernel_ms": kern_ms},

@@ -44,10 +44,11 @@ def main():
     probe = [v for k, v in keep.items() if k.startswith("probe_kernel") or k.startswith("probe_sorted_kernel")]
     if probe and os.path.exists(b):
         cfg = json.loads(open(b).read().strip().splitlines()[-1])["config"]
+        names = [k for k in keep if k.startswith("probe_kernel") or k.startswith("probe_sorted_kernel")]
         p = probe[0]
         fetch_kb, write_kb = p.get("FETCH_SIZE", 0.0), p.get("WRITE_SIZE", 0.0)
         traffic = {"frames": cfg["map_frames"], "queries": cfg["queries_per_step"], "keypoints": cfg["keypoints_per_frame"],
-                   "gpus": 1, "kernel": "probe_kernel", "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+                   "gpus": 1, "kernel": names[0], "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                    "correction": "read bytes = 2 * FETCH_SIZE (gfx950 wide-load undercount), write bytes = WRITE_SIZE",
                    "bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
                    "TCC_HIT_sum": p.get("TCC_HIT_sum"), "TCC_MISS_sum": p.get("TCC_MISS_sum")}
