@@ -178,6 +178,29 @@ int sgtd_result_rough(sgtd_handle h, int q, int32_t *q_idx, int32_t *cell,
                       int64_t *db_entry, uint32_t *frame, double *dis,
                       int64_t capacity, int64_t *n_rough);
 
+/* ---- geometric verification of the candidates of the last batch ----
+ * STDescManager::candidate_verify + triangle_solver (STDesc.cpp:462-571) for every
+ * (query, candidate) of the batch, on the device: hypotheses = every skip_len-th pair of the
+ * candidate's match_list_ (:467-468), votes with the 3.0 inlier radius (:469-505), first
+ * maximum, >= 4 votes (:507-515), inliers of the best hypothesis (:516-539).
+ * The 3x3 solver is a one-sided Jacobi SVD, not Eigen::JacobiSVD (not available here):
+ * parity with the reference binary's SVD is unpinned (rotations agree to rounding, inlier
+ * sets can differ only for pairs within rounding of the 3.0 radius). */
+int sgtd_verify(sgtd_handle h);
+/* verify_score (inlier count, -1 = rejected, :539-541) and relative_pose of every candidate
+ * of query q: score[candidate_num], pose[candidate_num*12] = rot row-major (9) then t (3);
+ * entries past the query's candidate count hold -1 / zeros.  Either pointer may be NULL. */
+int sgtd_result_verify(sgtd_handle h, int q, double *score, double *pose);
+/* sucess_match_vec of (query q, candidate cand) as positions into that candidate's
+ * match_list_ (ascending = list order); capacity in elements, *n = needed */
+int sgtd_result_inliers(sgtd_handle h, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n);
+/* STDescManager::SearchLoop's choice (STDesc.cpp:105-146) for every query of the batch:
+ * the first candidate with the strictly largest verify_score, accepted if it exceeds
+ * icp_threshold; best_frame = -1 and best_score = 0 otherwise (loop_result (-1, 0)).
+ * Arrays of n_queries; any may be NULL.  Requires sgtd_verify. */
+int sgtd_search_loop(sgtd_handle h, double icp_threshold, int32_t *best_cand, int32_t *best_frame,
+                     double *best_score);
+
 /* table entries by insertion index (to rebuild pair<STDesc,STDesc>) */
 int sgtd_fetch_entries(sgtd_handle h, const int64_t *db_entry, int64_t n,
                        sgtd_desc_soa *out);

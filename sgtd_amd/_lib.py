@@ -24,6 +24,7 @@ SYMBOLS = [
     "sgtd_result_candidates", "sgtd_export_candidates_dev", "sgtd_result_query_desc_count", "sgtd_result_pairs",
     "sgtd_result_query_descs", "sgtd_result_votes", "sgtd_result_rough", "sgtd_fetch_entries",
     "sgtd_table_dump", "sgtd_sync", "sgtd_get_stats",
+    "sgtd_verify", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_search_loop",
 ]
 
 
@@ -119,6 +120,10 @@ def lib():
     L.sgtd_table_dump.argtypes = [vp, vp, vp, vp, i64, i64]
     L.sgtd_sync.argtypes = [vp]
     L.sgtd_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.sgtd_verify.argtypes = [vp]
+    L.sgtd_result_verify.argtypes = [vp, C.c_int, vp, vp]
+    L.sgtd_result_inliers.argtypes = [vp, C.c_int, C.c_int, vp, i64, C.POINTER(i64)]
+    L.sgtd_search_loop.argtypes = [vp, C.c_double, vp, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
         if getattr(L, name).restype is C.c_int:

@@ -15,6 +15,7 @@
 #include "common.hip.h"
 #include "table_kernels.hip.h"
 #include "probe_kernels.hip.h"
+#include "verify_kernels.hip.h"
 
 namespace {
 
@@ -88,6 +89,8 @@ struct sgtd_engine {
   DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
   DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
+  DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
+  bool verified = false;
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
@@ -663,6 +666,7 @@ int launch_select(sgtd_engine *e) {
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
   e->batch_valid = true;
+  e->verified = false;
   e->batch_synced = false;
   return SGTD_OK;
 }
@@ -824,7 +828,7 @@ int sgtd_destroy(sgtd_handle e) {
   DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->cursors, &e->list_ptr, &e->n_visit,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
@@ -1121,6 +1125,84 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
     if (db_entry) db_entry[i] = (int64_t)g[i];
     if (cell) cell[i] = c[i];
   }
+  return SGTD_OK;
+}
+
+int sgtd_verify(sgtd_handle e) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(sync_batch(e));
+  if (!e->batch_valid) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num, nq = e->nq;
+  if (nq == 0) { e->verified = true; return SGTD_OK; }
+  int64_t total = 0;
+  for (int q = 0; q < nq; q++) total = std::max<int64_t>(total, (int64_t)e->h_pair_base[q] + e->h_pair_off[(size_t)q * (cn + 1) + cn]);
+  CHK(ensure(e, e->v_score, (size_t)nq * cn * sizeof(double)));
+  CHK(ensure(e, e->v_pose, (size_t)nq * cn * 12 * sizeof(double)));
+  CHK(ensure(e, e->v_inlier, (size_t)std::max<int64_t>(total, 1)));
+  HIPCHK(hipMemsetAsync(e->v_pose.p, 0, (size_t)nq * cn * 12 * sizeof(double), e->stream));
+  VerifyParams P;
+  P.pairs = e->pairs.as<u64>(); P.pair_off = e->pair_off.as<long long>(); P.q_pair_base = e->q_pair_base.as<u32>();
+  P.n_cand = e->n_cand.as<int>(); P.cand_num = cn; P.q_stride = e->q_stride;
+  P.q_vertex = e->qd.vertex.as<float>(); P.q_center = e->qd.center.as<double>();
+  P.t_vertex = e->tab.vertex.as<float>(); P.t_center = e->tab.center.as<double>();
+  P.score = e->v_score.as<double>(); P.pose = e->v_pose.as<double>(); P.inlier = e->v_inlier.as<unsigned char>();
+  P.thr2 = 9.0;   // sqrt_rn(y) < 3.0 <=> y < 9.0 (sqrt(9) = 3, sqrt(pred(9)) rounds to pred(3)); dis_threshold :469
+  verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
+  HIPCHK(hipGetLastError());
+  e->verified = true;
+  return SGTD_OK;
+}
+
+int sgtd_result_verify(sgtd_handle e, int q, double *score, double *pose) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num;
+  if (score) HIPCHK(hipMemcpyAsync(score, e->v_score.as<double>() + (size_t)q * cn, cn * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (pose) HIPCHK(hipMemcpyAsync(pose, e->v_pose.as<double>() + (size_t)q * cn * 12, (size_t)cn * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SGTD_OK;
+}
+
+int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n) {
+  if (!e || !n) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num;
+  if (cand < 0 || cand >= e->h_n_cand[q]) return SGTD_ERR_INVALID;
+  const int64_t lo = e->h_pair_off[(size_t)q * (cn + 1) + cand], hi = e->h_pair_off[(size_t)q * (cn + 1) + cand + 1];
+  std::vector<unsigned char> fl((size_t)(hi - lo));
+  if (hi > lo) {
+    HIPCHK(hipMemcpyAsync(fl.data(), e->v_inlier.as<unsigned char>() + e->h_pair_base[q] + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  int64_t cnt = 0;
+  for (int64_t j = 0; j < hi - lo; j++)
+    if (fl[(size_t)j]) {
+      if (idx && cnt < capacity) idx[cnt] = (int32_t)j;
+      cnt++;
+    }
+  *n = cnt;
+  return (idx && cnt > capacity) ? SGTD_ERR_CAPACITY : SGTD_OK;
+}
+
+int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, int32_t *best_frame, double *best_score) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->verified || !e->batch_valid) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num, nq = e->nq;
+  if (nq == 0) return SGTD_OK;
+  CHK(ensure(e, e->v_best, (size_t)nq * (2 * sizeof(int) + sizeof(double))));
+  double *d_score = e->v_best.as<double>();
+  int *d_cand = reinterpret_cast<int *>(d_score + nq), *d_frame = d_cand + nq;
+  search_loop_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->v_score.as<double>(), e->cand_frame.as<int>(), e->n_cand.as<int>(), cn, nq,
+                                                               icp_threshold, d_cand, d_frame, d_score);
+  HIPCHK(hipGetLastError());
+  if (best_cand) HIPCHK(hipMemcpyAsync(best_cand, d_cand, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  if (best_frame) HIPCHK(hipMemcpyAsync(best_frame, d_frame, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  if (best_score) HIPCHK(hipMemcpyAsync(best_score, d_score, nq * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   return SGTD_OK;
 }
 

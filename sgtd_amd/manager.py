@@ -92,6 +92,7 @@ class BatchResult:
 class STDescManager:
     def __init__(self, **kw):
         cfg = dict(DEFAULTS)
+        self.icp_threshold_ = float(kw.pop("icp_threshold", 0.4))   # SG_localization.yaml:89
         cfg.update(kw)
         self.config_setting_ = cfg
         self._L = _lib.lib()
@@ -270,6 +271,57 @@ class STDescManager:
         return out
 
     # ---- table access -------------------------------------------------------
+    # ---- geometric verification (STDesc.cpp:462-571) and SearchLoop's choice (:84-147)
+    def verify(self):
+        """candidate_verify for every (query, candidate) of the last batch, on the device"""
+        self._check(self._L.sgtd_verify(self._h))
+
+    def result_verify(self, q):
+        """-> (score[candidate_num], rot[candidate_num,3,3], t[candidate_num,3])"""
+        cn = self.config_setting_["candidate_num"]
+        score = np.zeros(cn, np.float64)
+        pose = np.zeros((cn, 12), np.float64)
+        self._check(self._L.sgtd_result_verify(self._h, q, _p(score), _p(pose)))
+        return score, pose[:, :9].reshape(cn, 3, 3).copy(), pose[:, 9:].copy()
+
+    def result_inliers(self, q, cand, n_pairs):
+        """sucess_match_vec of one candidate as positions into its match_list_"""
+        idx = np.zeros(max(int(n_pairs), 1), np.int32)
+        n = C.c_int64(0)
+        self._check(self._L.sgtd_result_inliers(self._h, q, cand, _p(idx), len(idx), C.byref(n)))
+        return idx[:n.value].copy()
+
+    def search_loop(self, icp_threshold=None):
+        """SearchLoop's result for every query of the last batch (after verify()):
+        (best_cand, best_frame, best_score) arrays; frame -1 / score 0 = no loop (:144)"""
+        if icp_threshold is None:
+            icp_threshold = self.icp_threshold_
+        nq = self._nq
+        bc = np.zeros(nq, np.int32)
+        bf = np.zeros(nq, np.int32)
+        bs = np.zeros(nq, np.float64)
+        self._check(self._L.sgtd_search_loop(self._h, float(icp_threshold), _p(bc), _p(bf), _p(bs)))
+        return bc, bf, bs
+
+    def SearchLoop(self, stds_vec, icp_threshold=None):
+        """mirror of STDescManager::SearchLoop (STDesc.cpp:84-147) for one query given as
+        descriptors -> (loop_result (frame, score), (t, rot), success pair positions,
+        match_result_list [(frame, score, (t, rot), positions)])"""
+        if stds_vec.n == 0:                       # "No STDescs!" (:89-93)
+            return (-1, 0.0), None, np.zeros(0, np.int32), []
+        cands = self.candidate_selector(stds_vec)
+        self.verify()
+        score, rot, t = self.result_verify(0)
+        mrl = []
+        for k, c in enumerate(cands):
+            inl = self.result_inliers(0, k, len(c.q_idx)) if score[k] >= 0 else np.zeros(0, np.int32)
+            mrl.append((int(c.match_id_[1]), float(score[k]), (t[k], rot[k]), inl))
+        bc, bf, bs = self.search_loop(icp_threshold)
+        if bf[0] < 0:
+            return (-1, 0.0), None, np.zeros(0, np.int32), mrl
+        k = int(bc[0])
+        return (int(bf[0]), float(bs[0])), (t[k], rot[k]), mrl[k][3], mrl
+
     def fetch_entries(self, db_entry):
         db_entry = np.ascontiguousarray(db_entry, dtype=np.int64)
         d = Descs(len(db_entry))

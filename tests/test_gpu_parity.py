@@ -340,3 +340,49 @@ def test_many_tied_frames_take_the_general_topk_path(mods):
     r = o.select(oq)
     assert [l.match_id_[1] for l in lists] == list(r["cand_frame"]) == list(range(50))
     assert all(l.votes == 6 for l in lists)
+
+
+# ---------------------------------------------------------------------------
+# candidate_verify + triangle_solver on the device vs the oracle's
+# restatement (STDesc.cpp:462-571).  Same arithmetic order, no FMA => exact equality.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n_kp,n_frames", [(40, 12), (120, 30), (200, 40)])
+def test_verify_parity(mods, n_kp, n_frames):
+    _, _, synth = mods
+    smap = synth.make_map(n_frames, n_kp, stream=77)
+    queries = synth.make_queries(smap, 6, stream=77)
+    mgr, orc = _pair(mods)
+    for f in range(n_frames):
+        orc.build(smap.xyz[f], smap.label[f], export=False)
+        orc.add_last()
+        mgr.AddSTDescs(mgr.BuildSingleScanSTD(smap.xyz[f], smap.label[f]))
+    mgr.query_frames(queries.xyz, queries.label)
+    res = mgr.results()
+    mgr.verify()
+    bc, bf, bs = mgr.search_loop()
+    checked = 0
+    for q in range(queries.xyz.shape[0]):
+        orc.build(queries.xyz[q], queries.label[q], export=False)
+        sel = orc.select()
+        n_c = len(sel["cand_frame"])
+        assert n_c == int(res.n_cand[q])
+        score, rot, t = mgr.result_verify(q)
+        best_s, best_k = 0.0, -1
+        for k in range(n_c):
+            n_pairs = int(res.pair_off[q, k + 1] - res.pair_off[q, k])
+            o_score, o_t, o_rot, o_idx = orc.verify(k, n_pairs)
+            assert score[k] == o_score, (q, k)
+            if o_score >= 0:
+                assert np.array_equal(t[k], o_t), (q, k)
+                assert np.array_equal(rot[k], o_rot), (q, k)
+                assert np.array_equal(mgr.result_inliers(q, k, n_pairs), o_idx), (q, k)
+                checked += 1
+            if o_score > best_s:
+                best_s, best_k = o_score, k
+        assert np.all(score[n_c:] == -1)
+        if best_s > mgr.icp_threshold_:
+            assert bc[q] == best_k and bf[q] == res.cand_frame[q, best_k] and bs[q] == best_s
+        else:
+            assert bc[q] == -1 and bf[q] == -1 and bs[q] == 0
+    assert checked > 0
+    mgr.close()
