@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the timed sample")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps timed per kernel for the roofline")
+    ap.add_argument("--verify", choices=["on", "off"], default="on",
+                    help="also time candidate_verify + SearchLoop on the device (reported beside, never inside, value)")
     return ap.parse_args()
 
 
@@ -227,6 +229,20 @@ def main():
             traffic = None
 
     res = mgr.results()
+    # ---- next stage of the reference's SearchLoop (STDesc.cpp:105-146), reported separately
+    verify = None
+    if mode == "single" and args.verify == "on":
+        mgr.verify(); mgr.sync(); torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(3):
+            mgr.verify()
+        torch.cuda.synchronize()
+        tv = (time.perf_counter() - tv) / 3
+        bc, bf, bs = mgr.search_loop()
+        hit = bf >= 0
+        ok = hit & (np.linalg.norm(smap.pose[np.clip(bf, 0, F - 1), :2] - queries.pose[:, :2], axis=1) < 5.0)
+        verify = {"ms_per_batch": 1000.0 * tv, "queries": Q, "loops_found": int(hit.sum()),
+                  "loop_pose_within_5m": int(ok.sum()), "pairs_verified": int(st["last_cand_pairs"])}
     out = None
     if rank == 0:
         value = Q * args.steps / elapsed
@@ -250,6 +266,8 @@ def main():
                          "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
                          "kernel_ms": kern_ms},
         }
+        if verify is not None:
+            out["verify"] = verify
         if mode == "single":
             out["recall"] = recall(smap, queries, res.top1())
         else:

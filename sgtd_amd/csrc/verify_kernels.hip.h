@@ -21,6 +21,9 @@
 
 #define SGTD_VERIFY_THREADS 256
 #define SGTD_VERIFY_MAX_HYP 64     // use_size <= 50 (:467-468)
+#ifndef SGTD_VERIFY_PPT
+#define SGTD_VERIFY_PPT 1         // pairs per thread per step of the vote pass (2 measured equal: VALU-bound)
+#endif
 
 struct VerifyParams {
   // candidate lists of the batch
@@ -187,20 +190,36 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) void verify_kernel(VerifyParam
   }
   __syncthreads();
 
-  // ---- votes of every hypothesis (:488-505)
+  // ---- votes of every hypothesis (:488-505): SGTD_VERIFY_PPT pairs per thread and step, so
+  // that one LDS read of a hypothesis serves that many tests
   u32 acc = 0;   // lane h of every wave: votes of hypothesis h seen by this wave
-  for (long long j0 = 0; j0 < n; j0 += SGTD_VERIFY_THREADS) {
-    const long long j = j0 + tid;
-    const bool valid = j < n;
-    double qv[9], ev[9];
-    size_t qd, g;
-    load_pair(valid ? j : 0, qv, ev, qd, g);
+  constexpr int PPT = SGTD_VERIFY_PPT;
+  for (long long j0 = 0; j0 < n; j0 += (long long)PPT * SGTD_VERIFY_THREADS) {
+    double qv[PPT][9], ev[PPT][9];
+    bool valid[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+      const long long j = j0 + (long long)u * SGTD_VERIFY_THREADS + tid;
+      valid[u] = j < n;
+      size_t qd, g;
+      load_pair(valid[u] ? j : 0, qv[u], ev[u], qd, g);
+    }
     for (int h = 0; h < use_size; h++) {
       const double *Rt = s_Rt[h];
-      bool in = valid && vertex_close(Rt, qv, ev, P.thr2);
-      if (__ballot(in)) {          // most hypotheses fail at vertex A for the whole wave
-        in = in && vertex_close(Rt, qv + 3, ev + 3, P.thr2) && vertex_close(Rt, qv + 6, ev + 6, P.thr2);
-        const u32 cnt = (u32)__popcll(__ballot(in));
+      bool in[PPT];
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < PPT; u++) {
+        in[u] = valid[u] && vertex_close(Rt, qv[u], ev[u], P.thr2);
+        any = any || in[u];
+      }
+      if (__ballot(any)) {         // most hypotheses fail at vertex A for the whole wave
+        u32 cnt = 0;
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+          in[u] = in[u] && vertex_close(Rt, qv[u] + 3, ev[u] + 3, P.thr2) && vertex_close(Rt, qv[u] + 6, ev[u] + 6, P.thr2);
+          cnt += (u32)__popcll(__ballot(in[u]));
+        }
         if (lane == h) acc += cnt;
       }
     }
