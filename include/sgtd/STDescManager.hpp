@@ -57,6 +57,17 @@ struct STDMatchList {
 };
 
 // ConfigSetting fields of the path (STDesc.h:38-72); defaults = shipped YAML
+struct Mat3 {
+  double m[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+};
+
+struct LOOP_RESULT {                       // STDesc.h:99-105
+  int match_id = -1;
+  double match_fitness = -1;               // the reference stores the score in an int (quirk 15)
+  std::pair<Vec3, Mat3> loop_transform;
+  std::vector<std::pair<STDesc, STDesc>> loop_std_pair;
+};
+
 struct ConfigSetting {
   int descriptor_near_num_ = 10;
   double descriptor_min_len_ = 0.5;
@@ -64,6 +75,7 @@ struct ConfigSetting {
   double std_side_resolution_ = 1;
   int candidate_num_ = 50;
   double rough_dis_threshold_ = 0.03;
+  double icp_threshold_ = 0.5;          // STDesc.h:68 (SG_localization.yaml:89 ships 0.4)
   int max_frame_n_ = 20000;   // MAX_FRAME_N (STDesc.h:33)
   int device_id_ = 0;
 };
@@ -154,6 +166,56 @@ class STDescManager {
     }
     auto t2 = std::chrono::high_resolution_clock::now();
     CS1 = (int)(std::chrono::duration<double>(t2 - t1).count() * 1000);   // int truncation as :455
+  }
+
+  // STDesc.cpp:84-147: candidate_selector, then candidate_verify (:462-547, on the device:
+  // sgtd_verify) for every candidate, best strictly-largest score above icp_threshold_
+  void SearchLoop(const std::vector<STDesc> &stds_vec, std::pair<int, double> &loop_result,
+                  std::pair<Vec3, Mat3> &loop_transform,
+                  std::vector<std::pair<STDesc, STDesc>> &loop_std_pair,
+                  std::vector<LOOP_RESULT> &match_result_list) {
+    if (stds_vec.empty()) {                        // "No STDescs!" (:89-93)
+      loop_result = std::pair<int, double>(-1, 0);
+      return;
+    }
+    std::vector<STDMatchList> candidate_matcher_vec;
+    candidate_selector(stds_vec, candidate_matcher_vec);
+    if (status_ != SGTD_OK) { loop_result = std::pair<int, double>(-1, 0); return; }
+    status_ = sgtd_verify(h_);
+    if (status_ != SGTD_OK) { loop_result = std::pair<int, double>(-1, 0); return; }
+    const int cn = config_setting_.candidate_num_;
+    std::vector<double> score(cn), pose((size_t)cn * 12);
+    status_ = sgtd_result_verify(h_, 0, score.data(), pose.data());
+    if (status_ != SGTD_OK) { loop_result = std::pair<int, double>(-1, 0); return; }
+    double best_score = 0;
+    int best = -1;
+    for (size_t i = 0; i < candidate_matcher_vec.size(); i++) {     // :105-131
+      LOOP_RESULT r;
+      r.match_id = candidate_matcher_vec[i].match_id_.second;
+      r.match_fitness = score[i];
+      for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) r.loop_transform.second.m[a][b] = pose[i * 12 + a * 3 + b];
+        r.loop_transform.first[a] = pose[i * 12 + 9 + a];
+      }
+      if (score[i] >= 0) {
+        const auto &ml = candidate_matcher_vec[i].match_list_;
+        std::vector<int32_t> idx(ml.size());
+        int64_t n = 0;
+        status_ = sgtd_result_inliers(h_, 0, (int)i, idx.data(), (int64_t)idx.size(), &n);
+        if (status_ != SGTD_OK) { loop_result = std::pair<int, double>(-1, 0); return; }
+        for (int64_t k = 0; k < n; k++) r.loop_std_pair.push_back(ml[idx[k]]);
+      }
+      if (score[i] > best_score) { best_score = score[i]; best = (int)i; }
+      match_result_list.push_back(std::move(r));
+    }
+    if (best_score > config_setting_.icp_threshold_) {             // :138-146
+      const LOOP_RESULT &b = match_result_list[match_result_list.size() - candidate_matcher_vec.size() + best];
+      loop_result = std::pair<int, double>(b.match_id, best_score);
+      loop_transform = b.loop_transform;
+      loop_std_pair = b.loop_std_pair;
+    } else {
+      loop_result = std::pair<int, double>(-1, 0);
+    }
   }
 
  private:

@@ -119,6 +119,39 @@ int main() {
     }
     std::printf("query of frame %d: %d candidates, top-1 frame %d with %d votes\n", qf, nc, cf[0], cv[0]);
     CHECK(std::abs(cf[0] - qf) <= 2);
+
+    // SearchLoop (STDesc.cpp:84-147) against candidate_verify of the restatement
+    std::pair<int, double> loop_result;
+    std::pair<sgtd::Vec3, sgtd::Mat3> loop_transform;
+    std::vector<std::pair<sgtd::STDesc, sgtd::STDesc>> loop_std_pair;
+    std::vector<sgtd::LOOP_RESULT> match_result_list;
+    std_manager->SearchLoop(query_stds_vec, loop_result, loop_transform, loop_std_pair, match_result_list);
+    CHECK(std_manager->last_status() == SGTD_OK);
+    CHECK((int)match_result_list.size() == nc);
+    double best_score = 0; int best = -1;
+    for (int k = 0; k < nc; k++) {
+      double t[3], rot[9];
+      std::vector<int32_t> sidx(co[k + 1] - co[k] + 1);
+      int32_t ns = 0;
+      const double sc = orc_verify(oracle, k, t, rot, sidx.data(), &ns);
+      CHECK(match_result_list[k].match_fitness == sc);
+      CHECK(match_result_list[k].match_id == cf[k]);
+      if (sc >= 0) {
+        CHECK((int)match_result_list[k].loop_std_pair.size() == ns);
+        for (int a = 0; a < 3; a++) {
+          CHECK(match_result_list[k].loop_transform.first[a] == t[a]);
+          for (int b = 0; b < 3; b++) CHECK(match_result_list[k].loop_transform.second.m[a][b] == rot[a * 3 + b]);
+        }
+      }
+      if (sc > best_score) { best_score = sc; best = k; }
+    }
+    if (best_score > cfg.icp_threshold_) {
+      CHECK(loop_result.first == cf[best] && loop_result.second == best_score);
+      CHECK((int)loop_std_pair.size() == (int)best_score);
+    } else {
+      CHECK(loop_result.first == -1 && loop_result.second == 0);
+    }
+    std::printf("SearchLoop: frame %d score %.0f\n", loop_result.first, loop_result.second);
   }
   orc_destroy(oracle);
   delete std_manager;
