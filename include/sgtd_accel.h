@@ -36,7 +36,8 @@ typedef enum sgtd_status {
   SGTD_ERR_FRAME_LIMIT = -5,  /* frame id >= max_frame_n (MAX_FRAME_N, STDesc.h:33:
                                  the reference indexes a fixed array there)   */
   SGTD_ERR_UNSUPPORTED = -6,  /* configuration outside the kernels' envelope   */
-  SGTD_ERR_STATE = -7         /* call order (e.g. results before a query)      */
+  SGTD_ERR_STATE = -7,        /* call order (e.g. results before a query)      */
+  SGTD_ERR_IO = -8            /* a graph file could not be opened or parsed    */
 } sgtd_status;
 
 /* ConfigSetting fields the path reads (STDesc.h:38-72); defaults in
@@ -200,6 +201,27 @@ int sgtd_result_inliers(sgtd_handle h, int q, int cand, int32_t *idx, int64_t ca
  * Arrays of n_queries; any may be NULL.  Requires sgtd_verify. */
 int sgtd_search_loop(sgtd_handle h, double icp_threshold, int32_t *best_cand, int32_t *best_frame,
                      double *best_score);
+
+/* ---- graph-JSON ingest (host code, no device needed) ----
+ * readGraphFromFile / fromJSON (include/Semantic_Graph.hpp:122-184) + Graph2CloudL
+ * (include/utility.hpp:646-659) for many files at once: {"nodes":[int], "centers":[[x,y,z]],
+ * "poses":[12 floats], ...} (producer get_json.cpp:332-341; only these three keys are read,
+ * numbers go through strtod and a cast like nlohmann::json's get<float>/get<int>) parsed on
+ * n_threads host threads into the arrays sgtd_add_frames / sgtd_query_frames take.  Frames
+ * keep the order of `paths`.  On SGTD_ERR_IO *out still holds an object whose
+ * sgtd_graphs_error() names the file ("Error opening file: ..." like Semantic_Graph.hpp:173);
+ * free it with sgtd_graphs_free. */
+typedef struct sgtd_graph_batch sgtd_graph_batch;
+int sgtd_graphs_load(const char *const *paths, int n_files, int n_threads, sgtd_graph_batch **out);
+/* binary cache of a parsed batch (skips JSON parsing at the next start) */
+int sgtd_graphs_save_cache(const sgtd_graph_batch *b, const char *path);
+int sgtd_graphs_load_cache(const char *path, sgtd_graph_batch **out);
+/* borrowed pointers, valid until sgtd_graphs_free: xyz f32 [n_keypoints*3], label u32
+ * [n_keypoints], kp_off i64 [n_frames+1], poses f32 [n_frames*12]; any pointer may be NULL */
+int sgtd_graphs_view(const sgtd_graph_batch *b, int *n_frames, int64_t *n_keypoints, const float **xyz,
+                     const uint32_t **label, const int64_t **kp_off, const float **poses);
+const char *sgtd_graphs_error(const sgtd_graph_batch *b);
+void sgtd_graphs_free(sgtd_graph_batch *b);
 
 /* table entries by insertion index (to rebuild pair<STDesc,STDesc>) */
 int sgtd_fetch_entries(sgtd_handle h, const int64_t *db_entry, int64_t n,

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SGTD_ACCEL_LIB") or os.path.join(_HERE, "libsgtd_acce
 CSRC = os.path.join(_HERE, "csrc")
 
 SGTD_OK = 0
-ERRORS = {-1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY",
+ERRORS = {-8: "IO", -1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY",
           -5: "FRAME_LIMIT", -6: "UNSUPPORTED", -7: "STATE"}
 
 # every symbol include/sgtd_accel.h declares
@@ -25,6 +25,8 @@ SYMBOLS = [
     "sgtd_result_query_descs", "sgtd_result_votes", "sgtd_result_rough", "sgtd_fetch_entries",
     "sgtd_table_dump", "sgtd_sync", "sgtd_get_stats",
     "sgtd_verify", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_search_loop",
+    "sgtd_graphs_load", "sgtd_graphs_save_cache", "sgtd_graphs_load_cache", "sgtd_graphs_view",
+    "sgtd_graphs_error", "sgtd_graphs_free",
 ]
 
 
@@ -124,6 +126,15 @@ def lib():
     L.sgtd_result_verify.argtypes = [vp, C.c_int, vp, vp]
     L.sgtd_result_inliers.argtypes = [vp, C.c_int, C.c_int, vp, i64, C.POINTER(i64)]
     L.sgtd_search_loop.argtypes = [vp, C.c_double, vp, vp, vp]
+    L.sgtd_graphs_load.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(vp)]
+    L.sgtd_graphs_save_cache.argtypes = [vp, C.c_char_p]
+    L.sgtd_graphs_load_cache.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.sgtd_graphs_view.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
+                                   C.POINTER(vp), C.POINTER(vp)]
+    L.sgtd_graphs_error.argtypes = [vp]
+    L.sgtd_graphs_error.restype = C.c_char_p
+    L.sgtd_graphs_free.argtypes = [vp]
+    L.sgtd_graphs_free.restype = None
     for name in SYMBOLS:
         getattr(L, name)
         if getattr(L, name).restype is C.c_int:

@@ -1,0 +1,256 @@
+// graph_ingest.hip.h — host side: the reference's on-disk graph format -> keypoint batches
+// (SURVEY §8f row 2).  Replaces readGraphFromFile / fromJSON
+// (src/sgtd/include/Semantic_Graph.hpp:122-184) + Graph2CloudL (include/utility.hpp:646-659)
+// for whole directories at once: files are parsed on host threads straight into the SoA
+// layout sgtd_add_frames / sgtd_query_frames take (xyz f32, label u32, CSR offsets), plus the
+// 12-float pose row of every frame (the node reads poses[3], [7], [11],
+// semantic_graph_localization.cpp:447).
+//
+// Format (producer: src/get_json.cpp:332-341, Graph::toJSON Semantic_Graph.hpp:79-110):
+//   {"nodes":[int...], "edges":[[..]], "weights":[..], "centers":[[x,y,z]...],
+//    "poses":[12 floats], "volumes":[..], "densitys":[..]}
+// Only "nodes", "centers", "poses" are read (fromJSON :157-164); every other key is skipped.
+// Numbers: nlohmann::json parses a number to double (strtod) and get<float>() / get<int>()
+// casts it — the same two steps here.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct sgtd_graph_batch {
+  std::vector<float> xyz;        // [n_keypoints * 3]
+  std::vector<uint32_t> label;   // [n_keypoints]
+  std::vector<int64_t> kp_off;   // [n_frames + 1]
+  std::vector<float> poses;      // [n_frames * 12]
+  std::string error;
+};
+
+namespace ingest {
+
+struct OneGraph {
+  std::vector<float> xyz;
+  std::vector<uint32_t> label;
+  float pose[12];
+  int n_pose = 0;
+  std::string error;
+};
+
+// minimal JSON scanner: enough to walk any valid document and pull three arrays out
+struct Scanner {
+  const char *p, *end;
+  std::string err;
+  bool fail(const char *what) {
+    if (err.empty()) err = what;
+    return false;
+  }
+  void ws() {
+    while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++;
+  }
+  bool expect(char c) {
+    ws();
+    if (p < end && *p == c) { p++; return true; }
+    return fail("unexpected character");
+  }
+  bool peek(char c) {
+    ws();
+    return p < end && *p == c;
+  }
+  bool string(std::string *out) {
+    ws();
+    if (p >= end || *p != '"') return fail("string expected");
+    p++;
+    while (p < end && *p != '"') {
+      if (*p == '\\') {
+        if (p + 1 >= end) return fail("bad escape");
+        if (out) out->push_back(p[1]);   // keys of this format carry no escapes; keep the raw char
+        p += 2;
+      } else {
+        if (out) out->push_back(*p);
+        p++;
+      }
+    }
+    if (p >= end) return fail("unterminated string");
+    p++;
+    return true;
+  }
+  bool number(double *out) {
+    ws();
+    if (p >= end) return fail("number expected");
+    char *q = nullptr;
+    const double v = strtod(p, &q);      // what nlohmann's lexer uses for floating numbers
+    if (q == p) return fail("number expected");
+    p = q;
+    if (out) *out = v;
+    return true;
+  }
+  bool skip_value() {
+    ws();
+    if (p >= end) return fail("value expected");
+    const char c = *p;
+    if (c == '"') return string(nullptr);
+    if (c == '{') {
+      p++;
+      if (peek('}')) { p++; return true; }
+      while (true) {
+        if (!string(nullptr) || !expect(':') || !skip_value()) return false;
+        if (peek(',')) { p++; continue; }
+        return expect('}');
+      }
+    }
+    if (c == '[') {
+      p++;
+      if (peek(']')) { p++; return true; }
+      while (true) {
+        if (!skip_value()) return false;
+        if (peek(',')) { p++; continue; }
+        return expect(']');
+      }
+    }
+    if (!strncmp(p, "true", 4)) { p += 4; return true; }
+    if (!strncmp(p, "false", 5)) { p += 5; return true; }
+    if (!strncmp(p, "null", 4)) { p += 4; return true; }
+    return number(nullptr);
+  }
+  template <class F>
+  bool array(F &&item) {   // [ item, item, ... ]
+    if (!expect('[')) return false;
+    if (peek(']')) { p++; return true; }
+    while (true) {
+      if (!item()) return false;
+      if (peek(',')) { p++; continue; }
+      return expect(']');
+    }
+  }
+};
+
+inline bool parse_graph(const char *text, size_t len, OneGraph &g) {
+  Scanner s{text, text + len, {}};
+  bool have_nodes = false, have_centers = false, have_poses = false;
+  if (!s.expect('{')) { g.error = s.err; return false; }
+  if (s.peek('}')) { g.error = "missing key \"nodes\""; return false; }
+  while (true) {
+    std::string key;
+    if (!s.string(&key) || !s.expect(':')) { g.error = s.err; return false; }
+    bool ok;
+    if (key == "nodes") {                       // vector<int> (fromJSON :157)
+      have_nodes = true;
+      g.label.clear();
+      ok = s.array([&] { double v; if (!s.number(&v)) return false; g.label.push_back((uint32_t)(int)v); return true; });
+    } else if (key == "centers") {              // vector<Vector3f> (:160, jsonToVector3f :147-153)
+      have_centers = true;
+      g.xyz.clear();
+      ok = s.array([&] {
+        int k = 0;
+        const bool in = s.array([&] { double v; if (!s.number(&v)) return false; if (k < 3) g.xyz.push_back((float)v); k++; return true; });
+        if (in && k < 3) return s.fail("a center needs three coordinates");
+        return in;
+      });
+    } else if (key == "poses") {                // vector<float> (:161)
+      have_poses = true;
+      g.n_pose = 0;
+      ok = s.array([&] { double v; if (!s.number(&v)) return false; if (g.n_pose < 12) g.pose[g.n_pose] = (float)v; g.n_pose++; return true; });
+    } else {
+      ok = s.skip_value();
+    }
+    if (!ok) { g.error = s.err; return false; }
+    if (s.peek(',')) { s.p++; continue; }
+    if (!s.expect('}')) { g.error = s.err; return false; }
+    break;
+  }
+  if (!have_nodes) { g.error = "missing key \"nodes\""; return false; }     // json.at()/operator[] would throw
+  if (!have_centers) { g.error = "missing key \"centers\""; return false; }
+  if (!have_poses) { g.error = "missing key \"poses\""; return false; }
+  // Graph2CloudL indexes label[i] for every center (utility.hpp:653-658): fewer labels is UB there
+  if (g.label.size() != g.xyz.size() / 3) { g.error = "nodes and centers differ in length"; return false; }
+  for (int k = g.n_pose; k < 12; k++) g.pose[k] = 0.f;
+  return true;
+}
+
+inline bool read_file(const std::string &path, std::string &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  const size_t got = n > 0 ? fread(&out[0], 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == out.size();
+}
+
+// frames in the order of `paths` (the caller decides: the reference's map order is the
+// unsorted directory order, its query order is sorted — quirk 13)
+inline bool load(const char *const *paths, int n_files, int n_threads, sgtd_graph_batch &b) {
+  std::vector<OneGraph> graphs((size_t)n_files);
+  std::atomic<int> next{0};
+  auto work = [&] {
+    std::string text;
+    for (int i = next++; i < n_files; i = next++) {
+      OneGraph g;   // parsed thread-locally: neighbouring slots of `graphs` share cache lines
+      if (!read_file(paths[i], text)) g.error = std::string("Error opening file: ") + paths[i];   // Semantic_Graph.hpp:172-174
+      else if (!parse_graph(text.data(), text.size(), g)) g.error = std::string(paths[i]) + ": " + g.error;
+      graphs[i] = std::move(g);
+    }
+  };
+  const int nt = n_threads < 1 ? 1 : (n_threads > n_files ? (n_files > 0 ? n_files : 1) : n_threads);
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; t++) pool.emplace_back(work);
+  work();
+  for (auto &t : pool) t.join();
+  b.kp_off.assign(1, 0);
+  b.xyz.clear(); b.label.clear(); b.poses.clear();
+  size_t total = 0;
+  for (auto &g : graphs) {
+    if (!g.error.empty()) { b.error = g.error; return false; }
+    total += g.label.size();
+  }
+  b.xyz.reserve(total * 3); b.label.reserve(total); b.poses.reserve((size_t)n_files * 12);
+  for (auto &g : graphs) {
+    b.xyz.insert(b.xyz.end(), g.xyz.begin(), g.xyz.end());
+    b.label.insert(b.label.end(), g.label.begin(), g.label.end());
+    b.poses.insert(b.poses.end(), g.pose, g.pose + 12);
+    b.kp_off.push_back((int64_t)b.label.size());
+  }
+  return true;
+}
+
+// binary cache of a parsed batch: magic, counts, then the four arrays
+static const char kMagic[8] = {'S', 'G', 'T', 'D', 'G', 'B', '0', '1'};
+
+inline bool save_cache(const sgtd_graph_batch &b, const char *path) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return false;
+  const int64_t nf = (int64_t)b.kp_off.size() - 1, nk = (int64_t)b.label.size();
+  bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&nf, 8, 1, f) == 1 && fwrite(&nk, 8, 1, f) == 1;
+  ok = ok && fwrite(b.kp_off.data(), 8, b.kp_off.size(), f) == b.kp_off.size();
+  ok = ok && fwrite(b.poses.data(), 4, b.poses.size(), f) == b.poses.size();
+  ok = ok && fwrite(b.label.data(), 4, b.label.size(), f) == b.label.size();
+  ok = ok && fwrite(b.xyz.data(), 4, b.xyz.size(), f) == b.xyz.size();
+  return fclose(f) == 0 && ok;
+}
+
+inline bool load_cache(const char *path, sgtd_graph_batch &b) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { b.error = std::string("Error opening file: ") + path; return false; }
+  char magic[8];
+  int64_t nf = 0, nk = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, kMagic, 8) && fread(&nf, 8, 1, f) == 1 && fread(&nk, 8, 1, f) == 1 &&
+            nf >= 0 && nk >= 0;
+  if (ok) {
+    b.kp_off.resize((size_t)nf + 1); b.poses.resize((size_t)nf * 12); b.label.resize((size_t)nk); b.xyz.resize((size_t)nk * 3);
+    ok = fread(b.kp_off.data(), 8, b.kp_off.size(), f) == b.kp_off.size() && fread(b.poses.data(), 4, b.poses.size(), f) == b.poses.size() &&
+         fread(b.label.data(), 4, b.label.size(), f) == b.label.size() && fread(b.xyz.data(), 4, b.xyz.size(), f) == b.xyz.size() &&
+         b.kp_off.front() == 0 && b.kp_off.back() == nk;
+  }
+  fclose(f);
+  if (!ok) b.error = std::string(path) + ": not a graph-batch cache";
+  return ok;
+}
+
+}  // namespace ingest

@@ -16,6 +16,7 @@
 #include "table_kernels.hip.h"
 #include "probe_kernels.hip.h"
 #include "verify_kernels.hip.h"
+#include "graph_ingest.hip.h"
 
 namespace {
 
@@ -782,6 +783,7 @@ const char *sgtd_strerror(int status) {
     case SGTD_ERR_FRAME_LIMIT: return "frame id beyond max_frame_n";
     case SGTD_ERR_UNSUPPORTED: return "configuration outside the kernels' envelope";
     case SGTD_ERR_STATE: return "call order";
+    case SGTD_ERR_IO: return "graph file could not be opened or parsed";
     default: return "unknown status";
   }
 }
@@ -1205,6 +1207,41 @@ int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, in
   HIPCHK(hipStreamSynchronize(e->stream));
   return SGTD_OK;
 }
+
+int sgtd_graphs_load(const char *const *paths, int n_files, int n_threads, sgtd_graph_batch **out) {
+  if (!out || n_files < 0 || (n_files > 0 && !paths)) return SGTD_ERR_INVALID;
+  sgtd_graph_batch *b = new sgtd_graph_batch();
+  *out = b;
+  return ingest::load(paths, n_files, n_threads, *b) ? SGTD_OK : SGTD_ERR_IO;
+}
+
+int sgtd_graphs_save_cache(const sgtd_graph_batch *b, const char *path) {
+  if (!b || !path) return SGTD_ERR_INVALID;
+  return ingest::save_cache(*b, path) ? SGTD_OK : SGTD_ERR_IO;
+}
+
+int sgtd_graphs_load_cache(const char *path, sgtd_graph_batch **out) {
+  if (!out || !path) return SGTD_ERR_INVALID;
+  sgtd_graph_batch *b = new sgtd_graph_batch();
+  *out = b;
+  return ingest::load_cache(path, *b) ? SGTD_OK : SGTD_ERR_IO;
+}
+
+int sgtd_graphs_view(const sgtd_graph_batch *b, int *n_frames, int64_t *n_keypoints, const float **xyz,
+                     const uint32_t **label, const int64_t **kp_off, const float **poses) {
+  if (!b || b->kp_off.empty()) return SGTD_ERR_INVALID;
+  if (n_frames) *n_frames = (int)b->kp_off.size() - 1;
+  if (n_keypoints) *n_keypoints = (int64_t)b->label.size();
+  if (xyz) *xyz = b->xyz.data();
+  if (label) *label = b->label.data();
+  if (kp_off) *kp_off = b->kp_off.data();
+  if (poses) *poses = b->poses.data();
+  return SGTD_OK;
+}
+
+const char *sgtd_graphs_error(const sgtd_graph_batch *b) { return b ? b->error.c_str() : ""; }
+
+void sgtd_graphs_free(sgtd_graph_batch *b) { delete b; }
 
 int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_desc_soa *out) {
   if (!e || n < 0 || (n > 0 && (!db_entry || !out))) return SGTD_ERR_INVALID;
