@@ -243,6 +243,21 @@ def main():
         ok = hit & (np.linalg.norm(smap.pose[np.clip(bf, 0, F - 1), :2] - queries.pose[:, :2], axis=1) < 5.0)
         verify = {"ms_per_batch": 1000.0 * tv, "queries": Q, "loops_found": int(hit.sum()),
                   "loop_pose_within_5m": int(ok.sum()), "pairs_verified": int(st["last_cand_pairs"])}
+        # the node's own metrics (semantic_graph_localization.cpp:605-745) on the synthetic ground truth
+        from sgtd_amd import evaluate as ev
+        map_pose4 = np.stack([ev.pose_matrix(*p) for p in smap.pose])
+        met = ev.LoopMetrics(mgr.config_setting_["candidate_num"])
+        for q in range(min(Q, 256)):
+            n_c = int(res.n_cand[q])
+            if bf[q] > 0:
+                score, rot, t = mgr.result_verify(q)
+                ev.account(met, ev.pose_matrix(*queries.pose[q]), map_pose4, int(bf[q]), rot[int(bc[q])], t[int(bc[q])],
+                           res.cand_frame[q, :n_c], score[:n_c])
+            else:
+                ev.account(met, ev.pose_matrix(*queries.pose[q]), map_pose4, int(bf[q]), None, None, (), ())
+        loc = met.summary()
+        loc["STD_num"] = loc["STD_num"][:10]
+        verify["localization_first_256_queries"] = loc
     out = None
     if rank == 0:
         value = Q * args.steps / elapsed
