@@ -202,6 +202,18 @@ int sgtd_result_inliers(sgtd_handle h, int q, int cand, int32_t *idx, int64_t ca
 int sgtd_search_loop(sgtd_handle h, double icp_threshold, int32_t *best_cand, int32_t *best_frame,
                      double *best_score);
 
+/* ---- persistent table ----
+ * The reference rebuilds data_base_ from the map files at every start
+ * (semantic_graph_localization.cpp:419-458) and only ever appends (STDesc.cpp:149-172).
+ * sgtd_save_table writes the table in insertion order (all descriptor fields, the frame
+ * counter, the frame range); sgtd_load_table replaces the handle's table with a saved one —
+ * the probe layout is re-derived by the next query (a sort of ~1 ms per 4 M entries), and
+ * sgtd_add / sgtd_add_frames keep appending after it (new session on an old map).  The file
+ * records std_side_resolution (sides are stored scaled): loading into a handle configured
+ * differently is SGTD_ERR_INVALID.  I/O problems are SGTD_ERR_IO (sgtd_last_error names the file). */
+int sgtd_save_table(sgtd_handle h, const char *path);
+int sgtd_load_table(sgtd_handle h, const char *path);
+
 /* ---- graph-JSON ingest (host code, no device needed) ----
  * readGraphFromFile / fromJSON (include/Semantic_Graph.hpp:122-184) + Graph2CloudL
  * (include/utility.hpp:646-659) for many files at once: {"nodes":[int], "centers":[[x,y,z]],

@@ -26,7 +26,7 @@ SYMBOLS = [
     "sgtd_table_dump", "sgtd_sync", "sgtd_get_stats",
     "sgtd_verify", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_search_loop",
     "sgtd_graphs_load", "sgtd_graphs_save_cache", "sgtd_graphs_load_cache", "sgtd_graphs_view",
-    "sgtd_graphs_error", "sgtd_graphs_free",
+    "sgtd_graphs_error", "sgtd_graphs_free", "sgtd_save_table", "sgtd_load_table",
 ]
 
 
@@ -135,6 +135,8 @@ def lib():
     L.sgtd_graphs_error.restype = C.c_char_p
     L.sgtd_graphs_free.argtypes = [vp]
     L.sgtd_graphs_free.restype = None
+    L.sgtd_save_table.argtypes = [vp, C.c_char_p]
+    L.sgtd_load_table.argtypes = [vp, C.c_char_p]
     for name in SYMBOLS:
         getattr(L, name)
         if getattr(L, name).restype is C.c_int:

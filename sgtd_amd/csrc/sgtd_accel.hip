@@ -758,6 +758,45 @@ int check_cfg(const sgtd_config *c) {
 // ===========================================================================
 // C ABI
 // ===========================================================================
+namespace {
+const char kTableMagic[8] = {'S', 'G', 'T', 'D', 'T', 'B', '0', '1'};
+struct TableHeader {
+  double side_resolution, min_len, max_len;
+  int32_t near_num, have_frames;
+  uint32_t current_frame_id, frame_lo, frame_hi, reserved;
+  int64_t n_entries, n_add_calls;
+};
+// one SoA field <-> file, staged through a bounded host buffer
+template <class T>
+int stream_field(sgtd_engine *e, FILE *f, T *dev, size_t n_items, bool to_file, std::vector<char> &stage) {
+  const size_t chunk = stage.size() / sizeof(T);
+  for (size_t o = 0; o < n_items; o += chunk) {
+    const size_t m = std::min(chunk, n_items - o);
+    if (to_file) {
+      HIPCHK(hipMemcpyAsync(stage.data(), dev + o, m * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (fwrite(stage.data(), sizeof(T), m, f) != m) return SGTD_ERR_IO;
+    } else {
+      if (fread(stage.data(), sizeof(T), m, f) != m) return SGTD_ERR_IO;
+      HIPCHK(hipMemcpyAsync(dev + o, stage.data(), m * sizeof(T), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+  }
+  return SGTD_OK;
+}
+int stream_table(sgtd_engine *e, FILE *f, size_t n, bool to_file) {
+  std::vector<char> stage((size_t)64 << 20);
+  CHK(stream_field(e, f, e->tab.side.as<double>(), n * 3, to_file, stage));
+  CHK(stream_field(e, f, e->tab.angle.as<double>(), n * 3, to_file, stage));
+  CHK(stream_field(e, f, e->tab.center.as<double>(), n * 3, to_file, stage));
+  CHK(stream_field(e, f, e->tab.vertex.as<float>(), n * 9, to_file, stage));
+  CHK(stream_field(e, f, e->tab.label.as<int>(), n * 3, to_file, stage));
+  CHK(stream_field(e, f, e->tab.frame.as<u32>(), n, to_file, stage));
+  CHK(stream_field(e, f, e->tab.node_id.as<int>(), n * 3, to_file, stage));
+  return SGTD_OK;
+}
+}  // namespace
+
 extern "C" {
 
 void sgtd_default_config(sgtd_config *cfg) {
@@ -1205,6 +1244,57 @@ int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, in
   if (best_frame) HIPCHK(hipMemcpyAsync(best_frame, d_frame, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   if (best_score) HIPCHK(hipMemcpyAsync(best_score, d_score, nq * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  return SGTD_OK;
+}
+
+int sgtd_save_table(sgtd_handle e, const char *path) {
+  if (!e || !path) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  FILE *f = fopen(path, "wb");
+  if (!f) { e->err = std::string("cannot open for writing: ") + path; return SGTD_ERR_IO; }
+  TableHeader h{};
+  h.side_resolution = e->cfg.std_side_resolution; h.min_len = e->cfg.descriptor_min_len; h.max_len = e->cfg.descriptor_max_len;
+  h.near_num = e->cfg.descriptor_near_num; h.have_frames = e->have_frames ? 1 : 0;
+  h.current_frame_id = e->current_frame_id; h.frame_lo = e->frame_lo; h.frame_hi = e->frame_hi;
+  h.n_entries = e->n_entries; h.n_add_calls = e->n_add_calls;
+  int st = (fwrite(kTableMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1) ? SGTD_OK : SGTD_ERR_IO;
+  if (st == SGTD_OK) st = stream_table(e, f, (size_t)e->n_entries, true);
+  if (fclose(f) != 0 && st == SGTD_OK) st = SGTD_ERR_IO;
+  if (st == SGTD_ERR_IO) e->err = std::string("write failed: ") + path;
+  return st;
+}
+
+int sgtd_load_table(sgtd_handle e, const char *path) {
+  if (!e || !path) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  FILE *f = fopen(path, "rb");
+  if (!f) { e->err = std::string("Error opening file: ") + path; return SGTD_ERR_IO; }
+  char magic[8];
+  TableHeader h{};
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kTableMagic, 8) || fread(&h, sizeof(h), 1, f) != 1 || h.n_entries < 0) {
+    fclose(f);
+    e->err = std::string(path) + ": not a saved table";
+    return SGTD_ERR_IO;
+  }
+  if (h.side_resolution != e->cfg.std_side_resolution) {
+    fclose(f);
+    e->err = "saved table was built with another std_side_resolution";
+    return SGTD_ERR_INVALID;
+  }
+  if (h.have_frames && h.frame_hi >= (u32)e->cfg.max_frame_n) { fclose(f); return SGTD_ERR_FRAME_LIMIT; }
+  if (h.n_entries >= (1ll << 32) - 2) { fclose(f); return SGTD_ERR_UNSUPPORTED; }
+  int st = ensure_store(e, e->tab, (size_t)std::max<int64_t>(h.n_entries, 1), false);
+  if (st == SGTD_OK) st = stream_table(e, f, (size_t)h.n_entries, false);
+  fclose(f);
+  if (st != SGTD_OK) {
+    if (st == SGTD_ERR_IO) e->err = std::string(path) + ": truncated table file";
+    e->n_entries = 0; e->have_frames = false; e->finalized = false; e->batch_valid = false;
+    return st;
+  }
+  e->n_entries = h.n_entries; e->n_add_calls = h.n_add_calls; e->current_frame_id = h.current_frame_id;
+  e->have_frames = h.have_frames != 0; e->frame_lo = h.frame_lo; e->frame_hi = h.frame_hi;
+  e->finalized = false;
+  e->batch_valid = false;
   return SGTD_OK;
 }
 

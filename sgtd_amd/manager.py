@@ -12,6 +12,7 @@ plus the batched, device-resident forms the GPU wants (`add_frames`,
 file only marshals numpy / torch buffers through the C ABI.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -321,6 +322,14 @@ class STDescManager:
             return (-1, 0.0), None, np.zeros(0, np.int32), mrl
         k = int(bc[0])
         return (int(bf[0]), float(bs[0])), (t[k], rot[k]), mrl[k][3], mrl
+
+    # ---- persistent table
+    def save_table(self, path):
+        self._check(self._L.sgtd_save_table(self._h, os.fspath(path).encode()))
+
+    def load_table(self, path):
+        """replace this manager's table with a saved one; AddSTDescs / add_frames keep appending"""
+        self._check(self._L.sgtd_load_table(self._h, os.fspath(path).encode()))
 
     def fetch_entries(self, db_entry):
         db_entry = np.ascontiguousarray(db_entry, dtype=np.int64)

@@ -386,3 +386,53 @@ def test_verify_parity(mods, n_kp, n_frames):
             assert bc[q] == -1 and bf[q] == -1 and bs[q] == 0
     assert checked > 0
     mgr.close()
+
+
+# ---------------------------------------------------------------------------
+# saved table == rebuilt table, and appending after a load
+# ---------------------------------------------------------------------------
+def test_saved_table_round_trip_and_append(mods, tmp_path):
+    _, manager, synth = mods
+    smap = synth.make_map(24, 80, stream=31)
+    q = synth.make_queries(smap, 5, stream=31)
+
+    def snapshot(mgr):
+        res = mgr.query_frames(q.xyz, q.label)
+        pairs = [mgr.result_pairs(i, res) for i in range(5)]
+        return (res.n_cand.copy(), res.cand_frame.copy(), res.cand_votes.copy(), res.pair_off.copy(),
+                [p[0] for p in pairs], [p[1] for p in pairs], mgr.current_frame_id_)
+
+    def same(a, b):
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        for x, y in zip(a[4] + a[5], b[4] + b[5]):
+            assert np.array_equal(x, y)
+        assert a[6] == b[6]
+
+    full = manager.STDescManager()
+    full.add_frames(smap.xyz, smap.label)
+    want_full = snapshot(full)
+
+    first = manager.STDescManager()
+    first.add_frames(smap.xyz[:16], smap.label[:16])
+    want_first = snapshot(first)
+    path = tmp_path / "map16.tbl"
+    first.save_table(path)
+
+    again = manager.STDescManager()
+    again.load_table(path)
+    same(snapshot(again), want_first)                      # the saved table answers like the original
+    assert np.array_equal(again.table_dump()[0], first.table_dump()[0])
+    again.add_frames(smap.xyz[16:], smap.label[16:])       # new session appends to the old map
+    same(snapshot(again), want_full)
+
+    other = manager.STDescManager(std_side_resolution=0.5)
+    with pytest.raises(manager.SgtdError):
+        other.load_table(path)                             # sides are stored scaled
+    with pytest.raises(manager.SgtdError):
+        other.load_table(tmp_path / "missing.tbl")
+    (tmp_path / "junk.tbl").write_bytes(b"x" * 100)
+    with pytest.raises(manager.SgtdError):
+        again.load_table(tmp_path / "junk.tbl")
+    for m in (full, first, again, other):
+        m.close()
