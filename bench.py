@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="map size F")
     ap.add_argument("--keypoints", type=int, default=200, help="keypoints per frame N")
-    ap.add_argument("--queries", type=int, default=1024, help="query frames per step (whole job)")
+    ap.add_argument("--queries", type=int, default=4096, help="query frames per step (whole job)")
     ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the timed sample")

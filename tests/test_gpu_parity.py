@@ -436,3 +436,78 @@ def test_saved_table_round_trip_and_append(mods, tmp_path):
         again.load_table(tmp_path / "junk.tbl")
     for m in (full, first, again, other):
         m.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE cfg5 ingredients: labels from 13 classes {0..12} (get_json_wild.cpp:10-12), labels
+# beyond 15 (low-4-bit wrap of Combinatorial_Binary_Encoding), two "sessions" of one world
+# ---------------------------------------------------------------------------
+def test_wild_labels_and_two_sessions(mods):
+    _, _, synth = mods
+    g, o = _pair(mods)
+    s1 = synth.make_map(10, 90, stream=41, label_lo=0, label_hi=12)
+    s2 = synth.make_map(10, 90, stream=41, label_lo=0, label_hi=12, sigma=0.04)   # same world, other noise draw
+    s2.label[:, ::7] += 16                                   # 16 + l collides with l in the 12-bit code
+    for sess in (s1, s2):
+        for f in range(10):
+            d = g.BuildSingleScanSTD(sess.xyz[f], sess.label[f])
+            assert_descs_equal(d, o.build(sess.xyz[f], sess.label[f]))
+            g.AddSTDescs(d)
+            o.add_last()
+    q = synth.make_queries(s1, 4, stream=41)
+    res = g.query_frames(q.xyz, q.label)
+    for i in range(4):
+        o.build(q.xyz[i], q.label[i], export=False)
+        r = o.select()
+        nc = int(res.n_cand[i])
+        assert np.array_equal(res.cand_frame[i, :nc], r["cand_frame"]) and np.array_equal(res.cand_votes[i, :nc], r["cand_votes"])
+        qi, de = g.result_pairs(i, res)
+        assert np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
+    assert res.n_cand.max() > 0
+
+
+# ---------------------------------------------------------------------------
+# SURVEY §8e on one GPU: G frame-range shards (first_frame_id), local top-50 each, merged with
+# the reference's rule == the single-table candidate list; owners hold the match lists
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_table_shards_merge_to_the_single_table_result(mods, n_shards):
+    import torch
+    from sgtd_amd.dist import merge_candidates, shard_range
+    _, manager, synth = mods
+    smap = synth.make_map(30, 100, stream=51)
+    q = synth.make_queries(smap, 6, stream=51)
+    single = manager.STDescManager()
+    single.add_frames(smap.xyz, smap.label)
+    want = single.query_frames(q.xyz, q.label)
+    cn = single.config_setting_["candidate_num"]
+    frames, votes, shards = [], [], []
+    for r in range(n_shards):
+        lo, hi = shard_range(30, n_shards, r)
+        m = manager.STDescManager(first_frame_id=lo)
+        m.add_frames(smap.xyz[lo:hi], smap.label[lo:hi])
+        res = m.query_frames(q.xyz, q.label)
+        f = np.where(np.arange(cn)[None, :] < res.n_cand[:, None], res.cand_frame, -1)
+        v = np.where(np.arange(cn)[None, :] < res.n_cand[:, None], res.cand_votes, 0)
+        frames.append(torch.from_numpy(f.astype(np.int32)))
+        votes.append(torch.from_numpy(v.astype(np.int32)))
+        shards.append((m, res, lo, hi))
+    mf, mv, n = merge_candidates(torch.stack(frames), torch.stack(votes), cn)
+    for i in range(6):
+        nc = int(want.n_cand[i])
+        assert int(n[i]) == nc
+        assert np.array_equal(mf[i, :nc].numpy(), want.cand_frame[i, :nc]) and np.array_equal(mv[i, :nc].numpy(), want.cand_votes[i, :nc])
+        # the owner of the global top-1 frame holds its complete match list, in the same order
+        top = int(want.cand_frame[i, 0])
+        m, res, lo, hi = next(s for s in shards if s[2] <= top < s[3])
+        k = int(np.where(res.cand_frame[i, :res.n_cand[i]] == top)[0][0])
+        qi_s, de_s = m.result_pairs(i, res)
+        qi_w, de_w = single.result_pairs(i, want)
+        a, b = res.pair_off[i, k], res.pair_off[i, k + 1]
+        assert np.array_equal(qi_s[a:b], qi_w[want.pair_off[i, 0]:want.pair_off[i, 1]])
+        ent_s = m.fetch_entries(de_s[a:b])
+        ent_w = single.fetch_entries(de_w[want.pair_off[i, 0]:want.pair_off[i, 1]])
+        assert np.array_equal(ent_s.side, ent_w.side) and np.array_equal(ent_s.frame, ent_w.frame)
+    single.close()
+    for s in shards:
+        s[0].close()
