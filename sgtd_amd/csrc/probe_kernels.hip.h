@@ -142,6 +142,12 @@ __global__ __launch_bounds__(SGTD_RESOLVE_THREADS) void resolve_kernel(TableView
 #define SGTD_VOTE_LDS 1     // LDS histogram of the work item, flushed by the caller
 #define SGTD_VOTE_GLOBAL 2  // one global atomic per match
 
+// per-descriptor results of the sweep when the caller stores them itself (one store per
+// ticket instead of one per descriptor)
+struct DescResult {
+  u32 ptr, visit, match;
+};
+
 struct WaveSlab {
   u32 next, end;   // this wave's private range of match records
 #ifdef SGTD_EXP_PHASE
@@ -198,7 +204,8 @@ __device__ __forceinline__ DescPlan plan_from_cell_row(const DescFetch &f) {
 template <int VOTE, bool DIAG, bool WIDE = true>
 __device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
                                                  long long d, const DescFetch &f, const DescPlan &pl,
-                                                 WaveSlab &slab, u32 *s_hist, u32 *votes) {
+                                                 WaveSlab &slab, u32 *s_hist, u32 *votes,
+                                                 DescResult *result = nullptr) {
   const int lane = lane_id();
   const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
   const u32 qframe = f.qframe;
@@ -319,7 +326,9 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   };
   if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
   else run(std::false_type{});
-  if (lane == 0) {
+  if (result) {
+    result->ptr = slab.next; result->visit = total; result->match = fits ? matches : 0;
+  } else if (lane == 0) {
     B.list_ptr[d] = slab.next;
     B.n_visit[d] = total;
     B.n_match[d] = fits ? matches : 0;
@@ -600,6 +609,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
 #endif
     u32 g_cur = (u32)__builtin_amdgcn_readlane((int)rec.z, 2);
     u32 row_next = load_row(g_cur);
+    u32 r_ptr = 0, r_visit = 0, r_match = 0;   // lane i: results of descriptor i of the chunk
     for (u32 i = 0; i < n; i++) {
       DescFetch f;
       f.row = row_next;
@@ -616,7 +626,17 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       f.qframe = (u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 2);
       f.gate = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
       const long long d = (long long)(u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
-      sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, f, plan_from_group_row(f), slab, nullptr, nullptr);
+      DescResult res;
+      sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, f, plan_from_group_row(f), slab, nullptr, nullptr, &res);
+      if ((u32)lane == i) { r_ptr = res.ptr; r_visit = res.visit; r_match = res.match; }
+    }
+    {   // the chunk's results: lane i < n stores for its descriptor (slot d in quarter 2 of record i)
+      const u32 d_mine = (u32)__shfl((int)rec.w, (4 * lane + 2) & 63);
+      if ((u32)lane < n) {
+        B.list_ptr[d_mine] = r_ptr;
+        B.n_visit[d_mine] = r_visit;
+        B.n_match[d_mine] = r_match;
+      }
     }
     cur_c = nxt_c;
     rec = rec_next;
