@@ -935,9 +935,21 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
 
 // pass 1: blk_count[(q*blocks+blk)*64 + s] = matches of the block in slot s;
 // also the per-query sums of visited entries / matches for the statistics
+// compact list of one query's candidate matches, block after block in list order: the pairs
+// (q_idx << 32 | g) of the records whose frame made the candidate list, and their slots.
+// Written by block_count_kernel, consumed by block_write_kernel (no second record walk).
+struct CompactLists {
+  u64 *pair;             // [cap]
+  unsigned char *slot;   // [cap]
+  u32 *blk_start;        // [nq * blocks_per_query] first entry of the block's list
+  u32 *blk_n;            // [nq * blocks_per_query] entries of the block's list
+  u32 *cursor;           // global allocation cursor
+  u32 cap;
+};
+
 __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
                                                           const int *cand_frame, int cand_num,
-                                                          int blocks_per_query, u32 *blk_count,
+                                                          int blocks_per_query, u32 *blk_count, CompactLists L,
                                                           u32 *q_M, unsigned long long *q_P) {
   constexpr int NW = 256 / SGTD_WAVE;
   __shared__ u32 s_pre[NW][32];
@@ -952,35 +964,69 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   if (!id.valid) return;
   const u32 cnt = Q.count[q];
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
-  u32 *out = blk_count + ((size_t)q * blocks_per_query + id.blk) * 64;
-  if (d_first >= cnt) { out[lane] = 0; return; }
+  const size_t bslot = (size_t)q * blocks_per_query + id.blk;
+  u32 *out = blk_count + bslot * 64;
+  if (d_first >= cnt) { out[lane] = 0; if (lane == 0) { L.blk_start[bslot] = 0; L.blk_n[bslot] = 0; } return; }
+  const u32 d_last = min(d_first + SGTD_PROBE_CHUNK, cnt);
+  // room for the block's compact list: at most every record of the block
+  u32 nm = 0;
+  for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.n_match[(long long)q * Q.stride + dd];
+  const u32 r_blk = wave_sum(nm);
+  u32 start = 0;
+  if (lane == 0) start = atomicAdd(L.cursor, r_blk);
+  start = (u32)__builtin_amdgcn_readfirstlane((int)start);
+  const bool fits = (unsigned long long)start + r_blk <= (unsigned long long)L.cap;
+  if (!fits && lane == 0) B.overflow[0] = 1;     // sized like the record buffer: grown and re-run with it
   s_hist[wid][lane] = 0;
-  u32 visits = 0, total = 0;
-  for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
+  u32 visits = 0, total = 0, running = 0;
+  for (u32 d0 = d_first; d0 < d_last; d0 += SGTD_SUB_DESCS) {
     const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
     total += R;
-    for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
-      u32 fr[4]; bool ok[4];
+    // the records of the next four words are loaded while the current four are looked up
+    u32 nfr[4], ngg[4], ndd[4];
+    auto load4 = [&](u32 r0) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const u32 r = r0 + u * SGTD_WAVE + lane;
-        ok[u] = r < R;
-        u32 dd, addr;
-        sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
-        fr[u] = B.rec_frame[addr];
+        u32 ad;
+        sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, ndd[u], ad);
+        nfr[u] = B.rec_frame[ad];
+        ngg[u] = B.rec_g[ad];     // with the frame, not after the slot lookup: no dependent load
       }
+    };
+    if (R) load4(0);
+    for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
+      u32 fr[4], gg[4], dd[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { fr[u] = nfr[u]; gg[u] = ngg[u]; dd[u] = ndd[u]; }
+      if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const u32 sl = ok[u] ? cand_slot(s_cand, fr[u]) : 0xFFu;
-        if (sl != 0xFFu) atomicAdd(&s_hist[wid][sl], 1u);   // counting needs no order
+        const bool ok = r0 + u * SGTD_WAVE + lane < R;
+        const u32 sl = ok ? cand_slot(s_cand, fr[u]) : 0xFFu;
+        const bool valid = sl != 0xFFu;
+        const u64 m = __ballot(valid);
+        if (valid) {
+          atomicAdd(&s_hist[wid][sl], 1u);   // counting needs no order
+          if (fits) {
+            const u32 pos = start + running + (u32)__popcll(m & lanemask_lt());
+            // slot rides in the top 6 bits of the q_idx half (q_idx < 36 * 65535 < 2^26)
+            L.pair[pos] = ((u64)((sl << 26) | (d0 + dd[u])) << 32) | (u64)gg[u];
+          }
+        }
+        running += (u32)__popcll(m);
       }
     }
   }
   __builtin_amdgcn_wave_barrier();
   out[lane] = s_hist[wid][lane];
-  if (lane == 0 && q_M) {   // statistics (the key-major pipeline takes them in votes_kernel)
-    atomicAdd(&q_M[q], total);
-    atomicAdd(&q_P[q], (unsigned long long)visits);
+  if (lane == 0) {
+    L.blk_start[bslot] = start;
+    L.blk_n[bslot] = fits ? running : 0;
+    if (q_M) {   // statistics (the key-major pipeline takes them in votes_kernel)
+      atomicAdd(&q_M[q], total);
+      atomicAdd(&q_P[q], (unsigned long long)visits);
+    }
   }
 }
 
@@ -1040,33 +1086,29 @@ __global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32
 
 // pass 2: every candidate's match_list_ in (i, cell, j) order (:437-449);
 // pair = query descriptor index << 32 | insertion index of the table entry
-__global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
-                                                          const int *cand_frame, int blocks_per_query,
+__global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuffers B, CompactLists L,
+                                                          int blocks_per_query,
                                                           const u32 *blk_excl, int cand_num,
                                                           const long long *pair_off, const u32 *q_pair_base,
                                                           u64 *pairs) {
   constexpr int NW = 256 / SGTD_WAVE;
   constexpr int CAP = 16;   // staged pairs per slot = one 128-B line
-  __shared__ u32 s_pre[NW][32];
-  __shared__ u32 s_ptr[NW][32];
-  __shared__ u32 s_cnt[NW][64];
-  __shared__ u64 s_cand[SGTD_CAND_HASH];
+  __shared__ u64 s_mask[NW][64];         // per wave and slot: lanes of the current word that carry the slot
   __shared__ u64 s_stage[NW][64][CAP];   // per wave and slot: pairs waiting for a full-line store
   if (B.overflow[0] || B.overflow[1]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
-  const int q = id.q;
-  cand_hash_build(s_cand, n_cand, cand_frame, q, Q.n_queries, cand_num);
   if (!id.valid) return;
-  const u32 cnt = Q.count[q];
-  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
-  if (d_first >= cnt) return;
+  const int q = id.q;
+  const size_t bslot = (size_t)q * blocks_per_query + id.blk;
+  const u32 nv = L.blk_n[bslot];
+  if (nv == 0) return;
+  const u64 *cp = L.pair + L.blk_start[bslot];
   // lane s carries, for candidate slot s, the output position of its first staged
   // pair (`running`) and the number of staged pairs (`fill`)
   u32 running = 0, fill = 0;
   if (lane < cand_num)
-    running = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + lane] +
-              blk_excl[((size_t)q * blocks_per_query + id.blk) * 64 + lane];
+    running = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + lane] + blk_excl[bslot * 64 + lane];
   // all staged pairs go out as 16-lane groups, 4 slots per store instruction
   auto flush = [&]() {
 #pragma unroll 4
@@ -1079,54 +1121,51 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
     fill = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  u32 visits = 0;
-  for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
-    const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
-    // the records of the next two words are loaded while the current two are split
-    u64 nrec[2]; u32 ndd[2];
-    auto load2 = [&](u32 r0) {
+  // the next two words of the compact list are loaded while the current two are split
+  u64 npair[2]; u32 nsl[2];
+  auto load2 = [&](u32 r0) {
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const u32 r = r0 + u * SGTD_WAVE + lane;
-        u32 addr;
-        sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, ndd[u], addr);
-        nrec[u] = ((u64)B.rec_frame[addr] << 32) | (u64)B.rec_g[addr];
+    for (int u = 0; u < 2; u++) {
+      const u32 r = r0 + u * SGTD_WAVE + lane;
+      const bool ok = r < nv;
+      const u64 v = cp[ok ? r : 0u];
+      npair[u] = v & 0x03FFFFFFFFFFFFFFull;
+      nsl[u] = ok ? (u32)(v >> 58) : 0xFFu;
+    }
+  };
+  load2(0);
+  for (u32 r0 = 0; r0 < nv; r0 += 2 * SGTD_WAVE) {
+    u64 pr[2]; u32 sl[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) { pr[u] = npair[u]; sl[u] = nsl[u]; }
+    if (r0 + 2 * SGTD_WAVE < nv) load2(r0 + 2 * SGTD_WAVE);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const bool valid = sl[u] != 0xFFu;
+      const int s = (int)(sl[u] & 63u);
+      // lanes with equal slot, by commutative LDS ORs (the result does not depend on the
+      // order the hardware applies them in): rank = lanes below me in my group
+      s_mask[wid][lane] = 0;
+      __builtin_amdgcn_wave_barrier();
+      if (valid) atomicOr(&s_mask[wid][s], 1ull << lane);
+      __builtin_amdgcn_wave_barrier();
+      const u64 gm = valid ? s_mask[wid][s] : 0ull;
+      const u32 c_own = (u32)__popcll(s_mask[wid][lane]);   // pairs this word adds to slot == lane
+      __builtin_amdgcn_wave_barrier();
+      const u32 rank = (u32)__popcll(gm & lanemask_lt()), count = (u32)__popcll(gm);
+      u32 have = __shfl(fill, s);
+      if (__ballot(valid && have + count > (u32)CAP)) {   // some slot would overflow its line: drain all
+        flush();
+        have = 0;
       }
-    };
-    if (R) load2(0);
-    for (u32 r0 = 0; r0 < R; r0 += 2 * SGTD_WAVE) {
-      u64 rec[2]; u32 dd[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) { rec[u] = nrec[u]; dd[u] = ndd[u]; }
-      if (r0 + 2 * SGTD_WAVE < R) load2(r0 + 2 * SGTD_WAVE);
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const bool ok = r0 + u * SGTD_WAVE + lane < R;
-        const u32 sl = ok ? cand_slot(s_cand, (u32)(rec[u] >> 32)) : 0xFFu;
-        const bool valid = sl != 0xFFu;
-        const int s = (int)(sl & 63u);
-        u32 rank, count;
-        wave_group_rank<6>((u32)s, valid, rank, count);
-        u32 have = __shfl(fill, s);
-        if (__ballot(valid && have + count > (u32)CAP)) {   // some slot would overflow its line: drain all
-          flush();
-          have = 0;
-        }
-        const u32 base = __shfl(running, s);
-        const bool direct = count > (u32)CAP;               // a group larger than a line bypasses the stage
-        const u64 pair = ((u64)(d0 + dd[u]) << 32) | (rec[u] & 0xFFFFFFFFull);
-        s_cnt[wid][lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-          if (direct) pairs[base + rank] = pair;            // its stage is empty here (just drained)
-          else s_stage[wid][s][have + rank] = pair;
-          if (rank == 0) s_cnt[wid][s] = direct ? (count | 0x80000000u) : count;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const u32 c = s_cnt[wid][lane];
-        if (c & 0x80000000u) running += c & 0x7FFFFFFFu; else fill += c;
-        __builtin_amdgcn_wave_barrier();
+      const u32 base = __shfl(running, s);
+      const bool direct = count > (u32)CAP;               // a group larger than a line bypasses the stage
+      if (valid) {
+        if (direct) pairs[base + rank] = pr[u];           // its stage is empty here (just drained)
+        else s_stage[wid][s][have + rank] = pr[u];
       }
+      if (c_own > (u32)CAP) running += c_own; else fill += c_own;
+      __builtin_amdgcn_wave_barrier();
     }
   }
   flush();

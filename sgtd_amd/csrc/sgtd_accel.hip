@@ -89,6 +89,7 @@ struct sgtd_engine {
   int last_max_n = 0;
   DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
   DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
+  DevBuf c_pair, c_slot, c_blk;   // compact candidate-match lists between block_count and block_write
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
   bool verified = false;
@@ -404,6 +405,8 @@ int do_finalize(sgtd_engine *e) {
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e) {
   CHK(ensure(e, e->rec, e->rec_cap * sizeof(u64)));
+  CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));
+  CHK(ensure(e, e->c_slot, e->rec_cap));
   if (e->diag) {
     CHK(ensure(e, e->rec_cell, e->rec_cap));
     CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
@@ -449,7 +452,7 @@ int launch_select(sgtd_engine *e) {
   const int cn = e->dc.cand_num;
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
-  CHK(ensure(e, e->cursors, 2 * sizeof(u32)));
+  CHK(ensure(e, e->cursors, 4 * sizeof(u32)));
   CHK(ensure(e, e->overflow, 2 * sizeof(int)));
   CHK(ensure(e, e->list_ptr, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
@@ -461,13 +464,14 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->q_pairs, (size_t)nq * sizeof(u32)));
   CHK(ensure(e, e->q_pair_base, (size_t)(nq + 1) * sizeof(u32)));
   CHK(ensure(e, e->blk_count, (size_t)nq * blocks * 64 * sizeof(u32)));
+  CHK(ensure(e, e->c_blk, (size_t)nq * blocks * 2 * sizeof(u32)));
   CHK(ensure(e, e->n_cand, (size_t)nq * sizeof(int)));
   CHK(ensure(e, e->cand_frame, (size_t)nq * cn * sizeof(int)));
   CHK(ensure(e, e->cand_votes, (size_t)nq * cn * sizeof(int)));
   CHK(ensure(e, e->pair_off, (size_t)nq * (cn + 1) * sizeof(long long)));
   CHK(rec_alloc(e));
 
-  HIPCHK(hipMemsetAsync(e->cursors.p, 0, 2 * sizeof(u32), e->stream));
+  HIPCHK(hipMemsetAsync(e->cursors.p, 0, 4 * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->overflow.p, 0, 2 * sizeof(int), e->stream));
   HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
@@ -646,8 +650,12 @@ int launch_select(sgtd_engine *e) {
                                           e->slot_of.as<unsigned char>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
+  CompactLists CL;
+  CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
+  CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
+  CL.cursor = e->cursors.as<u32>() + 2; CL.cap = v.B.rec_cap;
   block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
-                                                    blocks, e->blk_count.as<u32>(),
+                                                    blocks, e->blk_count.as<u32>(), CL,
                                                     e->key_major ? nullptr : e->q_M.as<u32>(),
                                                     e->key_major ? nullptr : e->q_P.as<unsigned long long>());
   HIPCHK(hipGetLastError());
@@ -660,7 +668,7 @@ int launch_select(sgtd_engine *e) {
                                                (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
-  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(),
+  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL,
                                                     blocks, e->blk_count.as<u32>(), cn,
                                                     e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
                                                     e->pairs.as<u64>());
@@ -871,7 +879,7 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
                     &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
-                    &e->blk_count, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
+                    &e->blk_count, &e->c_pair, &e->c_slot, &e->c_blk, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
                     &e->cand_votes, &e->pair_off, &e->pairs};
   for (DevBuf *b : bufs) free_buf(*b);
