@@ -232,32 +232,35 @@ def main():
     # ---- next stage of the reference's SearchLoop (STDesc.cpp:105-146), reported separately
     verify = None
     if mode == "single" and args.verify == "on":
-        mgr.verify(); mgr.sync(); torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(3):
-            mgr.verify()
-        torch.cuda.synchronize()
-        tv = (time.perf_counter() - tv) / 3
-        bc, bf, bs = mgr.search_loop()
-        hit = bf >= 0
-        ok = hit & (np.linalg.norm(smap.pose[np.clip(bf, 0, F - 1), :2] - queries.pose[:, :2], axis=1) < 5.0)
-        verify = {"ms_per_batch": 1000.0 * tv, "queries": Q, "loops_found": int(hit.sum()),
-                  "loop_pose_within_5m": int(ok.sum()), "pairs_verified": int(st["last_cand_pairs"])}
-        # the node's own metrics (semantic_graph_localization.cpp:605-745) on the synthetic ground truth
-        from sgtd_amd import evaluate as ev
-        map_pose4 = np.stack([ev.pose_matrix(*p) for p in smap.pose])
-        met = ev.LoopMetrics(mgr.config_setting_["candidate_num"])
-        for q in range(min(Q, 256)):
-            n_c = int(res.n_cand[q])
-            if bf[q] > 0:
-                score, rot, t = mgr.result_verify(q)
-                ev.account(met, ev.pose_matrix(*queries.pose[q]), map_pose4, int(bf[q]), rot[int(bc[q])], t[int(bc[q])],
-                           res.cand_frame[q, :n_c], score[:n_c])
-            else:
-                ev.account(met, ev.pose_matrix(*queries.pose[q]), map_pose4, int(bf[q]), None, None, (), ())
-        loc = met.summary()
-        loc["STD_num"] = loc["STD_num"][:10]
-        verify["localization_first_256_queries"] = loc
+        try:   # the extra stage must never cost the headline line
+            mgr.verify(); mgr.sync(); torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(3):
+                mgr.verify()
+            torch.cuda.synchronize()
+            tv = (time.perf_counter() - tv) / 3
+            bc, bf, bs = mgr.search_loop()
+            hit = bf >= 0
+            ok = hit & (np.linalg.norm(smap.pose[np.clip(bf, 0, F - 1), :2] - queries.pose[:, :2], axis=1) < 5.0)
+            verify = {"ms_per_batch": 1000.0 * tv, "queries": Q, "loops_found": int(hit.sum()),
+                      "loop_pose_within_5m": int(ok.sum()), "pairs_verified": int(st["last_cand_pairs"])}
+            # the node's own metrics (semantic_graph_localization.cpp:605-745) on the synthetic ground truth
+            from sgtd_amd import evaluate as ev
+            map_pose4 = np.stack([ev.pose_matrix(*p) for p in smap.pose])
+            met = ev.LoopMetrics(mgr.config_setting_["candidate_num"])
+            for q in range(min(Q, 256)):
+                n_c = int(res.n_cand[q])
+                if bf[q] > 0:
+                    score, rot, t = mgr.result_verify(q)
+                    ev.account(met, ev.pose_matrix(*queries.pose[q]), map_pose4, int(bf[q]), rot[int(bc[q])], t[int(bc[q])],
+                               res.cand_frame[q, :n_c], score[:n_c])
+                else:
+                    ev.account(met, ev.pose_matrix(*queries.pose[q]), map_pose4, int(bf[q]), None, None, (), ())
+            loc = met.summary()
+            loc["STD_num"] = loc["STD_num"][:10]
+            verify["localization_first_256_queries"] = loc
+        except Exception as exc:   # reported, not fatal
+            verify = {"error": "%s: %s" % (type(exc).__name__, exc)}
     out = None
     if rank == 0:
         value = Q * args.steps / elapsed
@@ -290,10 +293,14 @@ def main():
             out["recall"] = recall(smap, queries, f[:, 0].cpu().numpy())
         want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and F <= 2000)
         if mode == "single" and want_cpu:
-            cb, par = cpu_baseline(smap, queries, res, mgr, args.cpu_seconds)
-            out["cpu_baseline"] = cb
-            out["parity"] = par
-            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            try:
+                cb, par = cpu_baseline(smap, queries, res, mgr, args.cpu_seconds)
+                out["cpu_baseline"] = cb
+                out["parity"] = par
+                out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            except Exception as exc:   # a broken checker must not cost the measured line
+                out["cpu_baseline"] = None
+                out["cpu_baseline_error"] = "%s: %s" % (type(exc).__name__, exc)
         else:
             out["cpu_baseline"] = None
     if world > 1:
