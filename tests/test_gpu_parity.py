@@ -511,3 +511,46 @@ def test_table_shards_merge_to_the_single_table_result(mods, n_shards):
     single.close()
     for s in shards:
         s[0].close()
+
+
+# ---------------------------------------------------------------------------
+# Property test: random configurations and random small worlds — descriptors,
+# candidates, votes and match lists identical to the CPU restatement
+# ---------------------------------------------------------------------------
+def test_random_configs_property(mods):
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    _, _, synth = mods
+
+    @settings(max_examples=12, deadline=None, derandomize=True,
+              suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(k=st.integers(3, 12), res=st.sampled_from([0.25, 0.5, 1.0, 2.0]), min_len=st.sampled_from([0.0, 0.5, 2.0]),
+           max_len=st.sampled_from([15.0, 30.0, 50.0]), rough=st.sampled_from([0.01, 0.03, 0.1]),
+           cand=st.integers(1, 20), n_kp=st.integers(12, 70), n_frames=st.integers(2, 9),
+           labels=st.sampled_from([(3, 11), (0, 12), (5, 6), (0, 40)]), stream=st.integers(100, 10_000))
+    def run(k, res, min_len, max_len, rough, cand, n_kp, n_frames, labels, stream):
+        if n_kp < k:
+            n_kp = k
+        cfg = dict(descriptor_near_num=k, std_side_resolution=res, descriptor_min_len=min_len, descriptor_max_len=max_len,
+                   rough_dis_threshold=rough, candidate_num=cand)
+        g, o = _pair(mods, **cfg)
+        try:
+            m = synth.make_map(n_frames, n_kp, stream=stream, label_lo=labels[0], label_hi=labels[1])
+            q = synth.make_queries(m, 2, stream=stream)
+            for f in range(n_frames):
+                d = g.BuildSingleScanSTD(m.xyz[f], m.label[f])
+                assert_descs_equal(d, o.build(m.xyz[f], m.label[f]))
+                g.AddSTDescs(d)
+                o.add_last()
+            r = g.query_frames(q.xyz, q.label)
+            for i in range(2):
+                o.build(q.xyz[i], q.label[i], export=False)
+                want = o.select()
+                nc = int(r.n_cand[i])
+                assert np.array_equal(r.cand_frame[i, :nc], want["cand_frame"])
+                assert np.array_equal(r.cand_votes[i, :nc], want["cand_votes"])
+                qi, de = g.result_pairs(i, r)
+                assert np.array_equal(qi, want["q_idx"]) and np.array_equal(de, want["db_entry"])
+        finally:
+            g.close()
+
+    run()
