@@ -1,0 +1,171 @@
+// localize.cpp — the reference node's main loop (src/sgtd/src/semantic_graph_localization.cpp:
+// 376-458 map construction, 506-520 query loading, 567-646 + 716-745 query loop and metrics)
+// on the C ABI alone: graph-JSON directories in, localization statistics out.  No ROS, no PCL,
+// no GICP (enable_gicp = false); BASE2OUSTER = identity.
+//
+//   localize <map_dir> <query_dir> [batch=256] [icp_threshold=0.4]
+//
+// Map frames take the sorted file order here (the reference uses the unsorted directory order,
+// quirk 13: pass an explicit order if a run must be reproduced); queries are sorted (:386).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <string>
+#include <vector>
+
+#include "sgtd_accel.h"
+
+namespace fs = std::filesystem;
+
+struct Mat4 {
+  float m[4][4];
+};
+static Mat4 from_row(const float *p) {   // 12 floats, row-major 3x4 (:723-733)
+  Mat4 r{};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) r.m[i][j] = p[i * 4 + j];
+  r.m[3][3] = 1.f;
+  return r;
+}
+static Mat4 mul(const Mat4 &a, const Mat4 &b) {
+  Mat4 r{};
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float s = 0;
+      for (int k = 0; k < 4; k++) s += a.m[i][k] * b.m[k][j];
+      r.m[i][j] = s;
+    }
+  return r;
+}
+static Mat4 rigid_inverse(const Mat4 &a) {   // poses are rigid: R^T, -R^T t
+  Mat4 r{};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r.m[i][j] = a.m[j][i];
+  for (int i = 0; i < 3; i++) r.m[i][3] = -(r.m[i][0] * a.m[0][3] + r.m[i][1] * a.m[1][3] + r.m[i][2] * a.m[2][3]);
+  r.m[3][3] = 1.f;
+  return r;
+}
+// utility.hpp:109-123
+static void compute_adj_rpe(const Mat4 &gt, const Mat4 &lo, double &t_e, double &r_e) {
+  const Mat4 d = mul(rigid_inverse(lo), gt);
+  t_e = std::sqrt((double)d.m[0][3] * d.m[0][3] + (double)d.m[1][3] * d.m[1][3] + (double)d.m[2][3] * d.m[2][3]);
+  const double c = std::fmin(std::fmax(((double)d.m[0][0] + d.m[1][1] + d.m[2][2] - 1) / 2, -1.0), 1.0);
+  r_e = std::fabs(std::acos(c)) / M_PI * 180;
+}
+
+static std::vector<std::string> list_json(const char *dir) {
+  std::vector<std::string> v;
+  if (!fs::is_directory(dir)) {
+    std::fprintf(stderr, "not a directory: %s\n", dir);
+    std::exit(2);
+  }
+  for (auto &e : fs::recursive_directory_iterator(dir))
+    if (e.is_regular_file() && e.path().extension() == ".json") v.push_back(e.path().string());
+  std::sort(v.begin(), v.end());
+  return v;
+}
+
+#define OK(call)                                                                          \
+  do {                                                                                    \
+    const int st_ = (call);                                                               \
+    if (st_ != SGTD_OK) {                                                                 \
+      std::fprintf(stderr, "%s failed: %s\n", #call, sgtd_strerror(st_));                 \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+struct Graphs {
+  sgtd_graph_batch *b = nullptr;
+  int n = 0;
+  const float *xyz = nullptr, *poses = nullptr;
+  const uint32_t *label = nullptr;
+  const int64_t *off = nullptr;
+};
+static int load(const std::vector<std::string> &files, Graphs &g) {
+  std::vector<const char *> p;
+  for (auto &s : files) p.push_back(s.c_str());
+  const int st = sgtd_graphs_load(p.data(), (int)p.size(), 16, &g.b);
+  if (st != SGTD_OK) {
+    std::fprintf(stderr, "%s\n", sgtd_graphs_error(g.b));
+    return st;
+  }
+  return sgtd_graphs_view(g.b, &g.n, nullptr, &g.xyz, &g.label, &g.off, &g.poses);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s <map_dir> <query_dir> [batch] [icp_threshold]\n", argv[0]);
+    return 2;
+  }
+  const int batch = argc > 3 ? std::atoi(argv[3]) : 256;
+  const double icp_threshold = argc > 4 ? std::atof(argv[4]) : 0.4;   // SG_localization.yaml:89
+  auto t0 = std::chrono::steady_clock::now();
+  Graphs map, qs;
+  OK(load(list_json(argv[1]), map));
+  OK(load(list_json(argv[2]), qs));
+  auto t1 = std::chrono::steady_clock::now();
+
+  sgtd_config cfg;
+  sgtd_default_config(&cfg);                                 // SG_localization.yaml:74-89
+  if (map.n + 1 > cfg.max_frame_n) cfg.max_frame_n = map.n + 1;
+  sgtd_handle h = nullptr;
+  OK(sgtd_create(&cfg, &h));
+  OK(sgtd_add_frames(h, map.xyz, map.label, map.off, map.n, 0));   // :419-458
+  OK(sgtd_finalize(h));
+  auto t2 = std::chrono::steady_clock::now();
+
+  const int cn = cfg.candidate_num;
+  long total_num = 0, detected = 0, score_num = 0, test_10 = 0;
+  std::vector<long> STD_num(cn, 0);
+  double err_t = 0, err_r = 0;
+  std::vector<int32_t> n_cand(batch), cand_frame((size_t)batch * cn), best_cand(batch), best_frame(batch);
+  std::vector<double> best_score(batch), score(cn), pose((size_t)cn * 12);
+  for (int q0 = 0; q0 < qs.n; q0 += batch) {                 // :567-745, `batch` queries per call
+    const int nb = std::min(batch, qs.n - q0);
+    std::vector<int64_t> off(nb + 1);
+    for (int i = 0; i <= nb; i++) off[i] = qs.off[q0 + i] - qs.off[q0];
+    OK(sgtd_query_frames(h, qs.xyz + 3 * qs.off[q0], qs.label + qs.off[q0], off.data(), nb, 0));
+    OK(sgtd_verify(h));
+    OK(sgtd_search_loop(h, icp_threshold, best_cand.data(), best_frame.data(), best_score.data()));
+    OK(sgtd_result_candidates(h, n_cand.data(), cand_frame.data(), nullptr, nullptr));
+    for (int i = 0; i < nb; i++) {
+      total_num++;
+      if (!(best_frame[i] > 0)) continue;                    // search_result.first > 0 (:606-620)
+      detected++;
+      const Mat4 gt = from_row(qs.poses + (size_t)(q0 + i) * 12);
+      OK(sgtd_result_verify(h, i, score.data(), pose.data()));
+      std::vector<int> order(n_cand[i]);
+      for (int k = 0; k < n_cand[i]; k++) order[k] = k;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (int)score[a] > (int)score[b]; });   // :12-14, int member
+      for (int rank = 0; rank < n_cand[i]; rank++) {         // :621-645
+        double te, re;
+        compute_adj_rpe(gt, from_row(map.poses + (size_t)cand_frame[(size_t)i * cn + order[rank]] * 12), te, re);
+        if (te < 10) { test_10++; STD_num[rank]++; break; }
+      }
+      Mat4 nt{};                                             // new_trans (:716-720)
+      const double *p = &pose[(size_t)best_cand[i] * 12];
+      for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) nt.m[a][b] = (float)p[a * 3 + b];
+        nt.m[a][3] = (float)p[9 + a];
+      }
+      nt.m[3][3] = 1.f;
+      double te, re;
+      compute_adj_rpe(gt, mul(from_row(map.poses + (size_t)best_frame[i] * 12), nt), te, re);   // :733-735
+      if (te < 5 && re < 10) { score_num++; err_t += te; err_r += re; }
+    }
+  }
+  auto t3 = std::chrono::steady_clock::now();
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  std::printf("map frames %d, queries %ld: loops %ld, success(5m,10deg) %ld (%.4f), candidate<10m %ld, top-1 hit %ld\n", map.n,
+              total_num, detected, score_num, total_num ? (double)score_num / total_num : 0.0, test_10, STD_num[0]);
+  std::printf("mean errors of the successes: %.4f m, %.4f deg\n", score_num ? err_t / score_num : 0.0, score_num ? err_r / score_num : 0.0);
+  std::printf("time: load %.1f ms, map build %.1f ms, queries %.1f ms (%.3f ms per query incl. verification)\n", ms(t0, t1), ms(t1, t2),
+              ms(t2, t3), total_num ? ms(t2, t3) / total_num : 0.0);
+  sgtd_destroy(h);
+  sgtd_graphs_free(map.b);
+  sgtd_graphs_free(qs.b);
+  return 0;
+}
