@@ -57,7 +57,7 @@ struct ProbeBuffers {
   unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
-  u32 *rec_cursor;      // global slab cursor
+  unsigned long long *rec_cursor;   // global slab cursor (64-bit: requests can add up beyond 2^32)
   u32 *item_cursor;     // work queue head
   u32 *list_ptr;        // [n_slots] first record of descriptor
   u32 *n_visit;         // [n_slots] entries visited by descriptor
@@ -216,14 +216,15 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   u64 ph_t = PH_T(); (void)ph_t;
   // records of one descriptor are contiguous: make sure the slab can take
   // the worst case (every visited entry matches)
-  if (total && slab.next + total > slab.end) {
+  if (total && (u64)slab.next + total > (u64)slab.end) {
     const u32 take = total > SGTD_REC_SLAB ? total : SGTD_REC_SLAB;
-    u32 got = 0;
-    if (lane == 0) got = atomicAdd(B.rec_cursor, take);
-    got = __shfl(got, 0);
-    slab.next = got; slab.end = got + take;
+    u64 got = 0;
+    if (lane == 0) got = atomicAdd(B.rec_cursor, (unsigned long long)take);
+    got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
+    if (got + take <= (u64)B.rec_cap) { slab.next = (u32)got; slab.end = (u32)got + take; }
+    else { slab.next = 0; slab.end = 0; }      // the buffer is exhausted: nothing of this wave fits any more
   }
-  const bool fits = (unsigned long long)slab.next + total <= (unsigned long long)B.rec_cap;
+  const bool fits = (u64)slab.next + total <= (u64)slab.end;
   if (!fits && lane == 0) B.overflow[0] = 1;
   __builtin_amdgcn_wave_barrier();
   PH_ADD(0, ph_t);

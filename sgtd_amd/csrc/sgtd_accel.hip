@@ -439,7 +439,7 @@ Views make_views(sgtd_engine *e) {
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
   B.rec_frame = e->rec.as<u32>(); B.rec_g = e->rec.as<u32>() + e->rec_cap;   // two halves of one allocation
-  B.rec_cursor = e->cursors.as<u32>(); B.item_cursor = e->cursors.as<u32>() + 1;
+  B.rec_cursor = e->cursors.as<unsigned long long>(); B.item_cursor = e->cursors.as<u32>() + 2;
   B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
   B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
   v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
@@ -653,7 +653,7 @@ int launch_select(sgtd_engine *e) {
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
-  CL.cursor = e->cursors.as<u32>() + 2; CL.cap = v.B.rec_cap;
+  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = v.B.rec_cap;
   block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
                                                     blocks, e->blk_count.as<u32>(), CL,
                                                     e->key_major ? nullptr : e->q_M.as<u32>(),
@@ -702,17 +702,24 @@ int sync_batch(sgtd_engine *e) {
   e->stats.overflowed = 0;
   for (int attempt = 0; attempt < 8; attempt++) {
     int ovf[2] = {0, 0};
-    u32 cursor = 0, total = 0;
+    unsigned long long cursor = 0;
+    u32 total = 0;
     HIPCHK(hipMemcpyAsync(ovf, e->overflow.p, sizeof(ovf), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&cursor, e->cursors.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&cursor, e->cursors.p, sizeof(cursor), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!ovf[0] && !ovf[1]) break;
     e->stats.overflowed = 1;
     if (attempt == 7) return SGTD_ERR_CAPACITY;
-    if (ovf[0]) e->rec_cap = std::max<size_t>(e->rec_cap * 2, (size_t)cursor + (cursor >> 2) + 65536);
-    else if (ovf[1]) e->pair_cap = std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536);
-    if (e->rec_cap > 0xFFFFFFF0ull || e->pair_cap > 0xFFFFFFF0ull) return SGTD_ERR_CAPACITY;
+    // grow towards the u32 index limit; a batch that does not fit even there must be split
+    const size_t lim = 0xFFFFFFF0ull;
+    if (ovf[0]) {
+      if (e->rec_cap >= lim) return SGTD_ERR_CAPACITY;
+      e->rec_cap = std::min<size_t>(lim, std::max<size_t>(e->rec_cap * 2, (size_t)cursor + (size_t)(cursor >> 2) + 65536));
+    } else if (ovf[1]) {
+      if (e->pair_cap >= lim) return SGTD_ERR_CAPACITY;
+      e->pair_cap = std::min<size_t>(lim, std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536));
+    }
     CHK(rerun(e));
   }
   const int nq = e->nq, cn = e->dc.cand_num;
