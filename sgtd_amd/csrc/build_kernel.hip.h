@@ -24,6 +24,12 @@ struct DescArrays {
 };
 
 #define SGTD_BUILD_THREADS 1024
+#ifdef SGTD_EXP_PHASE
+__device__ unsigned long long g_bphase[8];
+#define BPH(i) do { if (tid == 0) { const unsigned long long _n = __builtin_readcyclecounter(); atomicAdd(&g_bphase[i], _n - bph_t); bph_t = _n; } } while (0)
+#else
+#define BPH(i) do { } while (0)
+#endif
 #define SGTD_TRI_INVALID 0xFFFFFFFFFFFFFFFFull
 #define SGTD_SLOT_EMPTY 0xFFFFFFFFu
 
@@ -137,6 +143,9 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     while (nslots < T + 1) nslots <<= 1;
     const int nwords = (T + 31) / 32;
 
+#ifdef SGTD_EXP_PHASE
+    unsigned long long bph_t = __builtin_readcyclecounter();
+#endif
     // ---- stage 0: keypoints -> LDS
     for (int i = tid; i < n; i += SGTD_BUILD_THREADS) {
       float4 p;
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     for (int w = tid; w < nwords; w += SGTD_BUILD_THREADS) winbits[w] = 0;
     __syncthreads();
 
+    BPH(0);
     // ---- stage 1: k-NN by sorted insertion networks in registers.  Four threads
     // share a keypoint: each scans a quarter of the candidates (ascending index),
     // parts 1..3 park their K best in the (not yet live) dedup-key area and part 0
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     }
     __syncthreads();
 
+    BPH(1);
     // ---- stage 2: keys of all triplets
     for (int t = tid; t < T; t += SGTD_BUILD_THREADS) {
       const int i = t / tpi, r = t - i * tpi;
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     if (!LDS_DEDUP) __threadfence_block();
     __syncthreads();
 
+    BPH(2);
     // ---- stage 3: first-wins dedup, slot value = min t of its key
     for (int t = tid; t < T; t += SGTD_BUILD_THREADS) {
       const u64 key = keys[t];
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     }
     __syncthreads();
 
+    BPH(3);
     // ---- stage 4: descriptor fill in (i,m,n) order of the surviving triplets
     const u32 frame_id = P.frame_id0 + (u32)(P.frame_id_step * f);
     for (int t = tid; t < T; t += SGTD_BUILD_THREADS) {
@@ -296,6 +309,10 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
       }
       out.node_id[o * 3 + 0] = i; out.node_id[o * 3 + 1] = m; out.node_id[o * 3 + 2] = nn;
     }
+#ifdef SGTD_EXP_PHASE
+    __syncthreads();
+    BPH(4);
+#endif
   }
 }
 

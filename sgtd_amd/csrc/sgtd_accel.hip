@@ -564,6 +564,16 @@ int launch_select(sgtd_engine *e) {
 #undef SGTD_LAUNCH_SORTED
 #ifdef SGTD_EXP_PHASE
     {
+      static int bcalls = 0;
+      if (++bcalls == 6) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        unsigned long long bp[8];
+        HIPCHK(hipMemcpyFromSymbol(bp, HIP_SYMBOL(g_bphase), sizeof(bp)));
+        const double tot = (double)(bp[0] + bp[1] + bp[2] + bp[3] + bp[4]);
+        fprintf(stderr, "BPHASE: load %.3f knn %.3f keys %.3f dedup+prefix %.3f fill %.3f\n", bp[0] / tot, bp[1] / tot, bp[2] / tot, bp[3] / tot, bp[4] / tot);
+      }
+    }
+    {
       static int pcalls = 0;
       if (++pcalls == 6) {
         HIPCHK(hipStreamSynchronize(e->stream));
