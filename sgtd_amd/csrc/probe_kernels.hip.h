@@ -217,7 +217,10 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   // records of one descriptor are contiguous: make sure the slab can take
   // the worst case (every visited entry matches)
   if (total && (u64)slab.next + total > (u64)slab.end) {
-    const u32 take = total > SGTD_REC_SLAB ? total : SGTD_REC_SLAB;
+    // a slab must have room for the worst case of a descriptor (every visit matches) when
+    // the descriptor starts, but only the matches stay: slabs of 8 worst cases keep the space
+    // abandoned at a slab's end to about an eighth however long the visit lists are
+    const u32 take = total > (1u << 28) ? total : max(SGTD_REC_SLAB, 8u * total);
     u64 got = 0;
     if (lane == 0) got = atomicAdd(B.rec_cursor, (unsigned long long)take);
     got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
