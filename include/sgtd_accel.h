@@ -192,6 +192,11 @@ int sgtd_verify(sgtd_handle h);
  * of query q: score[candidate_num], pose[candidate_num*12] = rot row-major (9) then t (3);
  * entries past the query's candidate count hold -1 / zeros.  Either pointer may be NULL. */
 int sgtd_result_verify(sgtd_handle h, int q, double *score, double *pose);
+/* asynchronous device-to-device export of the verification results of the whole batch into
+ * caller device buffers (score f64 [n_queries*candidate_num], pose f64 [n_queries*candidate_num*12]),
+ * enqueued on the handle's stream without synchronising: the table-sharded multi-GPU path
+ * all-gathers them with RCCL (every candidate frame is verified by the rank that owns it) */
+int sgtd_export_verify_dev(sgtd_handle h, double *d_score, double *d_pose);
 /* sucess_match_vec of (query q, candidate cand) as positions into that candidate's
  * match_list_ (ascending = list order); capacity in elements, *n = needed */
 int sgtd_result_inliers(sgtd_handle h, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n);

@@ -1231,6 +1231,17 @@ int sgtd_result_verify(sgtd_handle e, int q, double *score, double *pose) {
   return SGTD_OK;
 }
 
+int sgtd_export_verify_dev(sgtd_handle e, double *d_score, double *d_pose) {
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->verified || !e->batch_valid) return SGTD_ERR_STATE;
+  const size_t n = (size_t)e->nq * e->dc.cand_num;
+  if (n == 0) return SGTD_OK;
+  if (d_score) HIPCHK(hipMemcpyAsync(d_score, e->v_score.p, n * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  if (d_pose) HIPCHK(hipMemcpyAsync(d_pose, e->v_pose.p, n * 12 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  return SGTD_OK;
+}
+
 int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n) {
   if (!e || !n) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));

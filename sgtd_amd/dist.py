@@ -67,6 +67,57 @@ def gather_and_merge(local_frames, local_votes, cand_num, group=None):
     return merge_candidates(out[:, 0], out[:, 1], cand_num)
 
 
+def merge_verified(global_frames, shard_frames, shard_scores, shard_poses):
+    """Table-sharded verification: every candidate frame is verified by the rank that owns it
+    (its match list lives there), the results travel in one all_gather.  global_frames [Q, cn]
+    = merged candidate list (-1 unused); shard_frames [W, Q, cn] / shard_scores [W, Q, cn] /
+    shard_poses [W, Q, cn, 12] = every rank's local candidate frames and their verify results.
+    Returns (scores [Q, cn], poses [Q, cn, 12]) aligned with the global list (-1 / zeros where
+    unused) — what candidate_verify gives on a single table, because a frame's match list and
+    the descriptors in it are the same on its owner."""
+    w, q, cn = shard_frames.shape
+    sf = shard_frames.permute(1, 0, 2).reshape(q, w * cn)
+    ss = shard_scores.permute(1, 0, 2).reshape(q, w * cn)
+    sp = shard_poses.permute(1, 0, 2, 3).reshape(q, w * cn, 12)
+    eq = (sf[:, None, :] == global_frames[:, :, None]) & (global_frames[:, :, None] >= 0)   # [Q, cn, W*cn]
+    found = eq.any(dim=2)
+    idx = eq.to(torch.int8).argmax(dim=2)                                                   # frames are unique across shards
+    scores = torch.where(found, torch.gather(ss, 1, idx), torch.full_like(idx, -1, dtype=ss.dtype))
+    poses = torch.gather(sp, 1, idx[:, :, None].expand(q, idx.shape[1], 12)) * found[:, :, None].to(sp.dtype)
+    return scores, poses
+
+
+def gather_verified(local_frames, score, pose, group=None):
+    """one all_gather of every rank's (candidate frames [Q, cn] int32, verify_score [Q, cn] f64,
+    pose [Q, cn, 12] f64) -> stacked [W, ...] tensors, identical on every rank.  Frames travel
+    as f64 next to the scores (ids below 2^53 are exact)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_frames[None], score[None], pose[None]
+    nq, cn = local_frames.shape
+    packed = torch.cat([local_frames.to(torch.float64)[:, :, None], score[:, :, None], pose], dim=2).contiguous()
+    out = torch.empty((world * nq, cn, 14), dtype=torch.float64, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    out = out.view(world, nq, cn, 14)
+    return out[..., 0].to(torch.int32), out[..., 1].contiguous(), out[..., 2:].contiguous()
+
+
+def search_loop_choice(global_frames, n_cand, scores, icp_threshold):
+    """SearchLoop's choice (STDesc.cpp:105-146) on device tensors: per query the first
+    candidate with the strictly largest verify_score, accepted above icp_threshold.
+    Returns (best_cand, best_frame, best_score) with -1 / -1 / 0 for "no loop"."""
+    q, cn = scores.shape
+    live = torch.arange(cn, device=scores.device)[None, :] < n_cand[:, None].to(torch.int64)
+    s = torch.where(live, scores, torch.full_like(scores, -1.0))
+    best, arg = s.max(dim=1)                         # torch.max returns the first maximum
+    first = (s == best[:, None]).to(torch.int8).argmax(dim=1)
+    ok = (best > 0) & (best > icp_threshold)
+    best_frame = torch.gather(global_frames.to(torch.int64), 1, first[:, None])[:, 0]
+    neg = torch.full_like(first, -1)
+    return (torch.where(ok, first, neg).to(torch.int32), torch.where(ok, best_frame, neg).to(torch.int32),
+            torch.where(ok, best, torch.zeros_like(best)))
+
+
 class ShardedMap:
     """one rank's shard of the map + the collective query (one process per GPU)"""
 
@@ -95,6 +146,24 @@ class ShardedMap:
                           torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev))
         self.mgr.export_candidates(*self._bufs)
         return gather_and_merge(self._bufs[0], self._bufs[1], self.cand_num)
+
+    def search_loop(self, xyz, label, kp_off=None, icp_threshold=None, group=None):
+        """SearchLoop over the sharded map: query + merge, candidate_verify of the local
+        candidates on every rank, one all_gather of (frames, scores, poses), SearchLoop's
+        choice on the merged list.  Returns (frames, votes, n_cand, scores, poses, best_cand,
+        best_frame, best_score), identical on every rank."""
+        frames, votes, n_cand = self.query(xyz, label, kp_off)
+        self.mgr.verify()
+        nq, cn = frames.shape
+        dev = frames.device
+        score = torch.empty((nq, cn), dtype=torch.float64, device=dev)
+        pose = torch.empty((nq, cn, 12), dtype=torch.float64, device=dev)
+        self.mgr.export_verify(score, pose)
+        sf, ss, sp = gather_verified(self._bufs[0], score, pose, group)
+        scores, poses = merge_verified(frames, sf, ss, sp)
+        thr = self.mgr.icp_threshold_ if icp_threshold is None else icp_threshold
+        bc, bf, bs = search_loop_choice(frames, n_cand, scores, thr)
+        return frames, votes, n_cand, scores, poses, bc, bf, bs
 
 
 def query_slice(n_queries, world, rank):

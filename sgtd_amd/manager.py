@@ -277,6 +277,11 @@ class STDescManager:
         """candidate_verify for every (query, candidate) of the last batch, on the device"""
         self._check(self._L.sgtd_verify(self._h))
 
+    def export_verify(self, d_score, d_pose):
+        """async D2D copy of verify_score [n_queries, candidate_num] f64 and pose
+        [n_queries, candidate_num, 12] f64 into torch.cuda tensors (no host synchronisation)"""
+        self._check(self._L.sgtd_export_verify_dev(self._h, C.c_void_p(d_score.data_ptr()), C.c_void_p(d_pose.data_ptr())))
+
     def result_verify(self, q):
         """-> (score[candidate_num], rot[candidate_num,3,3], t[candidate_num,3])"""
         cn = self.config_setting_["candidate_num"]

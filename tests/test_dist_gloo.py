@@ -46,17 +46,29 @@ def _local_tables(rank, world):
     assert shard.current_frame_id == hi
     lf = np.full((N_Q, CAND), -1, np.int32)
     lv = np.zeros((N_Q, CAND), np.int32)
+    ls = np.full((N_Q, CAND), -1.0)              # candidate_verify of the local candidates
+    lp = np.zeros((N_Q, CAND, 12))
     truth = []
+
+    def verified(orc, sel):
+        sc, ps = [], []
+        for k in range(len(sel["cand_frame"])):
+            s_, t_, rot_, _ = orc.verify(k, int(sel["cand_off"][k + 1] - sel["cand_off"][k]))
+            sc.append(s_)
+            ps.append(np.concatenate([rot_.reshape(9), t_]) if s_ >= 0 else np.zeros(12))
+        return np.array(sc), np.array(ps).reshape(-1, 12)
+
     for q in range(N_Q):
         shard.build(qs.xyz[q], qs.label[q], export=False)
         r = shard.select()
         n = len(r["cand_frame"])
         lf[q, :n], lv[q, :n] = r["cand_frame"], r["cand_votes"]
+        ls[q, :n], lp[q, :n] = verified(shard, r)
         assert np.all((r["cand_frame"] >= lo) & (r["cand_frame"] < hi))
         full.build(qs.xyz[q], qs.label[q], export=False)
         t = full.select()
-        truth.append((t["cand_frame"], t["cand_votes"]))
-    return lf, lv, truth
+        truth.append((t["cand_frame"], t["cand_votes"]) + verified(full, t))
+    return lf, lv, truth, ls, lp
 
 
 def _worker(rank, world, port):
@@ -65,11 +77,24 @@ def _worker(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sgtd_amd.dist import gather_and_merge
-        lf, lv, truth = _local_tables(rank, world)
+        lf, lv, truth, ls, lp = _local_tables(rank, world)
         mf, mv, n = gather_and_merge(torch.from_numpy(lf), torch.from_numpy(lv), CAND)
+        # SearchLoop over the shards: every candidate is verified by its owner, one all_gather
+        from sgtd_amd.dist import gather_verified, merge_verified, search_loop_choice
+        sf, ss, sp = gather_verified(torch.from_numpy(lf), torch.from_numpy(ls), torch.from_numpy(lp))
+        scores, poses = merge_verified(mf, sf, ss, sp)
+        bc, bf, bs = search_loop_choice(mf, n, scores, 0.4)
         for q in range(N_Q):
             k = int(n[q])
-            tf, tv = truth[q]
+            tf, tv, tscore, tpose = truth[q]
+            assert scores[q, :k].tolist() == tscore.tolist() and (scores[q, k:] == -1).all()
+            assert np.array_equal(poses[q, :k].numpy(), tpose)
+            best = max(tscore.tolist() + [0.0])
+            if best > 0.4:
+                kk = tscore.tolist().index(best)
+                assert (int(bc[q]), int(bf[q]), float(bs[q])) == (kk, int(tf[kk]), best)
+            else:
+                assert (int(bc[q]), int(bf[q]), float(bs[q])) == (-1, -1, 0.0)
             assert k == len(tf), (k, len(tf))
             assert mf[q, :k].tolist() == tf.tolist(), (mf[q].tolist(), tf.tolist())
             assert mv[q, :k].tolist() == tv.tolist()
@@ -84,7 +109,7 @@ def _worker(rank, world, port):
         full_f = np.full((N_Q, CAND), -1, np.int32)
         full_v = np.zeros((N_Q, CAND), np.int32)
         for q in range(N_Q):
-            tf, tv = truth[q]
+            tf, tv = truth[q][:2]
             full_f[q, :len(tf)], full_v[q, :len(tv)] = tf, tv
         lo, hi = query_slice(N_Q, world, rank)
         gf, gv = gather_query_slices(torch.from_numpy(full_f[lo:hi].copy()), torch.from_numpy(full_v[lo:hi].copy()), N_Q)
@@ -105,7 +130,7 @@ def test_sharded_selection_matches_single_table_gloo():
 
 def test_single_process_merge_matches_oracle_without_process_group():
     from sgtd_amd.dist import gather_and_merge
-    lf, lv, truth = _local_tables(0, 1)
+    lf, lv, truth = _local_tables(0, 1)[:3]
     mf, mv, n = gather_and_merge(torch.from_numpy(lf), torch.from_numpy(lv), CAND)
     for q in range(N_Q):
         k = int(n[q])

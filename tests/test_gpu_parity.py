@@ -554,3 +554,54 @@ def test_random_configs_property(mods):
             g.close()
 
     run()
+
+
+# SearchLoop over frame-range shards (every candidate verified by its owner, results merged)
+# == SearchLoop on the single table
+def test_sharded_search_loop_equals_single_table(mods):
+    import torch
+    from sgtd_amd.dist import ShardedMap, merge_candidates, merge_verified, search_loop_choice, shard_range
+    _, manager, synth = mods
+    smap = synth.make_map(30, 100, stream=61)
+    q = synth.make_queries(smap, 6, stream=61)
+    single = manager.STDescManager()
+    single.add_frames(smap.xyz, smap.label)
+    want = single.query_frames(q.xyz, q.label)
+    single.verify()
+    w_bc, w_bf, w_bs = single.search_loop()
+    cn = single.config_setting_["candidate_num"]
+    dev = torch.device("cuda", 0)
+    sf, sv, ss, sp, shards = [], [], [], [], []
+    for r in range(3):
+        lo, hi = shard_range(30, 3, r)
+        m = manager.STDescManager(first_frame_id=lo)
+        m.add_frames(smap.xyz[lo:hi], smap.label[lo:hi])
+        m.query_frames(q.xyz, q.label, fetch=False)
+        f = torch.empty((6, cn), dtype=torch.int32, device=dev)
+        v = torch.empty((6, cn), dtype=torch.int32, device=dev)
+        m.export_candidates(f, v)
+        m.verify()
+        s = torch.empty((6, cn), dtype=torch.float64, device=dev)
+        p = torch.empty((6, cn, 12), dtype=torch.float64, device=dev)
+        m.export_verify(s, p)
+        m.sync()
+        sf.append(f); sv.append(v); ss.append(s); sp.append(p); shards.append(m)
+    torch.cuda.synchronize()
+    gf, gv, n = merge_candidates(torch.stack(sf), torch.stack(sv), cn)
+    scores, poses = merge_verified(gf, torch.stack(sf), torch.stack(ss), torch.stack(sp))
+    bc, bf, bs = search_loop_choice(gf, n, scores, single.icp_threshold_)
+    for i in range(6):
+        w_score, w_rot, w_t = single.result_verify(i)
+        nc = int(want.n_cand[i])
+        assert np.array_equal(gf[i, :nc].cpu().numpy(), want.cand_frame[i, :nc])
+        assert np.array_equal(scores[i].cpu().numpy(), w_score)
+        got_pose = poses[i].cpu().numpy()
+        assert np.array_equal(got_pose[:, :9].reshape(cn, 3, 3), w_rot) and np.array_equal(got_pose[:, 9:], w_t)
+    assert np.array_equal(bc.cpu().numpy(), w_bc) and np.array_equal(bf.cpu().numpy(), w_bf) and np.array_equal(bs.cpu().numpy(), w_bs)
+    # the one-rank form of the collective path
+    one = ShardedMap(30, 0, 1)
+    one.add_shard_frames(smap.xyz, smap.label)
+    out = one.search_loop(q.xyz, q.label)
+    assert np.array_equal(out[6].cpu().numpy(), w_bf) and np.array_equal(out[7].cpu().numpy(), w_bs)
+    for m in shards + [single, one.mgr]:
+        m.close()

@@ -99,3 +99,25 @@ def test_generator_is_deterministic_and_tie_free_checker():
     grid[:, 1] = np.arange(16) // 4
     assert synth.has_knn_ties(grid, 5)
     assert not synth.has_knn_ties(a.xyz[0], 10)
+
+
+def test_merge_verified_and_search_loop_choice():
+    import torch
+    from sgtd_amd.dist import merge_verified, search_loop_choice
+    # two ranks, two queries, cand_num 3.  Rank 0 owns frames < 10, rank 1 frames >= 10.
+    sf = torch.tensor([[[3, 7, -1], [2, -1, -1]], [[12, 15, 11], [19, 14, -1]]], dtype=torch.int32)
+    ss = torch.tensor([[[40.0, -1.0, -1.0], [8.0, -1.0, -1.0]], [[55.0, 40.0, 6.0], [-1.0, 8.0, -1.0]]], dtype=torch.float64)
+    sp = torch.arange(2 * 2 * 3 * 12, dtype=torch.float64).reshape(2, 2, 3, 12)
+    gf = torch.tensor([[12, 3, 15], [2, 14, -1]], dtype=torch.int32)      # merged lists (votes order)
+    scores, poses = merge_verified(gf, sf, ss, sp)
+    assert scores.tolist() == [[55.0, 40.0, 40.0], [8.0, 8.0, -1.0]]
+    assert torch.equal(poses[0, 0], sp[1, 0, 0]) and torch.equal(poses[0, 1], sp[0, 0, 0]) and torch.equal(poses[1, 1], sp[1, 1, 1])
+    assert torch.count_nonzero(poses[1, 2]) == 0
+    n_cand = torch.tensor([3, 2], dtype=torch.int32)
+    bc, bf, bs = search_loop_choice(gf, n_cand, scores, 0.4)
+    assert bc.tolist() == [0, 0] and bf.tolist() == [12, 2] and bs.tolist() == [55.0, 8.0]   # ties -> first candidate
+    bc, bf, bs = search_loop_choice(gf, n_cand, scores, 20.0)
+    assert bc.tolist() == [0, -1] and bf.tolist() == [12, -1] and bs.tolist() == [55.0, 0.0]  # (-1, 0): no loop
+    none = torch.full((1, 3), -1.0, dtype=torch.float64)
+    bc, bf, bs = search_loop_choice(gf[:1], n_cand[:1], none, 0.4)
+    assert bc.tolist() == [-1] and bs.tolist() == [0.0]
