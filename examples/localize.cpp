@@ -127,10 +127,17 @@ int main(int argc, char **argv) {
     const int nb = std::min(batch, qs.n - q0);
     std::vector<int64_t> off(nb + 1);
     for (int i = 0; i <= nb; i++) off[i] = qs.off[q0 + i] - qs.off[q0];
+    auto tb0 = std::chrono::steady_clock::now();
     OK(sgtd_query_frames(h, qs.xyz + 3 * qs.off[q0], qs.label + qs.off[q0], off.data(), nb, 0));
+    OK(sgtd_sync(h));
+    auto tb1 = std::chrono::steady_clock::now();
     OK(sgtd_verify(h));
     OK(sgtd_search_loop(h, icp_threshold, best_cand.data(), best_frame.data(), best_score.data()));
     OK(sgtd_result_candidates(h, n_cand.data(), cand_frame.data(), nullptr, nullptr));
+    auto tb2 = std::chrono::steady_clock::now();
+    if (std::getenv("LOCALIZE_VERBOSE"))
+      std::printf("  batch at %d: select %.1f ms, verify + choice %.1f ms\n", q0,
+                  std::chrono::duration<double, std::milli>(tb1 - tb0).count(), std::chrono::duration<double, std::milli>(tb2 - tb1).count());
     for (int i = 0; i < nb; i++) {
       total_num++;
       if (!(best_frame[i] > 0)) continue;                    // search_result.first > 0 (:606-620)

@@ -58,6 +58,7 @@ struct ProbeBuffers {
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
   unsigned long long *rec_cursor;   // global slab cursor (64-bit: requests can add up beyond 2^32)
+  unsigned long long *rec_need;     // matches that found no room (sizes the regrown buffer)
   u32 *item_cursor;     // work queue head
   u32 *list_ptr;        // [n_slots] first record of descriptor
   u32 *n_visit;         // [n_slots] entries visited by descriptor
@@ -330,6 +331,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   };
   if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
   else run(std::false_type{});
+  if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches);
   if (result) {
     result->ptr = slab.next; result->visit = total; result->match = fits ? matches : 0;
   } else if (lane == 0) {

@@ -440,6 +440,7 @@ Views make_views(sgtd_engine *e) {
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
   B.rec_frame = e->rec.as<u32>(); B.rec_g = e->rec.as<u32>() + e->rec_cap;   // two halves of one allocation
   B.rec_cursor = e->cursors.as<unsigned long long>(); B.item_cursor = e->cursors.as<u32>() + 2;
+  B.rec_need = e->cursors.as<unsigned long long>() + 2;
   B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
   B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
   v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
@@ -452,7 +453,7 @@ int launch_select(sgtd_engine *e) {
   const int cn = e->dc.cand_num;
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
-  CHK(ensure(e, e->cursors, 4 * sizeof(u32)));
+  CHK(ensure(e, e->cursors, 8 * sizeof(u32)));
   CHK(ensure(e, e->overflow, 2 * sizeof(int)));
   CHK(ensure(e, e->list_ptr, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
@@ -471,7 +472,7 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->pair_off, (size_t)nq * (cn + 1) * sizeof(long long)));
   CHK(rec_alloc(e));
 
-  HIPCHK(hipMemsetAsync(e->cursors.p, 0, 4 * sizeof(u32), e->stream));
+  HIPCHK(hipMemsetAsync(e->cursors.p, 0, 8 * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->overflow.p, 0, 2 * sizeof(int), e->stream));
   HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
@@ -712,10 +713,11 @@ int sync_batch(sgtd_engine *e) {
   e->stats.overflowed = 0;
   for (int attempt = 0; attempt < 8; attempt++) {
     int ovf[2] = {0, 0};
-    unsigned long long cursor = 0;
+    unsigned long long cursor = 0, need = 0;
     u32 total = 0;
     HIPCHK(hipMemcpyAsync(ovf, e->overflow.p, sizeof(ovf), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&cursor, e->cursors.p, sizeof(cursor), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&need, e->cursors.as<unsigned long long>() + 2, sizeof(need), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!ovf[0] && !ovf[1]) break;
@@ -725,7 +727,11 @@ int sync_batch(sgtd_engine *e) {
     const size_t lim = 0xFFFFFFF0ull;
     if (ovf[0]) {
       if (e->rec_cap >= lim) return SGTD_ERR_CAPACITY;
-      e->rec_cap = std::min<size_t>(lim, std::max<size_t>(e->rec_cap * 2, (size_t)cursor + (size_t)(cursor >> 2) + 65536));
+      // what was stored fits rec_cap, `need` matches did not; slabs leave about an eighth unused,
+      // every wave strands part of its last slab
+      const size_t want = (size_t)((double)(e->rec_cap + need) * 1.25) + (size_t)e->n_cus * 32 * SGTD_REC_SLAB;
+      (void)cursor;
+      e->rec_cap = std::min<size_t>(lim, std::max<size_t>(e->rec_cap * 2, want));
     } else if (ovf[1]) {
       if (e->pair_cap >= lim) return SGTD_ERR_CAPACITY;
       e->pair_cap = std::min<size_t>(lim, std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536));
