@@ -68,6 +68,18 @@ def make(name, cfg, n_frames, n_kp, n_q, stream):
         for kk in ("q_idx", "cell", "db_entry", "frame", "dis"):
             out["q%d_rough_%s" % (q, kk)] = rm[kk]
         out["q%d_votes" % q] = o.votes()[:n_frames + 1]
+        # next stage (candidate_verify, STDesc.cpp:462-547): score, pose (rot row-major + t), inliers
+        sc, ps, inl, ioff = [], [], [], [0]
+        for k in range(len(r["cand_frame"])):
+            s_, t_, rot_, idx_ = o.verify(k, int(r["cand_off"][k + 1] - r["cand_off"][k]))
+            sc.append(s_)
+            ps.append(np.concatenate([rot_.reshape(9), t_]) if s_ >= 0 else np.zeros(12))
+            inl.append(idx_)
+            ioff.append(ioff[-1] + len(idx_))
+        out["q%d_verify_score" % q] = np.array(sc, np.float64)
+        out["q%d_verify_pose" % q] = np.array(ps, np.float64).reshape(-1, 12)
+        out["q%d_verify_inliers" % q] = np.concatenate(inl).astype(np.int32) if inl else np.zeros(0, np.int32)
+        out["q%d_verify_inlier_off" % q] = np.array(ioff, np.int64)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "D per frame", counts)
