@@ -157,6 +157,7 @@ struct WaveSlab {
 };
 #ifdef SGTD_EXP_PHASE
 __device__ unsigned long long g_phase[8];
+__device__ unsigned long long g_words[2];   // 64-entry words swept, load groups (trips) issued
 #define PH_T() __builtin_readcyclecounter()
 #define PH_ADD(i, t0) do { const u64 _n = PH_T(); slab.ph[i] += _n - (t0); (t0) = _n; } while (0)
 #else
@@ -235,6 +236,12 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
 
   u32 matches = 0;
   const u32 n_words = (total + 63u) >> 6;
+#ifdef SGTD_EXP_PHASE
+  if (lane == 0 && n_words) {
+    atomicAdd(&g_words[0], (unsigned long long)n_words);
+    atomicAdd(&g_words[1], (unsigned long long)((n_words + SGTD_PROBE_UNROLL - 1) / SGTD_PROBE_UNROLL));
+  }
+#endif
   // position -> cell, the last c with off[c] <= pos (empty cells share their successor's
   // offset and are stepped over), read from the row registers by ds_bpermute — no memory.
   // Two forms, chosen per descriptor (wave-uniform):
