@@ -260,11 +260,11 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
       double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
       int cell[SGTD_PROBE_UNROLL];
       bool valid[SGTD_PROBE_UNROLL];
-#ifdef SGTD_EXP_PHASE
-      u32 ee[SGTD_PROBE_UNROLL];
-#endif
 #pragma unroll
       for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
+        if constexpr (BSEARCH) {   // short lists: 28 % of the slots are empty at F = 1 k — no loads for them
+          if (w0 + u >= n_words) { valid[u] = false; continue; }   // wave-uniform
+        }
         const u32 pos = ((w0 + u) << 6) + lane;
         valid[u] = pos < total;
         u32 c4;
@@ -285,14 +285,6 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
         cell[u] = (int)(c4 >> 2);
         const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
         const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
-#ifdef SGTD_EXP_PHASE
-        ee[u] = e;
-      }
-      PH_ADD(5, ph_t);
-#pragma unroll
-      for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-        const u32 e = ee[u];
-#endif
         const double2 *pa = WIDE ? reinterpret_cast<const double2 *>(T.head + e)
                                  : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.head) + (e << 4));
         const double2 *pb = WIDE ? reinterpret_cast<const double2 *>(T.tail + e)

@@ -585,7 +585,7 @@ int launch_select(sgtd_engine *e) {
         fprintf(stderr, "WORDS: %llu words in %llu load groups of %d: %.1f%% of the slots filled\n", wd[0], wd[1], SGTD_PROBE_UNROLL,
                 100.0 * (double)wd[0] / ((double)wd[1] * SGTD_PROBE_UNROLL));
         const double tot = (double)ph[7];
-        fprintf(stderr, "PHASE: slab %.3f locate %.3f issue %.3f wait %.3f compute %.3f tail %.3f outer %.3f (fractions of wave life)\n",
+        fprintf(stderr, "PHASE: slab %.3f (unused %.3f) locate+issue %.3f wait %.3f compute %.3f tail %.3f outer %.3f (fractions of wave life)\n",
                 ph[0] / tot, ph[5] / tot, ph[1] / tot, ph[2] / tot, ph[3] / tot, ph[4] / tot,
                 (tot - ph[0] - ph[1] - ph[2] - ph[3] - ph[4] - ph[5]) / tot);
       }
