@@ -21,12 +21,19 @@
 //   topk      (:423-433) candidate_num rounds of arg-max over the votes:
 //             votes desc, frame id asc, stop below 5 votes
 //   assemble  (:434-449) one wavefront per 128-descriptor block walks the
-//             block's match lists as one flattened stream: pass 1 counts
-//             matches per candidate slot, a scan over blocks gives every
-//             (block, slot) its output range, pass 2 writes each candidate's
-//             match_list_ in the reference's (i, cell, j) order — a stable split
-//             by slot done with wave_group_rank ballots, running positions in
-//             lane registers
+//             block's match lists as one flattened stream: pass 1
+//             (block_count_kernel) counts matches per candidate slot and
+//             compacts the candidate matches, in list order, into a dense
+//             per-block list; a scan over blocks gives every (block, slot) its
+//             output range; pass 2 (block_write_kernel) splits the dense list
+//             by slot — a stable split: equal-slot lanes find each other through
+//             commutative LDS ORs, running positions in lane registers — and
+//             writes each candidate's match_list_ in the reference's (i, cell, j)
+//             order through per-slot 128-B staging lines
+//
+// Diagnostics (never in the shipped build): -DSGTD_EXP_PHASE adds in-kernel phase
+// clocks and counters printed by the host after a few launches; -DSGTD_EXP_TRACE
+// records per-wave start/end times of the key-major sweep.
 #pragma once
 #include "common.hip.h"
 #include <type_traits>
