@@ -89,7 +89,9 @@ struct BuildParams {
   u32 *ws_slots;           // [gridDim.x * max_slots]
 };
 
-template <bool LDS_DEDUP>
+// KM = slots of the k-NN insertion network, the smallest of {4, 8, 10, 12, 16} that holds
+// descriptor_near_num (the shipped configuration is 10: a 16-slot network would do 60 % more work)
+template <bool LDS_DEDUP, int KM>
 __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     BuildParams P, DevCfg cfg, DescArrays out) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -169,14 +171,14 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
     const int per_pass = SGTD_BUILD_THREADS / parts;
     for (int i0 = 0; i0 < n; i0 += per_pass) {
       const int i = i0 + tid / parts, part = tid % parts;
-      float bd[SGTD_MAX_K];
-      int bi[SGTD_MAX_K];
+      float bd[KM];
+      int bi[KM];
 #pragma unroll
-      for (int k = 0; k < SGTD_MAX_K; k++) { bd[k] = __builtin_inff(); bi[k] = 0; }
+      for (int k = 0; k < KM; k++) { bd[k] = __builtin_inff(); bi[k] = 0; }
       auto insert = [&](float cd, int cj) {
         bool lt = false;
 #pragma unroll
-        for (int k = 0; k < SGTD_MAX_K; k++) {
+        for (int k = 0; k < KM; k++) {
           // strict '<': equal distance keeps the lower index first; once the new
           // point is placed every later slot shifts down by one (plain insertion)
           lt = lt || (cd < bd[k]);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
         }
         if (part > 0) {
 #pragma unroll
-          for (int k = 0; k < SGTD_MAX_K; k++)
+          for (int k = 0; k < KM; k++)
             if (k < K) keys[((size_t)i * 3 + (part - 1)) * K + k] = ((u64)__float_as_uint(bd[k]) << 32) | (u32)bi[k];
         }
       }
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
       }
       if (i < n && part == 0) {
 #pragma unroll
-        for (int k = 0; k < SGTD_MAX_K; k++)
+        for (int k = 0; k < KM; k++)
           if (k < K) knn[i * K + k] = (unsigned short)bi[k];
       }
       if (parts > 1) __syncthreads();   // the parking area is reused by the next pass

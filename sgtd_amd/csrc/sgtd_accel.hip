@@ -212,18 +212,30 @@ int launch_build(sgtd_engine *e, const float *d_xyz, const u32 *d_label, const l
   if (lds_full <= lds_limit) {
     int per_cu = (int)std::max<size_t>(1, lds_limit / lds_full);
     int grid = std::min(n_frames, e->n_cus * std::min(per_cu, 4));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&build_frames_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
-    build_frames_kernel<true><<<grid, SGTD_BUILD_THREADS, lds_full, e->stream>>>(P, e->dc, out);
+#define SGTD_LAUNCH_BUILD(DEDUP, KM_, LDS_)                                                                    \
+  do {                                                                                                          \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&build_frames_kernel<DEDUP, KM_>),                \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                       \
+    build_frames_kernel<DEDUP, KM_><<<grid, SGTD_BUILD_THREADS, (LDS_), e->stream>>>(P, e->dc, out);            \
+  } while (0)
+#define SGTD_LAUNCH_BUILD_K(DEDUP, LDS_)                                                                        \
+  do {                                                                                                          \
+    if (K <= 4) SGTD_LAUNCH_BUILD(DEDUP, 4, LDS_);                                                              \
+    else if (K <= 8) SGTD_LAUNCH_BUILD(DEDUP, 8, LDS_);                                                         \
+    else if (K <= 10) SGTD_LAUNCH_BUILD(DEDUP, 10, LDS_);                                                       \
+    else if (K <= 12) SGTD_LAUNCH_BUILD(DEDUP, 12, LDS_);                                                       \
+    else SGTD_LAUNCH_BUILD(DEDUP, 16, LDS_);                                                                    \
+  } while (0)
+    SGTD_LAUNCH_BUILD_K(true, lds_full);
   } else if (lds_base <= lds_limit) {
     int grid = std::min(n_frames, e->n_cus * 2);
     CHK(ensure(e, e->ws_keys, (size_t)grid * max_t * sizeof(u64)));
     CHK(ensure(e, e->ws_slots, (size_t)grid * max_slots * sizeof(u32)));
     P.ws_keys = e->ws_keys.as<u64>();
     P.ws_slots = e->ws_slots.as<u32>();
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&build_frames_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
-    build_frames_kernel<false><<<grid, SGTD_BUILD_THREADS, lds_base, e->stream>>>(P, e->dc, out);
+    SGTD_LAUNCH_BUILD_K(false, lds_base);
+#undef SGTD_LAUNCH_BUILD_K
+#undef SGTD_LAUNCH_BUILD
   } else {
     return SGTD_ERR_UNSUPPORTED;
   }
