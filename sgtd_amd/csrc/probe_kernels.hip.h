@@ -259,82 +259,93 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   // All lanes execute the permutes (sources must be active).
   // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
   // issued before the first use so that several KB per wave are in flight
-  auto run = [&](auto bsearch_tag) {
+  u32 cur4 = 0;   // cursor form: 4 * cell = ds_bpermute byte address
+  u32 nxt_off = (u32)__builtin_amdgcn_ds_bpermute(4, (int)pl.off);
+  // one load group: NW words located, their loads issued back to back, then tested.  NW is a
+  // compile-time count: each group size is straight-line code (branches around loads would
+  // make the compiler wait for earlier loads before every later one).
+  auto group = [&](auto bsearch_tag, auto nw_tag, u32 w0) {
     constexpr bool BSEARCH = decltype(bsearch_tag)::value;
-    u32 cur4 = 0;   // cursor form: 4 * cell = ds_bpermute byte address
-    u32 nxt_off = BSEARCH ? 0u : (u32)__builtin_amdgcn_ds_bpermute(4, (int)pl.off);
-    for (u32 w0 = 0; w0 < n_words; w0 += SGTD_PROBE_UNROLL) {
-      double2 v01[SGTD_PROBE_UNROLL], v2x[SGTD_PROBE_UNROLL];
-      int cell[SGTD_PROBE_UNROLL];
-      bool valid[SGTD_PROBE_UNROLL];
+    constexpr int NW = decltype(nw_tag)::value;
+    double2 v01[NW], v2x[NW];
+    int cell[NW];
+    bool valid[NW];
 #pragma unroll
-      for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-        if constexpr (BSEARCH) {   // short lists: 28 % of the slots are empty at F = 1 k — no loads for them
-          if (w0 + u >= n_words) { valid[u] = false; continue; }   // wave-uniform
-        }
-        const u32 pos = ((w0 + u) << 6) + lane;
-        valid[u] = pos < total;
-        u32 c4;
-        if constexpr (BSEARCH) {
-          c4 = 0;
+    for (int u = 0; u < NW; u++) {
+      const u32 pos = ((w0 + u) << 6) + lane;
+      valid[u] = pos < total;
+      u32 c4;
+      if constexpr (BSEARCH) {
+        c4 = 0;
 #pragma unroll
-          for (int s = 64; s >= 4; s >>= 1) {
-            const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)s), (int)pl.off);
-            c4 += (t <= pos) ? (u32)s : 0u;
-          }
-        } else {
-          while (__ballot(valid[u] && pos >= nxt_off)) {   // off[27] = total stops it
-            cur4 += (valid[u] && pos >= nxt_off) ? 4u : 0u;
-            nxt_off = (u32)__builtin_amdgcn_ds_bpermute((int)(cur4 + 4u), (int)pl.off);
-          }
-          c4 = cur4;
+        for (int s = 64; s >= 4; s >>= 1) {
+          const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)s), (int)pl.off);
+          c4 += (t <= pos) ? (u32)s : 0u;
         }
-        cell[u] = (int)(c4 >> 2);
-        const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
-        const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
-        const double2 *pa = WIDE ? reinterpret_cast<const double2 *>(T.head + e)
-                                 : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.head) + (e << 4));
-        const double2 *pb = WIDE ? reinterpret_cast<const double2 *>(T.tail + e)
-                                 : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.tail) + (e << 4));
-        v01[u] = *pa;           // s0, s1
-        v2x[u] = *pb;           // s2, {frame, g}
+      } else {
+        while (__ballot(valid[u] && pos >= nxt_off)) {   // off[27] = total stops it
+          cur4 += (valid[u] && pos >= nxt_off) ? 4u : 0u;
+          nxt_off = (u32)__builtin_amdgcn_ds_bpermute((int)(cur4 + 4u), (int)pl.off);
+        }
+        c4 = cur4;
       }
+      cell[u] = (int)(c4 >> 2);
+      const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
+      const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
+      const double2 *pa = WIDE ? reinterpret_cast<const double2 *>(T.head + e)
+                               : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.head) + (e << 4));
+      const double2 *pb = WIDE ? reinterpret_cast<const double2 *>(T.tail + e)
+                               : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.tail) + (e << 4));
+      v01[u] = *pa;           // s0, s1
+      v2x[u] = *pb;           // s2, {frame, g}
+    }
 #ifdef SGTD_EXP_PHASE
-      PH_ADD(1, ph_t);
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-      PH_ADD(2, ph_t);
+    PH_ADD(1, ph_t);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    PH_ADD(2, ph_t);
 #endif
 #pragma unroll
-      for (int u = 0; u < SGTD_PROBE_UNROLL; u++) {
-        if (w0 + u < n_words) {   // wave-uniform
-          const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
-          const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
-          const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
-          const u32 fr = (u32)fg;
-          // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-          bool hit;
-          double dis = 0.0;
-          if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
-          else hit = valid[u] && (qframe != fr) && (d2 < thr2);
-          if (hit) {                                                      // :410
-            if (VOTE == SGTD_VOTE_LDS) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
-            if (VOTE == SGTD_VOTE_GLOBAL) atomicAdd(&votes[fr - T.frame_lo], 1u);
-          }
-          const u64 m = __ballot(hit);
-          if (hit && fits) {
-            const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
-            u32 *df = WIDE ? B.rec_frame + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_frame) + (o << 2));
-            u32 *dg = WIDE ? B.rec_g + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_g) + (o << 2));
-            *df = fr;
-            *dg = (u32)(fg >> 32);
-            if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
-          }
-          matches += __popcll(m);
-        }
+    for (int u = 0; u < NW; u++) {
+      const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
+      const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
+      const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
+      const u32 fr = (u32)fg;
+      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
+      bool hit;
+      double dis = 0.0;
+      if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
+      else hit = valid[u] && (qframe != fr) && (d2 < thr2);
+      if (hit) {                                                      // :410
+        if (VOTE == SGTD_VOTE_LDS) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
+        if (VOTE == SGTD_VOTE_GLOBAL) atomicAdd(&votes[fr - T.frame_lo], 1u);
       }
-      PH_ADD(3, ph_t);
+      const u64 m = __ballot(hit);
+      if (hit && fits) {
+        const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
+        u32 *df = WIDE ? B.rec_frame + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_frame) + (o << 2));
+        u32 *dg = WIDE ? B.rec_g + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_g) + (o << 2));
+        *df = fr;
+        *dg = (u32)(fg >> 32);
+        if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
+      }
+      matches += __popcll(m);
+    }
+    PH_ADD(3, ph_t);
+  };
+  // full groups of SGTD_PROBE_UNROLL words, then one group of what is left (28 % of the slots
+  // of a uniform group size would stay empty at F = 1 k, where a list is about four words)
+  auto run = [&](auto bsearch_tag) {
+    u32 w0 = 0;
+    for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL)
+      group(bsearch_tag, std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
+    switch (n_words - w0) {   // wave-uniform
+      case 1: group(bsearch_tag, std::integral_constant<int, 1>{}, w0); break;
+      case 2: group(bsearch_tag, std::integral_constant<int, 2>{}, w0); break;
+      case 3: group(bsearch_tag, std::integral_constant<int, 3>{}, w0); break;
+      default: break;
     }
   };
+  static_assert(SGTD_PROBE_UNROLL == 4, "the remainder switch covers group sizes 1..3");
   if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
   else run(std::false_type{});
   if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches);
