@@ -156,6 +156,20 @@ struct DescResult {
   u32 ptr, visit, match;
 };
 
+// Loads that were issued before a descriptor's sweep and are first used after it (the next
+// descriptor's GroupRow, the next ticket's records): the sweep "touches" them once its first
+// load group has returned — vector loads return in order, so they are complete by then —
+// otherwise the compiler, which cannot count the stores of the loops in between, would wait
+// for every outstanding store (vmcnt(0)) at their first use.
+struct PendingLoads {
+  u32 *row = nullptr;
+  uint4 *rec = nullptr;
+  __device__ __forceinline__ void touch() const {
+    if (row) asm volatile("" : "+v"(*row));
+    if (rec) asm volatile("" : "+v"(rec->x), "+v"(rec->y), "+v"(rec->z), "+v"(rec->w));
+  }
+};
+
 struct WaveSlab {
   u32 next, end;   // this wave's private range of match records
 #ifdef SGTD_EXP_PHASE
@@ -214,7 +228,7 @@ template <int VOTE, bool DIAG, bool WIDE = true>
 __device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
                                                  long long d, const DescFetch &f, const DescPlan &pl,
                                                  WaveSlab &slab, u32 *s_hist, u32 *votes,
-                                                 DescResult *result = nullptr) {
+                                                 DescResult *result = nullptr, PendingLoads pending = PendingLoads()) {
   const int lane = lane_id();
   const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
   const u32 qframe = f.qframe;
@@ -336,14 +350,17 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   // of a uniform group size would stay empty at F = 1 k, where a list is about four words)
   auto run = [&](auto bsearch_tag) {
     u32 w0 = 0;
-    for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL)
+    for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL) {
       group(bsearch_tag, std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
+      if (w0 == 0) pending.touch();
+    }
     switch (n_words - w0) {   // wave-uniform
       case 1: group(bsearch_tag, std::integral_constant<int, 1>{}, w0); break;
       case 2: group(bsearch_tag, std::integral_constant<int, 2>{}, w0); break;
       case 3: group(bsearch_tag, std::integral_constant<int, 3>{}, w0); break;
       default: break;
     }
+    if (w0 == 0 && n_words) pending.touch();
   };
   static_assert(SGTD_PROBE_UNROLL == 4, "the remainder switch covers group sizes 1..3");
   if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
   while (cur_c != SGTD_NO_CHUNK) {
     const u32 nxt_c = tq.resolve(tk_next);        // requested one whole chunk ago
     tk_next = tq.issue();                         // in flight during this chunk
-    const uint4 rec_next = load_chunk(nxt_c);     // in flight during this chunk
+    uint4 rec_next = load_chunk(nxt_c);           // in flight during this chunk
     const u32 p_first = cur_c * chunk;
     const u32 n = min(chunk, n_valid - p_first);
 #ifdef SGTD_EXP_TRACE
@@ -650,7 +667,10 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       f.gate = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
       const long long d = (long long)(u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
       DescResult res;
-      sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, f, plan_from_group_row(f), slab, nullptr, nullptr, &res);
+      PendingLoads pend;
+      pend.row = &row_next;
+      pend.rec = &rec_next;
+      sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, f, plan_from_group_row(f), slab, nullptr, nullptr, &res, pend);
       if ((u32)lane == i) { r_ptr = res.ptr; r_visit = res.visit; r_match = res.match; }
     }
     {   // the chunk's results: lane i < n stores for its descriptor (slot d in quarter 2 of record i)
