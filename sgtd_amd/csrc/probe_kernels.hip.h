@@ -365,6 +365,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   static_assert(SGTD_PROBE_UNROLL == 4, "the remainder switch covers group sizes 1..3");
   if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
   else run(std::false_type{});
+  if (n_words == 0) pending.touch();   // every path through the sweep leaves them complete
   if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches);
   if (result) {
     result->ptr = slab.next; result->visit = total; result->match = fits ? matches : 0;
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
 
   u32 cur_c = tq.resolve(tq.issue());
   uint4 rec = load_chunk(cur_c);
+  asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));   // same for the ticket loop
   u32 tk_next = tq.issue();
   while (cur_c != SGTD_NO_CHUNK) {
     const u32 nxt_c = tq.resolve(tk_next);        // requested one whole chunk ago
@@ -649,6 +651,9 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
 #endif
     u32 g_cur = (u32)__builtin_amdgcn_readlane((int)rec.z, 2);
     u32 row_next = load_row(g_cur);
+    // waited for here, once per ticket: the loop below then carries no pending load into its
+    // header on either edge (the next rows are touched inside the sweep)
+    asm volatile("" : "+v"(row_next));
     u32 r_ptr = 0, r_visit = 0, r_match = 0;   // lane i: results of descriptor i of the chunk
     for (u32 i = 0; i < n; i++) {
       DescFetch f;
