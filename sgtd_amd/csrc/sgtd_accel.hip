@@ -736,7 +736,13 @@ int sync_batch(sgtd_engine *e) {
     HIPCHK(hipMemcpyAsync(&need, e->cursors.as<unsigned long long>() + 2, sizeof(need), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (!ovf[0] && !ovf[1]) break;
+    if (!ovf[0] && !ovf[1]) {
+      // slab use varies a little from run to run (which wave sweeps what): keep a fifth of
+      // headroom over what this batch took, so that the same batch fits again next time
+      const size_t lim0 = 0xFFFFFFF0ull;
+      if ((double)cursor * 1.2 > (double)e->rec_cap) e->rec_cap = std::min<size_t>(lim0, (size_t)((double)cursor * 1.3));
+      break;
+    }
     e->stats.overflowed = 1;
     if (attempt == 7) return SGTD_ERR_CAPACITY;
     // grow towards the u32 index limit; a batch that does not fit even there must be split
@@ -745,7 +751,7 @@ int sync_batch(sgtd_engine *e) {
       if (e->rec_cap >= lim) return SGTD_ERR_CAPACITY;
       // what was stored fits rec_cap, `need` matches did not; slabs leave about an eighth unused,
       // every wave strands part of its last slab
-      const size_t want = (size_t)((double)(e->rec_cap + need) * 1.25) + (size_t)e->n_cus * 32 * SGTD_REC_SLAB;
+      const size_t want = (size_t)((double)(e->rec_cap + need) * 1.4) + (size_t)e->n_cus * 32 * SGTD_REC_SLAB;
       (void)cursor;
       e->rec_cap = std::min<size_t>(lim, std::max<size_t>(e->rec_cap * 2, want));
     } else if (ovf[1]) {
