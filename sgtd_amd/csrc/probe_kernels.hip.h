@@ -1169,23 +1169,25 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
     fill = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  // the next two words of the compact list are loaded while the current two are split
-  u64 npair[2]; u32 nsl[2];
+  // the next two words of the compact list are loaded while the current two are split (the
+  // raw words are only unpacked at the top of the next step: touching them earlier would wait)
+  u64 nraw[2];
   auto load2 = [&](u32 r0) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const u32 r = r0 + u * SGTD_WAVE + lane;
-      const bool ok = r < nv;
-      const u64 v = cp[ok ? r : 0u];
-      npair[u] = v & 0x03FFFFFFFFFFFFFFull;
-      nsl[u] = ok ? (u32)(v >> 58) : 0xFFu;
+      nraw[u] = cp[r < nv ? r : 0u];
     }
   };
   load2(0);
   for (u32 r0 = 0; r0 < nv; r0 += 2 * SGTD_WAVE) {
     u64 pr[2]; u32 sl[2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) { pr[u] = npair[u]; sl[u] = nsl[u]; }
+    for (int u = 0; u < 2; u++) {
+      const bool ok = r0 + u * SGTD_WAVE + lane < nv;
+      pr[u] = nraw[u] & 0x03FFFFFFFFFFFFFFull;
+      sl[u] = ok ? (u32)(nraw[u] >> 58) : 0xFFu;
+    }
     if (r0 + 2 * SGTD_WAVE < nv) load2(r0 + 2 * SGTD_WAVE);
 #pragma unroll
     for (int u = 0; u < 2; u++) {

@@ -737,10 +737,10 @@ int sync_batch(sgtd_engine *e) {
     HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!ovf[0] && !ovf[1]) {
-      // slab use varies a little from run to run (which wave sweeps what): keep a fifth of
-      // headroom over what this batch took, so that the same batch fits again next time
+      // slab use varies a little from run to run (which wave sweeps what): when a batch comes within
+      // a tenth of the capacity, make room for half as much again (reallocated at the next launch)
       const size_t lim0 = 0xFFFFFFF0ull;
-      if ((double)cursor * 1.2 > (double)e->rec_cap) e->rec_cap = std::min<size_t>(lim0, (size_t)((double)cursor * 1.3));
+      if ((double)cursor * 1.1 > (double)e->rec_cap) e->rec_cap = std::min<size_t>(lim0, (size_t)((double)cursor * 1.5));
       break;
     }
     e->stats.overflowed = 1;
