@@ -948,19 +948,26 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
     for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
       const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
       total += R;
-      for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
-        u32 fr[4]; bool ok[4];
+      // the frames of the next four words are loaded while the current four are counted
+      u32 nfr[4];
+      auto load4 = [&](u32 r0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const u32 r = r0 + u * SGTD_WAVE + lane;
-          ok[u] = r < R;
           u32 dd, addr;
-          sub_locate(s_pre[wid], s_ptr[wid], ok[u] ? r : 0u, dd, addr);
-          fr[u] = B.rec_frame[addr];
+          sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, dd, addr);
+          nfr[u] = B.rec_frame[addr];
         }
+      };
+      if (R) load4(0);
+      for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
+        u32 fr[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) fr[u] = nfr[u];
+        if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          if (ok[u]) {
+          if (r0 + u * SGTD_WAVE + lane < R) {
             if (LDS_VOTES) atomicAdd(&s_hist[fr[u] - frame_lo], 1u);
             else atomicAdd(&votes[fr[u] - frame_lo], 1u);
           }
