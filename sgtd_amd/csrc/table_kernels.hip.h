@@ -9,8 +9,8 @@
 //   sort       stable LSD radix sort of (key, g) by key, 8-bit digits, passes
 //              whose digit is constant are skipped; stable => inside a bucket
 //              entries stay in insertion order == the reference's index j
-//   gather     hot probe array in sorted order p: {side0/1/2 f64, frame u32,
-//              g u32} = one 32-B record per entry (28 algorithmic bytes + g)
+//   gather     probe layout in sorted order p, two 16-B arrays: head {side0, side1 f64},
+//              tail {side2 f64, frame u32, g u32} = 32 B per entry (28 algorithmic + g)
 //   csr+hash   bucket boundaries -> open-addressing table key -> (start,len)
 #pragma once
 #include "common.hip.h"
