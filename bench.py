@@ -4,23 +4,30 @@
 A step = one pass of the hot path over one batch of Q synthetic query frames
 (keypoints already resident in HBM): BuildSingleScanSTD for every query frame,
 then candidate_selector (probe, votes, top-50, ordered match lists) against an
-F-frame map table — all on the GPU through the C ABI.  Default workload =
-BASELINE.json configs[1]: 200 keypoints/frame, 1k-frame map.
+F-frame map table — all on the GPU through the C ABI.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU; total work fixed =
-strong scaling), two modes (--shard):
+Default workload = the north-star point of BASELINE.json: 200 keypoints/frame,
+10 000-frame map, 1 GPU (`config.workload` names it).  The same line carries a
+`map_size_sweep` with F = 1 000 (configs[1]) and F = 4 541 (configs[2], the
+KITTI-00 length).
+
+N > 1: `python bench.py --gpus N` starts N ranks itself (child processes under
+torch.distributed.run, before anything touches a GPU); when it is already
+running under a launcher (RANK/WORLD_SIZE set) it is one rank.  Modes (--shard):
+  query  (default when the map fits one GPU) the map is replicated, every rank
+         serves its own Q query frames per step — weak scaling, no data-path
+         collective, one RCCL all_gather of the result tables per step;
   table  the map's hash table is sharded by frame range over the ranks, every
-         rank sweeps its shard with all Q queries, local top-50 tables are
-         all-gathered with RCCL and merged (sgtd_amd/dist.py::ShardedMap);
-  query  the table is replicated and every rank serves Q/N queries of the batch,
-         result tables are all-gathered with RCCL (ReplicatedMap);
-  auto   query when the whole table needs < 1/8 of one GPU's HBM, else table.
-
+         rank sweeps its shard with the same Q queries, the local top-50 tables
+         are all-gathered with RCCL and merged (sgtd_amd/dist.py::ShardedMap) —
+         strong scaling; also measured (as `table_sharded`) beside the default.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +36,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0   # aggregate L2 rate of the 8 XCDs, same guide §L2
 HBM_BYTES = 288e9
 KERNEL_KEYS = ("ms_build", "ms_sort", "ms_probe", "ms_votes", "ms_topk", "ms_count", "ms_scan", "ms_write", "ms_total")
 
@@ -39,56 +47,105 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1000, help="map size F")
+    ap.add_argument("--frames", type=int, default=10000, help="map size F")
     ap.add_argument("--keypoints", type=int, default=200, help="keypoints per frame N")
-    ap.add_argument("--queries", type=int, default=4096, help="query frames per step (whole job)")
+    ap.add_argument("--queries", type=int, default=1024, help="query frames per step (per rank in query mode)")
     ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto")
+    ap.add_argument("--also-table", choices=["on", "off"], default="on",
+                    help="N>1, query mode: also measure the table-sharded mode in the same run")
+    ap.add_argument("--sweep", default="1000,4541", help="other map sizes measured for map_size_sweep ('' = none)")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the timed sample")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU work budget of the timed sample")
+    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
+                    help="full = BASELINE.md §2: 10 warm-up + 200 queries at each of 3 thread settings (slow)")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps timed per kernel for the roofline")
     ap.add_argument("--verify", choices=["on", "off"], default="on",
                     help="also time candidate_verify + SearchLoop on the device (reported beside, never inside, value)")
+    ap.add_argument("--boundary", choices=["on", "off"], default="on",
+                    help="also time the per-frame host-pointer adapter path (reported beside value)")
     return ap.parse_args()
 
 
-def cpu_baseline(smap, queries, gpu_results, mgr, budget_s):
-    """the oracle (a port of the reference CPU path, reference data layout) timed on
-    this box's host cores on a bounded sample of the same workload"""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def pct(a):
+    a = np.asarray(a, dtype=np.float64)
+    return {"median": float(np.median(a)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)), "n": int(a.size)}
+
+
+def cpu_baseline(smap, queries, gpu_results, mgr, budget_s, protocol):
+    """the oracle (a port of the reference CPU path, reference data layout and flags) timed on
+    this box's host cores on a bounded sample of the same workload (three thread
+    settings; per query the build, the probe loop = the reference's CS1, the whole selector)"""
     from oracle.oracle import OracleManager
     ncpu = os.cpu_count() or 1
-    threads = ncpu - 4 if ncpu > 4 else (2 if ncpu > 3 else 1)  # the reference's MP_PROC_NUM rule, CMakeLists.txt:22-41
+    ref_threads = ncpu - 4 if ncpu > 4 else (2 if ncpu > 3 else 1)  # MP_PROC_NUM rule, CMakeLists.txt:22-41
     F = smap.xyz.shape[0]
-    o = OracleManager(num_threads=threads, max_frame_n=max(20000, F + 1))
+    o = OracleManager(num_threads=ref_threads, max_frame_n=max(20000, F + 1))
     t0 = time.time()
     for f in range(F):
         o.build(smap.xyz[f], smap.label[f], export=False)
         o.add_last()
     t_map = time.time() - t0
-    n_done, t_query, ident, P, M = 0, 0.0, 0, 0, 0
-    res = gpu_results
-    for q in range(queries.xyz.shape[0]):
-        t1 = time.time()
-        o.build(queries.xyz[q], queries.label[q], export=False)
-        r = o.select()
-        t_query += time.time() - t1
-        n_done += 1
-        c = o.counters()
-        P += c["P"]; M += c["M"]
-        nc = int(res.n_cand[q])
-        same = (np.array_equal(res.cand_frame[q, :nc], r["cand_frame"]) and
-                np.array_equal(res.cand_votes[q, :nc], r["cand_votes"]))
-        if same:
-            qi, de = mgr.result_pairs(q, res)
-            same = np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
-        ident += int(same)
-        if t_query > budget_s and n_done >= 3:
-            break
-    return dict(value=n_done / t_query, unit="frames/s", cores=threads, kind="port",
-                sample="%d of the %d query frames of one step, same %d-frame map; oracle map build %.1f s untimed"
-                       % (n_done, queries.xyz.shape[0], F, t_map),
-                ms_per_query=1000.0 * t_query / n_done,
-                host_cpus=ncpu), dict(queries_checked=n_done, identical_candidates_votes_matchlists=ident,
-                                      P_per_query=P / n_done, M_per_query=M / n_done)
+    nq_all = queries.xyz.shape[0]
+    settings = [("ref_rule_nproc_minus_4", ref_threads), ("all_cores", ncpu), ("one_thread", 1)]
+    share = {"ref_rule_nproc_minus_4": 0.5, "all_cores": 0.25, "one_thread": 0.25}
+    out_settings, parity = {}, None
+    q_next = 0
+    for name, thr in settings:
+        o.set_num_threads(thr)
+        warm = 10 if protocol == "full" else 1
+        want = 200 if protocol == "full" else 10 ** 9
+        lim = budget_s * share[name] if protocol == "bounded" else 1e9
+        for w in range(warm):
+            o.build(queries.xyz[w % nq_all], queries.label[w % nq_all], export=False)
+            o.select()
+        rows, spent, ident, P, M = [], 0.0, 0, 0, 0
+        while len(rows) < want and len(rows) < nq_all:
+            q = q_next % nq_all
+            q_next += 1
+            t1 = time.perf_counter()
+            o.build(queries.xyz[q], queries.label[q], export=False)
+            r = o.select()
+            wall = time.perf_counter() - t1
+            c = o.counters()
+            rows.append((1000.0 * wall, c["build_ms"], c["probe_ms"], c["select_ms"]))
+            spent += wall
+            P += c["P"]; M += c["M"]
+            if name == "ref_rule_nproc_minus_4":      # parity leg on the primary setting
+                res = gpu_results
+                nc = int(res.n_cand[q])
+                same = (np.array_equal(res.cand_frame[q, :nc], r["cand_frame"]) and
+                        np.array_equal(res.cand_votes[q, :nc], r["cand_votes"]))
+                if same:
+                    qi, de = mgr.result_pairs(q, res)
+                    same = np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
+                ident += int(same)
+            if spent > lim and len(rows) >= 3:
+                break
+        a = np.array(rows)
+        out_settings[name] = {"threads": thr, "queries_timed": len(rows), "frames_per_s": len(rows) / spent,
+                              "ms_per_query": pct(a[:, 0]), "ms_build": pct(a[:, 1]),
+                              "ms_probe_loop_CS1": pct(a[:, 2]), "ms_candidate_selector": pct(a[:, 3])}
+        if name == "ref_rule_nproc_minus_4":
+            parity = dict(queries_checked=len(rows), identical_candidates_votes_matchlists=ident,
+                          P_per_query=P / len(rows), M_per_query=M / len(rows))
+    prim = out_settings["ref_rule_nproc_minus_4"]
+    best = max(s["frames_per_s"] for s in out_settings.values())
+    cb = dict(value=prim["frames_per_s"], unit="frames/s", cores=ref_threads, kind="port",
+              sample="%d (nproc-4 threads) + %d (all cores) + %d (1 thread) of the step's query frames, same %d-frame map; "
+                     "oracle map build %.1f s untimed; protocol %s"
+                     % (prim["queries_timed"], out_settings["all_cores"]["queries_timed"],
+                        out_settings["one_thread"]["queries_timed"], F, t_map, protocol),
+              ms_per_query=prim["ms_per_query"]["median"], host_cpus=ncpu, best_setting_frames_per_s=best,
+              thread_settings=out_settings)
+    return cb, parity
 
 
 def recall(smap, queries, top1):
@@ -102,15 +159,47 @@ def recall(smap, queries, top1):
             "top1_pose_within_5m": float(np.mean(ok & (dist < 5.0)))}
 
 
+def load_traffic(F, N, Q, world):
+    """HBM bytes per sweep launch from the committed PMC passes (profiles/r02_traffic.json,
+    written by profiles/collect.sh for exactly this configuration), else None"""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    try:
+        for row in json.load(open(path)):
+            if (row.get("frames"), row.get("keypoints"), row.get("queries"), row.get("gpus", 1)) == (F, N, Q, world):
+                return row
+    except Exception:
+        pass
+    return None
+
+
+def run_steps(step, sync, steps):
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return time.perf_counter() - t0
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # start the ranks BEFORE anything touches a GPU (no exec after GPU init on this pool):
+        # child processes under torch.distributed.run, this process only relays the result
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+
     import torch
     import torch.distributed as dist
     from sgtd_amd import synth
-    from sgtd_amd.dist import ReplicatedMap, ShardedMap, query_slice, shard_range
+    from sgtd_amd.dist import ReplicatedMap, ShardedMap, shard_range
     from sgtd_amd.manager import STDescManager
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -131,30 +220,68 @@ def main():
 
     F, N, Q = args.frames, args.keypoints, args.queries
     smap = synth.make_map(F, N, stream=1)
-    queries = synth.make_queries(smap, Q, stream=1)
+    # cold + probe layout of the whole table: ~155 B per descriptor, <= 36*N per frame
+    table_bytes = 155.0 * 36 * N * F
+    mode = "single"
+    if world > 1:
+        mode = args.shard if args.shard != "auto" else ("query" if table_bytes < HBM_BYTES / 4 else "table")
+    n_q_total = Q * world if mode == "query" else Q
+    queries = synth.make_queries(smap, n_q_total, stream=1)
 
     def to_dev(xyz, label):
         return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
                 torch.from_numpy(np.ascontiguousarray(label).astype(np.int64)).to(dev).to(torch.int32).contiguous())
 
-    # cold + probe layout of the whole table: ~170 B per descriptor, <= 36*N per frame
-    table_bytes = 170.0 * 36 * N * F
-    mode = "single"
-    if world > 1:
-        mode = args.shard if args.shard != "auto" else ("query" if table_bytes < HBM_BYTES / 8 else "table")
-
     stream = torch.cuda.current_stream()
     merged = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step, mgr):
+        """warm-up (incl. work-buffer growth), then K steps between barrier + synchronize, max over ranks"""
+        for _ in range(max(args.warmup, 1)):
+            step()
+        mgr.sync()          # grows work buffers if the first batch overflowed them
+        step()
+        mgr.sync()
+        assert mgr.stats()["overflowed"] == 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        mgr.sync()
+        assert mgr.stats()["overflowed"] == 0, "a timed step overflowed a work buffer"
+        return elapsed
+
+    cold = {}
     if mode == "single":
         mgr = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 1))
         mgr.set_stream(stream.cuda_stream)
+        t0 = time.perf_counter()
         mgr.add_frames(*to_dev(smap.xyz, smap.label))
         mgr.finalize()
+        torch.cuda.synchronize()
+        cold["map_build_s"] = time.perf_counter() - t0
         d_qxyz, d_qlab = to_dev(queries.xyz, queries.label)
         q_lo, q_hi = 0, Q
 
         def step():
             mgr.query_frames(d_qxyz, d_qlab, fetch=False)
+        # cold start: the very first batch of a fresh handle (work buffers sized from the table
+        # statistics; re-run if they were too small)
+        t0 = time.perf_counter()
+        step(); mgr.sync(); torch.cuda.synchronize()
+        cold["first_batch_ms"] = 1000.0 * (time.perf_counter() - t0)
+        cold["first_batch_overflowed"] = int(mgr.stats()["overflowed"])
     elif mode == "table":
         sm = ShardedMap(F, rank, world, device_id=local_rank)
         mgr = sm.mgr
@@ -171,37 +298,14 @@ def main():
         mgr = rm.mgr
         mgr.set_stream(stream.cuda_stream)
         rm.add_frames(*to_dev(smap.xyz, smap.label))
-        q_lo, q_hi = query_slice(Q, world, rank)
+        q_lo, q_hi = rank * Q, (rank + 1) * Q
         d_qxyz, d_qlab = to_dev(queries.xyz[q_lo:q_hi], queries.label[q_lo:q_hi])
 
         def step():
-            merged["out"] = rm.query(d_qxyz, d_qlab, Q)
+            merged["out"] = rm.query(d_qxyz, d_qlab, n_q_total)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 1)):
-        step()
-    mgr.sync()          # grows work buffers if the first batch overflowed them
-    step()
-    mgr.sync()
-    assert mgr.stats()["overflowed"] == 0
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    mgr.sync()
+    elapsed = timed(step, mgr)
     st = mgr.stats()
-    assert st["overflowed"] == 0, "a timed step overflowed a work buffer"
 
     # ---- per-kernel timing for the roofline (HIP events on the handle's stream)
     mgr.set_timing(True)
@@ -216,17 +320,33 @@ def main():
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
     st = mgr.stats()
     P, M, D = st["last_P"], st["last_M"], st["last_D"]
-    probe_bytes = 28 * P + 64 * D + 8 * M     # algorithmic bytes of one sweep launch
-    achieved = probe_bytes / (kern_ms["ms_probe"] * 1e-3) / 1e9 if kern_ms["ms_probe"] > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "probe_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("frames") == F and tj.get("queries") == Q and tj.get("keypoints") == N and tj.get("gpus", 1) == world:
-                traffic = tj.get("bytes_per_launch")
-        except Exception:
-            traffic = None
+    t_probe = kern_ms["ms_probe"] * 1e-3
+    # SURVEY §8d's algorithmic bytes of one sweep launch: 28 B per visited entry, 64 B per query
+    # descriptor, 8 B per match record
+    algo_bytes = 28 * P + 64 * D + 8 * M
+    algo_gbs = algo_bytes / t_probe / 1e9 if t_probe > 0 else 0.0
+    # what can bound the sweep: the bytes the probe layout hands to the CUs per visit (L2 -> L1
+    # rate) and the HBM bytes the PMC counters saw (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+    entry_bytes = st["hbm_bytes_table"] // max(st["n_entries"], 1)   # probe-layout bytes one visit reads
+    l2_gbs = (entry_bytes * P + 8 * M) / t_probe / 1e9 if t_probe > 0 else 0.0
+    tr = load_traffic(F, N, Q, world)
+    traffic = tr.get("bytes_per_launch") if tr else None
+    hbm_gbs = traffic / t_probe / 1e9 if (traffic and t_probe > 0) else None
+    l2_frac = l2_gbs / L2_PEAK_GBS
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS if hbm_gbs is not None else None
+    if hbm_frac is not None and hbm_frac >= l2_frac:
+        bound, achieved, peak, frac = "hbm", hbm_gbs, HBM_PEAK_GBS, hbm_frac
+    else:
+        bound, achieved, peak, frac = "l2", l2_gbs, L2_PEAK_GBS, l2_frac
+    roofline = {"bound": bound, "kernel": "probe_sorted_kernel (sweep)", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                "frac": frac, "traffic": traffic, "hbm_frac": hbm_frac, "l2_frac": l2_frac,
+                "avg_launch_ms": kern_ms["ms_probe"], "probe_layout_bytes_per_visit": entry_bytes,
+                "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_gbs,
+                "algorithmic_over_hbm_peak": algo_gbs / HBM_PEAK_GBS,
+                "note": "the key-major sweep re-reads buckets from L2, so algorithmic bytes/s can exceed the HBM peak; "
+                        "frac is measured against the level that can bound the kernel (DESIGN.md §3)",
+                "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
+                "kernel_ms": kern_ms}
 
     res = mgr.results()
     # ---- next stage of the reference's SearchLoop (STDesc.cpp:105-146), reported separately
@@ -261,43 +381,152 @@ def main():
             verify["localization_first_256_queries"] = loc
         except Exception as exc:   # reported, not fatal
             verify = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    # ---- the drop-in boundary as the reference's caller uses it: one frame per call, host
+    # pointers in, descriptors and match lists out (semantic_graph_localization.cpp:590-601)
+    boundary = None
+    if mode == "single" and args.boundary == "on":
+        try:
+            nb = min(Q, 48)
+            mgr.BuildSingleScanSTD(queries.xyz[0], queries.label[0])   # warm
+            t0 = time.perf_counter()
+            pairs = 0
+            for q in range(nb):
+                d = mgr.BuildSingleScanSTD(queries.xyz[q], queries.label[q])
+                for c in mgr.candidate_selector(d):
+                    pairs += len(c)
+            t_frame = (time.perf_counter() - t0) / nb
+            nb2 = min(Q, 128)
+            t0 = time.perf_counter()
+            r2 = mgr.query_frames(queries.xyz[:nb2], queries.label[:nb2])
+            pairs2 = 0
+            for q in range(nb2):
+                qi, de = mgr.result_pairs(q, r2)
+                pairs2 += len(qi)
+            t_batch = (time.perf_counter() - t0) / nb2
+            boundary = {"per_frame_calls_host_pointers_frames_per_s": 1.0 / t_frame, "ms_per_frame": 1000.0 * t_frame,
+                        "frames": nb, "pairs_fetched_per_frame": pairs / nb,
+                        "batched_host_pointers_all_lists_fetched_frames_per_s": 1.0 / t_batch,
+                        "batch": nb2, "pairs_fetched_per_frame_batched": pairs2 / nb2,
+                        "note": "python ctypes adapter (sgtd_amd/manager.py); value above excludes PCIe and list fetches"}
+        except Exception as exc:
+            boundary = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        step(); mgr.sync()   # leave the handle on the headline batch
+        res = mgr.results()
+
+    # ---- N > 1, query mode: the table-sharded form of the same map beside it (strong scaling:
+    # the same Q queries on every rank, each rank sweeps its frame range, RCCL gather + merge)
+    table_sharded = None
+    if mode == "query" and args.also_table == "on":
+        sm = ShardedMap(F, rank, world, device_id=local_rank)
+        sm.mgr.set_stream(stream.cuda_stream)
+        lo, hi = shard_range(F, world, rank)
+        sm.add_shard_frames(*to_dev(smap.xyz[lo:hi], smap.label[lo:hi]))
+        tq_xyz, tq_lab = to_dev(queries.xyz[:Q], queries.label[:Q])
+        tmerged = {}
+
+        def tstep():
+            tmerged["out"] = sm.query(tq_xyz, tq_lab)
+        t_el = timed(tstep, sm.mgr)
+        ent = torch.tensor([sm.mgr.stats()["n_entries"]], dtype=torch.int64, device=dev)
+        ents = [torch.zeros_like(ent) for _ in range(world)]
+        dist.all_gather(ents, ent)
+        # the merged list of the sharded map must be the replicated map's list, query by query
+        ref_f, ref_v = merged["out"]
+        tf, tv_, _ = tmerged["out"]
+        same = bool(torch.equal(tf, ref_f[:Q]) and torch.equal(tv_, ref_v[:Q]))
+        table_sharded = {"value": Q * args.steps / t_el, "unit": "frames/s", "ms_per_step": 1000.0 * t_el / args.steps,
+                         "queries_per_step": Q, "scaling": "strong", "ranks_in_collective": dist.get_world_size(),
+                         "table_entries_per_rank": [int(e.item()) for e in ents],
+                         "merged_list_equals_replicated_map": same}
+        del sm
+
+    # ---- other map sizes (same batch, same pipeline), N = 1 only
+    sweep = None
+    if mode == "single" and args.sweep:
+        sweep = {str(F): {"frames_per_s": Q * args.steps / elapsed, "ms_per_step": 1000.0 * elapsed / args.steps}}
+        for f2 in [int(x) for x in args.sweep.split(",") if x]:
+            if f2 == F:
+                continue
+            try:
+                m2 = synth.make_map(f2, N, stream=1)
+                q2 = synth.make_queries(m2, Q, stream=1)
+                g2 = STDescManager(device_id=local_rank, max_frame_n=max(20000, f2 + 1))
+                g2.set_stream(stream.cuda_stream)
+                g2.add_frames(*to_dev(m2.xyz, m2.label))
+                g2.finalize()
+                x2, l2 = to_dev(q2.xyz, q2.label)
+
+                def s2():
+                    g2.query_frames(x2, l2, fetch=False)
+                s2(); g2.sync(); s2(); g2.sync()
+                assert g2.stats()["overflowed"] == 0
+                torch.cuda.synchronize()
+                k2 = max(3, args.steps // 2)
+                t2 = run_steps(s2, torch.cuda.synchronize, k2)
+                r2 = g2.results()
+                sweep[str(f2)] = {"frames_per_s": Q * k2 / t2, "ms_per_step": 1000.0 * t2 / k2,
+                                  "top1_pose_within_5m": recall(m2, q2, r2.top1())["top1_pose_within_5m"],
+                                  "table_entries": g2.stats()["n_entries"]}
+                g2.close()
+                del g2, x2, l2
+            except Exception as exc:
+                sweep[str(f2)] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    ranks_seen = 1
+    entries_per_rank = [int(st["n_entries"])]
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        ent = torch.tensor([st["n_entries"]], dtype=torch.int64, device=dev)
+        ents = [torch.zeros_like(ent) for _ in range(world)]
+        dist.all_gather(ents, ent)
+        entries_per_rank = [int(e.item()) for e in ents]
+
     out = None
     if rank == 0:
-        value = Q * args.steps / elapsed
+        value = n_q_total * args.steps / elapsed
         sharding = {"single": "none",
                     "table": "map frames range-sharded over %d GPUs, every rank sweeps all queries, RCCL all_gather + merge of top-50" % world,
-                    "query": "map replicated on %d GPUs, queries sharded, RCCL all_gather of the result tables" % world}[mode]
+                    "query": "map replicated on %d GPUs, %d query frames per rank and step, RCCL all_gather of the result tables" % (world, Q)}[mode]
         out = {
             "metric": "query frames/sec vs map size (descriptor build + candidate selection)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if mode == "table" else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic %d keypoints/frame, %d-frame map, descriptor build+match" % (N, F),
-                       "map_frames": F, "keypoints_per_frame": N, "queries_per_step": Q,
+            "config": {"workload": "synthetic %d keypoints/frame, %d-frame map, descriptor build+match (BASELINE north-star point: 10k-frame map, 1 GPU)" % (N, F)
+                       if F == 10000 else "synthetic %d keypoints/frame, %d-frame map, descriptor build+match" % (N, F),
+                       "map_frames": F, "keypoints_per_frame": N, "queries_per_step": n_q_total,
                        "sharding": sharding, "queries_this_rank": q_hi - q_lo,
+                       "ranks_in_collective": ranks_seen, "table_entries_per_rank": entries_per_rank,
                        "table_entries_this_rank": st["n_entries"], "table_buckets_this_rank": st["n_buckets"]},
-            "roofline": {"bound": "hbm", "kernel": "probe_sorted_kernel (sweep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_GBps": (traffic / (kern_ms["ms_probe"] * 1e-3) / 1e9) if traffic and kern_ms["ms_probe"] > 0 else None,
-                         "algorithmic_bytes_per_launch": probe_bytes,
-                         "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
-                         "kernel_ms": kern_ms},
+            "roofline": roofline,
         }
+        if cold:
+            out["cold_start"] = cold
+        if sweep is not None:
+            out["map_size_sweep"] = sweep
         if verify is not None:
             out["verify"] = verify
+        if boundary is not None:
+            out["boundary"] = boundary
+        if table_sharded is not None:
+            out["table_sharded"] = table_sharded
         if mode == "single":
             out["recall"] = recall(smap, queries, res.top1())
         else:
-            f, v = merged["out"]
+            f = merged["out"][0]
             out["recall"] = recall(smap, queries, f[:, 0].cpu().numpy())
-        want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and F <= 2000)
+        want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and F <= 12000)
         if mode == "single" and want_cpu:
             try:
-                cb, par = cpu_baseline(smap, queries, res, mgr, args.cpu_seconds)
+                cb, par = cpu_baseline(smap, queries, res, mgr, args.cpu_seconds, args.cpu_protocol)
                 out["cpu_baseline"] = cb
                 out["parity"] = par
                 out["speedup_vs_cpu_baseline"] = value / cb["value"]
+                out["speedup_vs_best_cpu_setting"] = value / cb["best_setting_frames_per_s"]
             except Exception as exc:   # a broken checker must not cost the measured line
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = "%s: %s" % (type(exc).__name__, exc)

@@ -73,6 +73,7 @@ def lib():
         L.orc_current_frame_id.restype = C.c_uint32
         L.orc_current_frame_id.argtypes = [vp]
         L.orc_set_current_frame_id.argtypes = [vp, C.c_uint32]
+        L.orc_set_num_threads.argtypes = [vp, C.c_int]
         L.orc_label_code.restype = C.c_int
         L.orc_label_code.argtypes = [C.c_int] * 3
         L.orc_build.restype = i64
@@ -158,6 +159,10 @@ class OracleManager:
 
     def set_current_frame_id(self, fid):
         lib().orc_set_current_frame_id(self._h, int(fid))
+
+    def set_num_threads(self, n):
+        lib().orc_set_num_threads(self._h, int(n))
+        self.cfg["num_threads"] = int(n)
 
     def build(self, xyz, label, export=True):
         """BuildSingleScanSTD; returns Descs (or the count if export=False)"""

@@ -579,6 +579,8 @@ orc_manager *orc_create(const orc_config *cfg) {
 void orc_destroy(orc_manager *m) { delete m; }
 uint32_t orc_current_frame_id(const orc_manager *m) { return m->current_frame_id_; }
 void orc_set_current_frame_id(orc_manager *m, uint32_t id) { m->current_frame_id_ = id; }
+// timing protocol of BASELINE.md §2: the same table timed at several OpenMP thread settings
+void orc_set_num_threads(orc_manager *m, int n) { m->cfg.num_threads = n > 0 ? n : 1; }
 int orc_label_code(int a, int b, int c) { return label_code(a, b, c); }
 
 int64_t orc_build(orc_manager *m, const float *xyz, const uint32_t *label, int n) {

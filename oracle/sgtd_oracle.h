@@ -61,6 +61,8 @@ void orc_destroy(orc_manager *m);
 uint32_t orc_current_frame_id(const orc_manager *m);
 /* start value of current_frame_id_ (a table shard of a multi-GPU map starts at its first frame) */
 void orc_set_current_frame_id(orc_manager *m, uint32_t id);
+/* OpenMP threads of the next select/verify calls (timing protocol) */
+void orc_set_num_threads(orc_manager *m, int n);
 
 /* Combinatorial_Binary_Encoding — STDesc.cpp:3-16 */
 int orc_label_code(int a, int b, int c);

@@ -89,16 +89,19 @@ struct Scanner {
     if (out) *out = v;
     return true;
   }
-  bool skip_value() {
+  // nesting is bounded (nlohmann's recursive-descent parser has no such bound, a hostile
+  // file would overflow its stack; here it is a parse error)
+  bool skip_value(int depth = 0) {
     ws();
     if (p >= end) return fail("value expected");
+    if (depth > 256) return fail("nesting too deep");
     const char c = *p;
     if (c == '"') return string(nullptr);
     if (c == '{') {
       p++;
       if (peek('}')) { p++; return true; }
       while (true) {
-        if (!string(nullptr) || !expect(':') || !skip_value()) return false;
+        if (!string(nullptr) || !expect(':') || !skip_value(depth + 1)) return false;
         if (peek(',')) { p++; continue; }
         return expect('}');
       }
@@ -107,7 +110,7 @@ struct Scanner {
       p++;
       if (peek(']')) { p++; return true; }
       while (true) {
-        if (!skip_value()) return false;
+        if (!skip_value(depth + 1)) return false;
         if (peek(',')) { p++; continue; }
         return expect(']');
       }
@@ -243,13 +246,24 @@ inline bool load_cache(const char *path, sgtd_graph_batch &b) {
   bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, kMagic, 8) && fread(&nf, 8, 1, f) == 1 && fread(&nk, 8, 1, f) == 1 &&
             nf >= 0 && nk >= 0;
   if (ok) {
+    // the header's counts must agree with the file's size before anything is allocated from them
+    ok = fseek(f, 0, SEEK_END) == 0;
+    const long long fsize = ok ? (long long)ftell(f) : -1;
+    ok = ok && nf < (1ll << 40) && nk < (1ll << 40) && fsize == 24 + (nf + 1) * 8 + nf * 48 + nk * 16 &&
+         fseek(f, 24, SEEK_SET) == 0;
+  }
+  if (ok) {
     b.kp_off.resize((size_t)nf + 1); b.poses.resize((size_t)nf * 12); b.label.resize((size_t)nk); b.xyz.resize((size_t)nk * 3);
     ok = fread(b.kp_off.data(), 8, b.kp_off.size(), f) == b.kp_off.size() && fread(b.poses.data(), 4, b.poses.size(), f) == b.poses.size() &&
          fread(b.label.data(), 4, b.label.size(), f) == b.label.size() && fread(b.xyz.data(), 4, b.xyz.size(), f) == b.xyz.size() &&
          b.kp_off.front() == 0 && b.kp_off.back() == nk;
+    for (size_t k = 1; ok && k < b.kp_off.size(); k++) ok = b.kp_off[k] >= b.kp_off[k - 1];   // frames are ranges
   }
   fclose(f);
-  if (!ok) b.error = std::string(path) + ": not a graph-batch cache";
+  if (!ok) {
+    b.kp_off.assign(1, 0); b.poses.clear(); b.label.clear(); b.xyz.clear();
+    b.error = std::string(path) + ": not a graph-batch cache";
+  }
   return ok;
 }
 

@@ -87,6 +87,7 @@ struct sgtd_engine {
   const u32 *last_label = nullptr;
   std::vector<long long> last_kp_off;
   int last_max_n = 0;
+  u32 last_qframe = 0;  // current_frame_id_ when the batch was enqueued (a re-run stamps the same id)
   DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
   DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
   DevBuf c_pair, c_slot, c_blk;   // compact candidate-match lists between block_count and block_write
@@ -95,6 +96,7 @@ struct sgtd_engine {
   bool verified = false;
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
+  bool rec_cap_fixed = false;          // SGTD_REC_CAP given: no pre-sizing from the table statistics
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
   bool key_major = true;               // sweep in locality-key order (SGTD_PROBE_ORDER=query|key)
   DevBuf n_valid, xcd_heads, cell_rows, gid, q_prefix, group_first, n_groups, sdesc;
@@ -712,7 +714,7 @@ int enqueue_frames(sgtd_engine *e) {
   const int nq = e->nq;
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));
   CHK(launch_build(e, e->last_xyz, e->last_label, e->kp_off_dev.as<long long>(), nq, e->last_max_n,
-                   e->current_frame_id, 0, e->qd.view(), e->q_stride, e->q_count.as<u32>()));
+                   e->last_qframe, 0, e->qd.view(), e->q_stride, e->q_count.as<u32>()));
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_BUILD], e->stream));
   return launch_select(e);
 }
@@ -795,6 +797,12 @@ int sync_batch(sgtd_engine *e) {
   return SGTD_OK;
 }
 
+// A pending query batch keeps its inputs in the handle's staging buffers for a re-run after a
+// work-buffer overflow: anything that is about to reuse them settles the batch first.
+int settle_pending(sgtd_engine *e) {
+  if (e->batch_valid && !e->batch_synced) return sync_batch(e);
+  return SGTD_OK;
+}
 
 int check_cfg(const sgtd_config *c) {
   if (c->descriptor_near_num < 3 || c->descriptor_near_num > SGTD_MAX_K) return SGTD_ERR_UNSUPPORTED;
@@ -908,6 +916,8 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   e->qd.with_thr2 = true;
   if (const char *o = getenv("SGTD_PROBE_ORDER")) e->key_major = std::strcmp(o, "key") == 0;
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
+  // test hook: start with a small match-record buffer so that the overflow / re-run path runs
+  if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }
   for (int i = 0; i < EV_COUNT; i++)
     if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
   *out = e;
@@ -964,6 +974,7 @@ int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sg
   HIPCHK(hipSetDevice(e->cfg.device_id));
   *n_out = 0;
   if (n == 0) return SGTD_OK;
+  CHK(settle_pending(e));
   int64_t off[2] = {0, n};
   const float *dx; const u32 *dl; int max_n;
   CHK(stage_inputs(e, xyz, label, off, 1, 0, &dx, &dl, &max_n));
@@ -989,6 +1000,7 @@ int sgtd_add(sgtd_handle e, const sgtd_desc_soa *d, int64_t n) {
     hi = std::max(hi, d->frame[i]);
   }
   if (n > 0 && hi >= (u32)e->cfg.max_frame_n) return SGTD_ERR_FRAME_LIMIT;
+  CHK(settle_pending(e));
   e->current_frame_id++;  // STDesc.cpp:151, before anything is inserted
   e->n_add_calls++;
   if (n == 0) return SGTD_OK;
@@ -1008,6 +1020,7 @@ int sgtd_add_frames(sgtd_handle e, const float *xyz, const uint32_t *label, cons
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if ((uint64_t)e->current_frame_id + (uint64_t)n_frames > (uint64_t)e->cfg.max_frame_n)
     return SGTD_ERR_FRAME_LIMIT;
+  CHK(settle_pending(e));
   const int chunk = 512;
   for (int f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = std::min(chunk, n_frames - f0);
@@ -1059,6 +1072,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
   e->nq = n_queries;
   e->q_stride = (long long)std::max(max_n, 1) * e->dc.tpi;
   e->last_kind = 1; e->last_xyz = dx; e->last_label = dl; e->last_max_n = max_n;
+  e->last_qframe = e->current_frame_id;
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride * n_queries));
   CHK(ensure(e, e->q_count, (size_t)n_queries * sizeof(u32)));
   return enqueue_frames(e);
@@ -1114,6 +1128,9 @@ int sgtd_export_candidates_dev(sgtd_handle e, int32_t *d_cand_frame, int32_t *d_
   if (!e || !d_cand_frame || !d_cand_votes) return SGTD_ERR_INVALID;
   if (!e->batch_valid) return SGTD_ERR_STATE;
   HIPCHK(hipSetDevice(e->cfg.device_id));
+  // a batch that outgrew a work buffer has empty candidate tables until it is re-run:
+  // resolve that first (one stream wait per batch; the tables of an intact batch are final)
+  CHK(sync_batch(e));
   const size_t bytes = (size_t)e->nq * e->dc.cand_num * sizeof(int);
   HIPCHK(hipMemcpyAsync(d_cand_frame, e->cand_frame.p, bytes, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(d_cand_votes, e->cand_votes.p, bytes, hipMemcpyDeviceToDevice, e->stream));
@@ -1331,6 +1348,7 @@ int sgtd_save_table(sgtd_handle e, const char *path) {
 int sgtd_load_table(sgtd_handle e, const char *path) {
   if (!e || !path) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(settle_pending(e));
   FILE *f = fopen(path, "rb");
   if (!f) { e->err = std::string("Error opening file: ") + path; return SGTD_ERR_IO; }
   char magic[8];
@@ -1345,13 +1363,33 @@ int sgtd_load_table(sgtd_handle e, const char *path) {
     e->err = "saved table was built with another std_side_resolution";
     return SGTD_ERR_INVALID;
   }
-  if (h.have_frames && h.frame_hi >= (u32)e->cfg.max_frame_n) { fclose(f); return SGTD_ERR_FRAME_LIMIT; }
+  if (h.near_num != e->cfg.descriptor_near_num || h.min_len != e->cfg.descriptor_min_len || h.max_len != e->cfg.descriptor_max_len) {
+    fclose(f);
+    e->err = "saved table was built with another descriptor_near_num / min_len / max_len";
+    return SGTD_ERR_INVALID;
+  }
+  if (h.have_frames && (h.frame_hi >= (u32)e->cfg.max_frame_n || h.frame_lo > h.frame_hi)) { fclose(f); return SGTD_ERR_FRAME_LIMIT; }
   if (h.n_entries >= (1ll << 32) - 2) { fclose(f); return SGTD_ERR_UNSUPPORTED; }
+  if ((h.n_entries > 0) != (h.have_frames != 0)) { fclose(f); e->err = std::string(path) + ": inconsistent table header"; return SGTD_ERR_IO; }
   int st = ensure_store(e, e->tab, (size_t)std::max<int64_t>(h.n_entries, 1), false);
   if (st == SGTD_OK) st = stream_table(e, f, (size_t)h.n_entries, false);
   fclose(f);
+  if (st == SGTD_OK && h.n_entries > 0) {
+    // the votes are indexed by frame - frame_lo: every stored frame id must lie in the header's range
+    int bad = 0;
+    st = ensure(e, e->bad_flag, sizeof(int));
+    if (st == SGTD_OK) {
+      HIPCHK(hipMemsetAsync(e->bad_flag.p, 0, sizeof(int), e->stream));
+      frame_range_check_kernel<<<grid_for(h.n_entries, 256), 256, 0, e->stream>>>(e->tab.frame.as<u32>(), h.n_entries, h.frame_lo, h.frame_hi,
+                                                                                   e->bad_flag.as<int>());
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&bad, e->bad_flag.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (bad) st = SGTD_ERR_IO;
+    }
+  }
   if (st != SGTD_OK) {
-    if (st == SGTD_ERR_IO) e->err = std::string(path) + ": truncated table file";
+    if (st == SGTD_ERR_IO) e->err = std::string(path) + ": truncated or damaged table file";
     e->n_entries = 0; e->have_frames = false; e->finalized = false; e->batch_valid = false;
     return st;
   }
@@ -1366,7 +1404,12 @@ int sgtd_graphs_load(const char *const *paths, int n_files, int n_threads, sgtd_
   if (!out || n_files < 0 || (n_files > 0 && !paths)) return SGTD_ERR_INVALID;
   sgtd_graph_batch *b = new sgtd_graph_batch();
   *out = b;
-  return ingest::load(paths, n_files, n_threads, *b) ? SGTD_OK : SGTD_ERR_IO;
+  try {
+    return ingest::load(paths, n_files, n_threads, *b) ? SGTD_OK : SGTD_ERR_IO;
+  } catch (const std::exception &ex) {   // nothing throws across the ABI
+    b->error = std::string("graph ingest: ") + ex.what();
+    return SGTD_ERR_IO;
+  }
 }
 
 int sgtd_graphs_save_cache(const sgtd_graph_batch *b, const char *path) {
@@ -1378,7 +1421,12 @@ int sgtd_graphs_load_cache(const char *path, sgtd_graph_batch **out) {
   if (!out || !path) return SGTD_ERR_INVALID;
   sgtd_graph_batch *b = new sgtd_graph_batch();
   *out = b;
-  return ingest::load_cache(path, *b) ? SGTD_OK : SGTD_ERR_IO;
+  try {
+    return ingest::load_cache(path, *b) ? SGTD_OK : SGTD_ERR_IO;
+  } catch (const std::exception &ex) {
+    b->error = std::string(path) + ": " + ex.what();
+    return SGTD_ERR_IO;
+  }
 }
 
 int sgtd_graphs_view(const sgtd_graph_batch *b, int *n_frames, int64_t *n_keypoints, const float **xyz,

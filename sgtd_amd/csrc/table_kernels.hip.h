@@ -93,6 +93,12 @@ __global__ void make_keys_kernel(const double *side, const int *label, u64 *keys
   vals[g] = (u32)g;
 }
 
+// a loaded table's frame ids must lie in the header's [lo, hi] (the votes are indexed by them)
+__global__ void frame_range_check_kernel(const u32 *frame, long long n, u32 lo, u32 hi, int *bad_flag) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n && (frame[g] < lo || frame[g] > hi)) *bad_flag = 1;
+}
+
 // ---------------------------------------------------------------------------
 // LSD radix sort, 8-bit digit per pass
 // ---------------------------------------------------------------------------

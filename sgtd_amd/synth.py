@@ -73,7 +73,7 @@ def _trajectory(n_frames, spacing, swath):
     return np.stack([px, py, yaw], axis=1), amp
 
 
-def _observe(landmarks, labels, tree, pose, n_kp, sigma, rng):
+def _observe(landmarks, labels, tree, pose, n_kp, sigma, rng, tie_k=10):
     """the n_kp landmarks nearest to each pose, in the sensor frame, noisy, f32, shuffled"""
     _, idx = tree.query(pose[:, :2], k=n_kp)
     idx = np.asarray(idx).reshape(pose.shape[0], n_kp)
@@ -86,8 +86,21 @@ def _observe(landmarks, labels, tree, pose, n_kp, sigma, rng):
     out[:, :, 0] = c * d[:, :, 0] - s * d[:, :, 1]
     out[:, :, 1] = s * d[:, :, 0] + c * d[:, :, 1]
     out[:, :, 2] = pts[:, :, 2]
-    out += rng.normal(0.0, sigma, size=out.shape)
-    return out.astype(np.float32), labels[idx].astype(np.uint32)
+    clean = out
+    out = (clean + rng.normal(0.0, sigma, size=clean.shape)).astype(np.float32)
+    # frames with duplicate points or exact f32 k-NN distance ties are regenerated
+    # (FLANN's tie order is unpinned): fresh noise from a sub-stream until the frame is tie-free
+    if tie_k:
+        bad = frames_with_knn_ties(out, tie_k)
+        attempt = 0
+        while bad.size:
+            attempt += 1
+            if attempt > 16:
+                raise RuntimeError("could not draw tie-free frames")
+            sub = np.random.Generator(np.random.PCG64(np.random.SeedSequence([BASE_SEED, 7919, attempt, int(bad[0]), int(bad.size)])))
+            out[bad] = (clean[bad] + sub.normal(0.0, sigma, size=clean[bad].shape)).astype(np.float32)
+            bad = bad[frames_with_knn_ties(out[bad], tie_k)]
+    return out, labels[idx].astype(np.uint32)
 
 
 def make_map(n_frames, n_kp=200, stream=1, spacing=2.0, swath=100.0, radius=50.0,
@@ -126,6 +139,26 @@ def make_queries(smap, n_queries, stream=1, sigma=0.05, shift_sigma=0.5, frames=
     n_kp = smap.xyz.shape[1]
     xyz, label = _observe(smap.landmarks, smap.landmark_label, smap._tree, pose, n_kp, sigma, rng)
     return SynthQueries(xyz=xyz, label=label, gt_frame=gt.astype(np.int64), pose=pose)
+
+
+def frames_with_knn_ties(xyz, k, chunk=512):
+    """indices of the frames of xyz (F, N, 3) f32 that have duplicate points or an exact f32
+    distance tie among the k+1 nearest of any point (the same test as has_knn_ties, batched;
+    torch CPU kernels: individually rounded IEEE f32 operations, all host threads)"""
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32))
+    kk = min(k + 1, x.shape[1])
+    bad = []
+    for f0 in range(0, x.shape[0], chunk):
+        c = x[f0:f0 + chunk]
+        dx = c[:, :, None, 0] - c[:, None, :, 0]
+        dy = c[:, :, None, 1] - c[:, None, :, 1]
+        dz = c[:, :, None, 2] - c[:, None, :, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz
+        part = torch.topk(d2, kk, dim=2, largest=False, sorted=True).values
+        tie = (part[:, :, 1:] == part[:, :, :-1]).any(dim=2).any(dim=1)
+        bad.append(f0 + torch.nonzero(tie)[:, 0].numpy())
+    return np.concatenate(bad) if bad else np.zeros(0, np.int64)
 
 
 def has_knn_ties(xyz, k):

@@ -605,3 +605,33 @@ def test_sharded_search_loop_equals_single_table(mods):
     assert np.array_equal(out[6].cpu().numpy(), w_bf) and np.array_equal(out[7].cpu().numpy(), w_bs)
     for m in shards + [single, one.mgr]:
         m.close()
+
+
+def test_overflowed_batch_is_resolved_before_the_sharded_export(mods, monkeypatch):
+    """a batch that outgrows the match-record buffer has empty candidate tables
+    until it is re-run; ShardedMap.query / search_loop must export the repaired tables"""
+    import torch
+    from sgtd_amd.dist import ShardedMap
+    _, manager, synth = mods
+    monkeypatch.setenv("SGTD_REC_CAP", "4096")       # every non-trivial batch overflows at first
+    m = synth.make_map(60, 200, stream=91)
+    qs = synth.make_queries(m, 8, stream=91)
+    sm = ShardedMap(60, 0, 1)
+    sm.add_shard_frames(m.xyz, m.label)
+    dx = torch.from_numpy(qs.xyz).cuda().contiguous()
+    dl = torch.from_numpy(qs.label.astype(np.int64)).cuda().to(torch.int32).contiguous()
+    frames, votes, n_cand, scores, poses, bc, bf, bs = sm.search_loop(dx, dl)
+    assert sm.mgr.stats()["overflowed"] == 1
+    monkeypatch.delenv("SGTD_REC_CAP")
+    g = manager.STDescManager()
+    g.add_frames(m.xyz, m.label)
+    res = g.query_frames(qs.xyz, qs.label)
+    g.verify()
+    gc, gf, gs = g.search_loop()
+    assert res.n_cand.max() > 0
+    for q in range(8):
+        nc = int(res.n_cand[q])
+        assert int(n_cand[q]) == nc
+        assert np.array_equal(frames[q, :nc].cpu().numpy(), res.cand_frame[q, :nc])
+        assert np.array_equal(votes[q, :nc].cpu().numpy(), res.cand_votes[q, :nc])
+    assert np.array_equal(bf.cpu().numpy(), gf) and np.array_equal(bs.cpu().numpy(), gs)
