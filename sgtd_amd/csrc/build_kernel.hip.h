@@ -302,13 +302,7 @@ __global__ __launch_bounds__(SGTD_BUILD_THREADS) void build_frames_kernel(
       out.label[o * 3 + 1] = (int)(double)__float_as_uint(B.w);
       out.label[o * 3 + 2] = (int)(double)__float_as_uint(C.w);
       out.frame[o] = frame_id;
-      if (out.qrec) {   // dis_threshold of :356-357 in squared, comparison-exact form; cell gate :366-369
-        const double s0 = cfg.scale * a, s1 = cfg.scale * b, s2 = cfg.scale * c;
-        double2 *qr = reinterpret_cast<double2 *>(out.qrec + o);
-        qr[0] = make_double2(s0, s1);
-        qr[1] = make_double2(s2, sq_threshold(norm3(s0, s1, s2) * cfg.rough));
-        reinterpret_cast<uint4 *>(qr)[2] = make_uint4(frame_id, gate_mask(s0, s1, s2), 0u, 0u);
-      }
+      if (out.qrec) write_query_rec(out.qrec + o, cfg.scale * a, cfg.scale * b, cfg.scale * c, cfg.rough, frame_id);
       out.node_id[o * 3 + 0] = i; out.node_id[o * 3 + 1] = m; out.node_id[o * 3 + 2] = nn;
     }
 #ifdef SGTD_EXP_PHASE

@@ -65,23 +65,44 @@ __host__ __device__ __forceinline__ u32 hash_key(u64 k) {
   return h;
 }
 
-// one table entry in the probe layout: 32 bytes in two 16-B halves kept in two arrays
-// (head[E], tail[E]) so that each 16-B-per-lane load of a wavefront covers 1 KB of
-// consecutive memory (8 full lines) instead of half of 16 lines
-struct __attribute__((aligned(16))) HotHead {
-  double s0, s1;      // side_length_ (scaled)
-};
-struct __attribute__((aligned(16))) HotTail {
-  double s2;
+// One table entry in the probe layout: 16 bytes — the three sides rounded to f32 and the frame
+// id.  The sweep decides almost every entry on these (f32_bounds below gives squared thresholds
+// that make the f32 test conservative on both sides); the few entries that fall between them are
+// decided on the exact f64 sides of the cold table, so every decision equals the reference's.
+// The insertion index of entry p is perm[p] (a second, 4-byte array: one 1-KB and one 256-B load
+// per 64 entries instead of two 1-KB loads).
+struct __attribute__((aligned(16))) HotEntry {
+  float s0, s1, s2;   // (float)side_length_ (scaled)
   u32 frame;          // frame_id_
-  u32 g;              // insertion index (bucket order == ascending g)
 };
-#define SGTD_HOT_BYTES 32   // per entry, both halves
+#define SGTD_HOT_BYTES 20   // per entry: HotEntry + its perm word
+
+// Inside a bucket (one reference cell + label code) the entries are partitioned into
+// SGTD_ZSLICES slices of the longest side's cell interval plus one overflow slice, each in
+// insertion order.  A query descriptor only visits the slices its threshold ball reaches
+// (|side2 - q2| <= thr) and the overflow slice.  All entries of one map frame in one bucket
+// that could match the same query descriptor lie in ONE slice (table_kernels.hip.h,
+// slice_assign_kernel), so the matches of any (query descriptor, cell, frame) still come out in
+// insertion order — the order of the reference's bucket scan restricted to a frame, which is
+// all that votes and per-candidate match lists depend on.
+#define SGTD_ZSLICES 4
+#define SGTD_NSLICE (SGTD_ZSLICES + 1)     // + overflow slice (always visited)
+// one bucket of the directory, 32 B: cum[k] = entries of the bucket in slices 0..k
+// (cum[SGTD_ZSLICES] = all of them, the reference's bucket length)
+struct __attribute__((aligned(32))) BucketDir {
+  u32 start;
+  u32 cum[SGTD_NSLICE];
+  u32 pad[2];
+};
+static_assert(sizeof(BucketDir) == 32 && SGTD_ZSLICES == 4, "the sweep unpacks {start, cum[0..4]} from two 16-B halves");
+#define SGTD_NRANGE (2 * SGTD_NCELL)       // visit ranges of one descriptor: (cell, regular | overflow)
+#define SGTD_GROUP_ROW_BYTES 1024          // 27 BucketDir rows (864 B), padded
 
 // What the sweep needs about ONE query descriptor, 64 B: written per descriptor slot by the
 // build kernel (gid, d unset), and per sorted position by sorted_desc_kernel.  A wavefront
 // loads 16 of them with one 16-B-per-lane load (lane j = quarter j & 3 of record j >> 2):
 //   quarter 0: q0, q1   quarter 1: q2, thr2   quarter 2: frame, gate mask, group id, slot d
+//   quarter 3: lo2, hi2 (f32 squared thresholds of the conservative f32 test)
 struct __attribute__((aligned(64))) QueryRec {
   double q0, q1, q2;  // side_length_ (scaled)
   double thr2;        // exact squared match threshold (sq_threshold)
@@ -89,7 +110,8 @@ struct __attribute__((aligned(64))) QueryRec {
   u32 gate;           // 27-bit mask of the probe cells that pass the 1.5 gate (gate_mask)
   u32 gid;            // key-major: group (home cell) of the descriptor
   u32 d;              // key-major: descriptor slot
-  u32 pad[4];
+  float lo2, hi2;     // f32 d2 below lo2: certainly a match; above hi2: certainly not (f32_bounds)
+  u32 pad[2];
 };
 
 // smallest y with sqrt_rn(y) >= thr:  (sqrt_rn(d2) < thr)  <=>  (d2 < y), because the
@@ -127,10 +149,55 @@ __device__ __forceinline__ u32 gate_mask(double q0, double q1, double q2) {
   return m;
 }
 
+// Squared thresholds for the sweep's f32 test.  The sweep computes, in f32 with individually
+// rounded (or fused) operations, d2f = (dx^2 + dy^2) + dz^2 from dxk = fl32(fl32(q_k) - fl32(s_k)).
+// With u = 2^-24, every visited entry within 2.5 of the query per axis (it lies in one of the 27
+// neighbouring cells), and |s_k| <= |q_k| + 2.5:
+//   |dxk - (q_k - s_k)| <= u (|q_k| + |s_k|)(1 + u) + u |q_k - s_k| (1 + u) <= u (4 |q_k| + 16) =: a_k
+// so | ||dxf|| - d | <= A = sqrt(a_0^2 + a_1^2 + a_2^2) for the true distance d, and
+// sqrt(d2f) is within (1 +- 2u) of ||dxf|| (three rounded operations on non-negative terms).
+// The reference's own f64 value of d differs from the true one by less than 1e-15 relative.
+// With the margin m = 2 A + 16 u thr + 1e-12 (twice what the bound needs):
+//   d2f < lo2 = rounddown_f32((thr - m)^2)  ==>  the reference's dis < thr
+//   d2f > hi2 = roundup_f32((thr + m)^2)    ==>  the reference's dis >= thr
+// anything else (including NaN/inf from sides beyond the f32 range) is decided exactly.
+__device__ __forceinline__ void f32_bounds(double q0, double q1, double q2, double thr, float &lo2, float &hi2) {
+  const double u = 5.9604644775390625e-08;   // 2^-24
+  const double a0 = u * (4.0 * fabs(q0) + 16.0), a1 = u * (4.0 * fabs(q1) + 16.0), a2 = u * (4.0 * fabs(q2) + 16.0);
+  const double A = sqrt((a0 * a0 + a1 * a1) + a2 * a2);
+  const double m = 2.0 * A + 16.0 * u * thr + 1e-12;
+  const double lo = thr - m, hi = thr + m;
+  float l = 0.0f;
+  if (lo > 0.0) {
+    const double l2 = lo * lo * (1.0 - 1e-15);
+    l = (float)l2;
+    if ((double)l > l2) l = __uint_as_float(__float_as_uint(l) - 1u);   // towards zero (l > 0 here)
+  }
+  const double h2 = hi * hi * (1.0 + 1e-15);
+  float h = (float)h2;
+  if ((double)h < h2) h = __uint_as_float(__float_as_uint(h) + 1u);     // upwards (h >= 0; inf stays inf)
+  if (!(thr > 0.0) || !(h2 == h2)) { l = 0.0f; h = 0.0f; }             // dis < thr is never true / NaN: nothing is a certain match,
+  lo2 = l;                                                              // every d2f > 0 a certain miss, d2f == 0 decided exactly
+  hi2 = h;
+}
+
+// the sweep record of one query descriptor (dis_threshold of STDesc.cpp:356-357 in squared,
+// comparison-exact form; cell gate :366-369; f32 thresholds)
+__device__ __forceinline__ void write_query_rec(QueryRec *out, double s0, double s1, double s2, double rough, u32 frame) {
+  const double thr = norm3(s0, s1, s2) * rough;
+  float lo2, hi2;
+  f32_bounds(s0, s1, s2, thr, lo2, hi2);
+  double2 *qr = reinterpret_cast<double2 *>(out);
+  qr[0] = make_double2(s0, s1);
+  qr[1] = make_double2(s2, sq_threshold(thr));
+  reinterpret_cast<uint4 *>(qr)[2] = make_uint4(frame, gate_mask(s0, s1, s2), 0u, 0u);
+  reinterpret_cast<uint4 *>(qr)[3] = make_uint4(__float_as_uint(lo2), __float_as_uint(hi2), 0u, 0u);
+}
+
 struct HashSlot {  // 16 bytes
   u64 key;
-  u32 start;
-  u32 len;
+  u32 bucket;   // index into the bucket directory
+  u32 len;      // entries of the bucket
 };
 #define SGTD_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 

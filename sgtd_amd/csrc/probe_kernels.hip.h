@@ -2,22 +2,24 @@
 //
 //   probe     (:351-400) one wavefront per query descriptor: its 27 cells
 //             (truncating (int)(side+inc), gate ||side-centre|| < 1.5, hash
-//             lookup key -> bucket) become one concatenated visit list that all
-//             64 lanes stream from the 32-B/entry probe layout (two 16-B loads
-//             per lane, 4 x 64 entries in flight).  The distance test runs on
-//             squared values against the exact squared threshold (common.hip.h
-//             sq_threshold) — no per-entry sqrt.  Matches are compacted in
-//             (cell, j) order by __ballot/popcount prefix into a per-descriptor
-//             list of (frame, entry) records.  Two schedules of the same sweep:
-//             * query-major (probe_kernel): work item = (query, 128 descriptors),
-//               resolve_kernel writes one CellRow per descriptor, votes (:404-420)
-//               go to an LDS histogram per work item;
-//             * key-major (probe_sorted_kernel, the default): the batch's
-//               descriptors are radix-sorted by home cell, descriptors of one home
-//               cell share ONE set of 27 bucket lookups (GroupRow), per-XCD ticket
-//               queues hand neighbouring cells to waves of one XCD so that the
-//               buckets stay in that XCD's L2; votes_kernel counts votes from the
-//               lists afterwards.
+//             lookup key -> bucket) become one concatenated visit list of up to 54
+//             ranges — per cell the z-slices of the bucket that the descriptor's
+//             threshold ball reaches, and the bucket's overflow slice
+//             (common.hip.h, table_kernels.hip.h) — that all 64 lanes stream from
+//             the 16-B/entry probe layout (one 16-B and one 4-B load per lane and
+//             64 entries, 4 x 64 entries in flight).  The distance test runs in
+//             f32 against two squared thresholds that make it conservative on
+//             both sides (common.hip.h f32_bounds); the few entries between them
+//             are decided on the exact f64 sides with the exact squared threshold
+//             (sq_threshold) — every decision is the reference's.  Matches are
+//             compacted in visit order by __ballot/popcount prefix into a
+//             per-descriptor list of (frame, entry) records; restricted to any one
+//             map frame that order is the reference's (cell, j) order.
+//             Schedule (probe_sorted_kernel): the batch's descriptors are
+//             radix-sorted by home cell, descriptors of one home cell share ONE
+//             set of 27 bucket lookups (GroupRow), per-XCD ticket queues hand
+//             neighbouring cells to waves of one XCD so that the buckets stay in
+//             that XCD's L2; votes_kernel counts votes from the lists afterwards.
 //   topk      (:423-433) candidate_num rounds of arg-max over the votes:
 //             votes desc, frame id asc, stop below 5 votes
 //   assemble  (:434-449) one wavefront per 128-descriptor block walks the
@@ -33,14 +35,16 @@
 //
 // Diagnostics (never in the shipped build): -DSGTD_EXP_PHASE adds in-kernel phase
 // clocks and counters printed by the host after a few launches; -DSGTD_EXP_TRACE
-// records per-wave start/end times of the key-major sweep.
+// records per-wave start/end times of the sweep.
 #pragma once
 #include "common.hip.h"
 #include <type_traits>
 
 struct TableView {
-  const HotHead *head;         // [E] sorted by key, insertion order inside a bucket
-  const HotTail *tail;         // [E] same order
+  const HotEntry *ent;         // [E] probe order: by key, by slice inside a bucket, insertion order inside a slice
+  const u32 *perm;             // [E] probe position -> insertion index g
+  const double *cold_side;     // [E*3] exact sides in insertion order (undecided f32 tests, diagnostic build)
+  const BucketDir *dir;        // [U] bucket directory
   const HashSlot *hash;
   u32 hash_mask;
   u32 n_entries;
@@ -50,7 +54,7 @@ struct TableView {
 
 struct QueryView {
   const double *side;   // [n_slots*3]
-  const QueryRec *qrec; // [n_slots] sweep record of the descriptor (threshold, gate mask)
+  const QueryRec *qrec; // [n_slots] sweep record of the descriptor (thresholds, gate mask)
   const int *label;     // [n_slots*3]
   const u32 *frame;     // [n_slots]
   const u32 *count;     // [n_queries] descriptors per query
@@ -66,92 +70,26 @@ struct ProbeBuffers {
   u32 rec_cap;
   unsigned long long *rec_cursor;   // global slab cursor (64-bit: requests can add up beyond 2^32)
   unsigned long long *rec_need;     // matches that found no room (sizes the regrown buffer)
-  u32 *item_cursor;     // work queue head
+  unsigned long long *swept;        // table entries the sweep really loaded (after slice pruning)
   u32 *list_ptr;        // [n_slots] first record of descriptor
-  u32 *n_visit;         // [n_slots] entries visited by descriptor
+  u32 *n_visit;         // [n_slots] entries the reference's loop visits for the descriptor (STDesc.cpp:372)
   u32 *n_match;         // [n_slots] matches of descriptor
   u32 *votes;           // [n_queries * frame_span]
   int *overflow;        // [2]: 0 match records, 1 candidate pairs
 };
 
 #define SGTD_PROBE_THREADS 256
-#define SGTD_PROBE_CHUNK 128    // query descriptors per work item = per assemble block
+#define SGTD_PROBE_CHUNK 128    // query descriptors per assemble block
 #define SGTD_REC_SLAB 8192u     // match records a wave takes from the global cursor at once
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
 #ifndef SGTD_PROBE_UNROLL
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
 #endif
 #ifndef SGTD_BSEARCH_BELOW
-#define SGTD_BSEARCH_BELOW 1024u  // visit lists shorter than this locate cells by binary search
+#define SGTD_BSEARCH_BELOW 1024u  // visit lists shorter than this locate ranges by binary search
 #endif
 
-// ---------------------------------------------------------------------------
-// resolve: STDesc.cpp:358-371 for every (query descriptor, cell) pair, one
-// thread each (32 lanes per descriptor, 27 busy): truncating (int)(side+inc),
-// gate ||side-centre|| < 1.5, hash lookup key -> bucket, then a 32-lane scan
-// gives the descriptor's concatenated visit list.  One 256-B CellRow per
-// descriptor hands the result to the sweep kernel with a single coalesced load.
-// ---------------------------------------------------------------------------
-struct __attribute__((aligned(256))) CellRow {
-  u32 off[32];     // [0..26] exclusive offsets of the 27 ranges, [27] = total, rest unused
-  u32 start[32];   // [0..26] first table entry of each range
-};
-
-// Row index = position p; descriptor = order[p] (key-major) or p itself.
-#define SGTD_RESOLVE_THREADS 256
-__global__ __launch_bounds__(SGTD_RESOLVE_THREADS) void resolve_kernel(TableView T, QueryView Q, CellRow *rows,
-                                                                        const u32 *order, const u32 *n_valid_p,
-                                                                        long long n_slots) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long p = t >> 5;
-  const int c = (int)(t & 31);
-  const long long n = order ? (long long)*n_valid_p : n_slots;
-  if (p >= n) return;
-  const long long d = order ? (long long)order[p] : p;
-  if (!order) {
-    const int q = (int)(d / Q.stride);
-    if ((u32)(d - (long long)q * Q.stride) >= Q.count[q]) return;   // uniform over the 32-lane group
-  }
-  u32 start = 0, len = 0;
-  if (c < SGTD_NCELL) {
-    const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
-    const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
-    const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
-    const int x = (int)(q0 + (double)ix), y = (int)(q1 + (double)iy), z = (int)(q2 + (double)iz);
-    const double dx = q0 - ((double)x + 0.5), dy = q1 - ((double)y + 0.5), dz = q2 - ((double)z + 0.5);
-    // ||side - centre|| < 1.5 (:366-369): sqrt_rn(v) < 1.5 <=> v < 2.25 exactly
-    // (sqrt(2.25) = 1.5 and sqrt(pred(2.25)) rounds below 1.5)
-    const bool gate = ((dx * dx + dy * dy) + dz * dz) < 2.25;
-    if (gate && x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
-      const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
-      u32 h = hash_key(key) & T.hash_mask;
-      while (true) {
-        const HashSlot s = T.hash[h];
-        if (s.key == key) { start = s.start; len = s.len; break; }
-        if (s.key == SGTD_EMPTY_KEY) break;
-        h = (h + 1) & T.hash_mask;
-      }
-    }
-  }
-  // inclusive scan over the 32-lane group
-  u32 inc = len;
-#pragma unroll
-  for (int dlt = 1; dlt < 32; dlt <<= 1) {
-    const u32 up = __shfl_up(inc, dlt, 32);
-    if (c >= dlt) inc += up;
-  }
-  CellRow &r = rows[p];
-  r.off[c] = (c < SGTD_NCELL) ? inc - len : inc;   // [27] = total (lanes >= 27 add nothing)
-  r.start[c] = start;
-}
-
-// vote sinks of the sweep
-#define SGTD_VOTE_NONE 0    // votes are counted later from the match lists (votes_kernel)
-#define SGTD_VOTE_LDS 1     // LDS histogram of the work item, flushed by the caller
-#define SGTD_VOTE_GLOBAL 2  // one global atomic per match
-
-// per-descriptor results of the sweep when the caller stores them itself (one store per
-// ticket instead of one per descriptor)
+// per-descriptor results of the sweep (stored once per ticket by the caller)
 struct DescResult {
   u32 ptr, visit, match;
 };
@@ -162,16 +100,17 @@ struct DescResult {
 // otherwise the compiler, which cannot count the stores of the loops in between, would wait
 // for every outstanding store (vmcnt(0)) at their first use.
 struct PendingLoads {
-  u32 *row = nullptr;
+  uint4 *row = nullptr;
   uint4 *rec = nullptr;
   __device__ __forceinline__ void touch() const {
-    if (row) asm volatile("" : "+v"(*row));
+    if (row) asm volatile("" : "+v"(row->x), "+v"(row->y), "+v"(row->z), "+v"(row->w));
     if (rec) asm volatile("" : "+v"(rec->x), "+v"(rec->y), "+v"(rec->z), "+v"(rec->w));
   }
 };
 
 struct WaveSlab {
   u32 next, end;   // this wave's private range of match records
+  u64 swept;       // entries this wave loaded
 #ifdef SGTD_EXP_PHASE
   u64 ph[8];
 #endif
@@ -187,263 +126,35 @@ __device__ unsigned long long g_words[2];   // 64-entry words swept, load groups
 #endif
 
 // what the sweep needs about one query descriptor; the loads are issued one descriptor
-// ahead (DescFetch), the per-lane plan is derived right before the sweep (plan_*)
+// ahead, the per-lane plan is derived right before the sweep (plan_from_group_row)
 struct DescFetch {
-  u32 row;              // lane l: word l of the descriptor's CellRow / of its group's GroupRow
+  uint4 row;            // lane l < 54: 16-B quarter l of the group's 27 directory rows
   double q0, q1, q2, thr2;
+  float lo2, hi2;       // conservative f32 thresholds (f32_bounds)
   u32 qframe;
-  u32 gate;             // key-major path: the descriptor's 27-bit gate mask
+  u32 gate;             // the descriptor's 27-bit gate mask
 };
 
-__device__ __forceinline__ DescFetch fetch_desc(const QueryView &Q, const CellRow *rows, long long p,
-                                                long long d) {
-  DescFetch f;
-  f.row = reinterpret_cast<const u32 *>(rows + p)[lane_id()];
-  f.q0 = Q.side[d * 3 + 0]; f.q1 = Q.side[d * 3 + 1]; f.q2 = Q.side[d * 3 + 2];
-  f.thr2 = Q.qrec[d].thr2;
-  f.qframe = Q.frame[d];
-  return f;
-}
-
-// the visit list of a descriptor as the sweep walks it: lane c < 27 holds the exclusive
-// offset off[c] of cell c (lane 27: the total = sentinel off[27]) and dl[c] = start[c] - off[c]
+// the visit list of a descriptor as the sweep walks it: lane r < 54 holds the exclusive
+// offset off[r] of range r = 2 * cell + (0 regular slices | 1 overflow slice), lanes >= 54 the
+// total, and dl[r] = start[r] - off[r]
 struct DescPlan {
   u32 off, dl;
+  u32 ref_visits;       // wave-uniform: entries the reference's loop visits (all slices of the gated cells)
 };
 
-// CellRow (resolve_kernel did gate + scan): off in lanes 0..27, start in lanes 32..58
-__device__ __forceinline__ DescPlan plan_from_cell_row(const DescFetch &f) {
-  DescPlan pl;
-  pl.off = f.row;
-  pl.dl = (u32)__shfl((int)f.row, (lane_id() + 32) & 63) - f.row;
-  return pl;
-}
-
-// STDesc.cpp:372-399 for ONE query descriptor d by one wavefront: streams the
-// descriptor's visit list, tests, compacts the matches in (cell, j) order
-// WIDE = false: the probe layout and the record buffer are each below 4 GB, so entry and
-// record addresses are a uniform base + a 32-bit byte offset (no quarter-rate 64-bit VALU
-// address arithmetic per entry); the host picks the variant from the buffer sizes
-template <int VOTE, bool DIAG, bool WIDE = true>
-__device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
-                                                 long long d, const DescFetch &f, const DescPlan &pl,
-                                                 WaveSlab &slab, u32 *s_hist, u32 *votes,
-                                                 DescResult *result = nullptr, PendingLoads pending = PendingLoads()) {
-  const int lane = lane_id();
-  const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
-  const u32 qframe = f.qframe;
-  const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;   // :356-357
-  // lane c < 27 holds off[c] (lane 27: total = the sentinel off[27]); dl[c] = start[c] - off[c]
-  const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_NCELL);
-  const u32 dl = pl.dl;
-  u64 ph_t = PH_T(); (void)ph_t;
-  // records of one descriptor are contiguous: make sure the slab can take
-  // the worst case (every visited entry matches)
-  if (total && (u64)slab.next + total > (u64)slab.end) {
-    // a slab must have room for the worst case of a descriptor (every visit matches) when
-    // the descriptor starts, but only the matches stay: slabs of 8 worst cases keep the space
-    // abandoned at a slab's end to about an eighth however long the visit lists are
-    const u32 take = total > (1u << 28) ? total : max(SGTD_REC_SLAB, 8u * total);
-    u64 got = 0;
-    if (lane == 0) got = atomicAdd(B.rec_cursor, (unsigned long long)take);
-    got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
-    if (got + take <= (u64)B.rec_cap) { slab.next = (u32)got; slab.end = (u32)got + take; }
-    else { slab.next = 0; slab.end = 0; }      // the buffer is exhausted: nothing of this wave fits any more
-  }
-  const bool fits = (u64)slab.next + total <= (u64)slab.end;
-  if (!fits && lane == 0) B.overflow[0] = 1;
-  __builtin_amdgcn_wave_barrier();
-  PH_ADD(0, ph_t);
-
-  u32 matches = 0;
-  const u32 n_words = (total + 63u) >> 6;
-#ifdef SGTD_EXP_PHASE
-  if (lane == 0 && n_words) {
-    atomicAdd(&g_words[0], (unsigned long long)n_words);
-    atomicAdd(&g_words[1], (unsigned long long)((n_words + SGTD_PROBE_UNROLL - 1) / SGTD_PROBE_UNROLL));
-  }
-#endif
-  // position -> cell, the last c with off[c] <= pos (empty cells share their successor's
-  // offset and are stepped over), read from the row registers by ds_bpermute — no memory.
-  // Two forms, chosen per descriptor (wave-uniform):
-  //  * short lists (many cell boundaries per 64-entry word): branch-free binary search over
-  //    the 32 offsets in lanes 0..31 (off[27..31] = total), five permutes per word;
-  //  * long lists (about one boundary per word): a per-lane cursor that only moves forward,
-  //    one permute per boundary crossed.
-  // All lanes execute the permutes (sources must be active).
-  // SGTD_PROBE_UNROLL words (64 entries each) per trip: all their loads are
-  // issued before the first use so that several KB per wave are in flight
-  u32 cur4 = 0;   // cursor form: 4 * cell = ds_bpermute byte address
-  u32 nxt_off = (u32)__builtin_amdgcn_ds_bpermute(4, (int)pl.off);
-  // one load group: NW words located, their loads issued back to back, then tested.  NW is a
-  // compile-time count: each group size is straight-line code (branches around loads would
-  // make the compiler wait for earlier loads before every later one).
-  auto group = [&](auto bsearch_tag, auto nw_tag, u32 w0) {
-    constexpr bool BSEARCH = decltype(bsearch_tag)::value;
-    constexpr int NW = decltype(nw_tag)::value;
-    double2 v01[NW], v2x[NW];
-    int cell[NW];
-    bool valid[NW];
-#pragma unroll
-    for (int u = 0; u < NW; u++) {
-      const u32 pos = ((w0 + u) << 6) + lane;
-      valid[u] = pos < total;
-      u32 c4;
-      if constexpr (BSEARCH) {
-        c4 = 0;
-#pragma unroll
-        for (int s = 64; s >= 4; s >>= 1) {
-          const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)s), (int)pl.off);
-          c4 += (t <= pos) ? (u32)s : 0u;
-        }
-      } else {
-        while (__ballot(valid[u] && pos >= nxt_off)) {   // off[27] = total stops it
-          cur4 += (valid[u] && pos >= nxt_off) ? 4u : 0u;
-          nxt_off = (u32)__builtin_amdgcn_ds_bpermute((int)(cur4 + 4u), (int)pl.off);
-        }
-        c4 = cur4;
-      }
-      cell[u] = (int)(c4 >> 2);
-      const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
-      const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
-      const double2 *pa = WIDE ? reinterpret_cast<const double2 *>(T.head + e)
-                               : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.head) + (e << 4));
-      const double2 *pb = WIDE ? reinterpret_cast<const double2 *>(T.tail + e)
-                               : reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.tail) + (e << 4));
-      v01[u] = *pa;           // s0, s1
-      v2x[u] = *pb;           // s2, {frame, g}
-    }
-#ifdef SGTD_EXP_PHASE
-    PH_ADD(1, ph_t);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    PH_ADD(2, ph_t);
-#endif
-#pragma unroll
-    for (int u = 0; u < NW; u++) {
-      const double dx = q0 - v01[u].x, dy = q1 - v01[u].y, dz = q2 - v2x[u].x;
-      const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
-      const u64 fg = (u64)__double_as_longlong(v2x[u].y);  // frame | g << 32 (little endian)
-      const u32 fr = (u32)fg;
-      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-      bool hit;
-      double dis = 0.0;
-      if (DIAG) { dis = sqrt(d2); hit = valid[u] && (qframe != fr) && (dis < thr); }  // :374-378 verbatim
-      else hit = valid[u] && (qframe != fr) && (d2 < thr2);
-      if (hit) {                                                      // :410
-        if (VOTE == SGTD_VOTE_LDS) atomicAdd(&s_hist[fr - T.frame_lo], 1u);
-        if (VOTE == SGTD_VOTE_GLOBAL) atomicAdd(&votes[fr - T.frame_lo], 1u);
-      }
-      const u64 m = __ballot(hit);
-      if (hit && fits) {
-        const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
-        u32 *df = WIDE ? B.rec_frame + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_frame) + (o << 2));
-        u32 *dg = WIDE ? B.rec_g + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_g) + (o << 2));
-        *df = fr;
-        *dg = (u32)(fg >> 32);
-        if (DIAG) { B.rec_cell[o] = (unsigned char)cell[u]; B.rec_dis[o] = dis; }
-      }
-      matches += __popcll(m);
-    }
-    PH_ADD(3, ph_t);
-  };
-  // full groups of SGTD_PROBE_UNROLL words, then one group of what is left (28 % of the slots
-  // of a uniform group size would stay empty at F = 1 k, where a list is about four words)
-  auto run = [&](auto bsearch_tag) {
-    u32 w0 = 0;
-    for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL) {
-      group(bsearch_tag, std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
-      if (w0 == 0) pending.touch();
-    }
-    switch (n_words - w0) {   // wave-uniform
-      case 1: group(bsearch_tag, std::integral_constant<int, 1>{}, w0); break;
-      case 2: group(bsearch_tag, std::integral_constant<int, 2>{}, w0); break;
-      case 3: group(bsearch_tag, std::integral_constant<int, 3>{}, w0); break;
-      default: break;
-    }
-    if (w0 == 0 && n_words) pending.touch();
-  };
-  static_assert(SGTD_PROBE_UNROLL == 4, "the remainder switch covers group sizes 1..3");
-  if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
-  else run(std::false_type{});
-  if (n_words == 0) pending.touch();   // every path through the sweep leaves them complete
-  if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches);
-  if (result) {
-    result->ptr = slab.next; result->visit = total; result->match = fits ? matches : 0;
-  } else if (lane == 0) {
-    B.list_ptr[d] = slab.next;
-    B.n_visit[d] = total;
-    B.n_match[d] = fits ? matches : 0;
-  }
-  if (fits) slab.next += matches;
-  __builtin_amdgcn_wave_barrier();
-  PH_ADD(4, ph_t);
-}
-
-// sweep, query-major: work item = (query, chunk of 128 of its descriptors),
-// dequeued by persistent workgroups; the votes of the item are privatised in
-// LDS when the histogram fits and flushed with one global atomic per frame
-template <bool LDS_VOTES, bool DIAG>
-__global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_kernel(TableView T, QueryView Q,
-                                                                   ProbeBuffers B, const CellRow *rows,
-                                                                   double rough, int chunks_per_query) {
-  constexpr int NW = SGTD_PROBE_THREADS / SGTD_WAVE;
-  extern __shared__ u32 s_hist[];  // [frame_span] when LDS_VOTES
-  __shared__ u32 s_item;
-  const int tid = threadIdx.x, wid = tid >> 6;
-  const u32 n_items = (u32)Q.n_queries * (u32)chunks_per_query;
-  WaveSlab slab{0, 0};
-
-  while (true) {
-    if (tid == 0) s_item = atomicAdd(B.item_cursor, 1u);
-    __syncthreads();
-    const u32 item = s_item;
-    if (item >= n_items) break;
-    const int q = (int)(item / (u32)chunks_per_query);
-    const u32 d_first = (item - (u32)q * (u32)chunks_per_query) * SGTD_PROBE_CHUNK;
-    const u32 cnt = Q.count[q];
-    if (d_first >= cnt) { __syncthreads(); continue; }
-    const u32 d_last = min(d_first + SGTD_PROBE_CHUNK, cnt);
-    if (LDS_VOTES) {
-      for (u32 f = tid; f < T.frame_span; f += SGTD_PROBE_THREADS) s_hist[f] = 0;
-    }
-    __syncthreads();
-    u32 *votes = B.votes + (size_t)q * T.frame_span;
-    // wave w owns the contiguous block [d_first + 32 w, +32): its match lists
-    // land back to back in the wave's slab
-    const u32 w_first = d_first + (u32)wid * (SGTD_PROBE_CHUNK / NW);
-    const u32 w_last = min(w_first + (u32)(SGTD_PROBE_CHUNK / NW), d_last);
-    if (w_first < w_last) {
-      const long long base = (long long)q * Q.stride;
-      DescFetch nxt = fetch_desc(Q, rows, base + w_first, base + w_first);
-      for (u32 i = w_first; i < w_last; i++) {
-        const DescFetch cur = nxt;
-        if (i + 1 < w_last) nxt = fetch_desc(Q, rows, base + i + 1, base + i + 1);   // in flight during the sweep of i
-        sweep_descriptor<LDS_VOTES ? SGTD_VOTE_LDS : SGTD_VOTE_GLOBAL, DIAG>(
-            T, B, rough, base + i, cur, plan_from_cell_row(cur), slab, s_hist, votes);
-      }
-    }
-    __syncthreads();
-    if (LDS_VOTES) {
-      for (u32 f = tid; f < T.frame_span; f += SGTD_PROBE_THREADS) {
-        const u32 v = s_hist[f];
-        if (v) atomicAdd(&votes[f], v);
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
-// sweep, key-major: the batch's descriptors are visited in the order of a
-// locality key (label code, cell x, cell y) and each XCD walks one contiguous
-// eighth of that order, so the buckets a wave needs were just used by its
-// neighbours on the same XCD and come from that XCD's L2 instead of HBM.
-// Results are independent of the order: every descriptor writes its own list.
+// sweep: the batch's descriptors are visited in the order of a locality key
+// (label code, cell x, y, z) and each XCD walks one contiguous eighth of that
+// order, so the buckets a wave needs were just used by its neighbours on the
+// same XCD and come from that XCD's L2 instead of HBM.  Results are independent
+// of the order: every descriptor writes its own list.
 // ---------------------------------------------------------------------------
 // Home key of a descriptor slot = (label code, (int)side0, (int)side1, (int)side2) packed
 // with `cbits` bits per cell coordinate; invalid slots sort last.  The 27 probed cells
 // (int)(side+inc) are a function of the home cell alone (per axis n = (int)s gives
 // {n ? n-1 : 0, n, n+1}), so all descriptors of the batch with equal home key share ONE set
-// of bucket lookups (a GroupRow); only the gate is per descriptor.
+// of bucket lookups (a GroupRow); gate and slice ranges are per descriptor.
 // exclusive prefix of the per-query descriptor counts and their total (one workgroup)
 __global__ __launch_bounds__(256) void query_prefix_kernel(const u32 *count, u32 *q_prefix, int n_queries,
                                                            u32 *n_valid) {
@@ -517,48 +228,253 @@ __global__ void sorted_desc_kernel(QueryView Q, const u32 *order, const u32 *gid
 }
 
 // One GroupRow per home cell of the batch: the 27 ungated bucket lookups (STDesc.cpp:358-371
-// minus the gate): words 0..31 = start[c], words 32..63 = len[c].  32 lanes per group, grid-stride.
+// minus the gate), each answered with the bucket's directory row {start, cum[5]} (all zero if
+// the table has no such bucket): 27 x 32 B at rows + g * SGTD_GROUP_ROW_BYTES.
+// 32 lanes per group, grid-stride.
 __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryView Q, const u32 *order,
                                                             const u32 *group_first, const u32 *n_groups_p,
-                                                            const u32 *n_valid_p, CellRow *rows) {
+                                                            const u32 *n_valid_p, unsigned char *rows) {
   const int c = (int)(threadIdx.x & 31);
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 5;
   const long long n_groups = (*n_valid_p) ? (long long)*n_groups_p : 0;
   for (long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; g < n_groups; g += stride) {
+    if (c >= SGTD_NCELL) continue;
     const long long d = (long long)order[group_first[g]];
-    u32 start = 0, len = 0;
-    if (c < SGTD_NCELL) {
-      const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
-      const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
-      const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
-      const int x = (int)(q0 + (double)ix), y = (int)(q1 + (double)iy), z = (int)(q2 + (double)iz);
-      if (x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
-        const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
-        u32 h = hash_key(key) & T.hash_mask;
-        while (true) {
-          const HashSlot s = T.hash[h];
-          if (s.key == key) { start = s.start; len = s.len; break; }
-          if (s.key == SGTD_EMPTY_KEY) break;
-          h = (h + 1) & T.hash_mask;
+    uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+    const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
+    const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
+    const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
+    const int x = (int)(q0 + (double)ix), y = (int)(q1 + (double)iy), z = (int)(q2 + (double)iz);
+    if (x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
+      const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
+      u32 h = hash_key(key) & T.hash_mask;
+      while (true) {
+        const HashSlot s = T.hash[h];
+        if (s.key == key) {
+          const uint4 *row = reinterpret_cast<const uint4 *>(T.dir + s.bucket);
+          lo = row[0]; hi = row[1];
+          break;
         }
+        if (s.key == SGTD_EMPTY_KEY) break;
+        h = (h + 1) & T.hash_mask;
       }
     }
-    CellRow &r = rows[g];
-    r.off[c] = start;     // GroupRow layout: words 0..31 = start, words 32..63 = len
-    r.start[c] = len;
+    uint4 *out = reinterpret_cast<uint4 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES) + 2 * c;
+    out[0] = lo;     // start, cum[0..2]
+    out[1] = hi;     // cum[3], cum[4], 0, 0
   }
 }
 
-// GroupRow + the descriptor's gate mask (:366-369): gated lengths, their exclusive scan
+// GroupRow + the descriptor's gate mask (:366-369) + its threshold: per range the gated, slice-
+// pruned length and start, and the exclusive scan of the lengths.
+// Lane r = 2 c + k: even lanes hold {start, cum0, cum1, cum2} of cell c, odd lanes
+// {cum3, cum4, 0, 0}.  Regular range (k = 0): the slices that hold entries with
+// |side2 - q2| <= thr' — an entry outside cannot match: its squared distance, as the reference
+// computes it, is at least fl(dz * dz) >= thr2.  Overflow range (k = 1): all of that slice.
 __device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
-  const int c = lane_id();
-  u32 len = (u32)__shfl((int)f.row, (c + 32) & 63);
-  len = (c < SGTD_NCELL && ((f.gate >> c) & 1u)) ? len : 0u;
+  const int lane = lane_id();
+  const int c = lane >> 1;
+  const bool odd = lane & 1;
+  // neighbour lane of the pair: even lanes receive cum3 / cum4, odd lanes start / cum0
+  const u32 nx = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  const u32 ny = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.y, 0xB1, 0xf, 0xf, false);
+  const bool live = lane < SGTD_NRANGE && ((f.gate >> c) & 1u);
+  // slices of cell z = (int)(q2 + iz) reached by [q2 - t, q2 + t]; slice s holds the entries with
+  // (side2 + 0.5 - z) * 4 in [s, s + 1).  t carries a relative margin over the exact threshold
+  // and the bounds another 1e-6 slice: visiting a slice too many is harmless.
+  const double t = sqrt(f.thr2) * (1.0 + 1e-9) + 1e-12;
+  const int iz = c % 3 - 1;
+  const double zc = (double)(int)(f.q2 + (double)iz);
+  const double a = ((f.q2 - t) + 0.5 - zc) * (double)SGTD_ZSLICES - 1e-6;
+  const double b = ((f.q2 + t) + 0.5 - zc) * (double)SGTD_ZSLICES + 1e-6;
+  const int s_lo = a <= 0.0 ? 0 : (a >= (double)SGTD_ZSLICES ? SGTD_ZSLICES : (int)a);          // floor, clamped to [0, 4]
+  const int s_hi = b < 0.0 ? -1 : (b >= (double)SGTD_ZSLICES ? SGTD_ZSLICES - 1 : (int)b);      // floor, clamped to [-1, 3]
+  // cum before slice s (s = 0..4): 0, cum0, cum1, cum2, cum3; even lanes only
+  const u32 cum3 = nx;
+  const u32 before_lo = s_lo == 0 ? 0u : (s_lo == 1 ? f.row.y : (s_lo == 2 ? f.row.z : (s_lo == 3 ? f.row.w : cum3)));
+  const u32 upto_hi = s_hi < 0 ? 0u : (s_hi == 0 ? f.row.y : (s_hi == 1 ? f.row.z : (s_hi == 2 ? f.row.w : cum3)));
+  u32 start, len;
+  if (!odd) {
+    start = f.row.x + before_lo;
+    len = (s_hi >= s_lo) ? upto_hi - before_lo : 0u;
+  } else {
+    start = nx + f.row.x;            // bucket start + cum3
+    len = f.row.y - f.row.x;         // cum4 - cum3
+  }
+  len = live ? len : 0u;
   const u32 inc = wave_incl_scan(len);
   DescPlan pl;
-  pl.off = inc - len;          // lanes >= 27 add nothing: lane 27 holds the total
-  pl.dl = f.row - pl.off;      // lanes < 27: start[c] - off[c]
+  pl.off = inc - len;          // lanes >= 54 add nothing: they hold the total
+  pl.dl = start - pl.off;      // start[r] - off[r]
+  // the reference's loop visits every entry of every gated cell: cum4 of the even lanes
+  pl.ref_visits = wave_sum((live && !odd) ? ny : 0u);
   return pl;
+}
+
+// STDesc.cpp:372-399 for ONE query descriptor d by one wavefront: streams the
+// descriptor's visit list, tests, compacts the matches in visit order.
+// WIDE = false: the probe layout and the record buffer are each below 4 GB, so entry and
+// record addresses are a uniform base + a 32-bit byte offset (no quarter-rate 64-bit VALU
+// address arithmetic per entry); the host picks the variant from the buffer sizes
+template <bool DIAG, bool WIDE = true>
+__device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
+                                                 const DescFetch &f, const DescPlan &pl,
+                                                 WaveSlab &slab, DescResult &result, PendingLoads pending) {
+  const int lane = lane_id();
+  const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
+  const float q0f = (float)q0, q1f = (float)q1, q2f = (float)q2;
+  const float lo2 = f.lo2, hi2 = f.hi2;
+  const u32 qframe = f.qframe;
+  const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;   // :356-357
+  const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_WAVE - 1);
+  const u32 dl = pl.dl;
+  u64 ph_t = PH_T(); (void)ph_t;
+  // records of one descriptor are contiguous: make sure the slab can take
+  // the worst case (every visited entry matches)
+  if (total && (u64)slab.next + total > (u64)slab.end) {
+    // a slab must have room for the worst case of a descriptor (every visit matches) when
+    // the descriptor starts, but only the matches stay: slabs of 8 worst cases keep the space
+    // abandoned at a slab's end to about an eighth however long the visit lists are
+    const u32 take = total > (1u << 28) ? total : max(SGTD_REC_SLAB, 8u * total);
+    u64 got = 0;
+    if (lane == 0) got = atomicAdd(B.rec_cursor, (unsigned long long)take);
+    got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
+    if (got + take <= (u64)B.rec_cap) { slab.next = (u32)got; slab.end = (u32)got + take; }
+    else { slab.next = 0; slab.end = 0; }      // the buffer is exhausted: nothing of this wave fits any more
+  }
+  const bool fits = (u64)slab.next + total <= (u64)slab.end;
+  if (!fits && lane == 0) B.overflow[0] = 1;
+  __builtin_amdgcn_wave_barrier();
+  PH_ADD(0, ph_t);
+
+  u32 matches = 0;
+  const u32 n_words = (total + 63u) >> 6;
+  slab.swept += total;
+#ifdef SGTD_EXP_PHASE
+  if (lane == 0 && n_words) {
+    atomicAdd(&g_words[0], (unsigned long long)n_words);
+    atomicAdd(&g_words[1], (unsigned long long)((n_words + SGTD_PROBE_UNROLL - 1) / SGTD_PROBE_UNROLL));
+  }
+#endif
+  // position -> range, the last r with off[r] <= pos (empty ranges share their successor's
+  // offset and are stepped over), read from the plan registers by ds_bpermute — no memory.
+  // Two forms, chosen per descriptor (wave-uniform):
+  //  * short lists (many range boundaries per 64-entry word): branch-free binary search over
+  //    the 64 offsets (off[54..63] = total), six permutes per word;
+  //  * long lists (about one boundary per word): a per-lane cursor that only moves forward,
+  //    one permute per boundary crossed.
+  // All lanes execute the permutes (sources must be active).
+  u32 cur4 = 0;   // cursor form: 4 * range = ds_bpermute byte address
+  u32 nxt_off = (u32)__builtin_amdgcn_ds_bpermute(4, (int)pl.off);
+  // one load group: NW words located, their loads issued back to back, then tested.  NW is a
+  // compile-time count: each group size is straight-line code (branches around loads would
+  // make the compiler wait for earlier loads before every later one).
+  auto group = [&](auto bsearch_tag, auto nw_tag, u32 w0) {
+    constexpr bool BSEARCH = decltype(bsearch_tag)::value;
+    constexpr int NW = decltype(nw_tag)::value;
+    float4 v[NW];
+    u32 gg[NW];
+    int rng[NW];
+    bool valid[NW];
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+      const u32 pos = ((w0 + u) << 6) + lane;
+      valid[u] = pos < total;
+      u32 c4;
+      if constexpr (BSEARCH) {
+        c4 = 0;
+#pragma unroll
+        for (int s = 128; s >= 4; s >>= 1) {
+          const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)s), (int)pl.off);
+          c4 += (t <= pos) ? (u32)s : 0u;
+        }
+      } else {
+        while (__ballot(valid[u] && pos >= nxt_off)) {   // off[54..63] = total stops it
+          cur4 += (valid[u] && pos >= nxt_off) ? 4u : 0u;
+          nxt_off = (u32)__builtin_amdgcn_ds_bpermute((int)(cur4 + 4u), (int)pl.off);
+        }
+        c4 = cur4;
+      }
+      rng[u] = (int)(c4 >> 2);
+      const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
+      const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
+      const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + e)
+                              : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(T.ent) + (e << 4));
+      const u32 *pg = WIDE ? T.perm + e : reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(T.perm) + (e << 2));
+      v[u] = *pa;             // s0, s1, s2 (f32), frame
+      gg[u] = *pg;            // insertion index
+    }
+#ifdef SGTD_EXP_PHASE
+    PH_ADD(1, ph_t);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    PH_ADD(2, ph_t);
+#endif
+    bool hit[NW], amb[NW];
+    double dis[NW];
+    bool any_amb = false;
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+      const float dx = q0f - v[u].x, dy = q1f - v[u].y, dz = q2f - v[u].z;
+      const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
+      const bool cand = valid[u] && (qframe != __float_as_uint(v[u].w));
+      hit[u] = cand && (d2 < lo2);                          // certainly dis < thr
+      amb[u] = DIAG ? cand : (cand && !(d2 < lo2) && !(d2 > hi2));   // NaN lands here too
+      if (DIAG) hit[u] = false;
+      dis[u] = 0.0;
+      any_amb |= amb[u];
+    }
+    if (__ballot(any_amb)) {   // rare (always in the diagnostic build): decide on the exact sides, :374-378
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+        if (amb[u]) {
+          const double *sp = T.cold_side + (size_t)gg[u] * 3;
+          const double dx = q0 - sp[0], dy = q1 - sp[1], dz = q2 - sp[2];
+          const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
+          if (DIAG) { dis[u] = sqrt(d2); hit[u] = dis[u] < thr; }   // the reference's form verbatim
+          else hit[u] = d2 < thr2;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+      const u64 m = __ballot(hit[u]);
+      if (hit[u] && fits) {
+        const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
+        u32 *df = WIDE ? B.rec_frame + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_frame) + (o << 2));
+        u32 *dg = WIDE ? B.rec_g + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_g) + (o << 2));
+        *df = __float_as_uint(v[u].w);
+        *dg = gg[u];
+        if (DIAG) { B.rec_cell[o] = (unsigned char)(rng[u] >> 1); B.rec_dis[o] = dis[u]; }
+      }
+      matches += __popcll(m);
+    }
+    PH_ADD(3, ph_t);
+  };
+  // full groups of SGTD_PROBE_UNROLL words, then one group of what is left
+  auto run = [&](auto bsearch_tag) {
+    u32 w0 = 0;
+    for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL) {
+      group(bsearch_tag, std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
+      if (w0 == 0) pending.touch();
+    }
+    switch (n_words - w0) {   // wave-uniform
+      case 1: group(bsearch_tag, std::integral_constant<int, 1>{}, w0); break;
+      case 2: group(bsearch_tag, std::integral_constant<int, 2>{}, w0); break;
+      case 3: group(bsearch_tag, std::integral_constant<int, 3>{}, w0); break;
+      default: break;
+    }
+    if (w0 == 0 && n_words) pending.touch();
+  };
+  static_assert(SGTD_PROBE_UNROLL == 4, "the remainder switch covers group sizes 1..3");
+  if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
+  else run(std::false_type{});
+  if (n_words == 0) pending.touch();   // every path through the sweep leaves them complete
+  if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches);
+  result.ptr = slab.next; result.visit = pl.ref_visits; result.match = fits ? matches : 0;
+  if (fits) slab.next += matches;
+  __builtin_amdgcn_wave_barrier();
+  PH_ADD(4, ph_t);
 }
 
 #ifndef SGTD_SWEEP_OCC
@@ -567,7 +483,7 @@ __device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
 #define SGTD_TICKET_MAX 16   // descriptors per ticket: 4 lanes each in one 64-lane load
 #define SGTD_NO_CHUNK 0xFFFFFFFFu
 
-// The per-XCD ticket queues of the key-major sweep: chunk ids [c_lo, c_hi) of queue x belong
+// The per-XCD ticket queues of the sweep: chunk ids [c_lo, c_hi) of queue x belong
 // to XCD x; a wave drains its own XCD's queue first, then helps the others (their ranges
 // lose locality but keep the chip busy).  Heads are 4 KB apart (own L2 channel each).
 struct TicketQueue {
@@ -600,7 +516,7 @@ struct TicketQueue {
 
 template <bool DIAG, bool WIDE>
 __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorted_kernel(
-    TableView T, ProbeBuffers B, const CellRow *rows, const QueryRec *sorted, double rough,
+    TableView T, ProbeBuffers B, const unsigned char *rows, const QueryRec *sorted, double rough,
     const u32 *n_valid_p, u32 *xcd_heads /*[8 * 1024]*/, u32 chunk /* 1..SGTD_TICKET_MAX */) {
   const int lane = lane_id();
   const u32 n_valid = *n_valid_p;
@@ -617,7 +533,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   tq.xcc = xcc & 7u;
   tq.select(0);
-  WaveSlab slab{0, 0};
+  WaveSlab slab{0, 0, 0};
 #ifdef SGTD_EXP_PHASE
   for (int i = 0; i < 8; i++) slab.ph[i] = 0;
   const u64 ph_start = PH_T();
@@ -634,7 +550,12 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       r = reinterpret_cast<const uint4 *>(sorted + p)[lane & 3];
     return r;
   };
-  auto load_row = [&](u32 g) { return reinterpret_cast<const u32 *>(rows + g)[lane]; };
+  // lane l < 54 loads 16-B quarter l of the group's 27 directory rows
+  auto load_row = [&](u32 g) {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (lane < SGTD_NRANGE) r = reinterpret_cast<const uint4 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES)[lane];
+    return r;
+  };
 
   u32 cur_c = tq.resolve(tq.issue());
   uint4 rec = load_chunk(cur_c);
@@ -650,10 +571,10 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
     if (tq.t == 0) tr_n_own += n; else { if (!tr_own) tr_own = wall_clock64(); tr_n_st += n; }
 #endif
     u32 g_cur = (u32)__builtin_amdgcn_readlane((int)rec.z, 2);
-    u32 row_next = load_row(g_cur);
+    uint4 row_next = load_row(g_cur);
     // waited for here, once per ticket: the loop below then carries no pending load into its
     // header on either edge (the next rows are touched inside the sweep)
-    asm volatile("" : "+v"(row_next));
+    asm volatile("" : "+v"(row_next.x), "+v"(row_next.y), "+v"(row_next.z), "+v"(row_next.w));
     u32 r_ptr = 0, r_visit = 0, r_match = 0;   // lane i: results of descriptor i of the chunk
     for (u32 i = 0; i < n; i++) {
       DescFetch f;
@@ -670,12 +591,13 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       f.thr2 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0 + 1), __builtin_amdgcn_readlane((int)rec.z, l0 + 1));
       f.qframe = (u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 2);
       f.gate = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
-      const long long d = (long long)(u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
+      f.lo2 = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 3));
+      f.hi2 = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 3));
       DescResult res;
       PendingLoads pend;
       pend.row = &row_next;
       pend.rec = &rec_next;
-      sweep_descriptor<SGTD_VOTE_NONE, DIAG, WIDE>(T, B, rough, d, f, plan_from_group_row(f), slab, nullptr, nullptr, &res, pend);
+      sweep_descriptor<DIAG, WIDE>(T, B, rough, f, plan_from_group_row(f), slab, res, pend);
       if ((u32)lane == i) { r_ptr = res.ptr; r_visit = res.visit; r_match = res.match; }
     }
     {   // the chunk's results: lane i < n stores for its descriptor (slot d in quarter 2 of record i)
@@ -689,6 +611,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
     cur_c = nxt_c;
     rec = rec_next;
   }
+  if (lane == 0 && slab.swept) atomicAdd(B.swept, (unsigned long long)slab.swept);
 #ifdef SGTD_EXP_PHASE
   if (lane == 0) {
     for (int i = 0; i < 6; i++) atomicAdd(&g_phase[i], slab.ph[i]);

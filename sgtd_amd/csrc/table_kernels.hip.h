@@ -9,9 +9,12 @@
 //   sort       stable LSD radix sort of (key, g) by key, 8-bit digits, passes
 //              whose digit is constant are skipped; stable => inside a bucket
 //              entries stay in insertion order == the reference's index j
-//   gather     probe layout in sorted order p, two 16-B arrays: head {side0, side1 f64},
-//              tail {side2 f64, frame u32, g u32} = 32 B per entry (28 algorithmic + g)
-//   csr+hash   bucket boundaries -> open-addressing table key -> (start,len)
+//   slices     every bucket is partitioned (stably) into SGTD_ZSLICES slices of the
+//              third side's cell interval + an overflow slice; entries of one frame
+//              that could match the same query descriptor never straddle slices
+//              (slice_assign_kernel), so per-frame match order stays the reference's
+//   gather     probe layout in that order p: HotEntry {f32 sides, frame} 16 B + perm[p] = g
+//   csr+hash   bucket directory (start + slice counts) and open-addressing table key -> bucket
 #pragma once
 #include "common.hip.h"
 
@@ -181,30 +184,131 @@ __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
 // gather hot arrays + bucket heads + hash insert
 // ---------------------------------------------------------------------------
 __global__ void gather_hot_kernel(const u32 *perm, const double *side, const u32 *frame,
-                                  HotHead *head, HotTail *tail, long long n) {
+                                  HotEntry *ent, long long n) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const u32 g = perm[p];
-  HotHead h;
-  HotTail t;
-  h.s0 = side[(size_t)g * 3 + 0];
-  h.s1 = side[(size_t)g * 3 + 1];
-  t.s2 = side[(size_t)g * 3 + 2];
-  t.frame = frame[g];
-  t.g = g;
-  head[p] = h;
-  tail[p] = t;
+  HotEntry h;
+  h.s0 = (float)side[(size_t)g * 3 + 0];   // round to nearest: the bound in f32_bounds assumes it
+  h.s1 = (float)side[(size_t)g * 3 + 1];
+  h.s2 = (float)side[(size_t)g * 3 + 2];
+  h.frame = frame[g];
+  ent[p] = h;
+}
+
+// frame ids non-decreasing in insertion order?  (true for maps built frame by frame; then the
+// stable sort by key alone leaves every bucket ordered by (frame, g))
+__global__ void frame_monotone_kernel(const u32 *frame, long long n, int *flag) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g + 1 < n && frame[g + 1] < frame[g]) *flag = 1;
+}
+
+// z-slice of an entry inside its cell: the cell is (int)(s2 + 0.5) (STDesc.cpp:157), the
+// slice the quarter of [cell, cell + 1) that s2 + 0.5 falls into (exact: a power-of-two scale)
+__device__ __forceinline__ u32 z_slice(double s2) {
+  const double y = s2 + 0.5;
+  const int cell = (int)y;
+  const int sl = (int)(y * (double)SGTD_ZSLICES) - cell * SGTD_ZSLICES;
+  return (u32)min(max(sl, 0), SGTD_ZSLICES - 1);
+}
+
+// Slice assignment.  Input: entries sorted by (key, frame, g) (order[p] = g, keys[p]).  One
+// thread per position; the head of every (key, frame) run decides for the run: if two of its
+// members lie in different z-slices AND could both match one query descriptor, the whole run
+// goes to the overflow slice, otherwise every member keeps its z-slice.  Two entries a, b can
+// both match a query q only if ||a - b|| < 2 thr(q) and thr(q) = rough ||q|| <=
+// rough (||a|| + thr(q)), i.e. thr(q) <= rough ||a|| / (1 - rough): the test below uses the
+// larger norm and a relative margin.  Runs longer than SGTD_RUN_MAX members go to the
+// overflow slice untested (always correct: that slice is in insertion order and always visited).
+#define SGTD_RUN_MAX 48
+__global__ void slice_assign_kernel(const u64 *keys, const u32 *order, const double *side, const u32 *frame,
+                                    long long n, double rough, unsigned char *slice_of /*[g]*/) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const u32 g0 = order[p];
+  const u64 key = keys[p];
+  const u32 fr = frame[g0];
+  if (p > 0 && keys[p - 1] == key && frame[order[p - 1]] == fr) return;   // not a run head
+  long long e = p + 1;
+  while (e < n && e - p <= SGTD_RUN_MAX && keys[e] == key && frame[order[e]] == fr) e++;
+  const int len = (int)(e - p);
+  if (len == 1) { slice_of[g0] = (unsigned char)z_slice(side[(size_t)g0 * 3 + 2]); return; }
+  bool overflow = len > SGTD_RUN_MAX;
+  if (overflow) {   // mark the rest of the long run as well
+    while (e < n && keys[e] == key && frame[order[e]] == fr) e++;
+  } else {
+    const double f = (rough < 1.0) ? 2.0 * rough / (1.0 - rough) * (1.0 + 1e-9) : __builtin_inf();
+    for (int i = 0; i < len && !overflow; i++) {
+      const u32 ga = order[p + i];
+      const double a0 = side[(size_t)ga * 3], a1 = side[(size_t)ga * 3 + 1], a2 = side[(size_t)ga * 3 + 2];
+      const u32 sa = z_slice(a2);
+      const double na = norm3(a0, a1, a2);
+      for (int j = i + 1; j < len; j++) {
+        const u32 gb = order[p + j];
+        const double b0 = side[(size_t)gb * 3], b1 = side[(size_t)gb * 3 + 1], b2 = side[(size_t)gb * 3 + 2];
+        if (z_slice(b2) == sa) continue;
+        const double nb = norm3(b0, b1, b2);
+        const double lim = f * fmax(na, nb) + 1e-9;
+        if (!(norm3(a0 - b0, a1 - b1, a2 - b2) > lim)) { overflow = true; break; }   // NaN counts as close
+      }
+    }
+  }
+  for (long long q = p; q < e; q++) {
+    const u32 g = order[q];
+    slice_of[g] = overflow ? (unsigned char)SGTD_ZSLICES : (unsigned char)z_slice(side[(size_t)g * 3 + 2]);
+  }
+}
+
+// Stable partition of every bucket by slice: one wavefront per bucket (grid-stride).  in[] holds
+// the bucket's entries in insertion order (sorted by key, ties by g); out[] receives slice 0's
+// entries, then slice 1's, ..., then the overflow slice's, each still in insertion order; the
+// directory row of the bucket gets the cumulative slice counts.
+__global__ __launch_bounds__(256) void slice_partition_kernel(const u32 *bucket_start, u32 n_buckets, u32 n_entries,
+                                                              const u32 *in, const unsigned char *slice_of, u32 *out,
+                                                              BucketDir *dir) {
+  const int lane = lane_id();
+  const u32 stride = (gridDim.x * blockDim.x) >> 6;
+  for (u32 b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < n_buckets; b += stride) {
+    const u32 start = bucket_start[b];
+    const u32 end = (b + 1 < n_buckets) ? bucket_start[b + 1] : n_entries;
+    u32 cnt[SGTD_NSLICE];
+#pragma unroll
+    for (int s = 0; s < SGTD_NSLICE; s++) cnt[s] = 0;
+    for (u32 i = start + lane; i < end; i += SGTD_WAVE) {
+      const u32 sl = slice_of[in[i]];
+#pragma unroll
+      for (int s = 0; s < SGTD_NSLICE; s++) cnt[s] += (sl == (u32)s) ? 1u : 0u;
+    }
+    u32 base[SGTD_NSLICE], acc = 0;
+    BucketDir row;
+    row.start = start; row.pad[0] = 0; row.pad[1] = 0;
+#pragma unroll
+    for (int s = 0; s < SGTD_NSLICE; s++) {
+      base[s] = start + acc;
+      acc += wave_sum(cnt[s]);
+      row.cum[s] = acc;
+    }
+    if (lane == 0) dir[b] = row;
+    for (u32 i0 = start; i0 < end; i0 += SGTD_WAVE) {
+      const u32 i = i0 + lane;
+      const bool valid = i < end;
+      const u32 g = valid ? in[i] : 0u;
+      const u32 sl = valid ? (u32)slice_of[g] : 0xFFu;
+#pragma unroll
+      for (int s = 0; s < SGTD_NSLICE; s++) {
+        const u64 m = __ballot(sl == (u32)s);
+        if (sl == (u32)s) out[base[s] + (u32)__popcll(m & lanemask_lt())] = g;
+        base[s] += (u32)__popcll(m);
+      }
+    }
+  }
 }
 
 // squared thresholds for caller-provided query descriptors
 __global__ void thr2_kernel(const double *side, const u32 *frame, QueryRec *qrec, long long n, double rough) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double s0 = side[i * 3], s1 = side[i * 3 + 1], s2 = side[i * 3 + 2];
-  double2 *qr = reinterpret_cast<double2 *>(qrec + i);
-  qr[0] = make_double2(s0, s1);
-  qr[1] = make_double2(s2, sq_threshold(norm3(s0, s1, s2) * rough));
-  reinterpret_cast<uint4 *>(qr)[2] = make_uint4(frame[i], gate_mask(s0, s1, s2), 0u, 0u);
+  write_query_rec(qrec + i, side[i * 3], side[i * 3 + 1], side[i * 3 + 2], rough, frame[i]);
 }
 
 __global__ void head_flags_kernel(const u64 *keys, u32 *flags, long long n) {
@@ -235,12 +339,27 @@ __global__ void hash_insert_kernel(const u64 *bucket_key, const u32 *bucket_star
   while (true) {
     u64 prev = atomicCAS(reinterpret_cast<u64 *>(&table[h].key), SGTD_EMPTY_KEY, key);
     if (prev == SGTD_EMPTY_KEY) {
-      table[h].start = start;
+      table[h].bucket = b;
       table[h].len = end - start;
       return;
     }
     h = (h + 1) & mask;
   }
+}
+
+// sum over buckets of len^2 (a query descriptor distributed like the table's entries visits a
+// bucket with probability len / E: sizes the first batch's work buffers, sgtd_accel.hip)
+__global__ void bucket_sq_kernel(const u32 *bucket_start, u32 n_buckets, u32 n_entries, unsigned long long *sum) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = 0;
+  if (b < n_buckets) {
+    const unsigned long long len = ((b + 1 < n_buckets) ? bucket_start[b + 1] : n_entries) - bucket_start[b];
+    v = len * len;
+  }
+  // wave reduction, one atomic per wave
+#pragma unroll
+  for (int d = SGTD_WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  if (lane_id() == 0 && v) atomicAdd(sum, v);
 }
 
 // scatter of a strided build result into the table's cold arrays (append):
