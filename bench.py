@@ -345,7 +345,7 @@ def main():
                 "algorithmic_over_hbm_peak": algo_gbs / HBM_PEAK_GBS,
                 "note": "the key-major sweep re-reads buckets from L2, so algorithmic bytes/s can exceed the HBM peak; "
                         "frac is measured against the level that can bound the kernel (DESIGN.md §3)",
-                "P_visited": P, "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
+                "P_visited": P, "P_swept_after_slice_pruning": st.get("last_P_swept"), "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
                 "kernel_ms": kern_ms}
 
     res = mgr.results()

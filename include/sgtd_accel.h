@@ -80,11 +80,14 @@ typedef struct sgtd_stats {
   int64_t last_P;          /* table entries visited (STDesc.cpp:372 iterations)*/
   int64_t last_M;          /* rough matches (STDesc.cpp:378)                   */
   int64_t last_cand_pairs; /* pairs in all candidate match lists               */
-  int64_t hbm_bytes_table; /* bytes of the hot (probed) table arrays           */
+  int64_t hbm_bytes_table; /* bytes of the hot (probed) table arrays (20 B/entry) */
   /* per-kernel device time of the last batch, ms (only when timing is enabled
    * with sgtd_set_timing; measured with hipEvents on the handle's stream)     */
   float ms_build, ms_sort, ms_probe, ms_votes, ms_topk, ms_count, ms_scan, ms_write, ms_total;
   int32_t overflowed;      /* last batch outgrew a work buffer and was re-run  */
+  int32_t reserved;
+  int64_t last_P_swept;    /* table entries the sweep really loaded: last_P minus the
+                              z-slices of the visited buckets that no match can lie in */
 } sgtd_stats;
 
 typedef struct sgtd_engine *sgtd_handle;

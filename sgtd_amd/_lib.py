@@ -65,7 +65,8 @@ class Stats(C.Structure):
         ("ms_build", C.c_float), ("ms_sort", C.c_float), ("ms_probe", C.c_float),
         ("ms_votes", C.c_float), ("ms_topk", C.c_float),
         ("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_write", C.c_float),
-        ("ms_total", C.c_float), ("overflowed", C.c_int32),
+        ("ms_total", C.c_float), ("overflowed", C.c_int32), ("reserved", C.c_int32),
+        ("last_P_swept", C.c_int64),
     ]
 
 

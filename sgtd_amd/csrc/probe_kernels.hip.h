@@ -76,7 +76,13 @@ struct ProbeBuffers {
   u32 *n_match;         // [n_slots] matches of descriptor
   u32 *votes;           // [n_queries * frame_span]
   int *overflow;        // [2]: 0 match records, 1 candidate pairs
+  // records whose f32 test fell between the two thresholds: stored provisionally as matches,
+  // queued here and decided on the exact sides by resolve_undecided_kernel right after the sweep
+  uint2 *amb_queue;     // [amb_cap] (record index, descriptor slot)
+  u32 *amb_count;
+  u32 amb_cap;
 };
+#define SGTD_DEAD_FRAME 0xFFFFFFFFu   // frame of a provisional record that turned out not to match
 
 #define SGTD_PROBE_THREADS 256
 #define SGTD_PROBE_CHUNK 128    // query descriptors per assemble block
@@ -85,8 +91,8 @@ struct ProbeBuffers {
 #ifndef SGTD_PROBE_UNROLL
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
 #endif
-#ifndef SGTD_BSEARCH_BELOW
-#define SGTD_BSEARCH_BELOW 1024u  // visit lists shorter than this locate ranges by binary search
+#ifndef SGTD_LOCATE
+#define SGTD_LOCATE 0           // position -> range: 0 binary search by ds_bpermute, 1 scalar boundary cursor
 #endif
 
 // per-descriptor results of the sweep (stored once per ticket by the caller)
@@ -133,6 +139,7 @@ struct DescFetch {
   float lo2, hi2;       // conservative f32 thresholds (f32_bounds)
   u32 qframe;
   u32 gate;             // the descriptor's 27-bit gate mask
+  u32 slot;             // descriptor slot d
 };
 
 // the visit list of a descriptor as the sweep walks it: lane r < 54 holds the exclusive
@@ -321,11 +328,10 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
                                                  const DescFetch &f, const DescPlan &pl,
                                                  WaveSlab &slab, DescResult &result, PendingLoads pending) {
   const int lane = lane_id();
-  const double q0 = f.q0, q1 = f.q1, q2 = f.q2, thr2 = f.thr2;
-  const float q0f = (float)q0, q1f = (float)q1, q2f = (float)q2;
+  const float q0f = (float)f.q0, q1f = (float)f.q1, q2f = (float)f.q2;
   const float lo2 = f.lo2, hi2 = f.hi2;
   const u32 qframe = f.qframe;
-  const double thr = DIAG ? norm3(q0, q1, q2) * rough : 0.0;   // :356-357
+  const double thr = DIAG ? norm3(f.q0, f.q1, f.q2) * rough : 0.0;   // :356-357
   const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_WAVE - 1);
   const u32 dl = pl.dl;
   u64 ph_t = PH_T(); (void)ph_t;
@@ -350,27 +356,26 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
   u32 matches = 0;
   const u32 n_words = (total + 63u) >> 6;
   slab.swept += total;
+  u32 *const list_frame = B.rec_frame + slab.next, *const list_g = B.rec_g + slab.next;   // wave-uniform
 #ifdef SGTD_EXP_PHASE
   if (lane == 0 && n_words) {
     atomicAdd(&g_words[0], (unsigned long long)n_words);
     atomicAdd(&g_words[1], (unsigned long long)((n_words + SGTD_PROBE_UNROLL - 1) / SGTD_PROBE_UNROLL));
   }
 #endif
-  // position -> range, the last r with off[r] <= pos (empty ranges share their successor's
-  // offset and are stepped over), read from the plan registers by ds_bpermute — no memory.
-  // Two forms, chosen per descriptor (wave-uniform):
-  //  * short lists (many range boundaries per 64-entry word): branch-free binary search over
-  //    the 64 offsets (off[54..63] = total), six permutes per word;
-  //  * long lists (about one boundary per word): a per-lane cursor that only moves forward,
-  //    one permute per boundary crossed.
-  // All lanes execute the permutes (sources must be active).
-  u32 cur4 = 0;   // cursor form: 4 * range = ds_bpermute byte address
-  u32 nxt_off = (u32)__builtin_amdgcn_ds_bpermute(4, (int)pl.off);
+  // position -> range: the last r with off[r] <= pos (empty ranges share their successor's
+  // offset and are stepped over).  The offsets are wave-uniform values held one per lane, and a
+  // word of 64 consecutive positions crosses only a few range boundaries: a SCALAR cursor walks
+  // the boundaries (v_readlane of the next offset, scalar compare with the word's last position)
+  // and every boundary inside the word costs the lanes one compare + select — no LDS permutes,
+  // no dependent per-lane search.  The cursor only moves forward over the descriptor's words.
+  int rcur = 0;                                                                   // current range
+  u32 off_next = (u32)__builtin_amdgcn_readlane((int)pl.off, 1);                  // off[rcur + 1]
+  u32 dl_cur = (u32)__builtin_amdgcn_readlane((int)dl, 0);                        // dl[rcur]
   // one load group: NW words located, their loads issued back to back, then tested.  NW is a
   // compile-time count: each group size is straight-line code (branches around loads would
   // make the compiler wait for earlier loads before every later one).
-  auto group = [&](auto bsearch_tag, auto nw_tag, u32 w0) {
-    constexpr bool BSEARCH = decltype(bsearch_tag)::value;
+  auto group = [&](auto nw_tag, u32 w0) {
     constexpr int NW = decltype(nw_tag)::value;
     float4 v[NW];
     u32 gg[NW];
@@ -378,25 +383,41 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
     bool valid[NW];
 #pragma unroll
     for (int u = 0; u < NW; u++) {
-      const u32 pos = ((w0 + u) << 6) + lane;
+      const u32 wbase = (w0 + u) << 6;
+      const u32 pos = wbase + lane;
+      const u32 wend = wbase + 63u;
       valid[u] = pos < total;
-      u32 c4;
-      if constexpr (BSEARCH) {
-        c4 = 0;
-#pragma unroll
-        for (int s = 128; s >= 4; s >>= 1) {
-          const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)s), (int)pl.off);
-          c4 += (t <= pos) ? (u32)s : 0u;
-        }
-      } else {
-        while (__ballot(valid[u] && pos >= nxt_off)) {   // off[54..63] = total stops it
-          cur4 += (valid[u] && pos >= nxt_off) ? 4u : 0u;
-          nxt_off = (u32)__builtin_amdgcn_ds_bpermute((int)(cur4 + 4u), (int)pl.off);
-        }
-        c4 = cur4;
+#if SGTD_LOCATE == 1
+      // scalar cursor: every boundary inside the word costs the lanes one compare + select
+      u32 dsel = dl_cur;
+      int r = rcur;
+      while (rcur < SGTD_WAVE - 2 && off_next <= wend) {    // wave-uniform: a boundary inside this word
+        rcur++;
+        dl_cur = (u32)__builtin_amdgcn_readlane((int)dl, rcur);
+        const bool past = pos >= off_next;
+        dsel = past ? dl_cur : dsel;
+        if (DIAG) r = past ? rcur : r;
+        off_next = (u32)__builtin_amdgcn_readlane((int)pl.off, rcur + 1);
       }
-      rng[u] = (int)(c4 >> 2);
+#elif SGTD_LOCATE == 2
+      // timing experiment only (wrong results): no per-lane range
+      (void)wend;
+      const u32 dsel = dl_cur;
+      const int r = rcur;
+#else
+      // branch-free binary search over the 64 offsets held one per lane (off[54..63] = total):
+      // six ds_bpermute steps, then one more for the range's start
+      (void)wend;
+      u32 c4 = 0;
+#pragma unroll
+      for (int sh = 128; sh >= 4; sh >>= 1) {
+        const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)sh), (int)pl.off);
+        c4 += (t <= pos) ? (u32)sh : 0u;
+      }
       const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
+      const int r = (int)(c4 >> 2);
+#endif
+      rng[u] = r;
       const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
       const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + e)
                               : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(T.ent) + (e << 4));
@@ -409,66 +430,62 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     PH_ADD(2, ph_t);
 #endif
-    bool hit[NW], amb[NW];
-    double dis[NW];
-    bool any_amb = false;
 #pragma unroll
     for (int u = 0; u < NW; u++) {
-      const float dx = q0f - v[u].x, dy = q1f - v[u].y, dz = q2f - v[u].z;
-      const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      const u32 fr = __float_as_uint(v[u].w);
       // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-      const bool cand = valid[u] && (qframe != __float_as_uint(v[u].w));
-      hit[u] = cand && (d2 < lo2);                          // certainly dis < thr
-      amb[u] = DIAG ? cand : (cand && !(d2 < lo2) && !(d2 > hi2));   // NaN lands here too
-      if (DIAG) hit[u] = false;
-      dis[u] = 0.0;
-      any_amb |= amb[u];
-    }
-    if (__ballot(any_amb)) {   // rare (always in the diagnostic build): decide on the exact sides, :374-378
-#pragma unroll
-      for (int u = 0; u < NW; u++) {
-        if (amb[u]) {
+      const bool cand = valid[u] && (qframe != fr);
+      bool hit, amb = false;
+      double dis = 0.0;
+      if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
+        hit = false;
+        if (cand) {
           const double *sp = T.cold_side + (size_t)gg[u] * 3;
-          const double dx = q0 - sp[0], dy = q1 - sp[1], dz = q2 - sp[2];
-          const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
-          if (DIAG) { dis[u] = sqrt(d2); hit[u] = dis[u] < thr; }   // the reference's form verbatim
-          else hit[u] = d2 < thr2;
+          const double ex = f.q0 - sp[0], ey = f.q1 - sp[1], ez = f.q2 - sp[2];
+          dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
+          hit = dis < thr;
         }
+      } else {
+        const float dx = q0f - v[u].x, dy = q1f - v[u].y, dz = q2f - v[u].z;
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        hit = cand && !(d2 > hi2);            // not certainly outside (NaN stays in)
+        amb = hit && !(d2 < lo2);             // not certainly inside either: provisional
       }
-    }
-#pragma unroll
-    for (int u = 0; u < NW; u++) {
-      const u64 m = __ballot(hit[u]);
-      if (hit[u] && fits) {
-        const u32 o = slab.next + matches + __popcll(m & lanemask_lt());
-        u32 *df = WIDE ? B.rec_frame + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_frame) + (o << 2));
-        u32 *dg = WIDE ? B.rec_g + o : reinterpret_cast<u32 *>(reinterpret_cast<char *>(B.rec_g) + (o << 2));
-        *df = __float_as_uint(v[u].w);
-        *dg = gg[u];
-        if (DIAG) { B.rec_cell[o] = (unsigned char)(rng[u] >> 1); B.rec_dis[o] = dis[u]; }
+      const u64 m = __ballot(hit);
+      const u32 k = matches + (u32)__popcll(m & lanemask_lt());
+      if (hit && fits) {
+        // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
+        *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_frame) + (k << 2)) = fr;
+        *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_g) + (k << 2)) = gg[u];
+        if (DIAG) { B.rec_cell[(size_t)slab.next + k] = (unsigned char)(rng[u] >> 1); B.rec_dis[(size_t)slab.next + k] = dis; }
+      }
+      if (!DIAG && __ballot(amb)) {   // rare: about one in 10^4 matches
+        if (amb && fits) {
+          const u32 at = atomicAdd(B.amb_count, 1u);
+          if (at < B.amb_cap) B.amb_queue[at] = make_uint2(slab.next + k, f.slot);
+          else B.overflow[0] = 1;    // re-run with a larger queue (grows with the record buffer)
+        }
       }
       matches += __popcll(m);
     }
     PH_ADD(3, ph_t);
   };
   // full groups of SGTD_PROBE_UNROLL words, then one group of what is left
-  auto run = [&](auto bsearch_tag) {
+  {
     u32 w0 = 0;
     for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL) {
-      group(bsearch_tag, std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
+      group(std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
       if (w0 == 0) pending.touch();
     }
     switch (n_words - w0) {   // wave-uniform
-      case 1: group(bsearch_tag, std::integral_constant<int, 1>{}, w0); break;
-      case 2: group(bsearch_tag, std::integral_constant<int, 2>{}, w0); break;
-      case 3: group(bsearch_tag, std::integral_constant<int, 3>{}, w0); break;
+      case 1: group(std::integral_constant<int, 1>{}, w0); break;
+      case 2: group(std::integral_constant<int, 2>{}, w0); break;
+      case 3: group(std::integral_constant<int, 3>{}, w0); break;
       default: break;
     }
     if (w0 == 0 && n_words) pending.touch();
-  };
+  }
   static_assert(SGTD_PROBE_UNROLL == 4, "the remainder switch covers group sizes 1..3");
-  if (total < SGTD_BSEARCH_BELOW) run(std::true_type{});
-  else run(std::false_type{});
   if (n_words == 0) pending.touch();   // every path through the sweep leaves them complete
   if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches);
   result.ptr = slab.next; result.visit = pl.ref_visits; result.match = fits ? matches : 0;
@@ -591,6 +608,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       f.thr2 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0 + 1), __builtin_amdgcn_readlane((int)rec.z, l0 + 1));
       f.qframe = (u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 2);
       f.gate = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
+      f.slot = (u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
       f.lo2 = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 3));
       f.hi2 = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 3));
       DescResult res;
@@ -626,6 +644,24 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
     tr[3] = ((u64)tq.xcc << 56) | ((u64)tr_n_own << 28) | (u64)tr_n_st;
   }
 #endif
+}
+
+// The provisional records of the sweep, decided exactly (STDesc.cpp:374-378 in the squared,
+// comparison-exact form): a record whose entry does not match after all gets the frame
+// SGTD_DEAD_FRAME (no vote, no candidate) and leaves the query's match count.
+__global__ void resolve_undecided_kernel(TableView T, QueryView Q, ProbeBuffers B, u32 *q_M) {
+  const u32 n = min(*B.amb_count, B.amb_cap);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint2 it = B.amb_queue[i];
+    const QueryRec &r = Q.qrec[it.y];
+    const double *sp = T.cold_side + (size_t)B.rec_g[it.x] * 3;
+    const double dx = r.q0 - sp[0], dy = r.q1 - sp[1], dz = r.q2 - sp[2];
+    const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
+    if (!(d2 < r.thr2)) {
+      B.rec_frame[it.x] = SGTD_DEAD_FRAME;
+      atomicSub(&q_M[(u32)((long long)it.y / Q.stride)], 1u);
+    }
+  }
 }
 
 // votes (:404-420) from the match lists: one wavefront per 128-descriptor block,
@@ -890,7 +926,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
         if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          if (r0 + u * SGTD_WAVE + lane < R) {
+          if (r0 + u * SGTD_WAVE + lane < R && fr[u] != SGTD_DEAD_FRAME) {
             if (LDS_VOTES) atomicAdd(&s_hist[fr[u] - frame_lo], 1u);
             else atomicAdd(&votes[fr[u] - frame_lo], 1u);
           }
@@ -1151,7 +1187,10 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   flush();
 }
 
-// diagnostic: the ordered rough-match list of ONE query (reference order i, cell, j)
+// diagnostic: the ordered rough-match list of ONE query (reference order i, cell, j).  The
+// sweep emits a descriptor's matches cell by cell, inside a cell slice by slice; the reference's
+// bucket order is insertion order, so every (descriptor, cell) run is put out by ascending
+// entry id (a selection sort per run: diagnostic path, runs are short).
 __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuffers B, int q,
                                                            u32 *out_qi, u32 *out_entry, u32 *out_frame,
                                                            unsigned char *out_cell, double *out_dis) {
@@ -1166,13 +1205,26 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
     const u32 ex = block_excl_scan(n, lds, tot);
     if (i < cnt) {
       const u32 p0 = B.list_ptr[d];
-      for (u32 k = 0; k < n; k++) {
-        const u32 o = carry + ex + k;
-        out_qi[o] = i;
-        out_entry[o] = B.rec_g[p0 + k];
-        out_frame[o] = B.rec_frame[p0 + k];
-        if (out_cell) out_cell[o] = B.rec_cell[p0 + k];
-        if (out_dis) out_dis[o] = B.rec_dis[p0 + k];
+      u32 a = 0;
+      while (a < n) {
+        u32 b = a + 1;
+        if (out_cell) while (b < n && B.rec_cell[p0 + b] == B.rec_cell[p0 + a]) b++;   // without cell tags: list order
+        long long last = -1;
+        for (u32 k = a; k < b; k++) {
+          u32 best = 0xFFFFFFFFu, at = a;
+          for (u32 j = a; j < b; j++) {
+            const u32 g = B.rec_g[p0 + j];
+            if ((long long)g > last && g < best) { best = g; at = j; }
+          }
+          last = best;
+          const u32 o = carry + ex + k;
+          out_qi[o] = i;
+          out_entry[o] = best;
+          out_frame[o] = B.rec_frame[p0 + at];
+          if (out_cell) out_cell[o] = B.rec_cell[p0 + at];
+          if (out_dis) out_dis[o] = B.rec_dis[p0 + at];
+        }
+        a = b;
       }
     }
     carry += tot;

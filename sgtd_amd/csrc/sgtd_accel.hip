@@ -63,7 +63,8 @@ struct sgtd_engine {
   bool finalized = false;  // the first query builds the (possibly empty) bucket directory
 
   // ---- table, probe layout (hot)
-  DevBuf hot, perm, hash, bucket_start, bucket_key;   // hot: HotHead[E] then HotTail[E], 32 B per entry
+  DevBuf hot, perm, hash, bucket_start, bucket_key, dir, slice_of, sq_sum;   // hot: HotEntry[E] (16 B) + perm[E]
+  double sum_len_sq = 0.0;               // sum over buckets of len^2 (sizes the first batch's work buffers)
   u32 hash_mask = 0;
   int64_t n_buckets = 0;
   // sort scratch
@@ -91,6 +92,7 @@ struct sgtd_engine {
   DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
   DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
   DevBuf c_pair, c_slot, c_blk;   // compact candidate-match lists between block_count and block_write
+  DevBuf amb_queue;               // provisional records awaiting the exact test
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
   bool verified = false;
@@ -98,7 +100,6 @@ struct sgtd_engine {
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   bool rec_cap_fixed = false;          // SGTD_REC_CAP given: no pre-sizing from the table statistics
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
-  bool key_major = true;               // sweep in locality-key order (SGTD_PROBE_ORDER=query|key)
   DevBuf n_valid, xcd_heads, cell_rows, gid, q_prefix, group_first, n_groups, sdesc;
   int sorted_chunk = 0;                // > 0: fixed descriptors per ticket (SGTD_SORTED_CHUNK), else adaptive
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
@@ -323,12 +324,46 @@ void note_frames(sgtd_engine *e, u32 lo, u32 hi) {
 // ---------------------------------------------------------------------------
 // finalize: sort + CSR + hash
 // ---------------------------------------------------------------------------
+// stable LSD radix sort of (key, val) pairs by the low `bits` of the key, 8-bit digits; passes
+// whose digit is the same for every key are skipped (skip_const: costs a host round trip per
+// pass, only used by the once-per-map table build).  The result is in kin / vin.
+int radix_sort_pairs(sgtd_engine *e, u64 *&kin, u64 *&kout, u32 *&vin, u32 *&vout, long long n, int bits,
+                     bool skip_const, const u32 *n_dev = nullptr) {
+  const int nblocks = (int)((n + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
+  CHK(ensure(e, e->hist, (size_t)256 * nblocks * sizeof(u32)));
+  CHK(ensure(e, e->digit_tot, 256 * sizeof(u32)));
+  std::vector<u32> tot(256);
+  for (int shift = 0; shift < bits; shift += 8) {
+    u32 *hist = e->hist.as<u32>();
+    radix_hist_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, n, shift, hist, nblocks, n_dev);
+    HIPCHK(hipGetLastError());
+    if (skip_const) {
+      radix_digit_totals_kernel<<<256, SGTD_SCAN_THREADS, 0, e->stream>>>(hist, nblocks, e->digit_tot.as<u32>());
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(tot.data(), e->digit_tot.p, 256 * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      bool constant = false;
+      for (int d = 0; d < 256; d++)
+        if ((long long)tot[d] == n) constant = true;
+      if (constant) continue;  // every key has the same digit here: the pass is the identity
+    }
+    CHK(device_scan(e, hist, hist, (long long)256 * nblocks));
+    radix_scatter_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, n, shift,
+                                                                       e->hist.as<u32>(), nblocks, n_dev);
+    HIPCHK(hipGetLastError());
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  return SGTD_OK;
+}
+
 int do_finalize(sgtd_engine *e) {
   if (e->finalized) return SGTD_OK;
   const long long E = e->n_entries;
   if (E >= (1ll << 32) - 2) return SGTD_ERR_UNSUPPORTED;
   e->n_buckets = 0;
   e->hash_mask = 1023;
+  e->sum_len_sq = 0.0;
   if (E == 0) {
     CHK(ensure(e, e->hash, (size_t)1024 * sizeof(HashSlot)));
     HIPCHK(hipMemsetAsync(e->hash.p, 0xFF, (size_t)1024 * sizeof(HashSlot), e->stream));
@@ -339,52 +374,46 @@ int do_finalize(sgtd_engine *e) {
   CHK(ensure(e, e->keyB, (size_t)E * sizeof(u64)));
   CHK(ensure(e, e->valA, (size_t)E * sizeof(u32)));
   CHK(ensure(e, e->valB, (size_t)E * sizeof(u32)));
-  CHK(ensure(e, e->bad_flag, sizeof(int)));
-  CHK(ensure(e, e->digit_tot, 256 * sizeof(u32)));
-  HIPCHK(hipMemsetAsync(e->bad_flag.p, 0, sizeof(int), e->stream));
+  CHK(ensure(e, e->bad_flag, 2 * sizeof(int)));
+  HIPCHK(hipMemsetAsync(e->bad_flag.p, 0, 2 * sizeof(int), e->stream));
   make_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.side.as<double>(), e->tab.label.as<int>(),
                                                              e->keyA.as<u64>(), e->valA.as<u32>(), E,
                                                              e->bad_flag.as<int>());
   HIPCHK(hipGetLastError());
-  int bad = 0;
-  HIPCHK(hipMemcpyAsync(&bad, e->bad_flag.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  frame_monotone_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.frame.as<u32>(), E, e->bad_flag.as<int>() + 1);
+  HIPCHK(hipGetLastError());
+  int bad[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(bad, e->bad_flag.p, sizeof(bad), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (bad) return SGTD_ERR_UNSUPPORTED;  // a cell coordinate beyond 16 bits
+  if (bad[0]) return SGTD_ERR_UNSUPPORTED;  // a cell coordinate beyond 16 bits
+  const bool monotone = bad[1] == 0;
 
-  const int nblocks = (int)((E + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
-  CHK(ensure(e, e->hist, (size_t)256 * nblocks * sizeof(u32)));
   u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
   u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
-  std::vector<u32> tot(256);
-  for (int pass = 0; pass < 8; pass++) {
-    const int shift = pass * 8;
-    if (shift >= 60) break;
-    u32 *hist = e->hist.as<u32>();
-    radix_hist_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, E, shift, hist, nblocks);
+  CHK(ensure(e, e->slice_of, (size_t)E));
+  if (!monotone) {
+    // frame ids out of insertion order (caller-stamped descriptors): the slice assignment needs
+    // every bucket grouped by frame, so sort by (key, frame, g) for it, then start over
+    frame_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.frame.as<u32>(), kin, vin, E);
     HIPCHK(hipGetLastError());
-    radix_digit_totals_kernel<<<256, SGTD_SCAN_THREADS, 0, e->stream>>>(hist, nblocks, e->digit_tot.as<u32>());
+    CHK(radix_sort_pairs(e, kin, kout, vin, vout, E, 32, true));
+    keys_of_order_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.side.as<double>(), e->tab.label.as<int>(), vin, kin, E);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(tot.data(), e->digit_tot.p, 256 * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    bool constant = false;
-    for (int d = 0; d < 256; d++)
-      if ((long long)tot[d] == E) constant = true;
-    if (constant) continue;  // every key has the same digit here: the pass is the identity
-    CHK(device_scan(e, hist, hist, (long long)256 * nblocks));
-    radix_scatter_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, E, shift,
-                                                                       e->hist.as<u32>(), nblocks);
+    CHK(radix_sort_pairs(e, kin, kout, vin, vout, E, 60, true));
+    slice_assign_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, vin, e->tab.side.as<double>(), e->tab.frame.as<u32>(), E,
+                                                                  e->dc.rough, e->slice_of.as<unsigned char>());
     HIPCHK(hipGetLastError());
-    std::swap(kin, kout);
-    std::swap(vin, vout);
+    kin = e->keyA.as<u64>(); kout = e->keyB.as<u64>(); vin = e->valA.as<u32>(); vout = e->valB.as<u32>();
+    make_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.side.as<double>(), e->tab.label.as<int>(), kin, vin, E,
+                                                               e->bad_flag.as<int>());
+    HIPCHK(hipGetLastError());
   }
-  // probe layout: one 32-B record per entry in sorted order
-  CHK(ensure(e, e->hot, (size_t)E * SGTD_HOT_BYTES));
-  CHK(ensure(e, e->perm, (size_t)E * sizeof(u32)));
-  HIPCHK(hipMemcpyAsync(e->perm.p, vin, (size_t)E * sizeof(u32), hipMemcpyDeviceToDevice, e->stream));
-  gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->perm.as<u32>(), e->tab.side.as<double>(),
-                                                              e->tab.frame.as<u32>(), e->hot.as<HotHead>(),
-                                                              reinterpret_cast<HotTail *>(e->hot.as<HotHead>() + E), E);
-  HIPCHK(hipGetLastError());
+  CHK(radix_sort_pairs(e, kin, kout, vin, vout, E, 60, true));   // (key, g): buckets in insertion order
+  if (monotone) {
+    slice_assign_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, vin, e->tab.side.as<double>(), e->tab.frame.as<u32>(), E,
+                                                                  e->dc.rough, e->slice_of.as<unsigned char>());
+    HIPCHK(hipGetLastError());
+  }
   // buckets
   CHK(ensure(e, e->flags, (size_t)E * sizeof(u32)));
   head_flags_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, e->flags.as<u32>(), E);
@@ -401,6 +430,17 @@ int do_finalize(sgtd_engine *e) {
   bucket_starts_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, e->flags.as<u32>(), e->bucket_start.as<u32>(),
                                                                  e->bucket_key.as<u64>(), E);
   HIPCHK(hipGetLastError());
+  // probe order: every bucket partitioned by slice, insertion order inside a slice
+  CHK(ensure(e, e->perm, (size_t)E * sizeof(u32)));
+  CHK(ensure(e, e->dir, (size_t)U * sizeof(BucketDir)));
+  slice_partition_kernel<<<e->n_cus * 8, 256, 0, e->stream>>>(e->bucket_start.as<u32>(), U, (u32)E, vin,
+                                                               e->slice_of.as<unsigned char>(), e->perm.as<u32>(),
+                                                               e->dir.as<BucketDir>());
+  HIPCHK(hipGetLastError());
+  CHK(ensure(e, e->hot, (size_t)E * sizeof(HotEntry)));
+  gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->perm.as<u32>(), e->tab.side.as<double>(),
+                                                              e->tab.frame.as<u32>(), e->hot.as<HotEntry>(), E);
+  HIPCHK(hipGetLastError());
   u32 cap = 1024;
   while (cap < 2ull * U) cap <<= 1;
   e->hash_mask = cap - 1;
@@ -409,7 +449,14 @@ int do_finalize(sgtd_engine *e) {
   hash_insert_kernel<<<grid_for(U, 256), 256, 0, e->stream>>>(e->bucket_key.as<u64>(), e->bucket_start.as<u32>(), U,
                                                                (u32)E, e->hash.as<HashSlot>(), e->hash_mask);
   HIPCHK(hipGetLastError());
+  CHK(ensure(e, e->sq_sum, sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(e->sq_sum.p, 0, sizeof(unsigned long long), e->stream));
+  bucket_sq_kernel<<<grid_for(U, 256), 256, 0, e->stream>>>(e->bucket_start.as<u32>(), U, (u32)E, e->sq_sum.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  unsigned long long sq = 0;
+  HIPCHK(hipMemcpyAsync(&sq, e->sq_sum.p, sizeof(sq), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->sum_len_sq = (double)sq;
   e->finalized = true;
   return SGTD_OK;
 }
@@ -426,6 +473,7 @@ int rec_alloc(sgtd_engine *e) {
     CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
   }
   CHK(ensure(e, e->pairs, e->pair_cap * sizeof(u64)));
+  CHK(ensure(e, e->amb_queue, std::max<size_t>(65536, e->rec_cap / 64) * sizeof(uint2)));
   return SGTD_OK;
 }
 
@@ -441,8 +489,8 @@ Views make_views(sgtd_engine *e) {
   Views v;
   v.span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   TableView &T = v.T;
-  T.head = e->hot.as<HotHead>();
-  T.tail = reinterpret_cast<const HotTail *>(T.head + e->n_entries);
+  T.ent = e->hot.as<HotEntry>(); T.perm = e->perm.as<u32>(); T.cold_side = e->tab.side.as<double>();
+  T.dir = e->dir.as<BucketDir>();
   T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
   T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
   QueryView &Q = v.Q;
@@ -453,8 +501,11 @@ Views make_views(sgtd_engine *e) {
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
   B.rec_frame = e->rec.as<u32>(); B.rec_g = e->rec.as<u32>() + e->rec_cap;   // two halves of one allocation
-  B.rec_cursor = e->cursors.as<unsigned long long>(); B.item_cursor = e->cursors.as<u32>() + 2;
+  B.rec_cursor = e->cursors.as<unsigned long long>();
   B.rec_need = e->cursors.as<unsigned long long>() + 2;
+  B.swept = e->cursors.as<unsigned long long>() + 3;
+  B.amb_queue = e->amb_queue.as<uint2>(); B.amb_count = e->cursors.as<u32>() + 2;
+  B.amb_cap = (u32)std::min<size_t>(e->amb_queue.bytes / sizeof(uint2), 0xFFFFFFF0u);
   B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
   B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
   v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
@@ -496,15 +547,14 @@ int launch_select(sgtd_engine *e) {
   HIPCHK(hipMemsetAsync(e->q_P.p, 0, (size_t)nq * sizeof(unsigned long long), e->stream));
 
   Views v = make_views(e);
-  const long long n_items = (long long)nq * blocks;
-  const int grid = (int)std::max<long long>(1, std::min<long long>(n_items, (long long)e->n_cus * 8));
   const size_t hist_bytes = (size_t)span * sizeof(u32);
   const bool lds_votes = hist_bytes <= 150 * 1024;
   const int groups = (blocks + 3) / 4;
   const int agrid = ((nq + 7) / 8) * groups * 8;   // workgroup b serves query (b/8/groups)*8 + b%8
-  CHK(ensure(e, e->cell_rows, (size_t)std::max<long long>(n_slots, 1) * sizeof(CellRow)));
-  const CellRow *rows = e->cell_rows.as<CellRow>();
-  if (e->key_major) {
+  // one GroupRow per distinct home cell of the batch (at most one per descriptor slot)
+  CHK(ensure(e, e->cell_rows, (size_t)std::max<long long>(n_slots, 1) * SGTD_GROUP_ROW_BYTES));
+  const unsigned char *rows = e->cell_rows.as<unsigned char>();
+  {
     // ---- order of the batch's descriptors by home key (label code + truncated cell):
     // stable 8-bit radix passes over 12 + 3*cbits key bits, then one GroupRow of bucket
     // lookups per distinct home cell
@@ -519,8 +569,6 @@ int launch_select(sgtd_engine *e) {
 #else
     CHK(ensure(e, e->xcd_heads, 8 * 1024 * sizeof(u32)));
 #endif
-    const int nb = (int)((n_slots + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
-    CHK(ensure(e, e->hist, (size_t)256 * nb * sizeof(u32)));
     u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
     u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
     // bits per cell coordinate of the sort key: the largest cell a built descriptor can have
@@ -535,16 +583,7 @@ int launch_select(sgtd_engine *e) {
     HIPCHK(hipGetLastError());
     home_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), kin, vin, n_slots, cbits);
     HIPCHK(hipGetLastError());
-    for (int shift = 0; shift < key_bits; shift += 8) {   // only the n_valid compact elements are live
-      radix_hist_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, n_slots, shift, e->hist.as<u32>(), nb, nv);
-      HIPCHK(hipGetLastError());
-      CHK(device_scan(e, e->hist.as<u32>(), e->hist.as<u32>(), (long long)256 * nb));
-      radix_scatter_kernel<<<nb, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, n_slots, shift,
-                                                                   e->hist.as<u32>(), nb, nv);
-      HIPCHK(hipGetLastError());
-      std::swap(kin, kout);
-      std::swap(vin, vout);
-    }
+    CHK(radix_sort_pairs(e, kin, kout, vin, vout, n_slots, key_bits, false, nv));   // only the n_valid compact elements are live
     HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * 1024 * sizeof(u32), e->stream));
     group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits);
     HIPCHK(hipGetLastError());
@@ -554,22 +593,22 @@ int launch_select(sgtd_engine *e) {
                                                                         e->group_first.as<u32>(), e->n_groups.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
     group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(v.T, v.Q, vin, e->group_first.as<u32>(),
-                                                                e->n_groups.as<u32>(), nv, e->cell_rows.as<CellRow>());
+                                                                e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>());
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
     // descriptors per wave ticket: about 2k entry visits, from the visits per descriptor the
     // previous batch measured (4 until there is one); SGTD_SORTED_CHUNK overrides
     u32 chunk = 4;
-    if (e->stats.last_D > 0 && e->stats.last_P > 0) {
-      const double per_desc = (double)e->stats.last_P / (double)e->stats.last_D;
+    if (e->stats.last_D > 0 && e->stats.last_P_swept > 0) {
+      const double per_desc = (double)e->stats.last_P_swept / (double)e->stats.last_D;
       chunk = (u32)std::min(8.0, std::max(1.0, std::floor(2048.0 / per_desc + 0.5)));
     }
     if (e->sorted_chunk > 0) chunk = (u32)std::min(SGTD_TICKET_MAX, e->sorted_chunk);
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
     const int sgrid = e->n_cus * 8;
-    // 32-bit byte offsets when both the probe layout and the record buffer stay below 4 GB
-    const bool narrow = (unsigned long long)v.T.n_entries * sizeof(HotHead) < (1ull << 32) &&
-                        (unsigned long long)v.B.rec_cap * sizeof(u32) < (1ull << 32);
+    // 32-bit byte offsets into the probe layout while it stays below 4 GB (record addresses
+    // are a wave-uniform base + a 32-bit lane offset either way)
+    const bool narrow = (unsigned long long)v.T.n_entries * sizeof(HotEntry) < (1ull << 32);
 #define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
   probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
       v.T, v.B, rows, e->sdesc.as<QueryRec>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
@@ -577,6 +616,8 @@ int launch_select(sgtd_engine *e) {
     else if (narrow) SGTD_LAUNCH_SORTED(false, false);
     else SGTD_LAUNCH_SORTED(false, true);
 #undef SGTD_LAUNCH_SORTED
+    HIPCHK(hipGetLastError());
+    resolve_undecided_kernel<<<64, 256, 0, e->stream>>>(v.T, v.Q, v.B, e->q_M.as<u32>());
 #ifdef SGTD_EXP_PHASE
     {
       static int bcalls = 0;
@@ -649,30 +690,6 @@ int launch_select(sgtd_engine *e) {
     }
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_VOTES], e->stream));
-  } else {
-    resolve_kernel<<<grid_for(n_slots * 32, SGTD_RESOLVE_THREADS), SGTD_RESOLVE_THREADS, 0, e->stream>>>(
-        v.T, v.Q, e->cell_rows.as<CellRow>(), nullptr, nullptr, n_slots);
-    HIPCHK(hipGetLastError());
-    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
-    if (lds_votes) {
-      if (e->diag) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-        probe_kernel<true, true><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
-      } else {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<true, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-        probe_kernel<true, false><<<grid, SGTD_PROBE_THREADS, hist_bytes, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
-      }
-    } else {
-      if (e->diag)
-        probe_kernel<false, true><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
-      else
-        probe_kernel<false, false><<<grid, SGTD_PROBE_THREADS, 0, e->stream>>>(v.T, v.Q, v.B, rows, e->dc.rough, blocks);
-    }
-    HIPCHK(hipGetLastError());
-    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
-    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_VOTES], e->stream));
   }
   topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, v.T.frame_lo, cn, e->n_cand.as<int>(),
                                           e->cand_frame.as<int>(), e->cand_votes.as<int>(),
@@ -684,9 +701,7 @@ int launch_select(sgtd_engine *e) {
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
   CL.cursor = e->cursors.as<u32>() + 3; CL.cap = v.B.rec_cap;
   block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
-                                                    blocks, e->blk_count.as<u32>(), CL,
-                                                    e->key_major ? nullptr : e->q_M.as<u32>(),
-                                                    e->key_major ? nullptr : e->q_P.as<unsigned long long>());
+                                                    blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr);
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
   block_scan_kernel<<<nq, 64, 0, e->stream>>>(e->blk_count.as<u32>(), blocks, cn, e->n_cand.as<int>(),
@@ -729,13 +744,16 @@ int sync_batch(sgtd_engine *e) {
   if (!e->batch_valid) return SGTD_ERR_STATE;
   if (e->batch_synced) return SGTD_OK;
   e->stats.overflowed = 0;
+  unsigned long long swept = 0;
   for (int attempt = 0; attempt < 8; attempt++) {
     int ovf[2] = {0, 0};
     unsigned long long cursor = 0, need = 0;
+    swept = 0;
     u32 total = 0;
     HIPCHK(hipMemcpyAsync(ovf, e->overflow.p, sizeof(ovf), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&cursor, e->cursors.p, sizeof(cursor), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&need, e->cursors.as<unsigned long long>() + 2, sizeof(need), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&swept, e->cursors.as<unsigned long long>() + 3, sizeof(swept), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!ovf[0] && !ovf[1]) {
@@ -778,6 +796,7 @@ int sync_batch(sgtd_engine *e) {
   sgtd_stats &s = e->stats;
   s.last_queries = nq;
   s.last_D = 0; s.last_P = 0; s.last_M = 0; s.last_cand_pairs = 0;
+  s.last_P_swept = (int64_t)swept;
   for (int q = 0; q < nq; q++) {
     s.last_D += e->h_count[q];
     s.last_P += (int64_t)e->h_q_P[q];
@@ -914,7 +933,6 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   e->current_frame_id = cfg->first_frame_id;
   e->qd.with_thr2 = true;
-  if (const char *o = getenv("SGTD_PROBE_ORDER")) e->key_major = std::strcmp(o, "key") == 0;
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }
@@ -929,12 +947,12 @@ int sgtd_destroy(sgtd_handle e) {
   (void)hipSetDevice(e->cfg.device_id);
   (void)hipStreamSynchronize(e->stream);
   free_store(e->tab); free_store(e->tmp); free_store(e->qd);
-  DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key,
+  DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key, &e->dir, &e->slice_of, &e->sq_sum,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
                     &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
-                    &e->blk_count, &e->c_pair, &e->c_slot, &e->c_blk, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
+                    &e->blk_count, &e->c_pair, &e->c_slot, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
                     &e->cand_votes, &e->pair_off, &e->pairs};
   for (DevBuf *b : bufs) free_buf(*b);
@@ -1073,6 +1091,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
   e->q_stride = (long long)std::max(max_n, 1) * e->dc.tpi;
   e->last_kind = 1; e->last_xyz = dx; e->last_label = dl; e->last_max_n = max_n;
   e->last_qframe = e->current_frame_id;
+  e->diag = false;   // a new batch runs the product sweep; sgtd_result_rough re-runs it in the diagnostic form
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride * n_queries));
   CHK(ensure(e, e->q_count, (size_t)n_queries * sizeof(u32)));
   return enqueue_frames(e);
@@ -1085,6 +1104,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   e->nq = 1;
   e->q_stride = std::max<long long>(nq, 1);
   e->last_kind = 2;
+  e->diag = false;
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
@@ -1197,9 +1217,9 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
   if (!e || !n_rough) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->batch_valid) return SGTD_ERR_STATE;
-  if ((dis || cell) && !e->diag) {
-    // cell index and distance per match come from the diagnostic probe build:
-    // switch it on and re-run the batch
+  if (!e->diag) {
+    // the ordered rough list (cell index, distance, reference order inside a cell) comes from the
+    // diagnostic probe build: switch it on and re-run the batch
     e->diag = true;
     CHK(rec_alloc(e));
     CHK(rerun(e));
@@ -1483,8 +1503,15 @@ int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *
     if (bucket_off) bucket_off[u] = st[u];
   }
   if (bucket_off) bucket_off[U] = E;
-  if (entry_ids)
+  if (entry_ids) {
+    // the probe layout keeps every bucket partitioned by slice; the dump shows each bucket in
+    // insertion order (ascending entry id), the order of the reference's bucket vector
+    for (int64_t u = 0; u < U; u++) {
+      const int64_t lo = st[u], hi = (u + 1 < U) ? (int64_t)st[u + 1] : E;
+      std::sort(pm.begin() + lo, pm.begin() + hi);
+    }
     for (int64_t p = 0; p < E; p++) entry_ids[p] = pm[p];
+  }
   return SGTD_OK;
 }
 

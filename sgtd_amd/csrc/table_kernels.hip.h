@@ -96,6 +96,21 @@ __global__ void make_keys_kernel(const double *side, const int *label, u64 *keys
   vals[g] = (u32)g;
 }
 
+// non-monotone frame ids only: (frame, g) pairs, and the table key of every g of an order
+__global__ void frame_keys_kernel(const u32 *frame, u64 *keys, u32 *vals, long long n) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  keys[g] = frame[g];
+  vals[g] = (u32)g;
+}
+__global__ void keys_of_order_kernel(const double *side, const int *label, const u32 *order, u64 *keys, long long n) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t g = order[p];
+  const int x = (int)(side[g * 3 + 0] + 0.5), y = (int)(side[g * 3 + 1] + 0.5), z = (int)(side[g * 3 + 2] + 0.5);
+  keys[p] = pack_key(label_code(label[g * 3], label[g * 3 + 1], label[g * 3 + 2]), (u32)x & 65535u, (u32)y & 65535u, (u32)z & 65535u);
+}
+
 // a loaded table's frame ids must lie in the header's [lo, hi] (the votes are indexed by them)
 __global__ void frame_range_check_kernel(const u32 *frame, long long n, u32 lo, u32 hi, int *bad_flag) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;

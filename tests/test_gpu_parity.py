@@ -97,7 +97,7 @@ def test_table_parity(mods, via_frames):
     ok, ooff, oid = o.table_dump()
     np.testing.assert_array_equal(gk, ok)
     np.testing.assert_array_equal(goff, ooff)
-    np.testing.assert_array_equal(gid, oid)   # bucket order == insertion order
+    np.testing.assert_array_equal(gid, oid)   # the dump lists every bucket in insertion order
     ids = np.arange(0, len(gid), 97, dtype=np.int64)
     assert_descs_equal(g.fetch_entries(ids), o.fetch_entries(ids))
 
@@ -126,12 +126,10 @@ def _check_query(g, o, res, q, oq_descs, check_rough=True):
     return r
 
 
-@pytest.mark.parametrize("order", ["query", "key"])
-def test_select_parity_batch(mods, order, monkeypatch):
-    """both sweep orders: query-major (LDS vote histograms) and key-major
-    (locality order over XCD queues, votes from the match lists)"""
+def test_select_parity_batch(mods):
+    """a batch of query frames: every result of candidate_selector against the oracle,
+    and the device's own counters of visited entries / rough matches against the oracle's"""
     _, _, synth = mods
-    monkeypatch.setenv("SGTD_PROBE_ORDER", order)
     g, o = _pair(mods)
     m = synth.make_map(40, 200, stream=41)
     _fill_both(mods, g, o, m)
@@ -286,11 +284,9 @@ def test_large_frames_use_the_global_dedup_path(mods, n_kp):
     _check_query(g, o, res, 0, od)
 
 
-@pytest.mark.parametrize("order", ["query", "key"])
-def test_skewed_labels_and_max_candidates(mods, order, monkeypatch):
+def test_skewed_labels_and_max_candidates(mods):
     """one dominant class (few label codes, long buckets), candidate_num = 64, K = 16"""
     _, _, synth = mods
-    monkeypatch.setenv("SGTD_PROBE_ORDER", order)
     cfg = dict(candidate_num=64, descriptor_near_num=16, rough_dis_threshold=0.02)
     g, o = _pair(mods, **cfg)
     m = synth.make_map(70, 40, stream=97, label_lo=5, label_hi=6)
@@ -635,3 +631,108 @@ def test_overflowed_batch_is_resolved_before_the_sharded_export(mods, monkeypatc
         assert np.array_equal(frames[q, :nc].cpu().numpy(), res.cand_frame[q, :nc])
         assert np.array_equal(votes[q, :nc].cpu().numpy(), res.cand_votes[q, :nc])
     assert np.array_equal(bf.cpu().numpy(), gf) and np.array_equal(bs.cpu().numpy(), gs)
+
+
+# ---------------------------------------------------------------------------
+# probe layout: z-slices + overflow slice inside a bucket, f32 pre-test with exact fallback
+# ---------------------------------------------------------------------------
+def _random_descs(oracle_mod, manager_mod, rng, n, frame, small):
+    """caller-made descriptors (AddSTDescs path) concentrated in a few cells: many entries of
+    one frame share a bucket, some of them close enough to match the same query descriptor"""
+    if small:
+        side = np.stack([rng.uniform(3, 5, n), rng.uniform(4, 6, n), rng.uniform(5, 7, n)], 1)
+    else:
+        side = np.stack([rng.uniform(20, 22, n), rng.uniform(30, 32, n), rng.uniform(40, 42, n)], 1)
+    lab = np.where(rng.random((n, 1)) < 0.5, np.int32([[3, 4, 5]]), np.int32([[3, 4, 9]]))
+    out = []
+    for mod in (manager_mod, oracle_mod):
+        d = mod.Descs(n)
+        d.side[:] = side
+        d.label[:] = lab
+        d.frame[:] = frame
+        d.node_id[:, 0] = np.arange(n)
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("monotone", [True, False])
+def test_bucket_slices_keep_the_reference_order_per_frame(mods, monotone):
+    oracle, manager, _ = mods
+    rng = np.random.default_rng(77 if monotone else 78)
+    g, o = _pair(mods, rough_dis_threshold=0.04, candidate_num=20)
+    ids = list(range(14))
+    if not monotone:
+        rng.shuffle(ids)                      # frame ids out of insertion order: the (key, frame) pre-sort path
+    for k, f in enumerate(ids):
+        n = 500
+        gd, od = _random_descs(oracle, manager, rng, n, f, small=(k % 2 == 0))
+        if not monotone and k % 3 == 0:       # one AddSTDescs call carrying two frame ids
+            gd.frame[n // 2:] = ids[(k + 5) % len(ids)]
+            od.frame[n // 2:] = ids[(k + 5) % len(ids)]
+        g.AddSTDescs(gd)
+        o.add(od)
+    gk, goff, gid = g.table_dump()
+    ok, ooff, oid = o.table_dump()
+    np.testing.assert_array_equal(gk, ok)
+    np.testing.assert_array_equal(goff, ooff)
+    np.testing.assert_array_equal(gid, oid)
+    for small in (True, False):
+        gq, oq = _random_descs(oracle, manager, rng, 300, 99, small)
+        lists = g.candidate_selector(gq)
+        res = g.results()
+        r = o.select(oq)
+        nc = int(res.n_cand[0])
+        assert nc > 0
+        np.testing.assert_array_equal(res.cand_frame[0, :nc], r["cand_frame"])
+        np.testing.assert_array_equal(res.cand_votes[0, :nc], r["cand_votes"])
+        qi, de = g.result_pairs(0, res)
+        np.testing.assert_array_equal(qi, r["q_idx"])
+        np.testing.assert_array_equal(de, r["db_entry"])     # (i, cell, j) order inside every frame's list
+        c = o.counters()
+        st = g.stats()
+        assert st["last_P"] == c["P"] and st["last_M"] == c["M"]
+        assert 0 < st["last_P_swept"] <= st["last_P"]
+        lo, v = g.result_votes(0)
+        np.testing.assert_array_equal(v.astype(np.float64), o.votes()[lo:lo + len(v)])
+        gr, orr = g.result_rough(0), o.rough_matches()       # diagnostic sweep: full (i, cell, j) order + distances
+        for key in ("q_idx", "cell", "db_entry", "frame", "dis"):
+            np.testing.assert_array_equal(gr[key], orr[key], err_msg=key)
+        assert len(lists) == nc
+
+
+def test_f32_pretest_decides_like_the_exact_test_at_the_threshold(mods):
+    """entries placed within a few ulps / 1e-7 relative of the match threshold: the votes (product
+    sweep: f32 test, provisional records, exact resolution) equal the oracle's f64 decisions"""
+    oracle, manager, _ = mods
+    g, o = _pair(mods)
+    q = np.array([10.3, 20.7, 25.9])
+    thr = np.sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) * 0.03
+    rels = [0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-13, -1e-13, 1e-9, -1e-9, 1e-7, -1e-7, 3e-6, -3e-6, 1e-5, -1e-5, 1e-3, -1e-3]
+    dirs = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.6, 0.8, 0], [0.36, 0.48, 0.8], [-1, 0, 0], [0, -0.6, 0.8]])
+    f = 0
+    for dvec in dirs:
+        for rel in rels:
+            e = q + dvec * (thr * (1.0 + rel))
+            if np.any((e + 0.5).astype(int) - (q + 0.5).astype(int) > 1):
+                continue
+            for mod, mgr in ((manager, g), (oracle, o)):
+                d = mod.Descs(1)
+                d.side[0] = e
+                d.label[0] = (3, 4, 5)
+                d.frame[0] = f
+                mgr.AddSTDescs(d) if mgr is g else mgr.add(d)
+            f += 1
+    assert f > 80
+    gq, oq = manager.Descs(1), oracle.Descs(1)
+    for d in (gq, oq):
+        d.side[0] = q
+        d.label[0] = (3, 4, 5)
+        d.frame[0] = 100000 % 20000 + 5000
+    g.candidate_selector(gq)
+    o.select(oq)
+    lo, v = g.result_votes(0)
+    ov = o.votes()
+    np.testing.assert_array_equal(v.astype(np.float64), ov[lo:lo + len(v)])
+    assert 0 < v.sum() < f                      # some inside, some outside
+    st = g.stats()
+    assert st["last_M"] == o.counters()["M"]
