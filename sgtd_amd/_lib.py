@@ -91,6 +91,16 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SgtdError(-2, "libsgtd_accel.so is not built (run __graft_entry__.build() or "
                             "make -C sgtd_amd/csrc); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (same SONAME as the system
+    # one this library is linked against).  Loaded first, it also serves this library; loaded
+    # second, it finds the GPU already opened by the other copy and reports "No HIP GPUs".  The
+    # package uses torch for device buffers, streams and torch.distributed anyway (dist.py,
+    # bench.py), so pin the order here.  C/C++ hosts link the system runtime and never see torch.
+    if os.environ.get("SGTD_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.sgtd_default_config.argtypes = [C.POINTER(Config)]

@@ -114,9 +114,12 @@ struct PendingLoads {
   }
 };
 
+#define SGTD_PAIR 2   // descriptors of one home cell swept together by a wave (shared plan, locate and loads)
+
 struct WaveSlab {
-  u32 next, end;   // this wave's private range of match records
-  u64 swept;       // entries this wave loaded
+  u32 next[SGTD_PAIR], end[SGTD_PAIR];   // this wave's private ranges of match records: one bump stream per
+                                         // descriptor of a pair, so that every descriptor's list stays contiguous
+  u64 swept;                             // entries this wave loaded
 #ifdef SGTD_EXP_PHASE
   u64 ph[8];
 #endif
@@ -131,23 +134,25 @@ __device__ unsigned long long g_words[2];   // 64-entry words swept, load groups
 #define PH_ADD(i, t0) do { } while (0)
 #endif
 
-// what the sweep needs about one query descriptor; the loads are issued one descriptor
-// ahead, the per-lane plan is derived right before the sweep (plan_from_group_row)
-struct DescFetch {
+// what the sweep needs about K query descriptors of ONE home cell (they share the GroupRow); the
+// loads are issued one step ahead, the per-lane plan is derived right before the sweep
+template <int K>
+struct DescSet {
   uint4 row;            // lane l < 54: 16-B quarter l of the group's 27 directory rows
-  double q0, q1, q2, thr2;
-  float lo2, hi2;       // conservative f32 thresholds (f32_bounds)
-  u32 qframe;
-  u32 gate;             // the descriptor's 27-bit gate mask
-  u32 slot;             // descriptor slot d
+  double q0[K], q1[K], q2[K], thr2[K];
+  float lo2[K], hi2[K]; // conservative f32 thresholds (f32_bounds)
+  u32 qframe[K];
+  u32 gate[K];          // the descriptor's 27-bit gate mask
+  u32 slot[K];          // descriptor slot d
 };
 
-// the visit list of a descriptor as the sweep walks it: lane r < 54 holds the exclusive
-// offset off[r] of range r = 2 * cell + (0 regular slices | 1 overflow slice), lanes >= 54 the
-// total, and dl[r] = start[r] - off[r]
+// the visit list as the sweep walks it: lane r < 54 holds the exclusive offset off[r] of range
+// r = 2 * cell + (0 regular slices | 1 overflow slice), lanes >= 54 the total, and
+// dl[r] = start[r] - off[r].  For a pair it is the union of the two descriptors' lists.
+template <int K>
 struct DescPlan {
   u32 off, dl;
-  u32 ref_visits;       // wave-uniform: entries the reference's loop visits (all slices of the gated cells)
+  u32 ref_visits[K];    // wave-uniform: entries the reference's loop visits (all slices of the gated cells)
 };
 
 // ---------------------------------------------------------------------------
@@ -272,30 +277,43 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
   }
 }
 
-// GroupRow + the descriptor's gate mask (:366-369) + its threshold: per range the gated, slice-
-// pruned length and start, and the exclusive scan of the lengths.
+// GroupRow + the descriptors' gate masks (:366-369) + their thresholds: per range the gated,
+// slice-pruned length and start, and the exclusive scan of the lengths.
 // Lane r = 2 c + k: even lanes hold {start, cum0, cum1, cum2} of cell c, odd lanes
 // {cum3, cum4, 0, 0}.  Regular range (k = 0): the slices that hold entries with
 // |side2 - q2| <= thr' — an entry outside cannot match: its squared distance, as the reference
 // computes it, is at least fl(dz * dz) >= thr2.  Overflow range (k = 1): all of that slice.
-__device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
+// K = 2: the union of the two descriptors' ranges; the sweep tests every loaded entry against
+// both and masks each with its own gate (a slice too many is harmless, a cell too many is not).
+template <int K>
+__device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f) {
   const int lane = lane_id();
   const int c = lane >> 1;
   const bool odd = lane & 1;
   // neighbour lane of the pair: even lanes receive cum3 / cum4, odd lanes start / cum0
   const u32 nx = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
   const u32 ny = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.y, 0xB1, 0xf, 0xf, false);
-  const bool live = lane < SGTD_NRANGE && ((f.gate >> c) & 1u);
-  // slices of cell z = (int)(q2 + iz) reached by [q2 - t, q2 + t]; slice s holds the entries with
-  // (side2 + 0.5 - z) * 4 in [s, s + 1).  t carries a relative margin over the exact threshold
-  // and the bounds another 1e-6 slice: visiting a slice too many is harmless.
-  const double t = sqrt(f.thr2) * (1.0 + 1e-9) + 1e-12;
   const int iz = c % 3 - 1;
-  const double zc = (double)(int)(f.q2 + (double)iz);
-  const double a = ((f.q2 - t) + 0.5 - zc) * (double)SGTD_ZSLICES - 1e-6;
-  const double b = ((f.q2 + t) + 0.5 - zc) * (double)SGTD_ZSLICES + 1e-6;
-  const int s_lo = a <= 0.0 ? 0 : (a >= (double)SGTD_ZSLICES ? SGTD_ZSLICES : (int)a);          // floor, clamped to [0, 4]
-  const int s_hi = b < 0.0 ? -1 : (b >= (double)SGTD_ZSLICES ? SGTD_ZSLICES - 1 : (int)b);      // floor, clamped to [-1, 3]
+  int s_lo = SGTD_ZSLICES, s_hi = -1;
+  bool live = false;
+  DescPlan<K> pl;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const bool lv = lane < SGTD_NRANGE && ((f.gate[k] >> c) & 1u);
+    // slices of cell z = (int)(q2 + iz) reached by [q2 - t, q2 + t]; slice s holds the entries with
+    // (side2 + 0.5 - z) * 4 in [s, s + 1).  t carries a relative margin over the exact threshold
+    // and the bounds another 1e-6 slice: visiting a slice too many is harmless.
+    const double t = sqrt(f.thr2[k]) * (1.0 + 1e-9) + 1e-12;
+    const double zc = (double)(int)(f.q2[k] + (double)iz);
+    const double a = ((f.q2[k] - t) + 0.5 - zc) * (double)SGTD_ZSLICES - 1e-6;
+    const double b = ((f.q2[k] + t) + 0.5 - zc) * (double)SGTD_ZSLICES + 1e-6;
+    const int lo_k = a <= 0.0 ? 0 : (a >= (double)SGTD_ZSLICES ? SGTD_ZSLICES : (int)a);          // floor, clamped to [0, 4]
+    const int hi_k = b < 0.0 ? -1 : (b >= (double)SGTD_ZSLICES ? SGTD_ZSLICES - 1 : (int)b);      // floor, clamped to [-1, 3]
+    if (lv && hi_k >= lo_k) { s_lo = min(s_lo, lo_k); s_hi = max(s_hi, hi_k); }
+    live |= lv;
+    // the reference's loop visits every entry of every gated cell: cum4 of the even lanes
+    pl.ref_visits[k] = wave_sum((lv && !odd) ? ny : 0u);
+  }
   // cum before slice s (s = 0..4): 0, cum0, cum1, cum2, cum3; even lanes only
   const u32 cum3 = nx;
   const u32 before_lo = s_lo == 0 ? 0u : (s_lo == 1 ? f.row.y : (s_lo == 2 ? f.row.z : (s_lo == 3 ? f.row.w : cum3)));
@@ -310,68 +328,72 @@ __device__ __forceinline__ DescPlan plan_from_group_row(const DescFetch &f) {
   }
   len = live ? len : 0u;
   const u32 inc = wave_incl_scan(len);
-  DescPlan pl;
   pl.off = inc - len;          // lanes >= 54 add nothing: they hold the total
   pl.dl = start - pl.off;      // start[r] - off[r]
-  // the reference's loop visits every entry of every gated cell: cum4 of the even lanes
-  pl.ref_visits = wave_sum((live && !odd) ? ny : 0u);
   return pl;
 }
 
-// STDesc.cpp:372-399 for ONE query descriptor d by one wavefront: streams the
-// descriptor's visit list, tests, compacts the matches in visit order.
-// WIDE = false: the probe layout and the record buffer are each below 4 GB, so entry and
-// record addresses are a uniform base + a 32-bit byte offset (no quarter-rate 64-bit VALU
-// address arithmetic per entry); the host picks the variant from the buffer sizes
-template <bool DIAG, bool WIDE = true>
-__device__ __forceinline__ void sweep_descriptor(const TableView &T, const ProbeBuffers &B, double rough,
-                                                 const DescFetch &f, const DescPlan &pl,
-                                                 WaveSlab &slab, DescResult &result, PendingLoads pending) {
+// STDesc.cpp:372-399 for K query descriptors of one home cell by one wavefront: streams the
+// (union) visit list once, tests every entry against each descriptor, compacts each
+// descriptor's matches in visit order into its own list.
+// WIDE = false: the probe layout is below 4 GB, so entry addresses are a uniform base + a
+// 32-bit byte offset (no quarter-rate 64-bit VALU address arithmetic per entry); the host
+// picks the variant from the table size.  Record addresses are a wave-uniform list base + a
+// 32-bit lane offset either way.
+template <bool DIAG, bool WIDE, int K>
+__device__ __forceinline__ void sweep_descriptors(const TableView &T, const ProbeBuffers &B, double rough,
+                                                  const DescSet<K> &f, const DescPlan<K> &pl,
+                                                  WaveSlab &slab, DescResult (&result)[K], PendingLoads pending) {
+  static_assert(!DIAG || K == 1, "the diagnostic sweep takes one descriptor at a time");
   const int lane = lane_id();
-  const float q0f = (float)f.q0, q1f = (float)f.q1, q2f = (float)f.q2;
-  const float lo2 = f.lo2, hi2 = f.hi2;
-  const u32 qframe = f.qframe;
-  const double thr = DIAG ? norm3(f.q0, f.q1, f.q2) * rough : 0.0;   // :356-357
+  float q0f[K], q1f[K], q2f[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) { q0f[k] = (float)f.q0[k]; q1f[k] = (float)f.q1[k]; q2f[k] = (float)f.q2[k]; }
+  const double thr = DIAG ? norm3(f.q0[0], f.q1[0], f.q2[0]) * rough : 0.0;   // :356-357
   const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_WAVE - 1);
   const u32 dl = pl.dl;
   u64 ph_t = PH_T(); (void)ph_t;
-  // records of one descriptor are contiguous: make sure the slab can take
-  // the worst case (every visited entry matches)
-  if (total && (u64)slab.next + total > (u64)slab.end) {
-    // a slab must have room for the worst case of a descriptor (every visit matches) when
-    // the descriptor starts, but only the matches stay: slabs of 8 worst cases keep the space
-    // abandoned at a slab's end to about an eighth however long the visit lists are
-    const u32 take = total > (1u << 28) ? total : max(SGTD_REC_SLAB, 8u * total);
-    u64 got = 0;
-    if (lane == 0) got = atomicAdd(B.rec_cursor, (unsigned long long)take);
-    got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
-    if (got + take <= (u64)B.rec_cap) { slab.next = (u32)got; slab.end = (u32)got + take; }
-    else { slab.next = 0; slab.end = 0; }      // the buffer is exhausted: nothing of this wave fits any more
+  // records of one descriptor are contiguous: make sure its stream's slab can take the worst
+  // case (every visited entry matches)
+  bool fits = true;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    if (total && (u64)slab.next[k] + total > (u64)slab.end[k]) {
+      // a slab must have room for the worst case of a descriptor (every visit matches) when
+      // the descriptor starts, but only the matches stay: slabs of 8 worst cases keep the space
+      // abandoned at a slab's end to about an eighth however long the visit lists are
+      const u32 take = total > (1u << 28) ? total : max(SGTD_REC_SLAB, 8u * total);
+      u64 got = 0;
+      if (lane == 0) got = atomicAdd(B.rec_cursor, (unsigned long long)take);
+      got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
+      if (got + take <= (u64)B.rec_cap) { slab.next[k] = (u32)got; slab.end[k] = (u32)got + take; }
+      else { slab.next[k] = 0; slab.end[k] = 0; }      // the buffer is exhausted: nothing of this stream fits any more
+    }
+    fits = fits && ((u64)slab.next[k] + total <= (u64)slab.end[k]);
   }
-  const bool fits = (u64)slab.next + total <= (u64)slab.end;
   if (!fits && lane == 0) B.overflow[0] = 1;
   __builtin_amdgcn_wave_barrier();
   PH_ADD(0, ph_t);
 
-  u32 matches = 0;
+  u32 matches[K];
+  u32 *list_frame[K], *list_g[K];   // wave-uniform
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    matches[k] = 0;
+    list_frame[k] = B.rec_frame + slab.next[k];
+    list_g[k] = B.rec_g + slab.next[k];
+  }
   const u32 n_words = (total + 63u) >> 6;
   slab.swept += total;
-  u32 *const list_frame = B.rec_frame + slab.next, *const list_g = B.rec_g + slab.next;   // wave-uniform
 #ifdef SGTD_EXP_PHASE
   if (lane == 0 && n_words) {
     atomicAdd(&g_words[0], (unsigned long long)n_words);
     atomicAdd(&g_words[1], (unsigned long long)((n_words + SGTD_PROBE_UNROLL - 1) / SGTD_PROBE_UNROLL));
   }
 #endif
-  // position -> range: the last r with off[r] <= pos (empty ranges share their successor's
-  // offset and are stepped over).  The offsets are wave-uniform values held one per lane, and a
-  // word of 64 consecutive positions crosses only a few range boundaries: a SCALAR cursor walks
-  // the boundaries (v_readlane of the next offset, scalar compare with the word's last position)
-  // and every boundary inside the word costs the lanes one compare + select — no LDS permutes,
-  // no dependent per-lane search.  The cursor only moves forward over the descriptor's words.
-  int rcur = 0;                                                                   // current range
-  u32 off_next = (u32)__builtin_amdgcn_readlane((int)pl.off, 1);                  // off[rcur + 1]
-  u32 dl_cur = (u32)__builtin_amdgcn_readlane((int)dl, 0);                        // dl[rcur]
+  // position -> range, the last r with off[r] <= pos (empty ranges share their successor's
+  // offset and are stepped over): the offsets are held one per lane (off[54..63] = total) and
+  // read by ds_bpermute — no memory.  All lanes execute the permutes (sources must be active).
   // one load group: NW words located, their loads issued back to back, then tested.  NW is a
   // compile-time count: each group size is straight-line code (branches around loads would
   // make the compiler wait for earlier loads before every later one).
@@ -379,35 +401,13 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
     constexpr int NW = decltype(nw_tag)::value;
     float4 v[NW];
     u32 gg[NW];
-    int rng[NW];
+    u32 c4v[NW];      // 4 * range of the lane's entry
     bool valid[NW];
 #pragma unroll
     for (int u = 0; u < NW; u++) {
-      const u32 wbase = (w0 + u) << 6;
-      const u32 pos = wbase + lane;
-      const u32 wend = wbase + 63u;
+      const u32 pos = ((w0 + u) << 6) + lane;
       valid[u] = pos < total;
-#if SGTD_LOCATE == 1
-      // scalar cursor: every boundary inside the word costs the lanes one compare + select
-      u32 dsel = dl_cur;
-      int r = rcur;
-      while (rcur < SGTD_WAVE - 2 && off_next <= wend) {    // wave-uniform: a boundary inside this word
-        rcur++;
-        dl_cur = (u32)__builtin_amdgcn_readlane((int)dl, rcur);
-        const bool past = pos >= off_next;
-        dsel = past ? dl_cur : dsel;
-        if (DIAG) r = past ? rcur : r;
-        off_next = (u32)__builtin_amdgcn_readlane((int)pl.off, rcur + 1);
-      }
-#elif SGTD_LOCATE == 2
-      // timing experiment only (wrong results): no per-lane range
-      (void)wend;
-      const u32 dsel = dl_cur;
-      const int r = rcur;
-#else
-      // branch-free binary search over the 64 offsets held one per lane (off[54..63] = total):
-      // six ds_bpermute steps, then one more for the range's start
-      (void)wend;
+      // branch-free binary search over the 64 offsets: six ds_bpermute steps, one more for the start
       u32 c4 = 0;
 #pragma unroll
       for (int sh = 128; sh >= 4; sh >>= 1) {
@@ -415,9 +415,7 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
         c4 += (t <= pos) ? (u32)sh : 0u;
       }
       const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
-      const int r = (int)(c4 >> 2);
-#endif
-      rng[u] = r;
+      c4v[u] = c4;
       const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
       const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + e)
                               : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(T.ent) + (e << 4));
@@ -433,63 +431,68 @@ __device__ __forceinline__ void sweep_descriptor(const TableView &T, const Probe
 #pragma unroll
     for (int u = 0; u < NW; u++) {
       const u32 fr = __float_as_uint(v[u].w);
-      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-      const bool cand = valid[u] && (qframe != fr);
-      bool hit, amb = false;
-      double dis = 0.0;
-      if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
-        hit = false;
-        if (cand) {
-          const double *sp = T.cold_side + (size_t)gg[u] * 3;
-          const double ex = f.q0 - sp[0], ey = f.q1 - sp[1], ez = f.q2 - sp[2];
-          dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
-          hit = dis < thr;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373); for a pair the
+        // entry's cell must also pass this descriptor's own gate (bit c4 >> 3 of its mask)
+        bool cand = valid[u] && (f.qframe[k] != fr);
+        if (K > 1) cand = cand && ((f.gate[k] >> (c4v[u] >> 3)) & 1u);
+        bool hit, amb = false;
+        double dis = 0.0;
+        if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
+          hit = false;
+          if (cand) {
+            const double *sp = T.cold_side + (size_t)gg[u] * 3;
+            const double ex = f.q0[k] - sp[0], ey = f.q1[k] - sp[1], ez = f.q2[k] - sp[2];
+            dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
+            hit = dis < thr;
+          }
+        } else {
+          const float dx = q0f[k] - v[u].x, dy = q1f[k] - v[u].y, dz = q2f[k] - v[u].z;
+          const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          hit = cand && !(d2 > f.hi2[k]);       // not certainly outside (NaN stays in)
+          amb = hit && !(d2 < f.lo2[k]);        // not certainly inside either: provisional
         }
-      } else {
-        const float dx = q0f - v[u].x, dy = q1f - v[u].y, dz = q2f - v[u].z;
-        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        hit = cand && !(d2 > hi2);            // not certainly outside (NaN stays in)
-        amb = hit && !(d2 < lo2);             // not certainly inside either: provisional
-      }
-      const u64 m = __ballot(hit);
-      const u32 k = matches + (u32)__popcll(m & lanemask_lt());
-      if (hit && fits) {
-        // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
-        *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_frame) + (k << 2)) = fr;
-        *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_g) + (k << 2)) = gg[u];
-        if (DIAG) { B.rec_cell[(size_t)slab.next + k] = (unsigned char)(rng[u] >> 1); B.rec_dis[(size_t)slab.next + k] = dis; }
-      }
-      if (!DIAG && __ballot(amb)) {   // rare: about one in 10^4 matches
-        if (amb && fits) {
-          const u32 at = atomicAdd(B.amb_count, 1u);
-          if (at < B.amb_cap) B.amb_queue[at] = make_uint2(slab.next + k, f.slot);
-          else B.overflow[0] = 1;    // re-run with a larger queue (grows with the record buffer)
+        const u64 m = __ballot(hit);
+        const u32 at = matches[k] + (u32)__popcll(m & lanemask_lt());
+        if (hit && fits) {
+          // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
+          *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_frame[k]) + (at << 2)) = fr;
+          *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_g[k]) + (at << 2)) = gg[u];
+          if (DIAG) { B.rec_cell[(size_t)slab.next[k] + at] = (unsigned char)(c4v[u] >> 3); B.rec_dis[(size_t)slab.next[k] + at] = dis; }
         }
+        if (!DIAG && __ballot(amb)) {   // rare: about one in 10^4 matches
+          if (amb && fits) {
+            const u32 qa = atomicAdd(B.amb_count, 1u);
+            if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.next[k] + at, f.slot[k]);
+            else B.overflow[0] = 1;    // re-run with a larger queue (grows with the record buffer)
+          }
+        }
+        matches[k] += __popcll(m);
       }
-      matches += __popcll(m);
     }
     PH_ADD(3, ph_t);
   };
-  // full groups of SGTD_PROBE_UNROLL words, then one group of what is left
+  // full groups of SGTD_PROBE_UNROLL words, then what is left in groups of 2 and 1
   {
     u32 w0 = 0;
     for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL) {
       group(std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
       if (w0 == 0) pending.touch();
     }
-    switch (n_words - w0) {   // wave-uniform
-      case 1: group(std::integral_constant<int, 1>{}, w0); break;
-      case 2: group(std::integral_constant<int, 2>{}, w0); break;
-      case 3: group(std::integral_constant<int, 3>{}, w0); break;
-      default: break;
-    }
-    if (w0 == 0 && n_words) pending.touch();
+    const bool touched = w0 != 0;
+    const u32 left = n_words - w0;   // wave-uniform
+    if (left & 2u) { group(std::integral_constant<int, 2>{}, w0); w0 += 2; }
+    if (left & 1u) { group(std::integral_constant<int, 1>{}, w0); w0 += 1; }
+    if (!touched) pending.touch();   // every path through the sweep leaves them complete
   }
-  static_assert(SGTD_PROBE_UNROLL == 4, "the remainder switch covers group sizes 1..3");
-  if (n_words == 0) pending.touch();   // every path through the sweep leaves them complete
-  if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches);
-  result.ptr = slab.next; result.visit = pl.ref_visits; result.match = fits ? matches : 0;
-  if (fits) slab.next += matches;
+  static_assert(SGTD_PROBE_UNROLL == 4, "remainder groups cover 2 and 1 words");
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches[k]);
+    result[k].ptr = slab.next[k]; result[k].visit = pl.ref_visits[k]; result[k].match = fits ? matches[k] : 0;
+    if (fits) slab.next[k] += matches[k];
+  }
   __builtin_amdgcn_wave_barrier();
   PH_ADD(4, ph_t);
 }
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   tq.xcc = xcc & 7u;
   tq.select(0);
-  WaveSlab slab{0, 0, 0};
+  WaveSlab slab{};
 #ifdef SGTD_EXP_PHASE
   for (int i = 0; i < 8; i++) slab.ph[i] = 0;
   const u64 ph_start = PH_T();
@@ -593,30 +596,54 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
     // header on either edge (the next rows are touched inside the sweep)
     asm volatile("" : "+v"(row_next.x), "+v"(row_next.y), "+v"(row_next.z), "+v"(row_next.w));
     u32 r_ptr = 0, r_visit = 0, r_match = 0;   // lane i: results of descriptor i of the chunk
-    for (u32 i = 0; i < n; i++) {
-      DescFetch f;
-      f.row = row_next;
-      if (i + 1 < n) {   // the next descriptor's GroupRow (often the same one)
-        const u32 g1 = (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * i + 6));
+    // descriptor i of the chunk -> its fields (records are 4 lanes each)
+    auto unpack = [&](auto &f, int k, u32 i) {
+      const int l0 = (int)(4 * i);
+      f.q0[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0), __builtin_amdgcn_readlane((int)rec.x, l0));
+      f.q1[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0), __builtin_amdgcn_readlane((int)rec.z, l0));
+      f.q2[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0 + 1), __builtin_amdgcn_readlane((int)rec.x, l0 + 1));
+      f.thr2[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0 + 1), __builtin_amdgcn_readlane((int)rec.z, l0 + 1));
+      f.qframe[k] = (u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 2);
+      f.gate[k] = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
+      f.slot[k] = (u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
+      f.lo2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 3));
+      f.hi2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 3));
+    };
+    for (u32 i = 0; i < n;) {
+      // two consecutive descriptors of one home cell are swept together (one plan, one locate and
+      // one load per 64 entries for both); the diagnostic build takes them one by one
+      const bool pair = !DIAG && i + 1 < n &&
+                        (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * i + 6)) == g_cur;
+      const u32 step = pair ? 2u : 1u;
+      const uint4 row = row_next;
+      if (i + step < n) {   // the GroupRow after this step (often the same one)
+        const u32 g1 = (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * (i + step) + 2));
         if (g1 != g_cur) row_next = load_row(g1);
         g_cur = g1;
       }
-      const int l0 = (int)(4 * i);
-      f.q0 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0), __builtin_amdgcn_readlane((int)rec.x, l0));
-      f.q1 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0), __builtin_amdgcn_readlane((int)rec.z, l0));
-      f.q2 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0 + 1), __builtin_amdgcn_readlane((int)rec.x, l0 + 1));
-      f.thr2 = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0 + 1), __builtin_amdgcn_readlane((int)rec.z, l0 + 1));
-      f.qframe = (u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 2);
-      f.gate = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
-      f.slot = (u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
-      f.lo2 = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 3));
-      f.hi2 = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 3));
-      DescResult res;
       PendingLoads pend;
       pend.row = &row_next;
       pend.rec = &rec_next;
-      sweep_descriptor<DIAG, WIDE>(T, B, rough, f, plan_from_group_row(f), slab, res, pend);
-      if ((u32)lane == i) { r_ptr = res.ptr; r_visit = res.visit; r_match = res.match; }
+      if (pair) {
+        if constexpr (!DIAG) {
+          DescSet<2> f;
+          f.row = row;
+          unpack(f, 0, i);
+          unpack(f, 1, i + 1);
+          DescResult res[2];
+          sweep_descriptors<DIAG, WIDE, 2>(T, B, rough, f, plan_from_group_row<2>(f), slab, res, pend);
+          if ((u32)lane == i) { r_ptr = res[0].ptr; r_visit = res[0].visit; r_match = res[0].match; }
+          if ((u32)lane == i + 1) { r_ptr = res[1].ptr; r_visit = res[1].visit; r_match = res[1].match; }
+        }
+      } else {
+        DescSet<1> f;
+        f.row = row;
+        unpack(f, 0, i);
+        DescResult res[1];
+        sweep_descriptors<DIAG, WIDE, 1>(T, B, rough, f, plan_from_group_row<1>(f), slab, res, pend);
+        if ((u32)lane == i) { r_ptr = res[0].ptr; r_visit = res[0].visit; r_match = res[0].match; }
+      }
+      i += step;
     }
     {   // the chunk's results: lane i < n stores for its descriptor (slot d in quarter 2 of record i)
       const u32 d_mine = (u32)__shfl((int)rec.w, (4 * lane + 2) & 63);
