@@ -88,6 +88,8 @@ typedef struct sgtd_stats {
   int32_t reserved;
   int64_t last_P_swept;    /* table entries the sweep really loaded: last_P minus the
                               z-slices of the visited buckets that no match can lie in */
+  double bucket_len_sq_over_E; /* sum over buckets of len^2 / E: the bucket length a table entry
+                              sees on average (sizes the first batch's work buffers)        */
 } sgtd_stats;
 
 typedef struct sgtd_engine *sgtd_handle;
@@ -251,6 +253,13 @@ int sgtd_fetch_entries(sgtd_handle h, const int64_t *db_entry, int64_t n,
  * (code,x,y,z); bucket_off [U+1]; entry ids [E] in bucket order */
 int sgtd_table_dump(sgtd_handle h, int64_t *keys, int64_t *bucket_off,
                     int64_t *entry_ids, int64_t cap_buckets, int64_t cap_entries);
+
+/* Largest number of query frames of n_keypoints keypoints each that one sgtd_query_frames call
+ * should carry: the rough matches of a batch are indexed with 32 bits (more returns
+ * SGTD_ERR_CAPACITY) and their records must fit the device memory that is free now.  Uses the
+ * matches per query of the last batch when there is one, else an estimate from the table's
+ * bucket statistics; conservative by a factor of about two. */
+int sgtd_max_batch(sgtd_handle h, int n_keypoints, int64_t *max_queries);
 
 /* waits for the stream, re-runs the last batch with larger work buffers if it
  * overflowed them, and fills the counters */

@@ -20,7 +20,7 @@ ERRORS = {-8: "IO", -1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY",
 SYMBOLS = [
     "sgtd_default_config", "sgtd_create", "sgtd_destroy", "sgtd_strerror", "sgtd_last_error",
     "sgtd_set_stream", "sgtd_set_timing", "sgtd_current_frame_id", "sgtd_max_descs", "sgtd_build",
-    "sgtd_add", "sgtd_add_frames", "sgtd_finalize", "sgtd_query_frames", "sgtd_query_descs",
+    "sgtd_add", "sgtd_add_frames", "sgtd_finalize", "sgtd_query_frames", "sgtd_query_descs", "sgtd_max_batch",
     "sgtd_result_candidates", "sgtd_export_candidates_dev", "sgtd_result_query_desc_count", "sgtd_result_pairs",
     "sgtd_result_query_descs", "sgtd_result_votes", "sgtd_result_rough", "sgtd_fetch_entries",
     "sgtd_table_dump", "sgtd_sync", "sgtd_get_stats",
@@ -66,7 +66,7 @@ class Stats(C.Structure):
         ("ms_votes", C.c_float), ("ms_topk", C.c_float),
         ("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_write", C.c_float),
         ("ms_total", C.c_float), ("overflowed", C.c_int32), ("reserved", C.c_int32),
-        ("last_P_swept", C.c_int64),
+        ("last_P_swept", C.c_int64), ("bucket_len_sq_over_E", C.c_double),
     ]
 
 
@@ -132,6 +132,7 @@ def lib():
     L.sgtd_fetch_entries.argtypes = [vp, vp, i64, C.POINTER(DescSoa)]
     L.sgtd_table_dump.argtypes = [vp, vp, vp, vp, i64, i64]
     L.sgtd_sync.argtypes = [vp]
+    L.sgtd_max_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.sgtd_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sgtd_verify.argtypes = [vp]
     L.sgtd_result_verify.argtypes = [vp, C.c_int, vp, vp]

@@ -818,6 +818,22 @@ int sync_batch(sgtd_engine *e) {
 
 // A pending query batch keeps its inputs in the handle's staging buffers for a re-run after a
 // work-buffer overflow: anything that is about to reuse them settles the batch first.
+// Expected rough matches of one query frame of n_keypoints keypoints, before any batch has been
+// measured: a query descriptor distributed like the table's entries meets buckets of sum(len^2)/E
+// entries on average, visits about 19 gated cells of the 27 and matches about 0.15 of what it
+// visits (0.06 .. 0.31 on the synthetic maps of 100 k .. 1 k frames); about 62 % of the
+// 36 n_keypoints triplets survive the length filter and the dedup.
+double est_matches_per_query(const sgtd_engine *e, int n_keypoints) {
+  if (e->stats.last_queries > 0 && e->stats.last_D > 0 && e->nq > 0 && e->q_stride > 0) {
+    // measured: matches per descriptor slot of the last batch, scaled to this frame size
+    const double per_slot = (double)e->stats.last_M / ((double)e->stats.last_queries * (double)e->q_stride);
+    return per_slot * (double)n_keypoints * e->dc.tpi;
+  }
+  if (e->n_entries <= 0) return 0.0;
+  const double per_desc = 0.15 * 19.0 * e->sum_len_sq / (double)e->n_entries;
+  return 0.62 * (double)n_keypoints * e->dc.tpi * per_desc;
+}
+
 int settle_pending(sgtd_engine *e) {
   if (e->batch_valid && !e->batch_synced) return sync_batch(e);
   return SGTD_OK;
@@ -1094,6 +1110,16 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
   e->diag = false;   // a new batch runs the product sweep; sgtd_result_rough re-runs it in the diagnostic form
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride * n_queries));
   CHK(ensure(e, e->q_count, (size_t)n_queries * sizeof(u32)));
+  if (!e->rec_cap_fixed && e->stats.last_queries == 0) {
+    // first batch of this handle: size the match-record buffer from the table statistics instead
+    // of growing it through overflow re-runs (each costs a whole sweep)
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const double want = 1.3 * est_matches_per_query(e, max_n) * (double)n_queries;
+    const double cap_mem = (double)free_b / 4.0 / 17.0;    // records + compact list, a quarter of what is free
+    const size_t cap = (size_t)std::min(std::min(want, cap_mem), (double)0xFFFFFFF0ull);
+    if (cap > e->rec_cap) e->rec_cap = cap;
+  }
   return enqueue_frames(e);
 }
 
@@ -1118,6 +1144,20 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   HIPCHK(hipStreamSynchronize(e->stream));
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));
   return launch_select(e);
+}
+
+int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
+  if (!e || !max_queries || n_keypoints < 0) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(do_finalize(e));
+  const double per_query = std::max(1.0, est_matches_per_query(e, n_keypoints)) * 2.0;   // margin: slab slack, variation
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  // 17 B per record (records + compact list) on top of what the buffers already hold
+  const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->c_slot.bytes) / 17.0;
+  const double lim = std::min((double)0xFFFFFFF0ull, mem_records);
+  *max_queries = (int64_t)std::max(1.0, std::floor(lim / per_query));
+  return SGTD_OK;
 }
 
 int sgtd_sync(sgtd_handle e) {
@@ -1521,6 +1561,7 @@ int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
   e->stats.n_buckets = e->n_buckets;
   e->stats.n_frames = e->n_add_calls;
   e->stats.hbm_bytes_table = e->n_entries * (int64_t)SGTD_HOT_BYTES;
+  e->stats.bucket_len_sq_over_E = e->n_entries > 0 ? e->sum_len_sq / (double)e->n_entries : 0.0;
   *out = e->stats;
   return SGTD_OK;
 }

@@ -143,6 +143,12 @@ class STDescManager:
     def sync(self):
         self._check(self._L.sgtd_sync(self._h))
 
+    def max_batch(self, n_keypoints):
+        """largest safe number of query frames (of n_keypoints keypoints each) per query_frames call"""
+        n = C.c_int64(0)
+        self._check(self._L.sgtd_max_batch(self._h, int(n_keypoints), C.byref(n)))
+        return n.value
+
     # ---- BuildSingleScanSTD ----------------------------------------------
     def BuildSingleScanSTD(self, xyz, label):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

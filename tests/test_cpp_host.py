@@ -24,6 +24,37 @@ def _build():
     subprocess.check_call(cmd)
 
 
+SHIM_EXE = os.path.join(ROOT, "tests", "cpp", "test_shim")
+
+
+def _build_shim():
+    from sgtd_amd import _lib
+    _lib.build_library()
+    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", SHIM_EXE,
+           "-L" + os.path.join(ROOT, "sgtd_amd"), "-lsgtd_accel", "-Wl,-rpath," + os.path.join(ROOT, "sgtd_amd"),
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    subprocess.check_call(cmd)
+
+
+def test_reference_typed_shim_compiles_and_links():
+    """adapter/STDesc_shim.hpp instantiated with declarations shaped like the reference's
+    (Eigen-style vectors, PCL-style cloud pointer, the reference's struct names and method
+    signatures); without a GPU the program stops at SGTD_ERR_NO_DEVICE"""
+    _build_shim()
+    out = subprocess.run([SHIM_EXE], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "shim" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_typed_shim_runs_the_callers_loops():
+    _build_shim()
+    out = subprocess.run([SHIM_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "shim ok" in out.stdout
+
+
 def test_cpp_host_mirror_compiles():
     _build()
     assert os.path.exists(EXE)
