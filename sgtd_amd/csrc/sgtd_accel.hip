@@ -740,6 +740,29 @@ int rerun(sgtd_engine *e) {
   return launch_select(e);
 }
 
+// the candidate-pair buffer was too small: everything up to the per-block counts is intact,
+// only the output offsets and the write pass run again
+int rerun_write(sgtd_engine *e) {
+  const int nq = e->nq, cn = e->dc.cand_num;
+  const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
+  const int groups = (blocks + 3) / 4;
+  const int agrid = ((nq + 7) / 8) * groups * 8;
+  CHK(ensure(e, e->pairs, e->pair_cap * sizeof(u64)));
+  HIPCHK(hipMemsetAsync(e->overflow.as<int>() + 1, 0, sizeof(int), e->stream));
+  Views v = make_views(e);
+  CompactLists CL;
+  CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
+  CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
+  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = v.B.rec_cap;
+  query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
+                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
+  HIPCHK(hipGetLastError());
+  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL, blocks, e->blk_count.as<u32>(), cn,
+                                                    e->pair_off.as<long long>(), e->q_pair_base.as<u32>(), e->pairs.as<u64>());
+  HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
 int sync_batch(sgtd_engine *e) {
   if (!e->batch_valid) return SGTD_ERR_STATE;
   if (e->batch_synced) return SGTD_OK;
@@ -777,6 +800,8 @@ int sync_batch(sgtd_engine *e) {
     } else if (ovf[1]) {
       if (e->pair_cap >= lim) return SGTD_ERR_CAPACITY;
       e->pair_cap = std::min<size_t>(lim, std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536));
+      CHK(rerun_write(e));
+      continue;
     }
     CHK(rerun(e));
   }
@@ -952,6 +977,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }
+  if (const char *o = getenv("SGTD_PAIR_CAP")) { e->pair_cap = (size_t)std::max(64ll, atoll(o)); e->rec_cap_fixed = true; }
   for (int i = 0; i < EV_COUNT; i++)
     if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
   *out = e;
@@ -1119,6 +1145,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
     const double cap_mem = (double)free_b / 4.0 / 17.0;    // records + compact list, a quarter of what is free
     const size_t cap = (size_t)std::min(std::min(want, cap_mem), (double)0xFFFFFFF0ull);
     if (cap > e->rec_cap) e->rec_cap = cap;
+    if (cap / 2 > e->pair_cap) e->pair_cap = cap / 2;   // candidate pairs: 0.2 .. 0.5 of the matches
   }
   return enqueue_frames(e);
 }

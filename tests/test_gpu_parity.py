@@ -631,6 +631,16 @@ def test_overflowed_batch_is_resolved_before_the_sharded_export(mods, monkeypatc
         assert np.array_equal(frames[q, :nc].cpu().numpy(), res.cand_frame[q, :nc])
         assert np.array_equal(votes[q, :nc].cpu().numpy(), res.cand_votes[q, :nc])
     assert np.array_equal(bf.cpu().numpy(), gf) and np.array_equal(bs.cpu().numpy(), gs)
+    # a candidate-pair buffer that is too small re-runs only the write pass
+    monkeypatch.setenv("SGTD_PAIR_CAP", "256")
+    p = manager.STDescManager()
+    p.add_frames(m.xyz, m.label)
+    pres = p.query_frames(qs.xyz, qs.label)
+    assert p.stats()["overflowed"] == 1
+    for q in range(8):
+        assert np.array_equal(pres.pair_off[q], res.pair_off[q])
+        a, b = p.result_pairs(q, pres), g.result_pairs(q, res)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 # ---------------------------------------------------------------------------
