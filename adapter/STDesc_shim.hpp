@@ -103,6 +103,21 @@ void from_soa(const SoaBuf &b, size_t n, std::vector<Desc> &out) {
 }
 
 // ---- constructor body (STDesc.h:359-365): ConfigSetting -> sgtd_config -------------------
+// device_ids: the GPUs of this node the table is sharded over (one id = an ordinary handle)
+template <class Config>
+int create(const Config &cs, int max_frame_n, sgtd_handle *out, const std::vector<int> &device_ids) {
+  sgtd_config c;
+  sgtd_default_config(&c);
+  c.descriptor_near_num = cs.descriptor_near_num_;
+  c.descriptor_min_len = cs.descriptor_min_len_;
+  c.descriptor_max_len = cs.descriptor_max_len_;
+  c.std_side_resolution = cs.std_side_resolution_;
+  c.candidate_num = cs.candidate_num_;
+  c.rough_dis_threshold = cs.rough_dis_threshold_;
+  c.max_frame_n = max_frame_n;
+  return sgtd_create_multi(&c, device_ids.data(), (int)device_ids.size(), out);
+}
+
 template <class Config>
 int create(const Config &cs, int max_frame_n, sgtd_handle *out, int device_id = 0) {
   sgtd_config c;

@@ -112,7 +112,12 @@ int main(int argc, char **argv) {
   sgtd_default_config(&cfg);                                 // SG_localization.yaml:74-89
   if (map.n + 1 > cfg.max_frame_n) cfg.max_frame_n = map.n + 1;
   sgtd_handle h = nullptr;
-  OK(sgtd_create(&cfg, &h));
+  // SGTD_DEVICES=0,1,...: the table sharded over several GPUs of this node behind the one handle
+  std::vector<int> devices;
+  if (const char *dv = std::getenv("SGTD_DEVICES"))
+    for (const char *p = dv; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+  if (devices.empty()) devices.push_back(0);
+  OK(sgtd_create_multi(&cfg, devices.data(), (int)devices.size(), &h));
   OK(sgtd_add_frames(h, map.xyz, map.label, map.off, map.n, 0));   // :419-458
   OK(sgtd_finalize(h));
   auto t2 = std::chrono::steady_clock::now();
@@ -169,8 +174,8 @@ int main(int argc, char **argv) {
   std::printf("map frames %d, queries %ld: loops %ld, success(5m,10deg) %ld (%.4f), candidate<10m %ld, top-1 hit %ld\n", map.n,
               total_num, detected, score_num, total_num ? (double)score_num / total_num : 0.0, test_10, STD_num[0]);
   std::printf("mean errors of the successes: %.4f m, %.4f deg\n", score_num ? err_t / score_num : 0.0, score_num ? err_r / score_num : 0.0);
-  std::printf("time: load %.1f ms, map build %.1f ms, queries %.1f ms (%.3f ms per query incl. verification)\n", ms(t0, t1), ms(t1, t2),
-              ms(t2, t3), total_num ? ms(t2, t3) / total_num : 0.0);
+  std::printf("time: load %.1f ms, map build %.1f ms, queries %.1f ms (%.3f ms per query incl. verification), %d device(s)\n", ms(t0, t1), ms(t1, t2),
+              ms(t2, t3), total_num ? ms(t2, t3) / total_num : 0.0, sgtd_device_count(h));
   sgtd_destroy(h);
   sgtd_graphs_free(map.b);
   sgtd_graphs_free(qs.b);

@@ -81,6 +81,7 @@ struct ConfigSetting {
   double icp_threshold_ = 0.5;          // STDesc.h:68 (SG_localization.yaml:89 ships 0.4)
   int max_frame_n_ = 20000;   // MAX_FRAME_N (STDesc.h:33)
   int device_id_ = 0;
+  std::vector<int> device_ids_;   // several ids: the table sharded over these GPUs behind the one manager
 };
 
 class STDescManager {
@@ -90,7 +91,8 @@ class STDescManager {
   unsigned int current_frame_id_ = 0;  // STDesc.h:350
 
   explicit STDescManager(const ConfigSetting &cfg) : config_setting_(cfg) {
-    status_ = sgtd_shim::create(cfg, cfg.max_frame_n_, &h_, cfg.device_id_);
+    status_ = cfg.device_ids_.empty() ? sgtd_shim::create(cfg, cfg.max_frame_n_, &h_, cfg.device_id_)
+                                      : sgtd_shim::create(cfg, cfg.max_frame_n_, &h_, cfg.device_ids_);
     if (status_ != SGTD_OK)   // the reference's constructor cannot fail; a missing device is fatal here
       throw std::runtime_error(std::string("sgtd_create: ") + sgtd_strerror(status_));
   }

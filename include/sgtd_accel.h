@@ -96,6 +96,23 @@ typedef struct sgtd_engine *sgtd_handle;
 
 void sgtd_default_config(sgtd_config *cfg);
 int sgtd_create(const sgtd_config *cfg, sgtd_handle *out);
+/* One handle over several GPUs of this process: map frames are dealt to the
+ * devices in blocks of 64 consecutive frames, round robin; every device holds a complete table
+ * for its frames; a query batch is swept on all devices concurrently and the per-device
+ * top-candidate_num tables are merged on the host with the reference's rule (votes descending,
+ * ties -> lowest frame id, STDesc.cpp:423-433) — the single-table result.  Match lists, entries
+ * and sgtd_verify stay with the owning device and are fetched from it; db_entry ids of such a
+ * handle are opaque (owner in the upper bits) and valid for sgtd_fetch_entries only.
+ * Host pointers only (device_ptrs must be 0); sgtd_add takes descriptors stamped with the
+ * current frame id (what sgtd_build stamps).  Not available on it: sgtd_set_stream,
+ * sgtd_export_*_dev, sgtd_result_rough, sgtd_table_dump, sgtd_save_table / sgtd_load_table
+ * (SGTD_ERR_UNSUPPORTED).  n_dev == 1 gives an ordinary handle on device_ids[0];
+ * cfg->device_id is ignored, cfg->first_frame_id must be a multiple of 64 * n_dev. */
+int sgtd_create_multi(const sgtd_config *cfg, const int *device_ids, int n_dev, sgtd_handle *out);
+/* devices behind the handle (1 for an ordinary handle) and the per-device engine k (borrowed;
+ * e.g. for per-device sgtd_get_stats) */
+int sgtd_device_count(sgtd_handle h);
+sgtd_handle sgtd_device_handle(sgtd_handle h, int k);
 int sgtd_destroy(sgtd_handle h);
 const char *sgtd_strerror(int status);
 /* text of the last HIP failure on this handle ("" if none) */

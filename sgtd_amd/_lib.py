@@ -18,7 +18,7 @@ ERRORS = {-8: "IO", -1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY",
 
 # every symbol include/sgtd_accel.h declares
 SYMBOLS = [
-    "sgtd_default_config", "sgtd_create", "sgtd_destroy", "sgtd_strerror", "sgtd_last_error",
+    "sgtd_default_config", "sgtd_create", "sgtd_create_multi", "sgtd_device_count", "sgtd_device_handle", "sgtd_destroy", "sgtd_strerror", "sgtd_last_error",
     "sgtd_set_stream", "sgtd_set_timing", "sgtd_current_frame_id", "sgtd_max_descs", "sgtd_build",
     "sgtd_add", "sgtd_add_frames", "sgtd_finalize", "sgtd_query_frames", "sgtd_query_descs", "sgtd_max_batch",
     "sgtd_result_candidates", "sgtd_export_candidates_dev", "sgtd_result_query_desc_count", "sgtd_result_pairs",
@@ -107,6 +107,10 @@ def lib():
     L.sgtd_default_config.restype = None
     L.sgtd_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.sgtd_destroy.argtypes = [vp]
+    L.sgtd_create_multi.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.sgtd_device_count.argtypes = [vp]
+    L.sgtd_device_handle.argtypes = [vp, C.c_int]
+    L.sgtd_device_handle.restype = vp
     L.sgtd_strerror.argtypes = [C.c_int]
     L.sgtd_strerror.restype = C.c_char_p
     L.sgtd_last_error.argtypes = [vp]

@@ -44,7 +44,10 @@ enum { EV_START = 0, EV_BUILD, EV_SORT, EV_PROBE, EV_VOTES, EV_TOPK, EV_COUNT_T,
 
 }  // namespace
 
+namespace multi { struct Group; }
+
 struct sgtd_engine {
+  multi::Group *grp = nullptr;   // set: this handle is a group of per-device engines (multi.hip.h)
   sgtd_config cfg;
   DevCfg dc;
   hipStream_t stream = nullptr;
@@ -110,6 +113,8 @@ struct sgtd_engine {
   std::vector<long long> h_pair_off;
   sgtd_stats stats{};
 };
+
+#include "multi.hip.h"
 
 namespace {
 
@@ -984,7 +989,25 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   return SGTD_OK;
 }
 
+int sgtd_create_multi(const sgtd_config *cfg, const int *device_ids, int n_dev, sgtd_handle *out) {
+  if (n_dev == 1 && cfg && device_ids && out) {   // one device: the ordinary handle
+    sgtd_config c = *cfg;
+    c.device_id = device_ids[0];
+    return sgtd_create(&c, out);
+  }
+  return multi::create(cfg, device_ids, n_dev, out);
+}
+
+int sgtd_device_count(sgtd_handle e) { return !e ? 0 : (e->grp ? multi::device_count(e) : 1); }
+
+sgtd_handle sgtd_device_handle(sgtd_handle e, int k) {
+  if (!e) return nullptr;
+  if (!e->grp) return k == 0 ? e : nullptr;
+  return multi::device_handle(e, k);
+}
+
 int sgtd_destroy(sgtd_handle e) {
+  if (e && e->grp) return multi::destroy(e);
   if (!e) return SGTD_OK;
   (void)hipSetDevice(e->cfg.device_id);
   (void)hipStreamSynchronize(e->stream);
@@ -1006,30 +1029,35 @@ int sgtd_destroy(sgtd_handle e) {
 }
 
 int sgtd_set_stream(sgtd_handle e, void *hip_stream) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e) return SGTD_ERR_INVALID;
   e->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return SGTD_OK;
 }
 
 int sgtd_set_timing(sgtd_handle e, int enabled) {
+  if (e && e->grp) { for (int k = 0; k < sgtd_device_count(e); k++) sgtd_set_timing(sgtd_device_handle(e, k), enabled); return SGTD_OK; }
   if (!e) return SGTD_ERR_INVALID;
   e->timing = enabled != 0;
   return SGTD_OK;
 }
 
 int sgtd_current_frame_id(sgtd_handle e, uint32_t *out) {
+  if (e && e->grp && out) { *out = multi::current_frame_id(e); return SGTD_OK; }
   if (!e || !out) return SGTD_ERR_INVALID;
   *out = e->current_frame_id;
   return SGTD_OK;
 }
 
 int64_t sgtd_max_descs(sgtd_handle e, int n_keypoints) {
+  if (e && e->grp) return (int64_t)n_keypoints * ((e->cfg.descriptor_near_num - 1) * (e->cfg.descriptor_near_num - 2) / 2);
   if (!e || n_keypoints < 0) return 0;
   return (int64_t)n_keypoints * e->dc.tpi;
 }
 
 int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sgtd_desc_soa *out,
                int64_t capacity, int64_t *n_out) {
+  if (e && e->grp) return multi::build(e, xyz, label, n, out, capacity, n_out);
   if (!e || !out || !n_out || n < 0 || (n > 0 && (!xyz || !label))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   *n_out = 0;
@@ -1052,6 +1080,7 @@ int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sg
 }
 
 int sgtd_add(sgtd_handle e, const sgtd_desc_soa *d, int64_t n) {
+  if (e && e->grp) return multi::add(e, d, n);
   if (!e || n < 0 || (n > 0 && (!d || !d->side || !d->label || !d->frame))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   u32 lo = 0xFFFFFFFFu, hi = 0;
@@ -1075,6 +1104,7 @@ int sgtd_add(sgtd_handle e, const sgtd_desc_soa *d, int64_t n) {
 
 int sgtd_add_frames(sgtd_handle e, const float *xyz, const uint32_t *label, const int64_t *kp_off,
                     int n_frames, int device_ptrs) {
+  if (e && e->grp) return multi::add_frames(e, xyz, label, kp_off, n_frames, device_ptrs);
   if (!e || n_frames < 0 || !kp_off) return SGTD_ERR_INVALID;
   if (n_frames == 0) return SGTD_OK;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1117,6 +1147,7 @@ int sgtd_add_frames(sgtd_handle e, const float *xyz, const uint32_t *label, cons
 }
 
 int sgtd_finalize(sgtd_handle e) {
+  if (e && e->grp) return multi::finalize(e);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   return do_finalize(e);
@@ -1124,6 +1155,7 @@ int sgtd_finalize(sgtd_handle e) {
 
 int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, const int64_t *kp_off,
                       int n_queries, int device_ptrs) {
+  if (e && e->grp) return multi::query_frames(e, xyz, label, kp_off, n_queries, device_ptrs);
   if (!e || n_queries <= 0 || !kp_off || !xyz || !label) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(do_finalize(e));
@@ -1151,6 +1183,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
 }
 
 int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
+  if (e && e->grp) return multi::query_descs(e, q, nq);
   if (!e || nq < 0 || (nq > 0 && (!q || !q->side || !q->label || !q->frame))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(do_finalize(e));
@@ -1174,6 +1207,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
 }
 
 int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
+  if (e && e->grp) return multi::max_batch(e, n_keypoints, max_queries);
   if (!e || !max_queries || n_keypoints < 0) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(do_finalize(e));
@@ -1188,6 +1222,7 @@ int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
 }
 
 int sgtd_sync(sgtd_handle e) {
+  if (e && e->grp) return multi::sync(e);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->batch_valid) {
@@ -1199,6 +1234,7 @@ int sgtd_sync(sgtd_handle e) {
 
 int sgtd_result_candidates(sgtd_handle e, int32_t *n_cand, int32_t *cand_frame, int32_t *cand_votes,
                            int64_t *pair_off) {
+  if (e && e->grp) return multi::result_candidates(e, n_cand, cand_frame, cand_votes, pair_off);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(sync_batch(e));
@@ -1212,6 +1248,7 @@ int sgtd_result_candidates(sgtd_handle e, int32_t *n_cand, int32_t *cand_frame, 
 }
 
 int sgtd_export_candidates_dev(sgtd_handle e, int32_t *d_cand_frame, int32_t *d_cand_votes) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e || !d_cand_frame || !d_cand_votes) return SGTD_ERR_INVALID;
   if (!e->batch_valid) return SGTD_ERR_STATE;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1225,6 +1262,7 @@ int sgtd_export_candidates_dev(sgtd_handle e, int32_t *d_cand_frame, int32_t *d_
 }
 
 int sgtd_result_query_desc_count(sgtd_handle e, int q, int64_t *n) {
+  if (e && e->grp) return multi::result_query_desc_count(e, q, n);
   if (!e || !n) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(sync_batch(e));
@@ -1235,6 +1273,7 @@ int sgtd_result_query_desc_count(sgtd_handle e, int q, int64_t *n) {
 
 int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, int64_t capacity,
                       int64_t *n_pairs) {
+  if (e && e->grp) return multi::result_pairs(e, q, q_idx, db_entry, capacity, n_pairs);
   if (!e || !n_pairs) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(sync_batch(e));
@@ -1255,6 +1294,7 @@ int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, i
 }
 
 int sgtd_result_query_descs(sgtd_handle e, int q, sgtd_desc_soa *out, int64_t capacity, int64_t *n_out) {
+  if (e && e->grp) return multi::result_query_descs(e, q, out, capacity, n_out);
   if (!e || !out || !n_out) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(sync_batch(e));
@@ -1265,6 +1305,7 @@ int sgtd_result_query_descs(sgtd_handle e, int q, sgtd_desc_soa *out, int64_t ca
 }
 
 int sgtd_result_votes(sgtd_handle e, int q, uint32_t *votes, int64_t capacity, uint32_t *frame_lo, int64_t *n) {
+  if (e && e->grp) return multi::result_votes(e, q, votes, capacity, frame_lo, n);
   if (!e || !n) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(sync_batch(e));
@@ -1281,6 +1322,7 @@ int sgtd_result_votes(sgtd_handle e, int q, uint32_t *votes, int64_t capacity, u
 
 int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64_t *db_entry, uint32_t *frame,
                       double *dis, int64_t capacity, int64_t *n_rough) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e || !n_rough) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->batch_valid) return SGTD_ERR_STATE;
@@ -1327,6 +1369,7 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
 }
 
 int sgtd_verify(sgtd_handle e) {
+  if (e && e->grp) return multi::verify(e);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(sync_batch(e));
@@ -1353,6 +1396,7 @@ int sgtd_verify(sgtd_handle e) {
 }
 
 int sgtd_result_verify(sgtd_handle e, int q, double *score, double *pose) {
+  if (e && e->grp) return multi::result_verify(e, q, score, pose);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
@@ -1364,6 +1408,7 @@ int sgtd_result_verify(sgtd_handle e, int q, double *score, double *pose) {
 }
 
 int sgtd_export_verify_dev(sgtd_handle e, double *d_score, double *d_pose) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->verified || !e->batch_valid) return SGTD_ERR_STATE;
@@ -1375,6 +1420,7 @@ int sgtd_export_verify_dev(sgtd_handle e, double *d_score, double *d_pose) {
 }
 
 int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n) {
+  if (e && e->grp) return multi::result_inliers(e, q, cand, idx, capacity, n);
   if (!e || !n) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
@@ -1397,6 +1443,7 @@ int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t ca
 }
 
 int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, int32_t *best_frame, double *best_score) {
+  if (e && e->grp) return multi::search_loop(e, icp_threshold, best_cand, best_frame, best_score);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->verified || !e->batch_valid) return SGTD_ERR_INVALID;
@@ -1416,6 +1463,7 @@ int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, in
 }
 
 int sgtd_save_table(sgtd_handle e, const char *path) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e || !path) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   FILE *f = fopen(path, "wb");
@@ -1433,6 +1481,7 @@ int sgtd_save_table(sgtd_handle e, const char *path) {
 }
 
 int sgtd_load_table(sgtd_handle e, const char *path) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e || !path) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(settle_pending(e));
@@ -1533,6 +1582,7 @@ const char *sgtd_graphs_error(const sgtd_graph_batch *b) { return b ? b->error.c
 void sgtd_graphs_free(sgtd_graph_batch *b) { delete b; }
 
 int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_desc_soa *out) {
+  if (e && e->grp) return multi::fetch_entries(e, db_entry, n, out);
   if (!e || n < 0 || (n > 0 && (!db_entry || !out))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   // contiguous runs are copied as one range; scattered ids one by one
@@ -1549,6 +1599,7 @@ int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_d
 
 int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *entry_ids,
                     int64_t cap_buckets, int64_t cap_entries) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   CHK(do_finalize(e));
@@ -1583,6 +1634,7 @@ int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *
 }
 
 int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
+  if (e && e->grp) return multi::get_stats(e, out);
   if (!e || !out) return SGTD_ERR_INVALID;
   e->stats.n_entries = e->n_entries;
   e->stats.n_buckets = e->n_buckets;
@@ -1594,3 +1646,5 @@ int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
 }
 
 }  // extern "C"
+
+#include "multi_impl.hip.h"

@@ -92,17 +92,28 @@ class BatchResult:
 
 class STDescManager:
     def __init__(self, **kw):
+        """devices=[ids]: one handle over several GPUs of this process (sgtd_create_multi: the
+        table sharded by frame blocks, host-side merge of the per-device candidate tables)"""
         cfg = dict(DEFAULTS)
         self.icp_threshold_ = float(kw.pop("icp_threshold", 0.4))   # SG_localization.yaml:89
+        devices = kw.pop("devices", None)
         cfg.update(kw)
         self.config_setting_ = cfg
         self._L = _lib.lib()
         c = Config(**cfg)
         h = C.c_void_p()
         self._h = None
-        self._check(self._L.sgtd_create(C.byref(c), C.byref(h)))
+        if devices is None:
+            self._check(self._L.sgtd_create(C.byref(c), C.byref(h)))
+        else:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            self._check(self._L.sgtd_create_multi(C.byref(c), ids, len(devices), C.byref(h)))
         self._h = h
         self._keep = None
+
+    @property
+    def device_count(self):
+        return self._L.sgtd_device_count(self._h)
 
     def close(self):
         if self._h is not None:

@@ -24,7 +24,7 @@ static double urand() {   // xorshift64*
   return (double)((rng_state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0;
 }
 
-int main() {
+int main(int argc, char **argv) {
   const int n_frames = 12, n_kp = 64;
   // landmarks on a 90 m square, frames = noisy re-observations from a slowly moving window
   std::vector<sgtd::PointXYZL> land(400);
@@ -49,6 +49,7 @@ int main() {
   };
 
   sgtd::ConfigSetting cfg;
+  if (argc > 1 && std::string(argv[1]) == "multi") cfg.device_ids_ = {0, 0};   // the table sharded over two "devices" behind the one manager
   sgtd::STDescManager *std_manager = new sgtd::STDescManager(cfg);   // as semantic_graph_localization.cpp:417
   orc_config oc{cfg.descriptor_near_num_, cfg.candidate_num_, cfg.max_frame_n_, 1, cfg.descriptor_min_len_,
                 cfg.descriptor_max_len_, cfg.std_side_resolution_, cfg.rough_dis_threshold_};

@@ -66,3 +66,7 @@ def test_cpp_host_mirror_matches_oracle():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "cpp host mirror ok" in out.stdout
+    # the same program with the manager's table sharded over two "devices" (sgtd_create_multi, both on GPU 0)
+    out2 = subprocess.run([EXE, "multi"], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    assert out2.stdout == out.stdout

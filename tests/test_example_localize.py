@@ -54,3 +54,8 @@ def test_example_matches_the_python_harness(tmp_path):
     mgr.close()
     assert got == [60, 14, met.detected, met.score_num, met.test_10, int(met.STD_num[0])], (got, met.summary())
     assert met.score_num >= 12
+    # the same run with the table sharded over "two devices" behind the one handle (both shards on GPU 0 here)
+    out2 = subprocess.run([EXE, str(tmp_path / "map"), str(tmp_path / "query"), "5"], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, SGTD_DEVICES="0,0"))
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    assert out2.stdout.splitlines()[:2] == out.stdout.splitlines()[:2] and "2 device(s)" in out2.stdout

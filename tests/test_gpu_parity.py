@@ -746,3 +746,89 @@ def test_f32_pretest_decides_like_the_exact_test_at_the_threshold(mods):
     assert 0 < v.sum() < f                      # some inside, some outside
     st = g.stats()
     assert st["last_M"] == o.counters()["M"]
+
+
+# ---------------------------------------------------------------------------
+# one handle over several devices (sgtd_create_multi): frame blocks dealt round robin,
+# host-side merge == the single table.  Three shards on this one GPU exercise all of it.
+# ---------------------------------------------------------------------------
+def _same_multi_vs_single(mg, sg, mres, sres, nq):
+    cn = sg.config_setting_["candidate_num"]
+    np.testing.assert_array_equal(mres.n_cand, sres.n_cand)
+    np.testing.assert_array_equal(mres.cand_frame, sres.cand_frame)
+    np.testing.assert_array_equal(mres.cand_votes, sres.cand_votes)
+    np.testing.assert_array_equal(mres.pair_off, sres.pair_off)
+    for q in range(nq):
+        mq, me = mg.result_pairs(q, mres)
+        sq, se = sg.result_pairs(q, sres)
+        np.testing.assert_array_equal(mq, sq)
+        pick = np.arange(0, len(se), max(1, len(se) // 400))
+        assert_descs_equal(mg.fetch_entries(me[pick]), sg.fetch_entries(se[pick]))   # the same table entries, global frame ids
+        lo1, v1 = mg.result_votes(q)
+        lo2, v2 = sg.result_votes(q)
+        assert lo1 == lo2
+        n = min(len(v1), len(v2))
+        np.testing.assert_array_equal(v1[:n], v2[:n])
+        assert v1[n:].sum() == 0 and v2[n:].sum() == 0
+
+
+def test_multi_device_handle_equals_single_table(mods):
+    _, manager, synth = mods
+    m = synth.make_map(200, 120, stream=71)          # 200 frames = 3+ blocks of 64 per shard round
+    qs = synth.make_queries(m, 12, stream=71)
+    sg = manager.STDescManager()
+    mg = manager.STDescManager(devices=[0, 0, 0])
+    assert mg.device_count == 3 and sg.device_count == 1
+    sg.add_frames(m.xyz, m.label)
+    mg.add_frames(m.xyz[:70], m.label[:70])          # uneven calls: block boundaries inside and between
+    mg.add_frames(m.xyz[70:], m.label[70:])
+    assert mg.current_frame_id_ == sg.current_frame_id_ == 200
+    assert mg.stats()["n_entries"] == sg.stats()["n_entries"]
+    sres = sg.query_frames(qs.xyz, qs.label)
+    mres = mg.query_frames(qs.xyz, qs.label)
+    assert sres.n_cand.max() > 0
+    _same_multi_vs_single(mg, sg, mres, sres, 12)
+    # verification on the owners + SearchLoop's choice on the merged list
+    sg.verify(); mg.verify()
+    for q in range(12):
+        s1, r1, t1 = sg.result_verify(q)
+        s2, r2, t2 = mg.result_verify(q)
+        np.testing.assert_array_equal(s1, s2)
+        np.testing.assert_array_equal(r1, r2)
+        np.testing.assert_array_equal(t1, t2)
+        for k in range(int(sres.n_cand[q])):
+            if s1[k] >= 0:
+                n = int(sres.pair_off[q, k + 1] - sres.pair_off[q, k])
+                np.testing.assert_array_equal(sg.result_inliers(q, k, n), mg.result_inliers(q, k, n))
+    for a, b in zip(sg.search_loop(), mg.search_loop()):
+        np.testing.assert_array_equal(a, b)
+    # the per-frame adapter path: BuildSingleScanSTD + AddSTDescs frame by frame, then candidate_selector
+    sg2, mg2 = manager.STDescManager(), manager.STDescManager(devices=[0, 0])
+    for f in range(140):
+        d1 = sg2.BuildSingleScanSTD(m.xyz[f], m.label[f])
+        d2 = mg2.BuildSingleScanSTD(m.xyz[f], m.label[f])
+        assert_descs_equal(d2, d1)
+        sg2.AddSTDescs(d1); mg2.AddSTDescs(d2)
+    dq = sg2.BuildSingleScanSTD(qs.xyz[0], qs.label[0])
+    l1, l2 = sg2.candidate_selector(dq), mg2.candidate_selector(mg2.BuildSingleScanSTD(qs.xyz[0], qs.label[0]))
+    assert len(l1) == len(l2) > 0
+    for a, b in zip(l1, l2):
+        assert a.match_id_ == b.match_id_ and a.votes == b.votes
+        np.testing.assert_array_equal(a.q_idx, b.q_idx)
+        assert_descs_equal(mg2.fetch_entries(b.db_entry[:50]), sg2.fetch_entries(a.db_entry[:50]))
+    for x in (sg, mg, sg2, mg2):
+        x.close()
+
+
+def test_multi_device_handle_on_two_gpus(mods):
+    """the same handle with its shards on two different GPUs (skipped on a one-GPU box)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _, manager, synth = mods
+    m = synth.make_map(300, 150, stream=72)
+    qs = synth.make_queries(m, 8, stream=72)
+    sg = manager.STDescManager()
+    mg = manager.STDescManager(devices=[0, 1])
+    sg.add_frames(m.xyz, m.label); mg.add_frames(m.xyz, m.label)
+    _same_multi_vs_single(mg, sg, mg.query_frames(qs.xyz, qs.label), sg.query_frames(qs.xyz, qs.label), 8)
