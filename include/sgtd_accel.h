@@ -90,6 +90,11 @@ typedef struct sgtd_stats {
                               z-slices of the visited buckets that no match can lie in */
   double bucket_len_sq_over_E; /* sum over buckets of len^2 / E: the bucket length a table entry
                               sees on average (sizes the first batch's work buffers)        */
+  int64_t tail_entries;    /* entries in the tail segment (appended after the last full build
+                              of the probe layout; 0 = one segment)                         */
+  float ms_finalize;       /* wall time of the last probe-layout build: proportional to the
+                              appended entries while they fit the tail segment              */
+  float reserved2;
 } sgtd_stats;
 
 typedef struct sgtd_engine *sgtd_handle;
@@ -149,8 +154,12 @@ int sgtd_add(sgtd_handle h, const sgtd_desc_soa *d, int64_t n);
 int sgtd_add_frames(sgtd_handle h, const float *xyz, const uint32_t *label,
                     const int64_t *kp_off, int n_frames, int device_ptrs);
 
-/* Sorts the appended entries into the probe layout (CSR by key + key hash).
- * Idempotent; called implicitly by the first query after an add. */
+/* Sorts the appended entries into the probe layout (by key, z-slices inside a bucket, bucket
+ * directory + key hash).  Idempotent; called implicitly by the first query after an add.
+ * Appending to a finalized table (AddSTDescs only ever appends, STDesc.cpp:149-172) sorts only
+ * the appended entries, into a tail segment that every query sweeps after the main one; the
+ * tail is merged into the main segment when it outgrows an eighth of it (sgtd_stats.tail_entries,
+ * .ms_finalize). */
 int sgtd_finalize(sgtd_handle h);
 
 /* ---- candidate_selector (STDesc.cpp:318-460) ---------------------------- */

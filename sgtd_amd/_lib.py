@@ -67,6 +67,7 @@ class Stats(C.Structure):
         ("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_write", C.c_float),
         ("ms_total", C.c_float), ("overflowed", C.c_int32), ("reserved", C.c_int32),
         ("last_P_swept", C.c_int64), ("bucket_len_sq_over_E", C.c_double),
+        ("tail_entries", C.c_int64), ("ms_finalize", C.c_float), ("reserved2", C.c_float),
     ]
 
 

@@ -71,9 +71,13 @@ struct ProbeBuffers {
   unsigned long long *rec_cursor;   // global slab cursor (64-bit: requests can add up beyond 2^32)
   unsigned long long *rec_need;     // matches that found no room (sizes the regrown buffer)
   unsigned long long *swept;        // table entries the sweep really loaded (after slice pruning)
-  u32 *list_ptr;        // [n_slots] first record of descriptor
-  u32 *n_visit;         // [n_slots] entries the reference's loop visits for the descriptor (STDesc.cpp:372)
-  u32 *n_match;         // [n_slots] matches of descriptor
+  // per table segment sg and descriptor slot d, at [sg * seg_stride + d] (the sweep of segment sg
+  // gets the three pointers advanced to its part):
+  u32 *list_ptr;        // first record of the descriptor's list from that segment
+  u32 *n_visit;         // entries the reference's loop visits for the descriptor there (STDesc.cpp:372)
+  u32 *n_match;         // matches of the descriptor there
+  long long seg_stride; // descriptor slots of the batch
+  int n_seg;            // table segments swept (main, tail)
   u32 *votes;           // [n_queries * frame_span]
   int *overflow;        // [2]: 0 match records, 1 candidate pairs
   // records whose f32 test fell between the two thresholds: stored provisionally as matches,
@@ -850,12 +854,12 @@ __device__ __forceinline__ BlockId assemble_block(int n_queries, int blocks_per_
 
 // the 32-descriptor sub-block [d0, d0+32) of query q: prefix of n_match and list
 // pointers into LDS; returns the number of records
-__device__ __forceinline__ u32 sub_open(const QueryView &Q, const ProbeBuffers &B, int q, u32 d0, u32 cnt,
+__device__ __forceinline__ u32 sub_open(const QueryView &Q, const ProbeBuffers &B, int sg, int q, u32 d0, u32 cnt,
                                         u32 *s_pre /*[32]*/, u32 *s_ptr /*[32]*/, u32 &visits) {
   const int lane = lane_id();
   u32 n = 0, p = 0, v = 0;
   if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
-    const long long d = (long long)q * Q.stride + d0 + lane;
+    const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
     n = B.n_match[d]; p = B.list_ptr[d]; v = B.n_visit[d];
   }
   const u32 inc = wave_incl_scan(n);
@@ -931,8 +935,9 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (id.valid && d_first < cnt) {
     u32 visits = 0, total = 0;
+    for (int sg = 0; sg < B.n_seg; sg++)
     for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
-      const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
+      const u32 R = sub_open(Q, B, sg, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
       total += R;
       // the frames of the next four words are loaded while the current four are counted
       u32 nfr[4];
@@ -1011,7 +1016,8 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   const u32 d_last = min(d_first + SGTD_PROBE_CHUNK, cnt);
   // room for the block's compact list: at most every record of the block
   u32 nm = 0;
-  for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.n_match[(long long)q * Q.stride + dd];
+  for (int sg = 0; sg < B.n_seg; sg++)
+    for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.n_match[(long long)sg * B.seg_stride + (long long)q * Q.stride + dd];
   const u32 r_blk = wave_sum(nm);
   u32 start = 0;
   if (lane == 0) start = atomicAdd(L.cursor, r_blk);
@@ -1020,8 +1026,11 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   if (!fits && lane == 0) B.overflow[0] = 1;     // sized like the record buffer: grown and re-run with it
   s_hist[wid][lane] = 0;
   u32 visits = 0, total = 0, running = 0;
+  // segment by segment: a candidate frame lives in one segment, so its matches still arrive in
+  // (i, cell, j) order
+  for (int sg = 0; sg < B.n_seg; sg++)
   for (u32 d0 = d_first; d0 < d_last; d0 += SGTD_SUB_DESCS) {
-    const u32 R = sub_open(Q, B, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
+    const u32 R = sub_open(Q, B, sg, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
     total += R;
     // the records of the next four words are loaded while the current four are looked up
     u32 nfr[4], ngg[4], ndd[4];
@@ -1215,9 +1224,10 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
 }
 
 // diagnostic: the ordered rough-match list of ONE query (reference order i, cell, j).  The
-// sweep emits a descriptor's matches cell by cell, inside a cell slice by slice; the reference's
-// bucket order is insertion order, so every (descriptor, cell) run is put out by ascending
-// entry id (a selection sort per run: diagnostic path, runs are short).
+// sweep emits a descriptor's matches segment by segment, cell by cell, inside a cell slice by
+// slice; the reference's bucket order is insertion order, so the descriptor's matches are put
+// out by ascending (cell, entry id) — tail entries have larger ids than main entries — with a
+// selection sort per descriptor (diagnostic path: lists are short).
 __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuffers B, int q,
                                                            u32 *out_qi, u32 *out_entry, u32 *out_frame,
                                                            unsigned char *out_cell, double *out_dis) {
@@ -1227,31 +1237,30 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
   for (u32 i0 = 0; i0 < cnt; i0 += 256) {
     const u32 i = i0 + threadIdx.x;
     const long long d = (long long)q * Q.stride + i;
-    const u32 n = (i < cnt) ? B.n_match[d] : 0;
+    u32 n = 0;
+    if (i < cnt)
+      for (int sg = 0; sg < B.n_seg; sg++) n += B.n_match[(long long)sg * B.seg_stride + d];
     u32 tot;
     const u32 ex = block_excl_scan(n, lds, tot);
     if (i < cnt) {
-      const u32 p0 = B.list_ptr[d];
-      u32 a = 0;
-      while (a < n) {
-        u32 b = a + 1;
-        if (out_cell) while (b < n && B.rec_cell[p0 + b] == B.rec_cell[p0 + a]) b++;   // without cell tags: list order
-        long long last = -1;
-        for (u32 k = a; k < b; k++) {
-          u32 best = 0xFFFFFFFFu, at = a;
-          for (u32 j = a; j < b; j++) {
-            const u32 g = B.rec_g[p0 + j];
-            if ((long long)g > last && g < best) { best = g; at = j; }
+      long long last = -1;    // key of the last record put out: cell << 32 | entry id
+      for (u32 k = 0; k < n; k++) {
+        long long best = 0x7FFFFFFFFFFFFFFFll;
+        u32 at = 0;
+        for (int sg = 0; sg < B.n_seg; sg++) {
+          const u32 p0 = B.list_ptr[(long long)sg * B.seg_stride + d], m = B.n_match[(long long)sg * B.seg_stride + d];
+          for (u32 j = 0; j < m; j++) {
+            const long long key = ((long long)B.rec_cell[p0 + j] << 32) | (long long)B.rec_g[p0 + j];
+            if (key > last && key < best) { best = key; at = p0 + j; }
           }
-          last = best;
-          const u32 o = carry + ex + k;
-          out_qi[o] = i;
-          out_entry[o] = best;
-          out_frame[o] = B.rec_frame[p0 + at];
-          if (out_cell) out_cell[o] = B.rec_cell[p0 + at];
-          if (out_dis) out_dis[o] = B.rec_dis[p0 + at];
         }
-        a = b;
+        last = best;
+        const u32 o = carry + ex + k;
+        out_qi[o] = i;
+        out_entry[o] = B.rec_g[at];
+        out_frame[o] = B.rec_frame[at];
+        if (out_cell) out_cell[o] = B.rec_cell[at];
+        if (out_dis) out_dis[o] = B.rec_dis[at];
       }
     }
     carry += tot;

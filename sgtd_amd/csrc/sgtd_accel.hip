@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -65,11 +66,25 @@ struct sgtd_engine {
   u32 frame_lo = 0, frame_hi = 0;
   bool finalized = false;  // the first query builds the (possibly empty) bucket directory
 
-  // ---- table, probe layout (hot)
-  DevBuf hot, perm, hash, bucket_start, bucket_key, dir, slice_of, sq_sum;   // hot: HotEntry[E] (16 B) + perm[E]
-  double sum_len_sq = 0.0;               // sum over buckets of len^2 (sizes the first batch's work buffers)
-  u32 hash_mask = 0;
-  int64_t n_buckets = 0;
+  // ---- table, probe layout (hot): a main segment and, after appends to a finalized table, a
+  // tail segment — each a complete probe layout (HotEntry[n] 16 B + perm[n], bucket directory,
+  // key hash) over a contiguous range of insertion indices.  Appending re-sorts only the tail;
+  // the tail is merged into the main segment when it outgrows an eighth of it.
+  struct Segment {
+    DevBuf hot, perm, hash, bucket_start, bucket_key, dir;
+    u32 hash_mask = 0;
+    int64_t n_buckets = 0;
+    int64_t g0 = 0, g1 = 0;              // insertion indices [g0, g1)
+    double sum_len_sq = 0.0;             // sum over buckets of len^2 (sizes the first batch's work buffers)
+    u32 frame_hi = 0;                    // largest frame id inside (at build time)
+    bool built = false;
+  };
+  Segment seg[2];
+  int n_seg = 1;
+  u32 append_min_frame = 0xFFFFFFFFu;    // smallest frame id appended since the main segment was built
+  int64_t tail_max = 0;                  // SGTD_TAIL_MAX: entries the tail may hold before a merge (0 = an eighth of the main segment)
+  float ms_finalize = 0.f;               // wall time of the last probe-layout build
+  DevBuf slice_of, sq_sum;
   // sort scratch
   DevBuf keyA, keyB, valA, valB, hist, digit_tot, flags, bad_flag;
   std::vector<DevBuf> scan_lvl;
@@ -362,35 +377,39 @@ int radix_sort_pairs(sgtd_engine *e, u64 *&kin, u64 *&kout, u32 *&vin, u32 *&vou
   return SGTD_OK;
 }
 
-int do_finalize(sgtd_engine *e) {
-  if (e->finalized) return SGTD_OK;
-  const long long E = e->n_entries;
-  if (E >= (1ll << 32) - 2) return SGTD_ERR_UNSUPPORTED;
-  e->n_buckets = 0;
-  e->hash_mask = 1023;
-  e->sum_len_sq = 0.0;
+// probe layout of the entries [g0, g1) into segment S: sort by key, slices, directory, hash
+int build_segment(sgtd_engine *e, sgtd_engine::Segment &S, long long g0, long long g1) {
+  const long long E = g1 - g0;
+  S.g0 = g0; S.g1 = g1;
+  S.n_buckets = 0;
+  S.hash_mask = 1023;
+  S.sum_len_sq = 0.0;
+  S.frame_hi = e->have_frames ? e->frame_hi : 0;
+  S.built = true;
   if (E == 0) {
-    CHK(ensure(e, e->hash, (size_t)1024 * sizeof(HashSlot)));
-    HIPCHK(hipMemsetAsync(e->hash.p, 0xFF, (size_t)1024 * sizeof(HashSlot), e->stream));
-    e->finalized = true;
+    CHK(ensure(e, S.hash, (size_t)1024 * sizeof(HashSlot)));
+    HIPCHK(hipMemsetAsync(S.hash.p, 0xFF, (size_t)1024 * sizeof(HashSlot), e->stream));
     return SGTD_OK;
   }
+  // the arrays of this range, indexed by the entry's position inside it
+  const double *side = e->tab.side.as<double>() + (size_t)g0 * 3;
+  const int *label = e->tab.label.as<int>() + (size_t)g0 * 3;
+  const u32 *frame = e->tab.frame.as<u32>() + (size_t)g0;
   CHK(ensure(e, e->keyA, (size_t)E * sizeof(u64)));
   CHK(ensure(e, e->keyB, (size_t)E * sizeof(u64)));
   CHK(ensure(e, e->valA, (size_t)E * sizeof(u32)));
   CHK(ensure(e, e->valB, (size_t)E * sizeof(u32)));
   CHK(ensure(e, e->bad_flag, 2 * sizeof(int)));
   HIPCHK(hipMemsetAsync(e->bad_flag.p, 0, 2 * sizeof(int), e->stream));
-  make_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.side.as<double>(), e->tab.label.as<int>(),
-                                                             e->keyA.as<u64>(), e->valA.as<u32>(), E,
+  make_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(side, label, e->keyA.as<u64>(), e->valA.as<u32>(), E,
                                                              e->bad_flag.as<int>());
   HIPCHK(hipGetLastError());
-  frame_monotone_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.frame.as<u32>(), E, e->bad_flag.as<int>() + 1);
+  frame_monotone_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(frame, E, e->bad_flag.as<int>() + 1);
   HIPCHK(hipGetLastError());
   int bad[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(bad, e->bad_flag.p, sizeof(bad), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (bad[0]) return SGTD_ERR_UNSUPPORTED;  // a cell coordinate beyond 16 bits
+  if (bad[0]) { S.built = false; return SGTD_ERR_UNSUPPORTED; }  // a cell coordinate beyond 16 bits
   const bool monotone = bad[1] == 0;
 
   u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
@@ -399,24 +418,21 @@ int do_finalize(sgtd_engine *e) {
   if (!monotone) {
     // frame ids out of insertion order (caller-stamped descriptors): the slice assignment needs
     // every bucket grouped by frame, so sort by (key, frame, g) for it, then start over
-    frame_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.frame.as<u32>(), kin, vin, E);
+    frame_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(frame, kin, vin, E);
     HIPCHK(hipGetLastError());
     CHK(radix_sort_pairs(e, kin, kout, vin, vout, E, 32, true));
-    keys_of_order_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.side.as<double>(), e->tab.label.as<int>(), vin, kin, E);
+    keys_of_order_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(side, label, vin, kin, E);
     HIPCHK(hipGetLastError());
     CHK(radix_sort_pairs(e, kin, kout, vin, vout, E, 60, true));
-    slice_assign_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, vin, e->tab.side.as<double>(), e->tab.frame.as<u32>(), E,
-                                                                  e->dc.rough, e->slice_of.as<unsigned char>());
+    slice_assign_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, vin, side, frame, E, e->dc.rough, e->slice_of.as<unsigned char>());
     HIPCHK(hipGetLastError());
     kin = e->keyA.as<u64>(); kout = e->keyB.as<u64>(); vin = e->valA.as<u32>(); vout = e->valB.as<u32>();
-    make_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->tab.side.as<double>(), e->tab.label.as<int>(), kin, vin, E,
-                                                               e->bad_flag.as<int>());
+    make_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(side, label, kin, vin, E, e->bad_flag.as<int>());
     HIPCHK(hipGetLastError());
   }
   CHK(radix_sort_pairs(e, kin, kout, vin, vout, E, 60, true));   // (key, g): buckets in insertion order
   if (monotone) {
-    slice_assign_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, vin, e->tab.side.as<double>(), e->tab.frame.as<u32>(), E,
-                                                                  e->dc.rough, e->slice_of.as<unsigned char>());
+    slice_assign_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, vin, side, frame, E, e->dc.rough, e->slice_of.as<unsigned char>());
     HIPCHK(hipGetLastError());
   }
   // buckets
@@ -429,39 +445,67 @@ int do_finalize(sgtd_engine *e) {
   HIPCHK(hipMemcpyAsync(&last_excl, e->flags.as<u32>() + (E - 1), sizeof(u32), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   const u32 U = last_excl + last_flag;
-  e->n_buckets = U;
-  CHK(ensure(e, e->bucket_start, (size_t)(U + 1) * sizeof(u32)));
-  CHK(ensure(e, e->bucket_key, (size_t)U * sizeof(u64)));
-  bucket_starts_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, e->flags.as<u32>(), e->bucket_start.as<u32>(),
-                                                                 e->bucket_key.as<u64>(), E);
+  S.n_buckets = U;
+  CHK(ensure(e, S.bucket_start, (size_t)(U + 1) * sizeof(u32)));
+  CHK(ensure(e, S.bucket_key, (size_t)U * sizeof(u64)));
+  bucket_starts_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, e->flags.as<u32>(), S.bucket_start.as<u32>(),
+                                                                 S.bucket_key.as<u64>(), E);
   HIPCHK(hipGetLastError());
   // probe order: every bucket partitioned by slice, insertion order inside a slice
-  CHK(ensure(e, e->perm, (size_t)E * sizeof(u32)));
-  CHK(ensure(e, e->dir, (size_t)U * sizeof(BucketDir)));
-  slice_partition_kernel<<<e->n_cus * 8, 256, 0, e->stream>>>(e->bucket_start.as<u32>(), U, (u32)E, vin,
-                                                               e->slice_of.as<unsigned char>(), e->perm.as<u32>(),
-                                                               e->dir.as<BucketDir>());
+  CHK(ensure(e, S.perm, (size_t)E * sizeof(u32)));
+  CHK(ensure(e, S.dir, (size_t)U * sizeof(BucketDir)));
+  slice_partition_kernel<<<e->n_cus * 8, 256, 0, e->stream>>>(S.bucket_start.as<u32>(), U, (u32)E, vin,
+                                                               e->slice_of.as<unsigned char>(), S.perm.as<u32>(),
+                                                               S.dir.as<BucketDir>());
   HIPCHK(hipGetLastError());
-  CHK(ensure(e, e->hot, (size_t)E * sizeof(HotEntry)));
-  gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(e->perm.as<u32>(), e->tab.side.as<double>(),
-                                                              e->tab.frame.as<u32>(), e->hot.as<HotEntry>(), E);
+  CHK(ensure(e, S.hot, (size_t)E * sizeof(HotEntry)));
+  gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(S.perm.as<u32>(), side, frame, S.hot.as<HotEntry>(), E, (u32)g0);
   HIPCHK(hipGetLastError());
   u32 cap = 1024;
   while (cap < 2ull * U) cap <<= 1;
-  e->hash_mask = cap - 1;
-  CHK(ensure(e, e->hash, (size_t)cap * sizeof(HashSlot)));
-  HIPCHK(hipMemsetAsync(e->hash.p, 0xFF, (size_t)cap * sizeof(HashSlot), e->stream));
-  hash_insert_kernel<<<grid_for(U, 256), 256, 0, e->stream>>>(e->bucket_key.as<u64>(), e->bucket_start.as<u32>(), U,
-                                                               (u32)E, e->hash.as<HashSlot>(), e->hash_mask);
+  S.hash_mask = cap - 1;
+  CHK(ensure(e, S.hash, (size_t)cap * sizeof(HashSlot)));
+  HIPCHK(hipMemsetAsync(S.hash.p, 0xFF, (size_t)cap * sizeof(HashSlot), e->stream));
+  hash_insert_kernel<<<grid_for(U, 256), 256, 0, e->stream>>>(S.bucket_key.as<u64>(), S.bucket_start.as<u32>(), U,
+                                                               (u32)E, S.hash.as<HashSlot>(), S.hash_mask);
   HIPCHK(hipGetLastError());
   CHK(ensure(e, e->sq_sum, sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(e->sq_sum.p, 0, sizeof(unsigned long long), e->stream));
-  bucket_sq_kernel<<<grid_for(U, 256), 256, 0, e->stream>>>(e->bucket_start.as<u32>(), U, (u32)E, e->sq_sum.as<unsigned long long>());
+  bucket_sq_kernel<<<grid_for(U, 256), 256, 0, e->stream>>>(S.bucket_start.as<u32>(), U, (u32)E, e->sq_sum.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   unsigned long long sq = 0;
   HIPCHK(hipMemcpyAsync(&sq, e->sq_sum.p, sizeof(sq), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  e->sum_len_sq = (double)sq;
+  S.sum_len_sq = (double)sq;
+  return SGTD_OK;
+}
+
+// AddSTDescs only ever appends (STDesc.cpp:149-172).  After an append to a finalized table only
+// the appended entries are sorted, into the tail segment (cost proportional to the tail); the
+// query sweeps both segments — inside a bucket the reference's order is insertion order, i.e.
+// main entries before tail entries, and a frame's entries all live in ONE segment (the tail only
+// takes frames newer than every frame of the main segment), so the per-frame match order is
+// unchanged.  The tail is merged (one full build) when it outgrows an eighth of the main
+// segment; force_merge asks for the single-segment form (table dump).
+int do_finalize(sgtd_engine *e, bool force_merge = false) {
+  if (e->finalized && !(force_merge && e->n_seg > 1)) return SGTD_OK;
+  const long long E = e->n_entries;
+  if (E >= (1ll << 32) - 2) return SGTD_ERR_UNSUPPORTED;
+  const auto t0 = std::chrono::steady_clock::now();
+  sgtd_engine::Segment &M = e->seg[0], &T = e->seg[1];
+  const long long tail_max = e->tail_max > 0 ? (long long)e->tail_max : std::max<long long>(262144, (M.g1 - M.g0) / 8);
+  const bool can_tail = !force_merge && M.built && M.g0 == 0 && M.g1 > 0 && M.g1 <= E && E - M.g1 <= tail_max &&
+                        (E == M.g1 || e->append_min_frame > M.frame_hi);
+  if (can_tail) {
+    if (E > M.g1) { CHK(build_segment(e, T, M.g1, E)); e->n_seg = 2; }
+    else { T.built = false; e->n_seg = 1; }
+  } else {
+    CHK(build_segment(e, M, 0, E));
+    T.built = false; T.g0 = T.g1 = E;
+    e->n_seg = 1;
+    e->append_min_frame = 0xFFFFFFFFu;
+  }
+  e->ms_finalize = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   e->finalized = true;
   return SGTD_OK;
 }
@@ -490,14 +534,15 @@ struct Views {
   int blocks_per_query;
 };
 
-Views make_views(sgtd_engine *e) {
+Views make_views(sgtd_engine *e, int sgi = 0) {
   Views v;
   v.span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   TableView &T = v.T;
-  T.ent = e->hot.as<HotEntry>(); T.perm = e->perm.as<u32>(); T.cold_side = e->tab.side.as<double>();
-  T.dir = e->dir.as<BucketDir>();
-  T.hash = e->hash.as<HashSlot>(); T.hash_mask = e->hash_mask;
-  T.n_entries = (u32)e->n_entries; T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
+  const sgtd_engine::Segment &S = e->seg[sgi];
+  T.ent = S.hot.as<HotEntry>(); T.perm = S.perm.as<u32>(); T.cold_side = e->tab.side.as<double>();
+  T.dir = S.dir.as<BucketDir>();
+  T.hash = S.hash.as<HashSlot>(); T.hash_mask = S.hash_mask;
+  T.n_entries = (u32)(S.g1 - S.g0); T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
   QueryView &Q = v.Q;
   Q.side = e->qd.side.as<double>(); Q.qrec = e->qd.qrec.as<QueryRec>();
   Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
@@ -512,6 +557,7 @@ Views make_views(sgtd_engine *e) {
   B.amb_queue = e->amb_queue.as<uint2>(); B.amb_count = e->cursors.as<u32>() + 2;
   B.amb_cap = (u32)std::min<size_t>(e->amb_queue.bytes / sizeof(uint2), 0xFFFFFFF0u);
   B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
+  B.seg_stride = (long long)e->nq * e->q_stride; B.n_seg = e->n_seg;
   B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
   v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   return v;
@@ -525,9 +571,9 @@ int launch_select(sgtd_engine *e) {
   const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   CHK(ensure(e, e->cursors, 8 * sizeof(u32)));
   CHK(ensure(e, e->overflow, 2 * sizeof(int)));
-  CHK(ensure(e, e->list_ptr, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
-  CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
-  CHK(ensure(e, e->n_match, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
+  CHK(ensure(e, e->list_ptr, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(u32)));
+  CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(u32)));
+  CHK(ensure(e, e->n_match, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(u32)));
   CHK(ensure(e, e->votes, (size_t)nq * span * sizeof(u32)));
   CHK(ensure(e, e->slot_of, (size_t)nq * span));
   CHK(ensure(e, e->q_M, (size_t)nq * sizeof(u32)));
@@ -597,9 +643,6 @@ int launch_select(sgtd_engine *e) {
     sorted_desc_kernel<<<grid_for(n_slots * 4, 256), 256, 0, e->stream>>>(v.Q, vin, e->gid.as<u32>(), nv, e->sdesc.as<QueryRec>(),
                                                                         e->group_first.as<u32>(), e->n_groups.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
-    group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(v.T, v.Q, vin, e->group_first.as<u32>(),
-                                                                e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>());
-    HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
     // descriptors per wave ticket: about 2k entry visits, from the visits per descriptor the
     // previous batch measured (4 until there is one); SGTD_SORTED_CHUNK overrides
@@ -611,18 +654,32 @@ int launch_select(sgtd_engine *e) {
     if (e->sorted_chunk > 0) chunk = (u32)std::min(SGTD_TICKET_MAX, e->sorted_chunk);
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
     const int sgrid = e->n_cus * 8;
-    // 32-bit byte offsets into the probe layout while it stays below 4 GB (record addresses
-    // are a wave-uniform base + a 32-bit lane offset either way)
-    const bool narrow = (unsigned long long)v.T.n_entries * sizeof(HotEntry) < (1ull << 32);
+    for (int sg = 0; sg < e->n_seg; sg++) {
+      // one GroupRow per home cell against this segment's directory, then its sweep; the
+      // descriptors' lists from segment sg are recorded in part sg of list_ptr / n_visit / n_match
+      Views vs = make_views(e, sg);
+      vs.B.list_ptr += (size_t)sg * n_slots; vs.B.n_visit += (size_t)sg * n_slots; vs.B.n_match += (size_t)sg * n_slots;
+      if (sg > 0) {
+        HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * 1024 * sizeof(u32), e->stream));
+        HIPCHK(hipMemsetAsync(e->cursors.as<u32>() + 2, 0, sizeof(u32), e->stream));   // the undecided-record queue
+      }
+      group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->group_first.as<u32>(),
+                                                                  e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>());
+      HIPCHK(hipGetLastError());
+      // 32-bit byte offsets into the probe layout while it stays below 4 GB (record addresses
+      // are a wave-uniform base + a 32-bit lane offset either way)
+      const bool narrow = (unsigned long long)vs.T.n_entries * sizeof(HotEntry) < (1ull << 32);
 #define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
   probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
-      v.T, v.B, rows, e->sdesc.as<QueryRec>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
-    if (e->diag) SGTD_LAUNCH_SORTED(true, true);
-    else if (narrow) SGTD_LAUNCH_SORTED(false, false);
-    else SGTD_LAUNCH_SORTED(false, true);
+      vs.T, vs.B, rows, e->sdesc.as<QueryRec>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
+      if (e->diag) SGTD_LAUNCH_SORTED(true, true);
+      else if (narrow) SGTD_LAUNCH_SORTED(false, false);
+      else SGTD_LAUNCH_SORTED(false, true);
 #undef SGTD_LAUNCH_SORTED
-    HIPCHK(hipGetLastError());
-    resolve_undecided_kernel<<<64, 256, 0, e->stream>>>(v.T, v.Q, v.B, e->q_M.as<u32>());
+      HIPCHK(hipGetLastError());
+      resolve_undecided_kernel<<<64, 256, 0, e->stream>>>(vs.T, vs.Q, vs.B, e->q_M.as<u32>());
+      HIPCHK(hipGetLastError());
+    }
 #ifdef SGTD_EXP_PHASE
     {
       static int bcalls = 0;
@@ -860,7 +917,7 @@ double est_matches_per_query(const sgtd_engine *e, int n_keypoints) {
     return per_slot * (double)n_keypoints * e->dc.tpi;
   }
   if (e->n_entries <= 0) return 0.0;
-  const double per_desc = 0.15 * 19.0 * e->sum_len_sq / (double)e->n_entries;
+  const double per_desc = 0.15 * 19.0 * (e->seg[0].sum_len_sq + (e->n_seg > 1 ? e->seg[1].sum_len_sq : 0.0)) / (double)e->n_entries;
   return 0.62 * (double)n_keypoints * e->dc.tpi * per_desc;
 }
 
@@ -980,6 +1037,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   e->current_frame_id = cfg->first_frame_id;
   e->qd.with_thr2 = true;
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
+  if (const char *o = getenv("SGTD_TAIL_MAX")) e->tail_max = atoll(o);
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }
   if (const char *o = getenv("SGTD_PAIR_CAP")) { e->pair_cap = (size_t)std::max(64ll, atoll(o)); e->rec_cap_fixed = true; }
@@ -1012,7 +1070,8 @@ int sgtd_destroy(sgtd_handle e) {
   (void)hipSetDevice(e->cfg.device_id);
   (void)hipStreamSynchronize(e->stream);
   free_store(e->tab); free_store(e->tmp); free_store(e->qd);
-  DevBuf *bufs[] = {&e->hot, &e->perm, &e->hash, &e->bucket_start, &e->bucket_key, &e->dir, &e->slice_of, &e->sq_sum,
+  DevBuf *bufs[] = {&e->seg[0].hot, &e->seg[0].perm, &e->seg[0].hash, &e->seg[0].bucket_start, &e->seg[0].bucket_key, &e->seg[0].dir,
+                    &e->seg[1].hot, &e->seg[1].perm, &e->seg[1].hash, &e->seg[1].bucket_start, &e->seg[1].bucket_key, &e->seg[1].dir, &e->slice_of, &e->sq_sum,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
                     &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list_ptr, &e->n_visit,
@@ -1097,6 +1156,7 @@ int sgtd_add(sgtd_handle e, const sgtd_desc_soa *d, int64_t n) {
   CHK(copy_in(e, e->tab, (size_t)e->n_entries, (size_t)n, d));
   e->n_entries += n;
   note_frames(e, lo, hi);
+  e->append_min_frame = std::min(e->append_min_frame, lo);
   e->finalized = false;
   e->batch_valid = false;
   return SGTD_OK;
@@ -1138,6 +1198,7 @@ int sgtd_add_frames(sgtd_handle e, const float *xyz, const uint32_t *label, cons
     HIPCHK(hipStreamSynchronize(e->stream));  // goff staging vector dies here
     e->n_entries += total;
     note_frames(e, e->current_frame_id, e->current_frame_id + (u32)nf - 1);
+    e->append_min_frame = std::min(e->append_min_frame, e->current_frame_id);
     e->current_frame_id += (u32)nf;   // one AddSTDescs (:151) per frame
     e->n_add_calls += nf;
   }
@@ -1527,10 +1588,12 @@ int sgtd_load_table(sgtd_handle e, const char *path) {
   if (st != SGTD_OK) {
     if (st == SGTD_ERR_IO) e->err = std::string(path) + ": truncated or damaged table file";
     e->n_entries = 0; e->have_frames = false; e->finalized = false; e->batch_valid = false;
+    e->seg[0].built = false; e->seg[1].built = false;
     return st;
   }
   e->n_entries = h.n_entries; e->n_add_calls = h.n_add_calls; e->current_frame_id = h.current_frame_id;
   e->have_frames = h.have_frames != 0; e->frame_lo = h.frame_lo; e->frame_hi = h.frame_hi;
+  e->seg[0].built = false; e->seg[1].built = false;
   e->finalized = false;
   e->batch_valid = false;
   return SGTD_OK;
@@ -1602,15 +1665,16 @@ int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *
   if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
-  CHK(do_finalize(e));
-  const int64_t U = e->n_buckets, E = e->n_entries;
+  CHK(do_finalize(e, /*force_merge=*/true));   // one segment: the dump shows whole buckets
+  const sgtd_engine::Segment &S = e->seg[0];
+  const int64_t U = S.n_buckets, E = e->n_entries;
   if (U > cap_buckets || E > cap_entries) return SGTD_ERR_CAPACITY;
   if (E == 0) { if (bucket_off) bucket_off[0] = 0; return SGTD_OK; }
   std::vector<u64> k(U);
   std::vector<u32> st(U), pm(E);
-  HIPCHK(hipMemcpy(k.data(), e->bucket_key.p, U * sizeof(u64), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(st.data(), e->bucket_start.p, U * sizeof(u32), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(pm.data(), e->perm.p, E * sizeof(u32), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(k.data(), S.bucket_key.p, U * sizeof(u64), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(st.data(), S.bucket_start.p, U * sizeof(u32), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(pm.data(), S.perm.p, E * sizeof(u32), hipMemcpyDeviceToHost));
   for (int64_t u = 0; u < U; u++) {
     if (keys) {
       keys[u * 4 + 0] = (int64_t)((k[u] >> 32) & 0xFFFF);
@@ -1637,10 +1701,12 @@ int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
   if (e && e->grp) return multi::get_stats(e, out);
   if (!e || !out) return SGTD_ERR_INVALID;
   e->stats.n_entries = e->n_entries;
-  e->stats.n_buckets = e->n_buckets;
+  e->stats.n_buckets = e->seg[0].n_buckets + (e->n_seg > 1 ? e->seg[1].n_buckets : 0);
   e->stats.n_frames = e->n_add_calls;
   e->stats.hbm_bytes_table = e->n_entries * (int64_t)SGTD_HOT_BYTES;
-  e->stats.bucket_len_sq_over_E = e->n_entries > 0 ? e->sum_len_sq / (double)e->n_entries : 0.0;
+  e->stats.bucket_len_sq_over_E = e->n_entries > 0 ? (e->seg[0].sum_len_sq + (e->n_seg > 1 ? e->seg[1].sum_len_sq : 0.0)) / (double)e->n_entries : 0.0;
+  e->stats.ms_finalize = e->ms_finalize;
+  e->stats.tail_entries = e->n_seg > 1 ? e->seg[1].g1 - e->seg[1].g0 : 0;
   *out = e->stats;
   return SGTD_OK;
 }

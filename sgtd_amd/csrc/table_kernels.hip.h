@@ -198,11 +198,14 @@ __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
 // ---------------------------------------------------------------------------
 // gather hot arrays + bucket heads + hash insert
 // ---------------------------------------------------------------------------
-__global__ void gather_hot_kernel(const u32 *perm, const double *side, const u32 *frame,
-                                  HotEntry *ent, long long n) {
+// side / frame are the arrays of the segment's range (indexed from its first entry g0); perm
+// comes in with positions inside the range and leaves with insertion indices
+__global__ void gather_hot_kernel(u32 *perm, const double *side, const u32 *frame,
+                                  HotEntry *ent, long long n, u32 g0) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const u32 g = perm[p];
+  perm[p] = g + g0;
   HotEntry h;
   h.s0 = (float)side[(size_t)g * 3 + 0];   // round to nearest: the bound in f32_bounds assumes it
   h.s1 = (float)side[(size_t)g * 3 + 1];

@@ -362,6 +362,9 @@ class STDescManager:
 
     def table_dump(self):
         self.finalize()
+        # the dump shows whole buckets: a table with a tail segment is merged first (the sizing
+        # call below does it and reports the capacity it needs)
+        self._L.sgtd_table_dump(self._h, None, None, None, 0, 0)
         st = self.stats()
         u, e = st["n_buckets"], st["n_entries"]
         keys = np.zeros((u, 4), np.int64)

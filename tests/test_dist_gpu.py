@@ -1,0 +1,42 @@
+"""Two real engine instances in two processes: bench.py --gpus 2 starts its
+own ranks; on a box with two GPUs they use one GPU each and RCCL, on a one-GPU box both ranks
+share cuda:0 and the collectives run over gloo (the SGTD_BENCH_* switches exist for exactly
+this).  Checks: the ranks really formed one group of 2, the table-sharded result (frame-range
+shards, all_gather + merge) equals the replicated-map result query by query, and both equal the
+single-process result."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--frames", "400", "--queries", "24", "--steps", "2", "--warmup", "1", "--cpu-baseline", "off",
+        "--sweep", "", "--verify", "off", "--boundary", "off"]
+
+
+def _bench(extra, env):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS + extra, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_shards_and_replicas_agree():
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env.update(SGTD_BENCH_BACKEND="gloo", SGTD_BENCH_SHARE_GPU="1")
+    two = _bench(["--gpus", "2"], env)
+    assert two["n_gpus"] == 2 and two["config"]["ranks_in_collective"] == 2
+    assert two["scaling"] == "weak" and two["config"]["queries_per_step"] == 48
+    assert len(two["config"]["table_entries_per_rank"]) == 2
+    ts = two["table_sharded"]
+    assert ts["ranks_in_collective"] == 2 and ts["merged_list_equals_replicated_map"] is True
+    assert sum(ts["table_entries_per_rank"]) == two["config"]["table_entries_per_rank"][0]   # shards add up to the replica
+    one = _bench(["--gpus", "1", "--queries", "48"], dict(os.environ))
+    assert one["n_gpus"] == 1 and one["recall"] == two["recall"]      # same 48 queries, same answers
+    tbl = _bench(["--gpus", "2", "--shard", "table"], env)
+    assert tbl["scaling"] == "strong" and tbl["config"]["queries_per_step"] == 24

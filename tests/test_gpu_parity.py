@@ -832,3 +832,60 @@ def test_multi_device_handle_on_two_gpus(mods):
     mg = manager.STDescManager(devices=[0, 1])
     sg.add_frames(m.xyz, m.label); mg.add_frames(m.xyz, m.label)
     _same_multi_vs_single(mg, sg, mg.query_frames(qs.xyz, qs.label), sg.query_frames(qs.xyz, qs.label), 8)
+
+
+# ---------------------------------------------------------------------------
+# incremental insert: appends after a query go to a tail segment
+# ---------------------------------------------------------------------------
+def test_appends_go_to_a_tail_segment_and_keep_parity(mods, monkeypatch):
+    _, manager, synth = mods
+    g, o = _pair(mods)
+    m = synth.make_map(60, 150, stream=33)
+    qs = synth.make_queries(m, 3, stream=33)
+
+    def add(lo, hi):
+        g.add_frames(m.xyz[lo:hi], m.label[lo:hi])
+        for f in range(lo, hi):
+            o.build(m.xyz[f], m.label[f], export=False)
+            o.add_last()
+
+    def check():
+        res = g.query_frames(qs.xyz, qs.label)
+        for q in range(3):
+            od = o.build(qs.xyz[q], qs.label[q])
+            _check_query(g, o, res, q, od)        # candidates, votes, lists, rough list + distances
+        return g.stats()
+
+    add(0, 40)
+    st = check()
+    assert st["tail_entries"] == 0
+    main_entries = st["n_entries"]
+    add(40, 50)                                   # appended to a finalized table: only these are sorted
+    st = check()
+    assert st["tail_entries"] == st["n_entries"] - main_entries > 0
+    add(50, 60)                                   # the tail grows (rebuilt from the first appended entry)
+    st = check()
+    assert st["tail_entries"] == st["n_entries"] - main_entries
+    gk, goff, gid = g.table_dump()                # the dump merges the segments: whole buckets, insertion order
+    ok, ooff, oid = o.table_dump()
+    np.testing.assert_array_equal(gk, ok)
+    np.testing.assert_array_equal(goff, ooff)
+    np.testing.assert_array_equal(gid, oid)
+    assert g.stats()["tail_entries"] == 0
+    check()
+    # descriptors stamped with an OLD frame id cannot live in a tail (a frame's entries stay in one
+    # segment): the append is merged
+    d = g.BuildSingleScanSTD(qs.xyz[0], qs.label[0])
+    d.frame[:] = 7
+    od = o.build(qs.xyz[0], qs.label[0])
+    od.frame[:] = 7
+    g.AddSTDescs(d); o.add(od)
+    st = check()
+    assert st["tail_entries"] == 0
+    # a tail that outgrows its bound is merged
+    monkeypatch.setenv("SGTD_TAIL_MAX", "2000")
+    g2 = manager.STDescManager()
+    g2.add_frames(m.xyz[:40], m.label[:40]); g2.query_frames(qs.xyz, qs.label)
+    g2.add_frames(m.xyz[40:41], m.label[40:41])   # one frame's descriptors (> 2000) exceed the bound
+    r2 = g2.query_frames(qs.xyz, qs.label)
+    assert g2.stats()["tail_entries"] == 0 and r2.n_cand.max() > 0
