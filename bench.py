@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto")
     ap.add_argument("--also-table", choices=["on", "off"], default="on",
                     help="N>1, query mode: also measure the table-sharded mode in the same run")
-    ap.add_argument("--sweep", default="1000,4541", help="other map sizes measured for map_size_sweep ('' = none)")
+    ap.add_argument("--sweep", default="1000,4541",
+                    help="other map sizes measured for map_size_sweep ('' = no other sizes, 'none' = also skip the incremental-insert leg)")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU work budget of the timed sample")
     ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
@@ -443,7 +444,7 @@ def main():
 
     # ---- other map sizes (same batch, same pipeline), N = 1 only
     sweep = None
-    if mode == "single" and args.sweep:
+    if mode == "single" and args.sweep not in ("", "none"):
         sweep = {str(F): {"frames_per_s": Q * args.steps / elapsed, "ms_per_step": 1000.0 * elapsed / args.steps}}
         for f2 in [int(x) for x in args.sweep.split(",") if x]:
             if f2 == F:
@@ -472,6 +473,35 @@ def main():
                 del g2, x2, l2
             except Exception as exc:
                 sweep[str(f2)] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    # ---- incremental insert: 100 frames appended to the finalized map are
+    # sorted into a tail segment (cost proportional to the appended entries), the batch then
+    # sweeps main + tail
+    incremental = None
+    if mode == "single" and args.sweep != "none":
+        try:
+            g3 = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 200))
+            g3.set_stream(stream.cuda_stream)
+            g3.add_frames(*to_dev(smap.xyz, smap.label))
+            g3.finalize()
+            full_ms = g3.stats()["ms_finalize"]
+
+            def s3():
+                g3.query_frames(d_qxyz, d_qlab, fetch=False)
+            s3(); g3.sync(); s3(); g3.sync(); torch.cuda.synchronize()
+            t_main = run_steps(s3, torch.cuda.synchronize, 3) / 3
+            g3.add_frames(*to_dev(smap.xyz[:100], smap.label[:100]))     # 100 more frames (ids F .. F+99)
+            g3.finalize()
+            s3_st = g3.stats()
+            s3(); g3.sync(); s3(); g3.sync(); torch.cuda.synchronize()
+            t_tail = run_steps(s3, torch.cuda.synchronize, 3) / 3
+            incremental = {"appended_frames": 100, "tail_entries": s3_st["tail_entries"], "table_entries": s3_st["n_entries"],
+                           "ms_finalize_full_table": full_ms, "ms_finalize_after_append": s3_st["ms_finalize"],
+                           "ms_per_step_one_segment": 1000.0 * t_main, "ms_per_step_main_plus_tail": 1000.0 * t_tail}
+            g3.close()
+            del g3
+        except Exception as exc:
+            incremental = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     ranks_seen = 1
     entries_per_rank = [int(st["n_entries"])]
@@ -512,6 +542,8 @@ def main():
             out["verify"] = verify
         if boundary is not None:
             out["boundary"] = boundary
+        if incremental is not None:
+            out["incremental_insert"] = incremental
         if table_sharded is not None:
             out["table_sharded"] = table_sharded
         if mode == "single":

@@ -60,7 +60,20 @@ def main():
                    "correction": "read bytes = 2 * FETCH_SIZE (gfx950 wide-load undercount), write bytes = WRITE_SIZE",
                    "bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
                    "TCC_HIT_sum": p.get("TCC_HIT_sum"), "TCC_MISS_sum": p.get("TCC_MISS_sum")}
-        json.dump(traffic, open(os.path.join(here, "probe_traffic.json"), "w"), indent=1, sort_keys=True)
+        json.dump(traffic, open(os.path.join(here, "%s_probe_traffic.json" % tag), "w"), indent=1, sort_keys=True)
+        # bench.py reads the rows of r02_traffic.json (one per measured configuration)
+        rows_path = os.path.join(here, "r02_traffic.json")
+        rows = []
+        if os.path.exists(rows_path):
+            try:
+                rows = json.load(open(rows_path))
+            except Exception:
+                rows = []
+        key = (traffic["frames"], traffic["keypoints"], traffic["queries"], traffic["gpus"])
+        rows = [r for r in rows if (r.get("frames"), r.get("keypoints"), r.get("queries"), r.get("gpus", 1)) != key]
+        traffic["profile_tag"] = tag
+        rows.append(traffic)
+        json.dump(rows, open(rows_path, "w"), indent=1, sort_keys=True)
         print(json.dumps(traffic))
 
 

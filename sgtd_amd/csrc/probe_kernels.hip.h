@@ -432,47 +432,64 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     PH_ADD(2, ph_t);
 #endif
+    u32 m_start[K];
 #pragma unroll
-    for (int u = 0; u < NW; u++) {
+    for (int k = 0; k < K; k++) m_start[k] = matches[k];
+    u64 amb_any = 0;     // wave mask: some entry of the group fell between the two f32 thresholds
+    // one (word, descriptor) test; PUSH = false: store the matches, true: replay of the group
+    // that only queues the provisional records (rare)
+    auto test = [&](auto push_tag, int u, int k, u32 &count) {
+      constexpr bool PUSH = decltype(push_tag)::value;
       const u32 fr = __float_as_uint(v[u].w);
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373); for a pair the
-        // entry's cell must also pass this descriptor's own gate (bit c4 >> 3 of its mask)
-        bool cand = valid[u] && (f.qframe[k] != fr);
-        if (K > 1) cand = cand && ((f.gate[k] >> (c4v[u] >> 3)) & 1u);
-        bool hit, amb = false;
-        double dis = 0.0;
-        if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
-          hit = false;
-          if (cand) {
-            const double *sp = T.cold_side + (size_t)gg[u] * 3;
-            const double ex = f.q0[k] - sp[0], ey = f.q1[k] - sp[1], ez = f.q2[k] - sp[2];
-            dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
-            hit = dis < thr;
-          }
-        } else {
-          const float dx = q0f[k] - v[u].x, dy = q1f[k] - v[u].y, dz = q2f[k] - v[u].z;
-          const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-          hit = cand && !(d2 > f.hi2[k]);       // not certainly outside (NaN stays in)
-          amb = hit && !(d2 < f.lo2[k]);        // not certainly inside either: provisional
+      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373); for a pair the
+      // entry's cell must also pass this descriptor's own gate (bit c4 >> 3 of its mask)
+      bool cand = valid[u] && (f.qframe[k] != fr);
+      if (K > 1) cand = cand && ((f.gate[k] >> (c4v[u] >> 3)) & 1u);
+      bool hit, amb = false;
+      double dis = 0.0;
+      if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
+        hit = false;
+        if (cand) {
+          const double *sp = T.cold_side + (size_t)gg[u] * 3;
+          const double ex = f.q0[k] - sp[0], ey = f.q1[k] - sp[1], ez = f.q2[k] - sp[2];
+          dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
+          hit = dis < thr;
         }
-        const u64 m = __ballot(hit);
-        const u32 at = matches[k] + (u32)__popcll(m & lanemask_lt());
+      } else {
+        const float dx = q0f[k] - v[u].x, dy = q1f[k] - v[u].y, dz = q2f[k] - v[u].z;
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        hit = cand && !(d2 > f.hi2[k]);       // not certainly outside (NaN stays in)
+        amb = hit && !(d2 < f.lo2[k]);        // not certainly inside either: provisional
+      }
+      const u64 m = __builtin_amdgcn_ballot_w64(hit);
+      const u32 at = count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+      if constexpr (!PUSH) {
         if (hit && fits) {
           // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
           *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_frame[k]) + (at << 2)) = fr;
           *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_g[k]) + (at << 2)) = gg[u];
           if (DIAG) { B.rec_cell[(size_t)slab.next[k] + at] = (unsigned char)(c4v[u] >> 3); B.rec_dis[(size_t)slab.next[k] + at] = dis; }
         }
-        if (!DIAG && __ballot(amb)) {   // rare: about one in 10^4 matches
-          if (amb && fits) {
-            const u32 qa = atomicAdd(B.amb_count, 1u);
-            if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.next[k] + at, f.slot[k]);
-            else B.overflow[0] = 1;    // re-run with a larger queue (grows with the record buffer)
-          }
+        if (!DIAG) amb_any |= __builtin_amdgcn_ballot_w64(amb);
+      } else {
+        if (amb && fits) {
+          const u32 qa = atomicAdd(B.amb_count, 1u);
+          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.next[k] + at, f.slot[k]);
+          else B.overflow[0] = 1;    // re-run with a larger queue (grows with the record buffer)
         }
-        matches[k] += __popcll(m);
+      }
+      count += (u32)__builtin_popcountll(m);
+    };
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+#pragma unroll
+      for (int k = 0; k < K; k++) test(std::false_type{}, u, k, matches[k]);
+    }
+    if (!DIAG && amb_any) {   // rare: about one in 10^4 matches
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) test(std::true_type{}, u, k, m_start[k]);
       }
     }
     PH_ADD(3, ph_t);
@@ -914,6 +931,44 @@ __device__ __forceinline__ u32 cand_slot(const u64 *s_tab, u32 frame) {
   }
 }
 
+// the match lists of one 128-descriptor block counted into a vote histogram (LDS or global)
+template <bool LDS_VOTES>
+__device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBuffers &B, int q, u32 d_first, u32 cnt,
+                                               u32 frame_lo, u32 *s_hist, u32 *votes, u32 *s_pre, u32 *s_ptr,
+                                               u32 &visits, u32 &total) {
+  const int lane = lane_id();
+  for (int sg = 0; sg < B.n_seg; sg++)
+  for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
+    const u32 R = sub_open(Q, B, sg, q, d0, cnt, s_pre, s_ptr, visits);
+    total += R;
+    // the frames of the next four words are loaded while the current four are counted
+    u32 nfr[4];
+    auto load4 = [&](u32 r0) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const u32 r = r0 + u * SGTD_WAVE + lane;
+        u32 dd, addr;
+        sub_locate(s_pre, s_ptr, r < R ? r : 0u, dd, addr);
+        nfr[u] = B.rec_frame[addr];
+      }
+    };
+    if (R) load4(0);
+    for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
+      u32 fr[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) fr[u] = nfr[u];
+      if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (r0 + u * SGTD_WAVE + lane < R && fr[u] != SGTD_DEAD_FRAME) {
+          if (LDS_VOTES) atomicAdd(&s_hist[fr[u] - frame_lo], 1u);
+          else atomicAdd(&votes[fr[u] - frame_lo], 1u);
+        }
+      }
+    }
+  }
+}
+
 template <bool LDS_VOTES>
 __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B, u32 frame_span, u32 frame_lo,
                                                     int blocks_per_query, u32 *q_M, unsigned long long *q_P) {
@@ -935,36 +990,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (id.valid && d_first < cnt) {
     u32 visits = 0, total = 0;
-    for (int sg = 0; sg < B.n_seg; sg++)
-    for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
-      const u32 R = sub_open(Q, B, sg, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
-      total += R;
-      // the frames of the next four words are loaded while the current four are counted
-      u32 nfr[4];
-      auto load4 = [&](u32 r0) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const u32 r = r0 + u * SGTD_WAVE + lane;
-          u32 dd, addr;
-          sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, dd, addr);
-          nfr[u] = B.rec_frame[addr];
-        }
-      };
-      if (R) load4(0);
-      for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
-        u32 fr[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) fr[u] = nfr[u];
-        if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (r0 + u * SGTD_WAVE + lane < R && fr[u] != SGTD_DEAD_FRAME) {
-            if (LDS_VOTES) atomicAdd(&s_hist[fr[u] - frame_lo], 1u);
-            else atomicAdd(&votes[fr[u] - frame_lo], 1u);
-          }
-        }
-      }
-    }
+    votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, frame_lo, s_hist, votes, s_pre[wid], s_ptr[wid], visits, total);
     if (lane == 0) {
       atomicAdd(&q_M[q], total);
       atomicAdd(&q_P[q], (unsigned long long)visits);
@@ -976,6 +1002,47 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
       const u32 v = s_hist[f];
       if (v) atomicAdd(&votes[f], v);
     }
+  }
+}
+
+// votes of a whole query by ONE workgroup of 16 wavefronts (batches with enough queries to fill
+// the chip that way): the LDS histogram is the query's final vote array — plain coalesced stores,
+// no global atomics, no pre-zeroed vote buffer
+#define SGTD_VOTES_Q_THREADS 1024
+__global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(QueryView Q, ProbeBuffers B, u32 frame_span,
+                                                                            u32 frame_lo, int blocks_per_query, u32 *q_M,
+                                                                            unsigned long long *q_P) {
+  constexpr int NW = SGTD_VOTES_Q_THREADS / SGTD_WAVE;
+  extern __shared__ u32 s_hist[];   // [frame_span]
+  __shared__ u32 s_pre[NW][32];
+  __shared__ u32 s_ptr[NW][32];
+  __shared__ u32 s_M;
+  __shared__ unsigned long long s_P;
+  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const int q = blockIdx.x;
+  const bool dead = B.overflow[0] != 0;     // the batch is re-run: leave zeros
+  for (u32 f = tid; f < frame_span; f += SGTD_VOTES_Q_THREADS) s_hist[f] = 0;
+  if (tid == 0) { s_M = 0; s_P = 0; }
+  __syncthreads();
+  const u32 cnt = Q.count[q];
+  if (!dead) {
+    u32 visits = 0, total = 0;
+    for (int blk = wid; blk < blocks_per_query; blk += NW) {
+      const u32 d_first = (u32)blk * SGTD_PROBE_CHUNK;
+      if (d_first >= cnt) break;
+      votes_of_block<true>(Q, B, q, d_first, cnt, frame_lo, s_hist, nullptr, s_pre[wid], s_ptr[wid], visits, total);
+    }
+    if (lane == 0) {
+      atomicAdd(&s_M, total);
+      atomicAdd(&s_P, (unsigned long long)visits);
+    }
+  }
+  __syncthreads();
+  u32 *votes = B.votes + (size_t)q * frame_span;
+  for (u32 f = tid; f < frame_span; f += SGTD_VOTES_Q_THREADS) votes[f] = s_hist[f];
+  if (tid == 0) {      // resolve_undecided_kernel has already subtracted the records it killed
+    atomicAdd(&q_M[q], s_M);
+    atomicAdd(&q_P[q], s_P);
   }
 }
 
@@ -993,11 +1060,17 @@ struct CompactLists {
   u32 cap;
 };
 
+// SLOT_TABLE: the frame -> candidate slot map of the query is the byte array topk_kernel wrote
+// (slot_of, 0xFF = not a candidate), staged in LDS and indexed directly — one ds_read_u8 per
+// record; for maps whose frame span does not fit LDS the 256-entry hash of the candidates
+template <bool SLOT_TABLE>
 __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
                                                           const int *cand_frame, int cand_num,
                                                           int blocks_per_query, u32 *blk_count, CompactLists L,
-                                                          u32 *q_M, unsigned long long *q_P) {
+                                                          u32 *q_M, unsigned long long *q_P,
+                                                          const unsigned char *slot_of_all, u32 frame_span, u32 frame_lo) {
   constexpr int NW = 256 / SGTD_WAVE;
+  extern __shared__ unsigned char s_slot8[];   // [frame_span rounded up to 16] when SLOT_TABLE
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
   __shared__ u32 s_hist[NW][64];
@@ -1006,7 +1079,15 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
   const int q = id.q;
-  cand_hash_build(s_cand, n_cand, cand_frame, q, Q.n_queries, cand_num);
+  if (SLOT_TABLE) {
+    if (q < Q.n_queries) {   // workgroup-uniform
+      const unsigned char *src = slot_of_all + (size_t)q * frame_span;
+      for (u32 f = threadIdx.x; f < frame_span; f += 256) s_slot8[f] = src[f];
+    }
+    __syncthreads();
+  } else {
+    cand_hash_build(s_cand, n_cand, cand_frame, q, Q.n_queries, cand_num);
+  }
   if (!id.valid) return;
   const u32 cnt = Q.count[q];
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
@@ -1053,18 +1134,20 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const bool ok = r0 + u * SGTD_WAVE + lane < R;
-        const u32 sl = ok ? cand_slot(s_cand, fr[u]) : 0xFFu;
+        u32 sl = 0xFFu;
+        if (SLOT_TABLE) { if (ok && fr[u] - frame_lo < frame_span) sl = s_slot8[fr[u] - frame_lo]; }   // a dead record's frame is out of range
+        else if (ok) sl = cand_slot(s_cand, fr[u]);
         const bool valid = sl != 0xFFu;
-        const u64 m = __ballot(valid);
+        const u64 m = __builtin_amdgcn_ballot_w64(valid);
         if (valid) {
           atomicAdd(&s_hist[wid][sl], 1u);   // counting needs no order
           if (fits) {
-            const u32 pos = start + running + (u32)__popcll(m & lanemask_lt());
+            const u32 pos = start + running + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
             // slot rides in the top 6 bits of the q_idx half (q_idx < 36 * 65535 < 2^26)
             L.pair[pos] = ((u64)((sl << 26) | (d0 + dd[u])) << 32) | (u64)gg[u];
           }
         }
-        running += (u32)__popcll(m);
+        running += (u32)__builtin_popcountll(m);
       }
     }
   }
@@ -1144,7 +1227,8 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   constexpr int NW = 256 / SGTD_WAVE;
   constexpr int CAP = 16;   // staged pairs per slot = one 128-B line
   __shared__ u64 s_mask[NW][64];         // per wave and slot: lanes of the current word that carry the slot
-  __shared__ u64 s_stage[NW][64][CAP];   // per wave and slot: pairs waiting for a full-line store
+  __shared__ u64 s_stage[NW][64][CAP + 1];   // per wave and slot: pairs waiting for a full-line store (rows padded by one
+                                             // word: a 128-byte row stride put every slot's k-th pair on the same banks)
   if (B.overflow[0] || B.overflow[1]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
@@ -1202,11 +1286,11 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
       if (valid) atomicOr(&s_mask[wid][s], 1ull << lane);
       __builtin_amdgcn_wave_barrier();
       const u64 gm = valid ? s_mask[wid][s] : 0ull;
-      const u32 c_own = (u32)__popcll(s_mask[wid][lane]);   // pairs this word adds to slot == lane
+      const u32 c_own = (u32)__builtin_popcountll(s_mask[wid][lane]);   // pairs this word adds to slot == lane
       __builtin_amdgcn_wave_barrier();
-      const u32 rank = (u32)__popcll(gm & lanemask_lt()), count = (u32)__popcll(gm);
+      const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(gm >> 32), __builtin_amdgcn_mbcnt_lo((u32)gm, 0u)), count = (u32)__builtin_popcountll(gm);
       u32 have = __shfl(fill, s);
-      if (__ballot(valid && have + count > (u32)CAP)) {   // some slot would overflow its line: drain all
+      if (__builtin_amdgcn_ballot_w64(valid && have + count > (u32)CAP)) {   // some slot would overflow its line: drain all
         flush();
         have = 0;
       }

@@ -741,7 +741,13 @@ int launch_select(sgtd_engine *e) {
 #endif
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
-    if (lds_votes) {
+    if (lds_votes && nq >= e->n_cus) {
+      // enough queries to fill the chip with one 16-wave workgroup each: no flush atomics
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_query_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+      votes_query_kernel<<<nq, SGTD_VOTES_Q_THREADS, hist_bytes, e->stream>>>(v.Q, v.B, span, v.T.frame_lo, blocks, e->q_M.as<u32>(),
+                                                                              e->q_P.as<unsigned long long>());
+    } else if (lds_votes) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
       votes_kernel<true><<<agrid, 256, hist_bytes, e->stream>>>(v.Q, v.B, span, v.T.frame_lo, blocks, e->q_M.as<u32>(),
@@ -762,8 +768,18 @@ int launch_select(sgtd_engine *e) {
   CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
   CL.cursor = e->cursors.as<u32>() + 3; CL.cap = v.B.rec_cap;
-  block_count_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
-                                                    blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr);
+  if (span <= 48 * 1024) {
+    const int sl_bytes = (int)((span + 15) & ~15u);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_count_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, sl_bytes));
+    block_count_kernel<true><<<agrid, 256, sl_bytes, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
+                                                                  blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr,
+                                                                  e->slot_of.as<unsigned char>(), span, v.T.frame_lo);
+  } else {
+    block_count_kernel<false><<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
+                                                             blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr,
+                                                             e->slot_of.as<unsigned char>(), span, v.T.frame_lo);
+  }
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
   block_scan_kernel<<<nq, 64, 0, e->stream>>>(e->blk_count.as<u32>(), blocks, cn, e->n_cand.as<int>(),
