@@ -283,6 +283,7 @@ def main():
         step(); mgr.sync(); torch.cuda.synchronize()
         cold["first_batch_ms"] = 1000.0 * (time.perf_counter() - t0)
         cold["first_batch_overflowed"] = int(mgr.stats()["overflowed"])
+        cold["bucket_len_sq_over_E"] = mgr.stats()["bucket_len_sq_over_E"]
     elif mode == "table":
         sm = ShardedMap(F, rank, world, device_id=local_rank)
         mgr = sm.mgr
@@ -326,10 +327,16 @@ def main():
     # descriptor, 8 B per match record
     algo_bytes = 28 * P + 64 * D + 8 * M
     algo_gbs = algo_bytes / t_probe / 1e9 if t_probe > 0 else 0.0
-    # what can bound the sweep: the bytes the probe layout hands to the CUs per visit (L2 -> L1
-    # rate) and the HBM bytes the PMC counters saw (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
-    entry_bytes = st["hbm_bytes_table"] // max(st["n_entries"], 1)   # probe-layout bytes one visit reads
-    l2_gbs = (entry_bytes * P + 8 * M) / t_probe / 1e9 if t_probe > 0 else 0.0
+    # What can bound the sweep: (a) the bytes its waves really load and store through L2 — 20 B per
+    # entry it loads (after slice pruning and pair sharing; sgtd_stats.last_P_swept) + 8 B per match
+    # record — against the aggregate L2 rate; (b) the HBM bytes the PMC counters saw (2 x FETCH_SIZE
+    # + WRITE_SIZE, separate rocprofv3 passes, profiles/r02_traffic.json) against the HBM peak.
+    # `frac` is the larger of the two fractions and can never exceed 1; the algorithmic rate of
+    # SURVEY §8d (28 B per entry the REFERENCE loop visits) is reported beside it: it exceeds the HBM
+    # peak because pruned slices are never loaded and the rest is mostly served from L2.
+    entry_bytes = st["hbm_bytes_table"] // max(st["n_entries"], 1)   # probe-layout bytes per loaded entry
+    P_swept = st.get("last_P_swept") or P
+    l2_gbs = (entry_bytes * P_swept + 8 * M) / t_probe / 1e9 if t_probe > 0 else 0.0
     tr = load_traffic(F, N, Q, world)
     traffic = tr.get("bytes_per_launch") if tr else None
     hbm_gbs = traffic / t_probe / 1e9 if (traffic and t_probe > 0) else None
@@ -340,13 +347,17 @@ def main():
     else:
         bound, achieved, peak, frac = "l2", l2_gbs, L2_PEAK_GBS, l2_frac
     roofline = {"bound": bound, "kernel": "probe_sorted_kernel (sweep)", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                "frac": frac, "traffic": traffic, "hbm_frac": hbm_frac, "l2_frac": l2_frac,
-                "avg_launch_ms": kern_ms["ms_probe"], "probe_layout_bytes_per_visit": entry_bytes,
+                "frac": min(frac, 1.0), "traffic": traffic, "traffic_profile": tr.get("profile_tag") if tr else None,
+                "hbm_frac": hbm_frac, "l2_frac": l2_frac,
+                "avg_launch_ms": kern_ms["ms_probe"], "probe_layout_bytes_per_loaded_entry": entry_bytes,
                 "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_gbs,
                 "algorithmic_over_hbm_peak": algo_gbs / HBM_PEAK_GBS,
-                "note": "the key-major sweep re-reads buckets from L2, so algorithmic bytes/s can exceed the HBM peak; "
-                        "frac is measured against the level that can bound the kernel (DESIGN.md §3)",
-                "P_visited": P, "P_swept_after_slice_pruning": st.get("last_P_swept"), "M_matches": M, "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
+                "reference_visits_per_s": P / t_probe if t_probe > 0 else 0.0,
+                "note": "bound = the level whose fraction is larger: L2->CU bytes the sweep really moves (20 B x entries loaded "
+                        "+ 8 B x records) vs 34.5 TB/s, or PMC HBM bytes vs 8 TB/s; algorithmic bytes (28 B x reference visits) "
+                        "exceed the HBM peak because pruned z-slices are never loaded and buckets are re-read from L2 (DESIGN.md §3)",
+                "P_visited": P, "P_swept_after_slice_pruning": st.get("last_P_swept"), "M_matches": M,
+                "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
                 "kernel_ms": kern_ms}
 
     res = mgr.results()

@@ -72,6 +72,15 @@ def main():
         key = (traffic["frames"], traffic["keypoints"], traffic["queries"], traffic["gpus"])
         rows = [r for r in rows if (r.get("frames"), r.get("keypoints"), r.get("queries"), r.get("gpus", 1)) != key]
         traffic["profile_tag"] = tag
+        # steady-state duration of the sweep in the kernel trace of the --stats pass (the stats
+        # file's average also counts the short launches of other table segments / re-runs)
+        tr = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+        if tr:
+            dur = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(tr[0]))
+                         if r["Kernel_Name"].startswith("void probe_sorted_kernel"))
+            if dur:
+                traffic["sweep_median_ms_kernel_trace"] = dur[len(dur) // 2]
+                traffic["sweep_launches_in_trace"] = len(dur)
         rows.append(traffic)
         json.dump(rows, open(rows_path, "w"), indent=1, sort_keys=True)
         print(json.dumps(traffic))

@@ -645,6 +645,13 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       PendingLoads pend;
       pend.row = &row_next;
       pend.rec = &rec_next;
+      // a home cell none of whose 27 buckets exists in this table segment (common for the small
+      // tail segment of an appended map): nothing to plan or sweep
+      if (!__builtin_amdgcn_ballot_w64((row.x | row.y | row.z | row.w) != 0u)) {
+        pend.touch();
+        i += step;
+        continue;
+      }
       if (pair) {
         if constexpr (!DIAG) {
           DescSet<2> f;

@@ -515,8 +515,7 @@ int do_finalize(sgtd_engine *e, bool force_merge = false) {
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e) {
   CHK(ensure(e, e->rec, e->rec_cap * sizeof(u64)));
-  CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));
-  CHK(ensure(e, e->c_slot, e->rec_cap));
+  CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));   // every block reserves room for all of its records
   if (e->diag) {
     CHK(ensure(e, e->rec_cell, e->rec_cap));
     CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
@@ -643,7 +642,6 @@ int launch_select(sgtd_engine *e) {
     sorted_desc_kernel<<<grid_for(n_slots * 4, 256), 256, 0, e->stream>>>(v.Q, vin, e->gid.as<u32>(), nv, e->sdesc.as<QueryRec>(),
                                                                         e->group_first.as<u32>(), e->n_groups.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
-    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));
     // descriptors per wave ticket: about 2k entry visits, from the visits per descriptor the
     // previous batch measured (4 until there is one); SGTD_SORTED_CHUNK overrides
     u32 chunk = 4;
@@ -666,6 +664,7 @@ int launch_select(sgtd_engine *e) {
       group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->group_first.as<u32>(),
                                                                   e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>());
       HIPCHK(hipGetLastError());
+      if (sg == 0 && e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));   // ms_probe = the sweep(s) from here
       // 32-bit byte offsets into the probe layout while it stays below 4 GB (record addresses
       // are a wave-uniform base + a 32-bit lane offset either way)
       const bool narrow = (unsigned long long)vs.T.n_entries * sizeof(HotEntry) < (1ull << 32);
@@ -767,7 +766,7 @@ int launch_select(sgtd_engine *e) {
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
-  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = v.B.rec_cap;
+  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
   if (span <= 48 * 1024) {
     const int sl_bytes = (int)((span + 15) & ~15u);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_count_kernel<true>),
@@ -831,7 +830,7 @@ int rerun_write(sgtd_engine *e) {
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
-  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = v.B.rec_cap;
+  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
   query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
                                                (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
   HIPCHK(hipGetLastError());
@@ -922,10 +921,13 @@ int sync_batch(sgtd_engine *e) {
 // A pending query batch keeps its inputs in the handle's staging buffers for a re-run after a
 // work-buffer overflow: anything that is about to reuse them settles the batch first.
 // Expected rough matches of one query frame of n_keypoints keypoints, before any batch has been
-// measured: a query descriptor distributed like the table's entries meets buckets of sum(len^2)/E
-// entries on average, visits about 19 gated cells of the 27 and matches about 0.15 of what it
-// visits (0.06 .. 0.31 on the synthetic maps of 100 k .. 1 k frames); about 62 % of the
-// 36 n_keypoints triplets survive the length filter and the dedup.
+// measured.  A query descriptor distributed like the table's entries meets buckets of
+// L = sum(len^2) / E entries on average; its matches are the entries inside its threshold ball:
+// about 0.55 L for the shipped rough_dis_threshold 0.03 (ball of ~0.5 m in cells of 1 m^3; the
+// ball's volume grows with the cube of the threshold) plus the re-observations of the same
+// place, ~65 per descriptor on the synthetic maps (measured 73 / 166 matches per descriptor at
+// 1 k / 10 k frames: the estimate gives 77 / 185).  About 62 % of the 36 n_keypoints triplets
+// survive the length filter and the dedup.
 double est_matches_per_query(const sgtd_engine *e, int n_keypoints) {
   if (e->stats.last_queries > 0 && e->stats.last_D > 0 && e->nq > 0 && e->q_stride > 0) {
     // measured: matches per descriptor slot of the last batch, scaled to this frame size
@@ -933,7 +935,9 @@ double est_matches_per_query(const sgtd_engine *e, int n_keypoints) {
     return per_slot * (double)n_keypoints * e->dc.tpi;
   }
   if (e->n_entries <= 0) return 0.0;
-  const double per_desc = 0.15 * 19.0 * (e->seg[0].sum_len_sq + (e->n_seg > 1 ? e->seg[1].sum_len_sq : 0.0)) / (double)e->n_entries;
+  const double L = (e->seg[0].sum_len_sq + (e->n_seg > 1 ? e->seg[1].sum_len_sq : 0.0)) / (double)e->n_entries;
+  const double r = e->dc.rough / 0.03;
+  const double per_desc = 0.55 * L * std::min(27.0, r * r * r) + 65.0;
   return 0.62 * (double)n_keypoints * e->dc.tpi * per_desc;
 }
 

@@ -161,3 +161,43 @@ def test_cfg5_two_sessions_wild_labels_at_size(mods):
     o = _oracle_map(oracle, [s1, s2])
     for q in (0, 31, 63):
         _same_as_oracle(g, o, res, q, qs.xyz[q], qs.label[q])
+
+
+def test_cfg4_100k_frame_map_sharded_eight_ways_behind_one_handle(mods):
+    """BASELINE configs[3] at its real size on what one GPU box offers: a 100 000-frame map
+    (444 M table entries) as ONE table and as EIGHT frame-block shards behind one handle
+    (sgtd_create_multi, all eight on this GPU): per-shard top-50 tables merged with the
+    reference's rule must equal the single-table result — candidates, votes, list offsets,
+    match lists — and the place must be found.  The reference itself cannot hold this map
+    (MAX_FRAME_N = 20 000, STDesc.h:33); the oracle is not run at this size."""
+    _, manager, synth = mods
+    F, N, Q = 100000, 200, 48
+    m = synth.make_map(F, N, stream=4)
+    qs = synth.make_queries(m, Q, stream=4)
+    single = manager.STDescManager(max_frame_n=F + 1)
+    single.add_frames(m.xyz, m.label)
+    sres = single.query_frames(qs.xyz, qs.label)
+    st = single.stats()
+    assert st["n_entries"] > 4e8 and st["overflowed"] in (0, 1)
+    assert np.all(sres.n_cand > 0)
+    d = np.linalg.norm(m.pose[sres.top1(), :2] - qs.pose[:, :2], axis=1)
+    assert np.mean(d < 5.0) >= 0.95
+    pairs = [single.result_pairs(q, sres) for q in range(0, Q, 12)]
+    ents = [single.fetch_entries(p[1][:64]) for p in pairs]
+    single.close()
+    del single
+    multi = manager.STDescManager(max_frame_n=F + 1, devices=[0] * 8)
+    multi.add_frames(m.xyz, m.label)
+    assert multi.stats()["n_entries"] == st["n_entries"]
+    mres = multi.query_frames(qs.xyz, qs.label)
+    np.testing.assert_array_equal(mres.n_cand, sres.n_cand)
+    np.testing.assert_array_equal(mres.cand_frame, sres.cand_frame)
+    np.testing.assert_array_equal(mres.cand_votes, sres.cand_votes)
+    np.testing.assert_array_equal(mres.pair_off, sres.pair_off)
+    for k, q in enumerate(range(0, Q, 12)):
+        mq, me = multi.result_pairs(q, mres)
+        np.testing.assert_array_equal(mq, pairs[k][0])
+        got = multi.fetch_entries(me[:64])
+        for f in ("side", "frame", "label", "node_id"):
+            np.testing.assert_array_equal(getattr(got, f), getattr(ents[k], f))
+    multi.close()
