@@ -118,7 +118,12 @@ struct PendingLoads {
   }
 };
 
-#define SGTD_PAIR 2   // descriptors of one home cell swept together by a wave (shared plan, locate and loads)
+#ifndef SGTD_PAIR
+// descriptors of one home cell swept together by a wave (shared plan, locate and loads): 1, 2 or 4.
+// Measured at F = 10 k: 2 -> sweep 6.2 ms; 4 halves the loads again but needs 129 VGPRs (3 waves
+// per SIMD: 7.6 ms; capped at 128: 6.6 ms)
+#define SGTD_PAIR 2
+#endif
 
 struct WaveSlab {
   u32 next[SGTD_PAIR], end[SGTD_PAIR];   // this wave's private ranges of match records: one bump stream per
@@ -350,9 +355,21 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
                                                   WaveSlab &slab, DescResult (&result)[K], PendingLoads pending) {
   static_assert(!DIAG || K == 1, "the diagnostic sweep takes one descriptor at a time");
   const int lane = lane_id();
-  float q0f[K], q1f[K], q2f[K];
+  // per-descriptor constants of the test.  They are wave-uniform; for K > 2 they are parked in
+  // vector registers (the kernel is at the scalar-register limit: uniform values the compiler
+  // cannot keep in SGPRs would be spilled to VGPR lanes and read back with v_readlane per use)
+  auto park = [](auto x) {
+    if constexpr (K > 2) { decltype(x) r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+    else return x;
+  };
+  float q0f[K], q1f[K], q2f[K], lo2[K], hi2[K];
+  u32 qframe[K], gatek[K];
 #pragma unroll
-  for (int k = 0; k < K; k++) { q0f[k] = (float)f.q0[k]; q1f[k] = (float)f.q1[k]; q2f[k] = (float)f.q2[k]; }
+  for (int k = 0; k < K; k++) {
+    q0f[k] = park((float)f.q0[k]); q1f[k] = park((float)f.q1[k]); q2f[k] = park((float)f.q2[k]);
+    lo2[k] = park(f.lo2[k]); hi2[k] = park(f.hi2[k]);
+    qframe[k] = park(f.qframe[k]); gatek[k] = park(f.gate[k]);
+  }
   const double thr = DIAG ? norm3(f.q0[0], f.q1[0], f.q2[0]) * rough : 0.0;   // :356-357
   const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_WAVE - 1);
   const u32 dl = pl.dl;
@@ -443,8 +460,8 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
       const u32 fr = __float_as_uint(v[u].w);
       // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373); for a pair the
       // entry's cell must also pass this descriptor's own gate (bit c4 >> 3 of its mask)
-      bool cand = valid[u] && (f.qframe[k] != fr);
-      if (K > 1) cand = cand && ((f.gate[k] >> (c4v[u] >> 3)) & 1u);
+      bool cand = valid[u] && (qframe[k] != fr);
+      if (K > 1) cand = cand && ((gatek[k] >> (c4v[u] >> 3)) & 1u);
       bool hit, amb = false;
       double dis = 0.0;
       if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
@@ -458,8 +475,8 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
       } else {
         const float dx = q0f[k] - v[u].x, dy = q1f[k] - v[u].y, dz = q2f[k] - v[u].z;
         const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        hit = cand && !(d2 > f.hi2[k]);       // not certainly outside (NaN stays in)
-        amb = hit && !(d2 < f.lo2[k]);        // not certainly inside either: provisional
+        hit = cand && !(d2 > hi2[k]);         // not certainly outside (NaN stays in)
+        amb = hit && !(d2 < lo2[k]);          // not certainly inside either: provisional
       }
       const u64 m = __builtin_amdgcn_ballot_w64(hit);
       const u32 at = count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
@@ -631,11 +648,14 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       f.hi2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 3));
     };
     for (u32 i = 0; i < n;) {
-      // two consecutive descriptors of one home cell are swept together (one plan, one locate and
-      // one load per 64 entries for both); the diagnostic build takes them one by one
-      const bool pair = !DIAG && i + 1 < n &&
-                        (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * i + 6)) == g_cur;
-      const u32 step = pair ? 2u : 1u;
+      // consecutive descriptors of one home cell are swept together, 4 or 2 at a time (one plan,
+      // one locate and one load per 64 entries for all of them); the diagnostic build takes them
+      // one by one
+      u32 run = 1;
+      if (!DIAG)
+        while (run < (u32)SGTD_PAIR && i + run < n &&
+               (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * (i + run) + 2)) == g_cur) run++;
+      const u32 step = run >= 4 ? 4u : (run >= 2 ? 2u : 1u);
       const uint4 row = row_next;
       if (i + step < n) {   // the GroupRow after this step (often the same one)
         const u32 g1 = (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * (i + step) + 2));
@@ -652,25 +672,21 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
         i += step;
         continue;
       }
-      if (pair) {
-        if constexpr (!DIAG) {
-          DescSet<2> f;
-          f.row = row;
-          unpack(f, 0, i);
-          unpack(f, 1, i + 1);
-          DescResult res[2];
-          sweep_descriptors<DIAG, WIDE, 2>(T, B, rough, f, plan_from_group_row<2>(f), slab, res, pend);
-          if ((u32)lane == i) { r_ptr = res[0].ptr; r_visit = res[0].visit; r_match = res[0].match; }
-          if ((u32)lane == i + 1) { r_ptr = res[1].ptr; r_visit = res[1].visit; r_match = res[1].match; }
-        }
-      } else {
-        DescSet<1> f;
+      auto pass = [&](auto k_tag) {
+        constexpr int KK = decltype(k_tag)::value;
+        DescSet<KK> f;
         f.row = row;
-        unpack(f, 0, i);
-        DescResult res[1];
-        sweep_descriptors<DIAG, WIDE, 1>(T, B, rough, f, plan_from_group_row<1>(f), slab, res, pend);
-        if ((u32)lane == i) { r_ptr = res[0].ptr; r_visit = res[0].visit; r_match = res[0].match; }
-      }
+#pragma unroll
+        for (int k = 0; k < KK; k++) unpack(f, k, i + (u32)k);
+        DescResult res[KK];
+        sweep_descriptors<DIAG, WIDE, KK>(T, B, rough, f, plan_from_group_row<KK>(f), slab, res, pend);
+#pragma unroll
+        for (int k = 0; k < KK; k++)
+          if ((u32)lane == i + (u32)k) { r_ptr = res[k].ptr; r_visit = res[k].visit; r_match = res[k].match; }
+      };
+      if constexpr (!DIAG && SGTD_PAIR >= 4) { if (step == 4) pass(std::integral_constant<int, 4>{}); }
+      if constexpr (!DIAG && SGTD_PAIR >= 2) { if (step == 2) pass(std::integral_constant<int, 2>{}); }
+      if (step == 1) pass(std::integral_constant<int, 1>{});
       i += step;
     }
     {   // the chunk's results: lane i < n stores for its descriptor (slot d in quarter 2 of record i)
@@ -1059,8 +1075,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
 // (q_idx << 32 | g) of the records whose frame made the candidate list, and their slots.
 // Written by block_count_kernel, consumed by block_write_kernel (no second record walk).
 struct CompactLists {
-  u64 *pair;             // [cap]
-  unsigned char *slot;   // [cap]
+  u64 *pair;             // [cap] slot << 58 | q_idx << 32 | g
   u32 *blk_start;        // [nq * blocks_per_query] first entry of the block's list
   u32 *blk_n;            // [nq * blocks_per_query] entries of the block's list
   u32 *cursor;           // global allocation cursor

@@ -109,7 +109,7 @@ struct sgtd_engine {
   u32 last_qframe = 0;  // current_frame_id_ when the batch was enqueued (a re-run stamps the same id)
   DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
   DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
-  DevBuf c_pair, c_slot, c_blk;   // compact candidate-match lists between block_count and block_write
+  DevBuf c_pair, c_blk;           // compact candidate-match lists between block_count and block_write
   DevBuf amb_queue;               // provisional records awaiting the exact test
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
@@ -648,6 +648,10 @@ int launch_select(sgtd_engine *e) {
     if (e->stats.last_D > 0 && e->stats.last_P_swept > 0) {
       const double per_desc = (double)e->stats.last_P_swept / (double)e->stats.last_D;
       chunk = (u32)std::min(8.0, std::max(1.0, std::floor(2048.0 / per_desc + 0.5)));
+      // descriptors of a home cell are swept together up to SGTD_PAIR at a time: a ticket must
+      // hold whole runs
+      chunk = std::max<u32>(chunk, SGTD_PAIR);
+      chunk = (chunk + SGTD_PAIR - 1) / SGTD_PAIR * SGTD_PAIR;
     }
     if (e->sorted_chunk > 0) chunk = (u32)std::min(SGTD_TICKET_MAX, e->sorted_chunk);
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
@@ -764,7 +768,7 @@ int launch_select(sgtd_engine *e) {
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
   CompactLists CL;
-  CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
+  CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
   CL.cursor = e->cursors.as<u32>() + 3; CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
   if (span <= 48 * 1024) {
@@ -828,7 +832,7 @@ int rerun_write(sgtd_engine *e) {
   HIPCHK(hipMemsetAsync(e->overflow.as<int>() + 1, 0, sizeof(int), e->stream));
   Views v = make_views(e);
   CompactLists CL;
-  CL.pair = e->c_pair.as<u64>(); CL.slot = e->c_slot.as<unsigned char>();
+  CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
   CL.cursor = e->cursors.as<u32>() + 3; CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
   query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
@@ -1096,7 +1100,7 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
                     &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list_ptr, &e->n_visit,
                     &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
-                    &e->blk_count, &e->c_pair, &e->c_slot, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
+                    &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
                     &e->cand_votes, &e->pair_off, &e->pairs};
   for (DevBuf *b : bufs) free_buf(*b);
@@ -1255,7 +1259,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const double want = 1.3 * est_matches_per_query(e, max_n) * (double)n_queries;
-    const double cap_mem = (double)free_b / 4.0 / 17.0;    // records + compact list, a quarter of what is free
+    const double cap_mem = (double)free_b / 4.0 / 20.0;    // records + compact list + pairs, a quarter of what is free
     const size_t cap = (size_t)std::min(std::min(want, cap_mem), (double)0xFFFFFFF0ull);
     if (cap > e->rec_cap) e->rec_cap = cap;
     if (cap / 2 > e->pair_cap) e->pair_cap = cap / 2;   // candidate pairs: 0.2 .. 0.5 of the matches
@@ -1295,8 +1299,8 @@ int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
   const double per_query = std::max(1.0, est_matches_per_query(e, n_keypoints)) * 2.0;   // margin: slab slack, variation
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  // 17 B per record (records + compact list) on top of what the buffers already hold
-  const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->c_slot.bytes) / 17.0;
+  // 20 B per record (records 8, compact list 8, candidate pairs ~4) on top of what the buffers already hold
+  const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->pairs.bytes) / 20.0;
   const double lim = std::min((double)0xFFFFFFF0ull, mem_records);
   *max_queries = (int64_t)std::max(1.0, std::floor(lim / per_query));
   return SGTD_OK;
