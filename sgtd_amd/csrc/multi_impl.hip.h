@@ -50,6 +50,7 @@ int destroy(sgtd_engine *e) {
 
 // BuildSingleScanSTD of one frame: any device will do; stamped with the GLOBAL frame id
 int build(sgtd_engine *e, const float *xyz, const uint32_t *label, int n, sgtd_desc_soa *out, int64_t capacity, int64_t *n_out) {
+  if (!out || !n_out || n < 0 || (n > 0 && (!xyz || !label))) return SGTD_ERR_INVALID;
   Group *g = G(e);
   sgtd_engine *c = g->dev[shard_of(g->current_frame_id, g->n)];
   MCHK(sgtd_build(c, xyz, label, n, out, capacity, n_out));
@@ -61,6 +62,7 @@ int build(sgtd_engine *e, const float *xyz, const uint32_t *label, int n, sgtd_d
 // AddSTDescs: the frame goes to the owner of the current global id; descriptors must carry
 // that id (what BuildSingleScanSTD stamped, STDesc.cpp:305) — it becomes the owner's local id
 int add(sgtd_engine *e, const sgtd_desc_soa *d, int64_t n) {
+  if (n < 0 || (n > 0 && (!d || !d->side || !d->label || !d->frame))) return SGTD_ERR_INVALID;
   Group *g = G(e);
   const u32 gid = g->current_frame_id;
   if ((uint64_t)gid >= (uint64_t)e->cfg.max_frame_n) return SGTD_ERR_FRAME_LIMIT;
@@ -80,6 +82,8 @@ int add(sgtd_engine *e, const sgtd_desc_soa *d, int64_t n) {
 }
 
 int add_frames(sgtd_engine *e, const float *xyz, const uint32_t *label, const int64_t *kp_off, int n_frames, int device_ptrs) {
+  if (n_frames < 0 || !kp_off) return SGTD_ERR_INVALID;
+  if (n_frames == 0) return SGTD_OK;
   Group *g = G(e);
   if (device_ptrs) { e->err = "multi-device tables take host pointers"; return SGTD_ERR_UNSUPPORTED; }
   if ((uint64_t)g->current_frame_id + (uint64_t)n_frames > (uint64_t)e->cfg.max_frame_n) return SGTD_ERR_FRAME_LIMIT;
@@ -102,6 +106,7 @@ int finalize(sgtd_engine *e) {
 }
 
 int query_frames(sgtd_engine *e, const float *xyz, const uint32_t *label, const int64_t *kp_off, int n_queries, int device_ptrs) {
+  if (n_queries <= 0 || !kp_off || !xyz || !label) return SGTD_ERR_INVALID;
   Group *g = G(e);
   if (device_ptrs) { e->err = "multi-device tables take host pointers"; return SGTD_ERR_UNSUPPORTED; }
   // every device builds the query descriptors itself and sweeps its shard; the calls only
@@ -112,6 +117,7 @@ int query_frames(sgtd_engine *e, const float *xyz, const uint32_t *label, const 
 }
 
 int query_descs(sgtd_engine *e, const sgtd_desc_soa *q, int64_t nq) {
+  if (nq < 0 || (nq > 0 && (!q || !q->side || !q->label || !q->frame))) return SGTD_ERR_INVALID;
   Group *g = G(e);
   std::vector<uint32_t> lf((size_t)std::max<int64_t>(nq, 1));
   for (int s = 0; s < g->n; s++) {
@@ -190,6 +196,7 @@ int result_candidates(sgtd_engine *e, int32_t *n_cand, int32_t *cand_frame, int3
 
 // match lists of query q in the merged candidate order, each fetched from its owner
 int result_pairs(sgtd_engine *e, int q, int32_t *q_idx, int64_t *db_entry, int64_t capacity, int64_t *n_pairs) {
+  if (!n_pairs) return SGTD_ERR_INVALID;
   CHK(merge(e));
   Group *g = G(e);
   if (q < 0 || q >= g->nq) return SGTD_ERR_INVALID;
@@ -224,6 +231,7 @@ int result_pairs(sgtd_engine *e, int q, int32_t *q_idx, int64_t *db_entry, int64
 }
 
 int fetch_entries(sgtd_engine *e, const int64_t *db_entry, int64_t n, sgtd_desc_soa *out) {
+  if (n < 0 || (n > 0 && (!db_entry || !out))) return SGTD_ERR_INVALID;
   Group *g = G(e);
   // runs of one owner are fetched together; frame ids come back global
   int64_t i = 0;
@@ -261,6 +269,7 @@ int result_query_descs(sgtd_engine *e, int q, sgtd_desc_soa *out, int64_t capaci
 
 int result_votes(sgtd_engine *e, int q, uint32_t *votes, int64_t capacity, uint32_t *frame_lo, int64_t *n) {
   Group *g = G(e);
+  if (!n || !g->batch_valid || q < 0 || q >= g->nq) return SGTD_ERR_INVALID;
   const u32 lo = e->cfg.first_frame_id;
   const int64_t span = std::max<int64_t>((int64_t)g->current_frame_id - lo, 1);
   *n = span;

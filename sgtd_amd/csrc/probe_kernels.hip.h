@@ -955,9 +955,10 @@ __device__ __forceinline__ u32 cand_slot(const u64 *s_tab, u32 frame) {
 }
 
 // the match lists of one 128-descriptor block counted into a vote histogram (LDS or global)
+// (bins [frame_lo, frame_lo + limit): records of other frames — another tile's, or dead ones — are skipped)
 template <bool LDS_VOTES>
 __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBuffers &B, int q, u32 d_first, u32 cnt,
-                                               u32 frame_lo, u32 *s_hist, u32 *votes, u32 *s_pre, u32 *s_ptr,
+                                               u32 frame_lo, u32 limit, u32 *s_hist, u32 *votes, u32 *s_pre, u32 *s_ptr,
                                                u32 &visits, u32 &total) {
   const int lane = lane_id();
   for (int sg = 0; sg < B.n_seg; sg++)
@@ -983,9 +984,10 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
       if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (r0 + u * SGTD_WAVE + lane < R && fr[u] != SGTD_DEAD_FRAME) {
-          if (LDS_VOTES) atomicAdd(&s_hist[fr[u] - frame_lo], 1u);
-          else atomicAdd(&votes[fr[u] - frame_lo], 1u);
+        const u32 bin = fr[u] - frame_lo;
+        if (r0 + u * SGTD_WAVE + lane < R && bin < limit) {
+          if (LDS_VOTES) atomicAdd(&s_hist[bin], 1u);
+          else atomicAdd(&votes[bin], 1u);
         }
       }
     }
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (id.valid && d_first < cnt) {
     u32 visits = 0, total = 0;
-    votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, frame_lo, s_hist, votes, s_pre[wid], s_ptr[wid], visits, total);
+    votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, frame_lo, frame_span, s_hist, votes, s_pre[wid], s_ptr[wid], visits, total);
     if (lane == 0) {
       atomicAdd(&q_M[q], total);
       atomicAdd(&q_P[q], (unsigned long long)visits);
@@ -1030,21 +1032,25 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
 
 // votes of a whole query by ONE workgroup of 16 wavefronts (batches with enough queries to fill
 // the chip that way): the LDS histogram is the query's final vote array — plain coalesced stores,
-// no global atomics, no pre-zeroed vote buffer
+// no global atomics, no pre-zeroed vote buffer.  A frame span beyond LDS is cut into tiles of
+// tile_span bins, one workgroup per (query, tile) = blockIdx.(x, y): every tile's workgroup walks
+// all of the query's records and counts the ones of its frames.
 #define SGTD_VOTES_Q_THREADS 1024
 __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(QueryView Q, ProbeBuffers B, u32 frame_span,
-                                                                            u32 frame_lo, int blocks_per_query, u32 *q_M,
-                                                                            unsigned long long *q_P) {
+                                                                            u32 frame_lo, u32 tile_span, int blocks_per_query,
+                                                                            u32 *q_M, unsigned long long *q_P) {
   constexpr int NW = SGTD_VOTES_Q_THREADS / SGTD_WAVE;
-  extern __shared__ u32 s_hist[];   // [frame_span]
+  extern __shared__ u32 s_hist[];   // [tile_span]
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
   __shared__ u32 s_M;
   __shared__ unsigned long long s_P;
   const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
   const int q = blockIdx.x;
+  const u32 tile_lo = blockIdx.y * tile_span;
+  const u32 n_bins = min(tile_span, frame_span - tile_lo);
   const bool dead = B.overflow[0] != 0;     // the batch is re-run: leave zeros
-  for (u32 f = tid; f < frame_span; f += SGTD_VOTES_Q_THREADS) s_hist[f] = 0;
+  for (u32 f = tid; f < n_bins; f += SGTD_VOTES_Q_THREADS) s_hist[f] = 0;
   if (tid == 0) { s_M = 0; s_P = 0; }
   __syncthreads();
   const u32 cnt = Q.count[q];
@@ -1053,17 +1059,17 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
     for (int blk = wid; blk < blocks_per_query; blk += NW) {
       const u32 d_first = (u32)blk * SGTD_PROBE_CHUNK;
       if (d_first >= cnt) break;
-      votes_of_block<true>(Q, B, q, d_first, cnt, frame_lo, s_hist, nullptr, s_pre[wid], s_ptr[wid], visits, total);
+      votes_of_block<true>(Q, B, q, d_first, cnt, frame_lo + tile_lo, n_bins, s_hist, nullptr, s_pre[wid], s_ptr[wid], visits, total);
     }
-    if (lane == 0) {
+    if (lane == 0 && blockIdx.y == 0) {
       atomicAdd(&s_M, total);
       atomicAdd(&s_P, (unsigned long long)visits);
     }
   }
   __syncthreads();
-  u32 *votes = B.votes + (size_t)q * frame_span;
-  for (u32 f = tid; f < frame_span; f += SGTD_VOTES_Q_THREADS) votes[f] = s_hist[f];
-  if (tid == 0) {      // resolve_undecided_kernel has already subtracted the records it killed
+  u32 *votes = B.votes + (size_t)q * frame_span + tile_lo;
+  for (u32 f = tid; f < n_bins; f += SGTD_VOTES_Q_THREADS) votes[f] = s_hist[f];
+  if (tid == 0 && blockIdx.y == 0) {      // resolve_undecided_kernel has already subtracted the records it killed
     atomicAdd(&q_M[q], s_M);
     atomicAdd(&q_P[q], s_P);
   }

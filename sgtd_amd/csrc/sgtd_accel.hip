@@ -744,12 +744,16 @@ int launch_select(sgtd_engine *e) {
 #endif
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
-    if (lds_votes && nq >= e->n_cus) {
-      // enough queries to fill the chip with one 16-wave workgroup each: no flush atomics
+    // one 16-wave workgroup per (query, frame tile) when that fills the chip: the tile's LDS
+    // histogram is final (no flush atomics); spans beyond LDS take several tiles of 36 Ki frames
+    const u32 tile_span = span <= 36 * 1024 ? span : 36 * 1024;
+    const u32 n_tiles = (span + tile_span - 1) / tile_span;
+    if (n_tiles == 1 ? nq >= e->n_cus : ((long long)nq * n_tiles >= e->n_cus / 4 && n_tiles <= 8)) {
+      const size_t tile_bytes = (size_t)tile_span * sizeof(u32);
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_query_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-      votes_query_kernel<<<nq, SGTD_VOTES_Q_THREADS, hist_bytes, e->stream>>>(v.Q, v.B, span, v.T.frame_lo, blocks, e->q_M.as<u32>(),
-                                                                              e->q_P.as<unsigned long long>());
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
+      votes_query_kernel<<<dim3(nq, n_tiles), SGTD_VOTES_Q_THREADS, tile_bytes, e->stream>>>(
+          v.Q, v.B, span, v.T.frame_lo, tile_span, blocks, e->q_M.as<u32>(), e->q_P.as<unsigned long long>());
     } else if (lds_votes) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));

@@ -117,6 +117,14 @@ def test_north_star_10k_frame_map_sampled_parity_and_8_shards(mods):
     sub = g.query_frames(qs.xyz[list(checked)], qs.label[list(checked)])
     st = g.stats()
     assert st["last_P"] == P and st["last_M"] == M and np.array_equal(sub.cand_frame, res.cand_frame[list(checked)])
+    # the safe batch size the library reports keeps the batch's rough matches under the 32-bit
+    # record index: ~740 k matches per query here -> a few thousand query frames
+    mb = g.max_batch(N)
+    assert 1024 <= mb <= 0xFFFFFFF0 // 700000, mb
+    fresh = manager.STDescManager()                 # before any batch: the estimate from the table statistics
+    fresh.add_frames(m.xyz[:2000], m.label[:2000])
+    assert fresh.max_batch(N) >= 1024
+    fresh.close()
     # cfg4's mechanism: the same map as 8 frame-range shards, local top-50 each, merged
     cn = g.config_setting_["candidate_num"]
     fr, vo = [], []
