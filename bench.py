@@ -408,6 +408,15 @@ def main():
                 for c in mgr.candidate_selector(d):
                     pairs += len(c)
             t_frame = (time.perf_counter() - t0) / nb
+            # ... and with the table entries of every match fetched too, as the adapter does to rebuild
+            # the reference's pair<STDesc, STDesc> lists for candidate_verify on the host
+            nb_e = min(nb, 8)
+            t0 = time.perf_counter()
+            for q in range(nb_e):
+                d = mgr.BuildSingleScanSTD(queries.xyz[q], queries.label[q])
+                for c in mgr.candidate_selector(d):
+                    mgr.fetch_entries(c.db_entry)
+            t_frame_e = (time.perf_counter() - t0) / nb_e
             nb2 = min(Q, 128)
             t0 = time.perf_counter()
             r2 = mgr.query_frames(queries.xyz[:nb2], queries.label[:nb2])
@@ -418,6 +427,7 @@ def main():
             t_batch = (time.perf_counter() - t0) / nb2
             boundary = {"per_frame_calls_host_pointers_frames_per_s": 1.0 / t_frame, "ms_per_frame": 1000.0 * t_frame,
                         "frames": nb, "pairs_fetched_per_frame": pairs / nb,
+                        "ms_per_frame_with_entries_fetched": 1000.0 * t_frame_e,
                         "batched_host_pointers_all_lists_fetched_frames_per_s": 1.0 / t_batch,
                         "batch": nb2, "pairs_fetched_per_frame_batched": pairs2 / nb2,
                         "note": "python ctypes adapter (sgtd_amd/manager.py); value above excludes PCIe and list fetches"}

@@ -92,6 +92,8 @@ struct sgtd_engine {
   // ---- build scratch
   DevBuf kp_off_dev, xyz_dev, label_dev, ws_keys, ws_slots, cnt_scan;
   DescStore tmp;        // strided build output for map construction
+  DescStore fetch;      // sgtd_fetch_entries staging
+  DevBuf fetch_idx;
   DevBuf tmp_count;
 
   // ---- query batch
@@ -1097,7 +1099,7 @@ int sgtd_destroy(sgtd_handle e) {
   if (!e) return SGTD_OK;
   (void)hipSetDevice(e->cfg.device_id);
   (void)hipStreamSynchronize(e->stream);
-  free_store(e->tab); free_store(e->tmp); free_store(e->qd);
+  free_store(e->tab); free_store(e->tmp); free_store(e->qd); free_store(e->fetch); free_buf(e->fetch_idx);
   DevBuf *bufs[] = {&e->seg[0].hot, &e->seg[0].perm, &e->seg[0].hash, &e->seg[0].bucket_start, &e->seg[0].bucket_key, &e->seg[0].dir,
                     &e->seg[1].hot, &e->seg[1].perm, &e->seg[1].hash, &e->seg[1].bucket_start, &e->seg[1].bucket_key, &e->seg[1].dir, &e->slice_of, &e->sq_sum,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
@@ -1676,16 +1678,20 @@ int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_d
   if (e && e->grp) return multi::fetch_entries(e, db_entry, n, out);
   if (!e || n < 0 || (n > 0 && (!db_entry || !out))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
-  // contiguous runs are copied as one range; scattered ids one by one
-  int64_t i = 0;
-  while (i < n) {
+  if (n == 0) return SGTD_OK;
+  bool contiguous = true;
+  for (int64_t i = 0; i < n; i++) {
     if (db_entry[i] < 0 || db_entry[i] >= e->n_entries) return SGTD_ERR_INVALID;
-    int64_t j = i + 1;
-    while (j < n && db_entry[j] == db_entry[j - 1] + 1) j++;
-    CHK(copy_out(e, e->tab, (size_t)db_entry[i], (size_t)(j - i), out, (size_t)i));
-    i = j;
+    if (i && db_entry[i] != db_entry[i - 1] + 1) contiguous = false;
   }
-  return SGTD_OK;
+  if (contiguous) return copy_out(e, e->tab, (size_t)db_entry[0], (size_t)n, out, 0);
+  // scattered ids (a match list): gathered on the device, then one copy per field
+  CHK(ensure(e, e->fetch_idx, (size_t)n * sizeof(long long)));
+  CHK(ensure_store(e, e->fetch, (size_t)n));
+  HIPCHK(hipMemcpyAsync(e->fetch_idx.p, db_entry, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, e->stream));
+  gather_entries_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->fetch_idx.as<long long>(), n, e->tab.view(), e->fetch.view());
+  HIPCHK(hipGetLastError());
+  return copy_out(e, e->fetch, 0, (size_t)n, out, 0);
 }
 
 int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *entry_ids,

@@ -380,6 +380,25 @@ __global__ void bucket_sq_kernel(const u32 *bucket_start, u32 n_buckets, u32 n_e
   if (lane_id() == 0 && v) atomicAdd(sum, v);
 }
 
+// sgtd_fetch_entries: table entries idx[0..n) gathered into contiguous staging arrays (one
+// device-to-host copy per field afterwards instead of one per entry)
+__global__ void gather_entries_kernel(const long long *idx, long long n, DescArrays tab, DescArrays out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t g = (size_t)idx[i];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    out.side[i * 3 + k] = tab.side[g * 3 + k];
+    out.angle[i * 3 + k] = tab.angle[g * 3 + k];
+    out.center[i * 3 + k] = tab.center[g * 3 + k];
+    out.label[i * 3 + k] = tab.label[g * 3 + k];
+    out.node_id[i * 3 + k] = tab.node_id[g * 3 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) out.vertex[i * 9 + k] = tab.vertex[g * 9 + k];
+  out.frame[i] = tab.frame[g];
+}
+
 // scatter of a strided build result into the table's cold arrays (append):
 // frame k's count[k] descriptors go to g = gbase[k] + r
 struct AppendParams {
