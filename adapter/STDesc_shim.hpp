@@ -44,6 +44,7 @@
 #pragma once
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <utility>
 #include <vector>
 
@@ -166,36 +167,49 @@ int AddSTDescs(sgtd_handle h, const std::vector<Desc> &stds_vec, unsigned int &c
 }
 
 // ---- STDesc.cpp:318-460 --------------------------------------------------------------------
-template <class Desc, class MatchList>
-int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::vector<MatchList> &candidate_matcher_vec,
-                       unsigned int current_frame_id, int candidate_num, int &CS1) {
-  const auto t1 = std::chrono::high_resolution_clock::now();
+// the device part of candidate_selector: candidates, votes, list offsets and the (query
+// descriptor, table entry) index pairs of every list, in the reference's order
+struct Selection {
+  int32_t n_cand = 0;
+  std::vector<int32_t> frame, votes, q_idx;
+  std::vector<int64_t> off, entry;
+};
+
+template <class Desc>
+int select(sgtd_handle h, const std::vector<Desc> &stds_vec, int candidate_num, Selection &s) {
   SoaBuf q(stds_vec.size());
   to_soa(stds_vec, q);
   int st = sgtd_query_descs(h, &q.v, (int64_t)stds_vec.size());
   if (st != SGTD_OK) return st;
   const int cn = candidate_num;
-  int32_t n_cand = 0;
-  std::vector<int32_t> frame(cn), votes(cn);
-  std::vector<int64_t> off(cn + 1);
-  st = sgtd_result_candidates(h, &n_cand, frame.data(), votes.data(), off.data());
+  s.frame.assign(cn, -1); s.votes.assign(cn, 0); s.off.assign(cn + 1, 0);
+  st = sgtd_result_candidates(h, &s.n_cand, s.frame.data(), s.votes.data(), s.off.data());
   if (st != SGTD_OK) return st;
-  const int64_t total = off[n_cand];
-  std::vector<int32_t> qi((size_t)total);
-  std::vector<int64_t> en((size_t)total);
+  const int64_t total = s.off[s.n_cand];
+  s.q_idx.resize((size_t)total); s.entry.resize((size_t)total);
   int64_t got = 0;
-  st = sgtd_result_pairs(h, 0, qi.data(), en.data(), total, &got);
+  return sgtd_result_pairs(h, 0, s.q_idx.data(), s.entry.data(), total, &got);
+}
+
+template <class Desc, class MatchList>
+int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::vector<MatchList> &candidate_matcher_vec,
+                       unsigned int current_frame_id, int candidate_num, int &CS1) {
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  Selection s;
+  int st = select(h, stds_vec, candidate_num, s);
   if (st != SGTD_OK) return st;
-  SoaBuf ent((size_t)total);
-  st = sgtd_fetch_entries(h, en.data(), total, &ent.v);
+  const int64_t total = s.off[s.n_cand];
+  SoaBuf ent((size_t)total);                       // the table side of every pair<STDesc, STDesc>
+  st = sgtd_fetch_entries(h, s.entry.data(), total, &ent.v);
   if (st != SGTD_OK) return st;
   std::vector<Desc> db;
   from_soa(ent, (size_t)total, db);
-  for (int k = 0; k < n_cand; k++) {
+  for (int k = 0; k < s.n_cand; k++) {
     MatchList ml;
     ml.match_id_.first = (int)current_frame_id;    // :436
-    ml.match_id_.second = frame[k];                // :437
-    for (int64_t r = off[k]; r < off[k + 1]; r++) ml.match_list_.emplace_back(stds_vec[qi[(size_t)r]], db[(size_t)r]);
+    ml.match_id_.second = s.frame[k];              // :437
+    ml.match_list_.reserve((size_t)(s.off[k + 1] - s.off[k]));
+    for (int64_t r = s.off[k]; r < s.off[k + 1]; r++) ml.match_list_.emplace_back(stds_vec[s.q_idx[(size_t)r]], std::move(db[(size_t)r]));
     candidate_matcher_vec.push_back(std::move(ml));
   }
   const auto t2 = std::chrono::high_resolution_clock::now();
@@ -204,49 +218,81 @@ int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::ve
 }
 
 // ---- STDesc.cpp:84-147 with candidate_verify (:462-547) on the device ---------------------
-// Vec3 / Mat3 = Eigen::Vector3d / Eigen::Matrix3d (operator[] and operator()(row, col))
+// Vec3 / Mat3 = Eigen::Vector3d / Eigen::Matrix3d (operator[] and operator()(row, col)).
+// The match lists stay on the device: only the inlier pairs of every candidate
+// (sucess_match_vec, what LOOP_RESULT::loop_std_pair holds) are fetched, a few thousand
+// descriptors instead of the ~10^5 of the full lists.
 template <class Desc, class Vec3, class Mat3, class LoopResult>
 int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, double> &loop_result,
                std::pair<Vec3, Mat3> &loop_transform, std::vector<std::pair<Desc, Desc>> &loop_std_pair,
                std::vector<LoopResult> &match_result_list, unsigned int current_frame_id, int candidate_num,
                double icp_threshold, int &CS1) {
-  struct ML {   // STDMatchList's two fields the loop needs
-    std::vector<std::pair<Desc, Desc>> match_list_;
-    std::pair<int, int> match_id_;
-  };
+  (void)current_frame_id;
   loop_result = std::pair<int, double>(-1, 0);
   if (stds_vec.empty()) return SGTD_OK;            // "No STDescs!" (:89-93)
-  std::vector<ML> cands;
-  int st = candidate_selector(h, stds_vec, cands, current_frame_id, candidate_num, CS1);
+  const auto t1 = std::chrono::high_resolution_clock::now();
+#ifdef SGTD_SHIM_TIMING
+  auto lap = [&](const char *what) {
+    static thread_local std::chrono::high_resolution_clock::time_point last = t1;
+    const auto now = std::chrono::high_resolution_clock::now();
+    std::fprintf(stderr, "  [shim] %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+  };
+  { static thread_local bool first = true; (void)first; }
+#define SGTD_LAP(x) lap(x)
+#else
+#define SGTD_LAP(x) do { } while (0)
+#endif
+  Selection s;
+  int st = select(h, stds_vec, candidate_num, s);  // :98
   if (st != SGTD_OK) return st;
+  CS1 = (int)(std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count() * 1000);
+  SGTD_LAP("select");
   st = sgtd_verify(h);                             // :105-118 for every candidate
   if (st != SGTD_OK) return st;
   const int cn = candidate_num;
   std::vector<double> score(cn), pose((size_t)cn * 12);   // rot row-major (9), then t (3)
   st = sgtd_result_verify(h, 0, score.data(), pose.data());
   if (st != SGTD_OK) return st;
+  SGTD_LAP("verify");
+  // inlier positions of every accepted candidate, then ONE fetch of the table entries they name
+  std::vector<std::vector<int32_t>> inl((size_t)s.n_cand);
+  std::vector<int64_t> want;
+  for (int k = 0; k < s.n_cand; k++) {
+    if (!(score[k] >= 0)) continue;                // sucess_match_vec, :516-539
+    inl[k].resize((size_t)(s.off[k + 1] - s.off[k]));
+    int64_t n = 0;
+    st = sgtd_result_inliers(h, 0, k, inl[k].data(), (int64_t)inl[k].size(), &n);
+    if (st != SGTD_OK) return st;
+    inl[k].resize((size_t)n);
+    for (int32_t p : inl[k]) want.push_back(s.entry[(size_t)(s.off[k] + p)]);
+  }
+  SGTD_LAP("inliers");
+  SoaBuf ent(want.size());
+  st = sgtd_fetch_entries(h, want.data(), (int64_t)want.size(), &ent.v);
+  if (st != SGTD_OK) return st;
+  SGTD_LAP("fetch");
+  std::vector<Desc> db;
+  from_soa(ent, want.size(), db);
+  SGTD_LAP("from_soa");
   double best_score = 0;
   int best = -1;
   const size_t first = match_result_list.size();
-  for (size_t i = 0; i < cands.size(); i++) {      // :105-131
+  size_t w = 0;
+  for (int k = 0; k < s.n_cand; k++) {             // :105-131
     LoopResult r;
-    r.match_id = cands[i].match_id_.second;
-    r.match_fitness = score[i];                    // an int member in the reference: truncates like :119
+    r.match_id = s.frame[k];
+    r.match_fitness = score[k];                    // an int member in the reference: truncates like :119
     for (int a = 0; a < 3; a++) {
-      for (int b = 0; b < 3; b++) r.loop_transform.second(a, b) = pose[i * 12 + a * 3 + b];
-      r.loop_transform.first[a] = pose[i * 12 + 9 + a];
+      for (int b = 0; b < 3; b++) r.loop_transform.second(a, b) = pose[(size_t)k * 12 + a * 3 + b];
+      r.loop_transform.first[a] = pose[(size_t)k * 12 + 9 + a];
     }
-    if (score[i] >= 0) {                           // sucess_match_vec, :516-539
-      const auto &ml = cands[i].match_list_;
-      std::vector<int32_t> idx(ml.size());
-      int64_t n = 0;
-      st = sgtd_result_inliers(h, 0, (int)i, idx.data(), (int64_t)idx.size(), &n);
-      if (st != SGTD_OK) return st;
-      for (int64_t k = 0; k < n; k++) r.loop_std_pair.push_back(ml[(size_t)idx[(size_t)k]]);
-    }
-    if (score[i] > best_score) { best_score = score[i]; best = (int)i; }   // :125-131
+    r.loop_std_pair.reserve(inl[k].size());
+    for (int32_t p : inl[k]) r.loop_std_pair.emplace_back(stds_vec[s.q_idx[(size_t)(s.off[k] + p)]], std::move(db[w++]));
+    if (score[k] > best_score) { best_score = score[k]; best = k; }   // :125-131
     match_result_list.push_back(std::move(r));
   }
+  SGTD_LAP("pairs");
   if (best >= 0 && best_score > icp_threshold) {   // :138-146
     const LoopResult &b = match_result_list[first + (size_t)best];
     loop_result = std::pair<int, double>(b.match_id, best_score);

@@ -4,6 +4,9 @@
 // no GICP (enable_gicp = false); BASE2OUSTER = identity.
 //
 //   localize <map_dir> <query_dir> [batch=256] [icp_threshold=0.4]
+//   LOCALIZE_PER_FRAME=n: additionally run the first n queries the way the reference node does —
+//   one BuildSingleScanSTD + SearchLoop call per frame through the STDescManager adapter
+//   (semantic_graph_localization.cpp:590-601) — and report the time per frame
 //
 // Map frames take the sorted file order here (the reference uses the unsorted directory order,
 // quirk 13: pass an explicit order if a run must be reproduced); queries are sorted (:386).
@@ -17,6 +20,7 @@
 #include <vector>
 
 #include "sgtd_accel.h"
+#include "sgtd/STDescManager.hpp"
 
 namespace fs = std::filesystem;
 
@@ -176,6 +180,48 @@ int main(int argc, char **argv) {
   std::printf("mean errors of the successes: %.4f m, %.4f deg\n", score_num ? err_t / score_num : 0.0, score_num ? err_r / score_num : 0.0);
   std::printf("time: load %.1f ms, map build %.1f ms, queries %.1f ms (%.3f ms per query incl. verification), %d device(s)\n", ms(t0, t1), ms(t1, t2),
               ms(t2, t3), total_num ? ms(t2, t3) / total_num : 0.0, sgtd_device_count(h));
+  if (const char *pf = std::getenv("LOCALIZE_PER_FRAME")) {
+    // the reference's own call pattern: one frame per call, host containers in and out
+    const int n_pf = std::min(std::atoi(pf), qs.n);
+    sgtd::ConfigSetting cs;
+    cs.icp_threshold_ = icp_threshold;
+    cs.max_frame_n_ = cfg.max_frame_n;
+    cs.device_ids_ = devices;
+    sgtd::STDescManager mgr(cs);
+    OK(sgtd_add_frames(mgr.handle(), map.xyz, map.label, map.off, map.n, 0));   // the map, batched (the per-frame form is tests/cpp/test_manager.cpp)
+    OK(sgtd_current_frame_id(mgr.handle(), &mgr.current_frame_id_));
+    OK(sgtd_finalize(mgr.handle()));
+    double ms_build = 0, ms_search = 0;
+    long same = 0, pairs = 0;
+    std::vector<int32_t> bf(1);
+    for (int i = 0; i < n_pf; i++) {
+      std::vector<sgtd::PointXYZL> cloud;
+      for (int64_t k = qs.off[i]; k < qs.off[i + 1]; k++) cloud.push_back({qs.xyz[3 * k], qs.xyz[3 * k + 1], qs.xyz[3 * k + 2], qs.label[k]});
+      auto a = std::chrono::steady_clock::now();
+      std::vector<sgtd::STDesc> stds;
+      mgr.BuildSingleScanSTD(cloud, stds);                                  // :592
+      auto b = std::chrono::steady_clock::now();
+      std::pair<int, double> search_result(-1, 0);
+      std::pair<sgtd::Vec3, sgtd::Mat3> loop_transform;
+      std::vector<std::pair<sgtd::STDesc, sgtd::STDesc>> loop_std_pair;
+      std::vector<sgtd::LOOP_RESULT> match_result_list;
+      mgr.SearchLoop(stds, search_result, loop_transform, loop_std_pair, match_result_list);   // :601
+      auto c = std::chrono::steady_clock::now();
+      OK(mgr.last_status());
+      ms_build += std::chrono::duration<double, std::milli>(b - a).count();
+      ms_search += std::chrono::duration<double, std::milli>(c - b).count();
+      // the batched run above must have chosen the same frame for this query
+      std::vector<int64_t> off1 = {0, qs.off[i + 1] - qs.off[i]};
+      OK(sgtd_query_frames(h, qs.xyz + 3 * qs.off[i], qs.label + qs.off[i], off1.data(), 1, 0));
+      OK(sgtd_verify(h));
+      OK(sgtd_search_loop(h, icp_threshold, nullptr, bf.data(), nullptr));
+      same += bf[0] == search_result.first;
+      pairs += (long)loop_std_pair.size();
+    }
+    std::printf("per-frame calls through STDescManager (%d frames): %.3f ms per frame = BuildSingleScanSTD %.3f + SearchLoop %.3f; "
+                "%ld/%d agree with the batched run, %.1f inlier pairs per loop\n",
+                n_pf, (ms_build + ms_search) / n_pf, ms_build / n_pf, ms_search / n_pf, same, n_pf, (double)pairs / n_pf);
+  }
   sgtd_destroy(h);
   sgtd_graphs_free(map.b);
   sgtd_graphs_free(qs.b);

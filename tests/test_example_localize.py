@@ -56,6 +56,7 @@ def test_example_matches_the_python_harness(tmp_path):
     assert met.score_num >= 12
     # the same run with the table sharded over "two devices" behind the one handle (both shards on GPU 0 here)
     out2 = subprocess.run([EXE, str(tmp_path / "map"), str(tmp_path / "query"), "5"], capture_output=True, text=True, timeout=300,
-                          env=dict(os.environ, SGTD_DEVICES="0,0"))
+                          env=dict(os.environ, SGTD_DEVICES="0,0", LOCALIZE_PER_FRAME="14"))
+    assert "14/14 agree with the batched run" in out2.stdout, out2.stdout
     assert out2.returncode == 0, out2.stdout + out2.stderr
     assert out2.stdout.splitlines()[:2] == out.stdout.splitlines()[:2] and "2 device(s)" in out2.stdout
