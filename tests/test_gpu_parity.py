@@ -674,7 +674,7 @@ def test_bucket_slices_keep_the_reference_order_per_frame(mods, monotone):
     if not monotone:
         rng.shuffle(ids)                      # frame ids out of insertion order: the (key, frame) pre-sort path
     for k, f in enumerate(ids):
-        n = 500
+        n = 500 if k % 5 else 1600            # 1600: (bucket, frame) runs beyond SGTD_RUN_MAX go to the overflow slice untested
         gd, od = _random_descs(oracle, manager, rng, n, f, small=(k % 2 == 0))
         if not monotone and k % 3 == 0:       # one AddSTDescs call carrying two frame ids
             gd.frame[n // 2:] = ids[(k + 5) % len(ids)]

@@ -1,0 +1,104 @@
+"""Randomised differential stress of the GPU path against the oracle (not part of the pytest
+suite: run on the GPU box, `python tools/stress_parity.py [seconds] [seed]`).  Every round draws
+a configuration (K, resolution, thresholds, labels), a small map, an insertion pattern
+(frames in one batch / frame by frame / appended after queries = tail segment / caller-stamped
+frame ids out of order), optionally a multi-device handle, and compares candidates, votes,
+match lists, counters and the ordered rough list with the oracle."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from oracle import oracle  # noqa: E402
+from sgtd_amd import manager, synth  # noqa: E402
+
+
+def one_round(rng, rnd):
+    k = int(rng.integers(3, 13))
+    cfg = dict(descriptor_near_num=k, std_side_resolution=float(rng.choice([0.25, 0.5, 1.0, 2.0])),
+               descriptor_min_len=float(rng.choice([0.0, 0.5, 2.0])), descriptor_max_len=float(rng.choice([15.0, 30.0, 50.0])),
+               rough_dis_threshold=float(rng.choice([0.01, 0.03, 0.06, 0.12])), candidate_num=int(rng.integers(1, 30)))
+    n_kp = max(k, int(rng.integers(12, 120)))
+    n_frames = int(rng.integers(3, 40))
+    labels = [(3, 11), (0, 12), (5, 6), (0, 40)][int(rng.integers(0, 4))]
+    stream = int(rng.integers(100, 100000))
+    pattern = ["batch", "per_frame", "tail", "stamped"][int(rng.integers(0, 4))]
+    multi = pattern in ("batch", "per_frame", "tail") and rng.random() < 0.3
+    sigma = float(rng.choice([0.0, 0.02, 0.3]))          # 0.0: re-observed frames are exact copies (many twins)
+    m = synth.make_map(n_frames, n_kp, stream=stream, label_lo=labels[0], label_hi=labels[1], sigma=max(sigma, 1e-4))
+    q = synth.make_queries(m, 3, stream=stream)
+    g = manager.STDescManager(devices=[0, 0, 0] if multi else None, **cfg)
+    o = oracle.OracleManager(**cfg)
+    desc = "round %d: K=%d res=%g rough=%g cand=%d n_kp=%d F=%d labels=%s %s%s sigma=%g" % (
+        rnd, k, cfg["std_side_resolution"], cfg["rough_dis_threshold"], cfg["candidate_num"], n_kp, n_frames, labels, pattern,
+        " multi" if multi else "", sigma)
+
+    def add(lo, hi, how):
+        if how == "batch":
+            g.add_frames(m.xyz[lo:hi], m.label[lo:hi])
+            for f in range(lo, hi):
+                o.build(m.xyz[f], m.label[f], export=False); o.add_last()
+        else:
+            for f in range(lo, hi):
+                d = g.BuildSingleScanSTD(m.xyz[f], m.label[f])
+                od = o.build(m.xyz[f], m.label[f])
+                if how == "stamped":            # caller-stamped ids, out of insertion order
+                    fid = int(rng.integers(0, 50))
+                    d.frame[:] = fid; od.frame[:] = fid
+                    o.add(od)
+                else:
+                    o.add_last()
+                g.AddSTDescs(d)
+
+    def check():
+        r = g.query_frames(q.xyz, q.label)
+        for i in range(3):
+            o.build(q.xyz[i], q.label[i], export=False)
+            want = o.select()
+            nc = int(r.n_cand[i])
+            assert np.array_equal(r.cand_frame[i, :nc], want["cand_frame"]), desc
+            assert np.array_equal(r.cand_votes[i, :nc], want["cand_votes"]), desc
+            qi, de = g.result_pairs(i, r)
+            assert np.array_equal(qi, want["q_idx"]), desc
+            if multi:
+                got = g.fetch_entries(de[:200]); ref = o.fetch_entries(want["db_entry"][:200])
+                assert np.array_equal(got.side, ref.side) and np.array_equal(got.frame, ref.frame), desc
+            else:
+                assert np.array_equal(de, want["db_entry"]), desc
+        if not multi:
+            c = o.counters(); st = g.stats()
+            one = g.query_frames(q.xyz[2:3], q.label[2:3])
+            st = g.stats()
+            assert st["last_P"] == c["P"] and st["last_M"] == c["M"], desc
+            gr, orr = g.result_rough(0), o.rough_matches()
+            for key in ("q_idx", "cell", "db_entry", "frame", "dis"):
+                assert np.array_equal(gr[key], orr[key]), desc + " rough " + key
+
+    if pattern == "tail":
+        cut = max(1, n_frames // 2)
+        add(0, cut, "batch"); check()
+        add(cut, n_frames, "per_frame" if rng.random() < 0.5 else "batch"); check()
+    else:
+        add(0, n_frames, pattern)
+        check()
+    g.close()
+    return desc
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    oracle.build_library()
+    rng = np.random.default_rng(seed)
+    t0, rnd = time.time(), 0
+    while time.time() - t0 < budget:
+        d = one_round(rng, rnd)
+        rnd += 1
+        if rnd % 10 == 0:
+            print(d, flush=True)
+    print("stress ok: %d rounds in %.0f s (seed %d)" % (rnd, time.time() - t0, seed))
+
+
+if __name__ == "__main__":
+    main()
