@@ -163,7 +163,7 @@ def recall(smap, queries, top1):
 
 def load_traffic(F, N, Q, world):
     """HBM bytes per sweep launch from the committed PMC passes (profiles/r02_traffic.json,
-    written by profiles/collect.sh for exactly this configuration), else None"""
+    written by profiles/collect_r02.sh for exactly this configuration), else None"""
     path = os.path.join(ROOT, "profiles", "r02_traffic.json")
     try:
         for row in json.load(open(path)):

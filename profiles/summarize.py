@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 output of profiles/collect.sh into the small files that
+"""Turns the rocprofv3 output of profiles/collect_r02.sh into the small files that
 are committed under profiles/: per-kernel duration stats, per-kernel PMC means,
-and probe_traffic.json (HBM bytes per probe launch, read by bench.py).
+<tag>_probe_traffic.json and a row of r02_traffic.json (HBM bytes per sweep launch, read by bench.py).
 
 HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md §HBM:
 FETCH_SIZE (KB) counts 128-B requests as 64 B for wide coalesced reads (the
