@@ -1245,6 +1245,9 @@ __global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32
   }
 }
 
+#ifndef SGTD_WRITE_CAP
+#define SGTD_WRITE_CAP 16
+#endif
 // pass 2: every candidate's match_list_ in (i, cell, j) order (:437-449);
 // pair = query descriptor index << 32 | insertion index of the table entry
 __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuffers B, CompactLists L,
@@ -1253,7 +1256,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
                                                           const long long *pair_off, const u32 *q_pair_base,
                                                           u64 *pairs) {
   constexpr int NW = 256 / SGTD_WAVE;
-  constexpr int CAP = 16;   // staged pairs per slot = one 128-B line
+  constexpr int CAP = SGTD_WRITE_CAP;   // staged pairs per slot = one 128-B (16) or 64-B (8) line
   __shared__ u64 s_mask[NW][64];         // per wave and slot: lanes of the current word that carry the slot
   __shared__ u64 s_stage[NW][64][CAP + 1];   // per wave and slot: pairs waiting for a full-line store (rows padded by one
                                              // word: a 128-byte row stride put every slot's k-th pair on the same banks)
@@ -1271,11 +1274,12 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   u32 running = 0, fill = 0;
   if (lane < cand_num)
     running = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + lane] + blk_excl[bslot * 64 + lane];
-  // all staged pairs go out as 16-lane groups, 4 slots per store instruction
+  // all staged pairs go out as CAP-lane groups, 64 / CAP slots per store instruction
   auto flush = [&]() {
+    constexpr int SPI = SGTD_WAVE / CAP;
 #pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-      const int s = it * 4 + (lane >> 4), k = lane & 15;
+    for (int it = 0; it < 64 / SPI; it++) {
+      const int s = it * SPI + (lane / CAP), k = lane % CAP;
       const u32 f = __shfl(fill, s), base = __shfl(running, s);
       if ((u32)k < f) pairs[base + k] = s_stage[wid][s][k];
     }
