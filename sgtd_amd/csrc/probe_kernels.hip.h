@@ -265,7 +265,17 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
     const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
     const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
     const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
-    const int x = (int)(q0 + (double)ix), y = (int)(q1 + (double)iy), z = (int)(q2 + (double)iz);
+    // (int)(side + inc) from the HOME cell n = (int)side, the same for every member of the group:
+    // n + inc, and 0 for inc = -1 at n = 0 (C truncation of a value in (-1, 0)).  The float form
+    // differs only for a side that is the largest double below a power of two (side + 1 rounds up
+    // across the integer): such a descriptor's own gate mask, computed with the float form like
+    // the reference, excludes that cell on both sides.
+    // (a descriptor with a negative side — outside the envelope — is a group of its own,
+    // home_keys_kernel, and keeps the float form)
+    const bool nonneg = q0 >= 0.0 && q1 >= 0.0 && q2 >= 0.0;
+    const int x = nonneg ? max((int)q0 + ix, 0) : (int)(q0 + (double)ix);
+    const int y = nonneg ? max((int)q1 + iy, 0) : (int)(q1 + (double)iy);
+    const int z = nonneg ? max((int)q2 + iz, 0) : (int)(q2 + (double)iz);
     if (x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
       const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
       u32 h = hash_key(key) & T.hash_mask;

@@ -121,3 +121,14 @@ def test_merge_verified_and_search_loop_choice():
     none = torch.full((1, 3), -1.0, dtype=torch.float64)
     bc, bf, bs = search_loop_choice(gf[:1], n_cand[:1], none, 0.4)
     assert bc.tolist() == [-1] and bs.tolist() == [0.0]
+
+
+def test_bench_refuses_a_gpu_count_that_disagrees_with_the_launcher():
+    """bench.py --gpus N under a launcher that started another number of ranks must fail loudly,
+    before anything touches a GPU"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in (out.stderr + out.stdout)

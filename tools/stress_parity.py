@@ -19,8 +19,9 @@ def one_round(rng, rnd):
     cfg = dict(descriptor_near_num=k, std_side_resolution=float(rng.choice([0.25, 0.5, 1.0, 2.0])),
                descriptor_min_len=float(rng.choice([0.0, 0.5, 2.0])), descriptor_max_len=float(rng.choice([15.0, 30.0, 50.0])),
                rough_dis_threshold=float(rng.choice([0.01, 0.03, 0.06, 0.12])), candidate_num=int(rng.integers(1, 30)))
-    n_kp = max(k, int(rng.integers(12, 120)))
-    n_frames = int(rng.integers(3, 40))
+    big = rnd % 25 == 24                      # every 25th round: a map large enough for long lists, pairs and slab refills
+    n_kp = max(k, int(rng.integers(150, 220) if big else rng.integers(12, 120)))
+    n_frames = int(rng.integers(120, 400) if big else rng.integers(3, 40))
     labels = [(3, 11), (0, 12), (5, 6), (0, 40)][int(rng.integers(0, 4))]
     stream = int(rng.integers(100, 100000))
     pattern = ["batch", "per_frame", "tail", "stamped"][int(rng.integers(0, 4))]
