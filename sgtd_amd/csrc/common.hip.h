@@ -102,7 +102,7 @@ static_assert(sizeof(BucketDir) == 32 && SGTD_ZSLICES == 4, "the sweep unpacks {
 // build kernel (gid, d unset), and per sorted position by sorted_desc_kernel.  A wavefront
 // loads 16 of them with one 16-B-per-lane load (lane j = quarter j & 3 of record j >> 2):
 //   quarter 0: q0, q1   quarter 1: q2, thr2   quarter 2: frame, gate mask, group id, slot d
-//   quarter 3: lo2, hi2 (f32 squared thresholds of the conservative f32 test)
+//   quarter 3: lo2, hi2 (f32 squared thresholds of the conservative f32 test), t_up
 struct __attribute__((aligned(64))) QueryRec {
   double q0, q1, q2;  // side_length_ (scaled)
   double thr2;        // exact squared match threshold (sq_threshold)
@@ -111,7 +111,8 @@ struct __attribute__((aligned(64))) QueryRec {
   u32 gid;            // key-major: group (home cell) of the descriptor
   u32 d;              // key-major: descriptor slot
   float lo2, hi2;     // f32 d2 below lo2: certainly a match; above hi2: certainly not (f32_bounds)
-  u32 pad[2];
+  float t_up;         // f32 upper bound of the match threshold (slice pruning in the sweep's plan)
+  u32 pad;
 };
 
 // smallest y with sqrt_rn(y) >= thr:  (sqrt_rn(d2) < thr)  <=>  (d2 < y), because the
@@ -191,7 +192,13 @@ __device__ __forceinline__ void write_query_rec(QueryRec *out, double s0, double
   qr[0] = make_double2(s0, s1);
   qr[1] = make_double2(s2, sq_threshold(thr));
   reinterpret_cast<uint4 *>(qr)[2] = make_uint4(frame, gate_mask(s0, s1, s2), 0u, 0u);
-  reinterpret_cast<uint4 *>(qr)[3] = make_uint4(__float_as_uint(lo2), __float_as_uint(hi2), 0u, 0u);
+  // upper bound of thr in f32 (relative margin, then rounded up): an entry whose third side is
+  // further than this from q2 cannot match
+  const double tm = thr * (1.0 + 1e-9) + 1e-12;
+  float t_up = (float)tm;
+  if ((double)t_up < tm) t_up = __uint_as_float(__float_as_uint(t_up) + 1u);
+  if (!(tm == tm)) t_up = __builtin_inff();       // NaN threshold: prune nothing (nothing matches anyway)
+  reinterpret_cast<uint4 *>(qr)[3] = make_uint4(__float_as_uint(lo2), __float_as_uint(hi2), __float_as_uint(t_up), 0u);
 }
 
 struct HashSlot {  // 16 bytes
@@ -216,10 +223,10 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
   return (u32)x;
 }
 
+// sum over the 64 lanes, the same value in every lane: the inclusive DPP scan's last lane holds
+// it (six DPP adds and a v_readlane: no LDS crossbar round trips).  All 64 lanes must be active.
 __device__ __forceinline__ u32 wave_sum(u32 v) {
-#pragma unroll
-  for (int d = SGTD_WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
-  return v;
+  return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(v), SGTD_WAVE - 1);
 }
 
 // Stable multi-split rank inside one wave: lanes with equal `digit` (BITS wide)

@@ -150,6 +150,7 @@ struct DescSet {
   uint4 row;            // lane l < 54: 16-B quarter l of the group's 27 directory rows
   double q0[K], q1[K], q2[K], thr2[K];
   float lo2[K], hi2[K]; // conservative f32 thresholds (f32_bounds)
+  float t_up[K];        // f32 upper bound of the match threshold
   u32 qframe[K];
   u32 gate[K];          // the descriptor's 27-bit gate mask
   u32 slot[K];          // descriptor slot d
@@ -320,14 +321,14 @@ __device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f) 
   for (int k = 0; k < K; k++) {
     const bool lv = lane < SGTD_NRANGE && ((f.gate[k] >> c) & 1u);
     // slices of cell z = (int)(q2 + iz) reached by [q2 - t, q2 + t]; slice s holds the entries with
-    // (side2 + 0.5 - z) * 4 in [s, s + 1).  t carries a relative margin over the exact threshold
-    // and the bounds another 1e-6 slice: visiting a slice too many is harmless.
-    const double t = sqrt(f.thr2[k]) * (1.0 + 1e-9) + 1e-12;
-    const double zc = (double)(int)(f.q2[k] + (double)iz);
-    const double a = ((f.q2[k] - t) + 0.5 - zc) * (double)SGTD_ZSLICES - 1e-6;
-    const double b = ((f.q2[k] + t) + 0.5 - zc) * (double)SGTD_ZSLICES + 1e-6;
-    const int lo_k = a <= 0.0 ? 0 : (a >= (double)SGTD_ZSLICES ? SGTD_ZSLICES : (int)a);          // floor, clamped to [0, 4]
-    const int hi_k = b < 0.0 ? -1 : (b >= (double)SGTD_ZSLICES ? SGTD_ZSLICES - 1 : (int)b);      // floor, clamped to [-1, 3]
+    // (side2 + 0.5 - z) * 4 in [s, s + 1).  q2 - z is below 2.5 in magnitude for every gated cell:
+    // the bounds are computed in f32 from it (error < 1e-6) with a margin of 1e-4 slice on top of
+    // the threshold's own upward rounding; visiting a slice too many is harmless.
+    const float dq = (float)(f.q2[k] - (double)(int)(f.q2[k] + (double)iz));
+    const float a = ((dq - f.t_up[k]) + 0.5f) * (float)SGTD_ZSLICES - 1e-4f;
+    const float b = ((dq + f.t_up[k]) + 0.5f) * (float)SGTD_ZSLICES + 1e-4f;
+    const int lo_k = !(a > 0.0f) ? 0 : (a >= (float)SGTD_ZSLICES ? SGTD_ZSLICES : (int)a);          // floor, clamped to [0, 4]; NaN -> 0
+    const int hi_k = b < 0.0f ? -1 : (!(b < (float)SGTD_ZSLICES) ? SGTD_ZSLICES - 1 : (int)b);      // floor, clamped to [-1, 3]; NaN -> 3
     if (lv && hi_k >= lo_k) { s_lo = min(s_lo, lo_k); s_hi = max(s_hi, hi_k); }
     live |= lv;
     // the reference's loop visits every entry of every gated cell: cum4 of the even lanes
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       f.slot[k] = (u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
       f.lo2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 3));
       f.hi2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 3));
+      f.t_up[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.z, l0 + 3));
     };
     for (u32 i = 0; i < n;) {
       // consecutive descriptors of one home cell are swept together, 4 or 2 at a time (one plan,

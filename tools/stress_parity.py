@@ -23,6 +23,15 @@ def one_round(rng, rnd):
     n_kp = max(k, int(rng.integers(150, 220) if big else rng.integers(12, 120)))
     n_frames = int(rng.integers(120, 400) if big else rng.integers(3, 40))
     labels = [(3, 11), (0, 12), (5, 6), (0, 40)][int(rng.integers(0, 4))]
+    if big:   # keep the ORACLE's cost bounded: its serial tail copies 832 B per match (tens of millions of
+              # matches per query with two labels, 2 m cells and a 0.12 threshold take it hours)
+        cfg["rough_dis_threshold"] = min(cfg["rough_dis_threshold"], 0.03)
+        cfg["std_side_resolution"] = min(cfg["std_side_resolution"], 1.0)
+        if labels == (5, 6):
+            labels = (3, 11)
+        if k > 10:
+            k = 10
+            cfg["descriptor_near_num"] = 10
     stream = int(rng.integers(100, 100000))
     pattern = ["batch", "per_frame", "tail", "stamped"][int(rng.integers(0, 4))]
     multi = pattern in ("batch", "per_frame", "tail") and rng.random() < 0.3
@@ -34,6 +43,8 @@ def one_round(rng, rnd):
     desc = "round %d: K=%d res=%g rough=%g cand=%d n_kp=%d F=%d labels=%s %s%s sigma=%g" % (
         rnd, k, cfg["std_side_resolution"], cfg["rough_dis_threshold"], cfg["candidate_num"], n_kp, n_frames, labels, pattern,
         " multi" if multi else "", sigma)
+    if __import__("os").environ.get("STRESS_VERBOSE") == "1":
+        print("  config:", desc, "stream", stream, flush=True)
 
     def add(lo, hi, how):
         if how == "batch":
@@ -93,10 +104,13 @@ def main():
     oracle.build_library()
     rng = np.random.default_rng(seed)
     t0, rnd = time.time(), 0
+    verbose = __import__("os").environ.get("STRESS_VERBOSE") == "1"
     while time.time() - t0 < budget:
+        if verbose:
+            print("start round %d at %.1f s" % (rnd, time.time() - t0), flush=True)
         d = one_round(rng, rnd)
         rnd += 1
-        if rnd % 10 == 0:
+        if rnd % 10 == 0 or verbose:
             print(d, flush=True)
     print("stress ok: %d rounds in %.0f s (seed %d)" % (rnd, time.time() - t0, seed))
 
