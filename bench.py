@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=10000, help="map size F")
     ap.add_argument("--keypoints", type=int, default=200, help="keypoints per frame N")
     ap.add_argument("--queries", type=int, default=2048,
-                    help="query frames per step (per rank in query mode); 512 / 1024 / 2048 / 4096 give 81 / 92 / 96 / 101 k frames/s at F = 10 k")
+                    help="query frames per step (per rank in query mode); 512 / 1024 / 2048 / 4096 give 81 / 92 / 98 / 101 k frames/s at F = 10 k")
     ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto")
     ap.add_argument("--also-table", choices=["on", "off"], default="on",
                     help="N>1, query mode: also measure the table-sharded mode in the same run")
@@ -548,6 +548,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if mode == "table" else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "arithmetic": "every decision equals the reference's f64 result: the sweep pre-tests in f32 against two "
+                          "conservative thresholds and decides the few entries between them on the exact f64 sides",
             "config": {"workload": "synthetic %d keypoints/frame, %d-frame map, descriptor build+match (BASELINE north-star point: 10k-frame map, 1 GPU)" % (N, F)
                        if F == 10000 else "synthetic %d keypoints/frame, %d-frame map, descriptor build+match" % (N, F),
                        "map_frames": F, "keypoints_per_frame": N, "queries_per_step": n_q_total,
