@@ -205,7 +205,9 @@ int sgtd_result_votes(sgtd_handle h, int q, uint32_t *votes, int64_t capacity,
                       uint32_t *frame_lo, int64_t *n);
 /* all rough matches of query q in the reference's (i, cell, j) order
  * (STDesc.cpp:378-384): q_idx, voxel_round index 0..26, db_entry, frame, dis.
- * Diagnostic / parity output; any pointer may be NULL. */
+ * Diagnostic / parity output; any pointer may be NULL.  The first call after a batch re-runs
+ * the batch with the diagnostic sweep (the reference's distance test verbatim on the exact f64
+ * sides, cell index and distance recorded per match); the product sweep keeps neither. */
 int sgtd_result_rough(sgtd_handle h, int q, int32_t *q_idx, int32_t *cell,
                       int64_t *db_entry, uint32_t *frame, double *dis,
                       int64_t capacity, int64_t *n_rough);
