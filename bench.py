@@ -515,11 +515,17 @@ def main():
             g3.add_frames(*to_dev(smap.xyz[:100], smap.label[:100]))     # 100 more frames (ids F .. F+99)
             g3.finalize()
             s3_st = g3.stats()
-            s3(); g3.sync(); s3(); g3.sync(); torch.cuda.synchronize()
-            t_tail = run_steps(s3, torch.cuda.synchronize, 3) / 3
+            s3(); g3.sync(); torch.cuda.synchronize()
+            t_tail = run_steps(s3, torch.cuda.synchronize, 2) / 2     # (a tail that stays unchanged for 4 batches is merged)
+            tail_after = g3.stats()["tail_entries"]
+            for _ in range(3):
+                s3()
+            g3.sync()
+            merged_after = g3.stats()["tail_entries"]
             incremental = {"appended_frames": 100, "tail_entries": s3_st["tail_entries"], "table_entries": s3_st["n_entries"],
                            "ms_finalize_full_table": full_ms, "ms_finalize_after_append": s3_st["ms_finalize"],
-                           "ms_per_step_one_segment": 1000.0 * t_main, "ms_per_step_main_plus_tail": 1000.0 * t_tail}
+                           "ms_per_step_one_segment": 1000.0 * t_main, "ms_per_step_main_plus_tail": 1000.0 * t_tail,
+                           "tail_entries_while_timed": tail_after, "tail_entries_after_4_more_batches": merged_after}
             g3.close()
             del g3
         except Exception as exc:

@@ -84,6 +84,7 @@ struct sgtd_engine {
   u32 append_min_frame = 0xFFFFFFFFu;    // smallest frame id appended since the main segment was built
   int64_t tail_max = 0;                  // SGTD_TAIL_MAX: entries the tail may hold before a merge (0 = an eighth of the main segment)
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
+  int tail_batches = 0;                  // query batches swept with the current tail (it is merged after a few: see settle_tail)
   DevBuf slice_of, sq_sum;
   // sort scratch
   DevBuf keyA, keyB, valA, valB, hist, digit_tot, flags, bad_flag;
@@ -956,6 +957,21 @@ int settle_pending(sgtd_engine *e) {
   return SGTD_OK;
 }
 
+// A tail segment makes every batch sweep the descriptors twice (+20 % step time).  While appends
+// keep arriving that is the cheap side of the trade (each append sorts only the tail); once
+// SGTD_TAIL_BATCHES batches in a row have used the same tail the next one merges it into the main segment
+// (one full build, ~0.25 ms per million entries).
+#define SGTD_TAIL_BATCHES 4
+int settle_tail(sgtd_engine *e) {
+  if (e->finalized && e->n_seg == 2) {
+    if (e->tail_batches >= SGTD_TAIL_BATCHES) { e->tail_batches = 0; return do_finalize(e, /*force_merge=*/true); }
+    e->tail_batches++;
+  } else {
+    e->tail_batches = 1;    // no tail, or an append since the last batch (do_finalize rebuilds the tail): its first batch
+  }
+  return do_finalize(e);
+}
+
 int check_cfg(const sgtd_config *c) {
   if (c->descriptor_near_num < 3 || c->descriptor_near_num > SGTD_MAX_K) return SGTD_ERR_UNSUPPORTED;
   if (c->candidate_num < 1 || c->candidate_num > SGTD_MAX_CAND) return SGTD_ERR_UNSUPPORTED;
@@ -1249,7 +1265,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
   if (e && e->grp) return multi::query_frames(e, xyz, label, kp_off, n_queries, device_ptrs);
   if (!e || n_queries <= 0 || !kp_off || !xyz || !label) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
-  CHK(do_finalize(e));
+  CHK(settle_tail(e));
   const float *dx; const u32 *dl; int max_n;
   CHK(stage_inputs(e, xyz, label, kp_off, n_queries, device_ptrs, &dx, &dl, &max_n));
   e->nq = n_queries;
@@ -1277,7 +1293,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   if (e && e->grp) return multi::query_descs(e, q, nq);
   if (!e || nq < 0 || (nq > 0 && (!q || !q->side || !q->label || !q->frame))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
-  CHK(do_finalize(e));
+  CHK(settle_tail(e));
   e->nq = 1;
   e->q_stride = std::max<long long>(nq, 1);
   e->last_kind = 2;

@@ -866,6 +866,9 @@ def test_appends_go_to_a_tail_segment_and_keep_parity(mods, monkeypatch):
     add(50, 60)                                   # the tail grows (rebuilt from the first appended entry)
     st = check()
     assert st["tail_entries"] == st["n_entries"] - main_entries
+    for _ in range(4):                            # a tail nobody appends to any more is merged after a few batches
+        st = check()
+    assert st["tail_entries"] == 0
     gk, goff, gid = g.table_dump()                # the dump merges the segments: whole buckets, insertion order
     ok, ooff, oid = o.table_dump()
     np.testing.assert_array_equal(gk, ok)
