@@ -76,6 +76,9 @@ struct __attribute__((aligned(16))) HotEntry {
   u32 frame;          // frame_id_
 };
 #define SGTD_HOT_BYTES 20   // per entry: HotEntry + its perm word
+// behind the last entry of a probe layout: entries with sides +inf that match nothing; the lanes of
+// a sweep's last 64-entry word beyond the visit list read them (no validity test per entry)
+#define SGTD_SENTINELS 64
 
 // Inside a bucket (one reference cell + label code) the entries are partitioned into
 // SGTD_ZSLICES slices of the longest side's cell interval plus one overflow slice, each in
@@ -161,7 +164,7 @@ __device__ __forceinline__ u32 gate_mask(double q0, double q1, double q2) {
 // With the margin m = 2 A + 16 u thr + 1e-12 (twice what the bound needs):
 //   d2f < lo2 = rounddown_f32((thr - m)^2)  ==>  the reference's dis < thr
 //   d2f > hi2 = roundup_f32((thr + m)^2)    ==>  the reference's dis >= thr
-// anything else (including NaN/inf from sides beyond the f32 range) is decided exactly.
+// anything else (including NaN) is decided exactly.
 __device__ __forceinline__ void f32_bounds(double q0, double q1, double q2, double thr, float &lo2, float &hi2) {
   const double u = 5.9604644775390625e-08;   // 2^-24
   const double a0 = u * (4.0 * fabs(q0) + 16.0), a1 = u * (4.0 * fabs(q1) + 16.0), a2 = u * (4.0 * fabs(q2) + 16.0);
@@ -176,7 +179,11 @@ __device__ __forceinline__ void f32_bounds(double q0, double q1, double q2, doub
   }
   const double h2 = hi * hi * (1.0 + 1e-15);
   float h = (float)h2;
-  if ((double)h < h2) h = __uint_as_float(__float_as_uint(h) + 1u);     // upwards (h >= 0; inf stays inf)
+  if ((double)h < h2) h = __uint_as_float(__float_as_uint(h) + 1u);     // upwards (h >= 0)
+  // hi2 stays finite: the sweep gives d2f = +inf to what must never match (sentinel entries behind
+  // the table, cells that fail a descriptor's gate); real entries have finite d2f (their sides and
+  // the query's are below 65 541), so a threshold beyond the f32 range sends them all to the exact test
+  if (!(h < __builtin_inff())) h = 3.4028234663852886e38f;
   if (!(thr > 0.0) || !(h2 == h2)) { l = 0.0f; h = 0.0f; }             // dis < thr is never true / NaN: nothing is a certain match,
   lo2 = l;                                                              // every d2f > 0 a certain miss, d2f == 0 decided exactly
   hi2 = h;

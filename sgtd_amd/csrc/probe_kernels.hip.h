@@ -95,9 +95,6 @@ struct ProbeBuffers {
 #ifndef SGTD_PROBE_UNROLL
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
 #endif
-#ifndef SGTD_LOCATE
-#define SGTD_LOCATE 0           // position -> range: 0 binary search by ds_bpermute, 1 scalar boundary cursor
-#endif
 
 // per-descriptor results of the sweep (stored once per ticket by the caller)
 struct DescResult {
@@ -119,11 +116,12 @@ struct PendingLoads {
 };
 
 #ifndef SGTD_PAIR
-// descriptors of one home cell swept together by a wave (shared plan, locate and loads): 1, 2 or 4.
-// Measured at F = 10 k: 2 -> sweep 6.2 ms; 4 halves the loads again but needs 129 VGPRs (3 waves
-// per SIMD: 7.6 ms; capped at 128: 6.6 ms)
+// descriptors of one home cell swept together by a wave (shared plan, locate and loads): 1 or 2.
+// (4 at a time halves the loads again but needs 129 VGPRs — 3 waves per SIMD: measured slower)
 #define SGTD_PAIR 2
 #endif
+static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2, "the pair sweep computes both distances with packed f32 math");
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WaveSlab {
   u32 next[SGTD_PAIR], end[SGTD_PAIR];   // this wave's private ranges of match records: one bump stream per
@@ -157,11 +155,20 @@ struct DescSet {
 };
 
 // the visit list as the sweep walks it: lane r < 54 holds the exclusive offset off[r] of range
-// r = 2 * cell + (0 regular slices | 1 overflow slice), lanes >= 54 the total, and
-// dl[r] = start[r] - off[r].  For a pair it is the union of the two descriptors' lists.
+// r = 2 * cell + (0 regular slices | 1 overflow slice), lanes >= 54 the total.  For a pair it
+// is the union of the two descriptors' lists.  Lane 54 stands for one more range that starts at
+// `total` and maps onto the 64 sentinel entries behind the table's last entry (sides +inf: no
+// match), so the lanes of the last 64-entry word beyond the list need no special case.
+// The non-empty ranges, numbered in order, are what the sweep addresses: lane j holds for the
+// j-th one dlc = start - off, its cell (diagnostic sweep) and, for a pair, per descriptor the
+// penalty 0 / +inf that starts the squared-distance sum (+inf: the cell fails that descriptor's
+// gate); `ne` marks the lanes r whose range r is not empty.
 template <int K>
 struct DescPlan {
-  u32 off, dl;
+  u32 off;
+  u32 dlc, cellc;
+  float penc[K];
+  u64 ne;               // wave-uniform
   u32 ref_visits[K];    // wave-uniform: entries the reference's loop visits (all slices of the gated cells)
 };
 
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
 // K = 2: the union of the two descriptors' ranges; the sweep tests every loaded entry against
 // both and masks each with its own gate (a slice too many is harmless, a cell too many is not).
 template <int K>
-__device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f) {
+__device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f, u32 n_entries) {
   const int lane = lane_id();
   const int c = lane >> 1;
   const bool odd = lane & 1;
@@ -349,7 +356,21 @@ __device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f) 
   len = live ? len : 0u;
   const u32 inc = wave_incl_scan(len);
   pl.off = inc - len;          // lanes >= 54 add nothing: they hold the total
-  pl.dl = start - pl.off;      // start[r] - off[r]
+  // compaction of the non-empty ranges (and the sentinel range, lane 54) to lanes 0..n-1 by a
+  // forward permute; the empty ones all write lane 63, which no ordinal reaches (at most 55)
+  const bool sentinel = lane == SGTD_NRANGE;
+  if (sentinel) start = n_entries;
+  const bool keep = len != 0u || sentinel;
+  pl.ne = __builtin_amdgcn_ballot_w64(keep);
+  const u32 ord = __builtin_amdgcn_mbcnt_hi((u32)(pl.ne >> 32), __builtin_amdgcn_mbcnt_lo((u32)pl.ne, 0u));
+  const u32 dst = (keep ? ord : 63u) << 2;
+  pl.dlc = (u32)__builtin_amdgcn_ds_permute((int)dst, (int)(start - pl.off));   // start[r] - off[r]
+  pl.cellc = (u32)__builtin_amdgcn_ds_permute((int)dst, c);
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const bool open = lane < SGTD_NRANGE && ((f.gate[k] >> c) & 1u);
+    pl.penc[k] = __uint_as_float((u32)__builtin_amdgcn_ds_permute((int)dst, open ? 0 : 0x7F800000));
+  }
   return pl;
 }
 
@@ -362,28 +383,21 @@ __device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f) 
 // 32-bit lane offset either way.
 template <bool DIAG, bool WIDE, int K>
 __device__ __forceinline__ void sweep_descriptors(const TableView &T, const ProbeBuffers &B, double rough,
-                                                  const DescSet<K> &f, const DescPlan<K> &pl,
+                                                  const DescSet<K> &f, const DescPlan<K> &pl, u64 *bits,
                                                   WaveSlab &slab, DescResult (&result)[K], PendingLoads pending) {
   static_assert(!DIAG || K == 1, "the diagnostic sweep takes one descriptor at a time");
   const int lane = lane_id();
-  // per-descriptor constants of the test.  They are wave-uniform; for K > 2 they are parked in
-  // vector registers (the kernel is at the scalar-register limit: uniform values the compiler
-  // cannot keep in SGPRs would be spilled to VGPR lanes and read back with v_readlane per use)
-  auto park = [](auto x) {
-    if constexpr (K > 2) { decltype(x) r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
-    else return x;
-  };
+  // per-descriptor constants of the test (wave-uniform)
   float q0f[K], q1f[K], q2f[K], lo2[K], hi2[K];
-  u32 qframe[K], gatek[K];
+  u32 qframe[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    q0f[k] = park((float)f.q0[k]); q1f[k] = park((float)f.q1[k]); q2f[k] = park((float)f.q2[k]);
-    lo2[k] = park(f.lo2[k]); hi2[k] = park(f.hi2[k]);
-    qframe[k] = park(f.qframe[k]); gatek[k] = park(f.gate[k]);
+    q0f[k] = (float)f.q0[k]; q1f[k] = (float)f.q1[k]; q2f[k] = (float)f.q2[k];
+    lo2[k] = f.lo2[k]; hi2[k] = f.hi2[k];
+    qframe[k] = f.qframe[k];
   }
   const double thr = DIAG ? norm3(f.q0[0], f.q1[0], f.q2[0]) * rough : 0.0;   // :356-357
   const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_WAVE - 1);
-  const u32 dl = pl.dl;
   u64 ph_t = PH_T(); (void)ph_t;
   // records of one descriptor are contiguous: make sure its stream's slab can take the worst
   // case (every visited entry matches)
@@ -423,32 +437,45 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
     atomicAdd(&g_words[1], (unsigned long long)((n_words + SGTD_PROBE_UNROLL - 1) / SGTD_PROBE_UNROLL));
   }
 #endif
-  // position -> range, the last r with off[r] <= pos (empty ranges share their successor's
-  // offset and are stepped over): the offsets are held one per lane (off[54..63] = total) and
-  // read by ds_bpermute — no memory.  All lanes execute the permutes (sources must be active).
+  // position -> range.  The starts of the non-empty ranges are marked in a bit array over the
+  // positions of the visit list (this wave's 64 x 64-bit LDS window, rebuilt every 4096
+  // positions; the mark of a range that starts at position p > 0 is bit p - 1): the range of
+  // position 64 w + l is the number of ranges that start at or before 64 w (one compare against
+  // the per-lane offsets + popcount, scalar) plus the marks of positions 64 w + 1 .. 64 w + l
+  // (v_mbcnt over the window word) — one LDS read and one ds_bpermute per 64 entries (three for
+  // a pair: the two gate penalties), whatever the number of ranges.
   // one load group: NW words located, their loads issued back to back, then tested.  NW is a
   // compile-time count: each group size is straight-line code (branches around loads would
   // make the compiler wait for earlier loads before every later one).
+  const bool marks = ((pl.ne >> lane) & 1ull) && pl.off != 0u;
+  auto window = [&](u32 w_first) {     // w_first: a multiple of 64 words
+    bits[lane] = 0;
+    const u32 wr = ((pl.off - 1u) >> 6) - w_first;
+    if (marks && wr < 64u) atomicOr(reinterpret_cast<unsigned long long *>(bits + wr), 1ull << ((pl.off - 1u) & 63u));
+    __builtin_amdgcn_wave_barrier();
+  };
   auto group = [&](auto nw_tag, u32 w0) {
     constexpr int NW = decltype(nw_tag)::value;
     float4 v[NW];
     u32 gg[NW];
-    u32 c4v[NW];      // 4 * range of the lane's entry
-    bool valid[NW];
+    u32 cellv[NW];    // cell (0..26) of the lane's entry (diagnostic sweep)
+    f32x2 pen[NW];    // pair: 0 / +inf per descriptor (the entry's cell passes its gate or not)
+    bool valid[NW];   // diagnostic sweep (the exact test reads the cold table, not the sentinel's sides)
 #pragma unroll
     for (int u = 0; u < NW; u++) {
-      const u32 pos = ((w0 + u) << 6) + lane;
+      const u32 w_lo = (w0 + u) << 6;
+      const u32 pos = w_lo + lane;
       valid[u] = pos < total;
-      // branch-free binary search over the 64 offsets: six ds_bpermute steps, one more for the start
-      u32 c4 = 0;
-#pragma unroll
-      for (int sh = 128; sh >= 4; sh >>= 1) {
-        const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(c4 + (u32)sh), (int)pl.off);
-        c4 += (t <= pos) ? (u32)sh : 0u;
+      const u64 bm = bits[(w0 + u) & 63u];      // marks of positions w_lo + 1 .. w_lo + 64
+      const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pl.off <= w_lo) & pl.ne) - 1u;
+      const u32 j4 = __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, before)) << 2;
+      const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)pl.dlc);
+      if (DIAG) cellv[u] = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)pl.cellc);
+      if constexpr (K == 2) {
+        pen[u].x = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(pl.penc[0])));
+        pen[u].y = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(pl.penc[1])));
       }
-      const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)c4, (int)dl);
-      c4v[u] = c4;
-      const u32 e = valid[u] ? pos + dsel : 0u;     // entry 0 always exists when total > 0
+      const u32 e = pos + dsel;       // beyond the list: the sentinel entries
       const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + e)
                               : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(T.ent) + (e << 4));
       const u32 *pg = WIDE ? T.perm + e : reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(T.perm) + (e << 2));
@@ -464,41 +491,57 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
 #pragma unroll
     for (int k = 0; k < K; k++) m_start[k] = matches[k];
     u64 amb_any = 0;     // wave mask: some entry of the group fell between the two f32 thresholds
+    // squared f32 distances of word u's entries to the K descriptors; the pair's two sums run
+    // in the halves of packed f32 operations and start from the gate penalties
+    auto dist2 = [&](int u, float (&d2)[K]) {
+      if constexpr (K == 2) {
+        const f32x2 qx = {q0f[0], q0f[1]}, qy = {q1f[0], q1f[1]}, qz = {q2f[0], q2f[1]};
+        const f32x2 sx = {v[u].x, v[u].x}, sy = {v[u].y, v[u].y}, sz = {v[u].z, v[u].z};
+        const f32x2 dx = qx - sx, dy = qy - sy, dz = qz - sz;
+        f32x2 acc = __builtin_elementwise_fma(dx, dx, pen[u]);      // pen 0: fl(dx * dx) as in f32_bounds
+        acc = __builtin_elementwise_fma(dy, dy, acc);
+        acc = __builtin_elementwise_fma(dz, dz, acc);
+        d2[0] = acc.x; d2[1] = acc.y;
+      } else {
+        const float dx = q0f[0] - v[u].x, dy = q1f[0] - v[u].y, dz = q2f[0] - v[u].z;
+        d2[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      }
+    };
     // one (word, descriptor) test; PUSH = false: store the matches, true: replay of the group
     // that only queues the provisional records (rare)
-    auto test = [&](auto push_tag, int u, int k, u32 &count) {
+    auto test = [&](auto push_tag, int u, int k, float d2, u32 &count) {
       constexpr bool PUSH = decltype(push_tag)::value;
       const u32 fr = __float_as_uint(v[u].w);
-      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373); for a pair the
-      // entry's cell must also pass this descriptor's own gate (bit c4 >> 3 of its mask)
-      bool cand = valid[u] && (qframe[k] != fr);
-      if (K > 1) cand = cand && ((gatek[k] >> (c4v[u] >> 3)) & 1u);
+      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
+      const bool other = qframe[k] != fr;
       bool hit, amb = false;
+      u64 m;
       double dis = 0.0;
       if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
         hit = false;
-        if (cand) {
+        if (valid[u] && other) {
           const double *sp = T.cold_side + (size_t)gg[u] * 3;
           const double ex = f.q0[k] - sp[0], ey = f.q1[k] - sp[1], ez = f.q2[k] - sp[2];
           dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
           hit = dis < thr;
         }
+        m = __builtin_amdgcn_ballot_w64(hit);
       } else {
-        const float dx = q0f[k] - v[u].x, dy = q1f[k] - v[u].y, dz = q2f[k] - v[u].z;
-        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        hit = cand && !(d2 > hi2[k]);         // not certainly outside (NaN stays in)
+        // (sentinel entries and gated-out cells: d2 = +inf, above every hi2 — f32_bounds keeps it finite)
+        const bool near = !(d2 > hi2[k]);     // not certainly outside (NaN stays in)
+        hit = near && other;
         amb = hit && !(d2 < lo2[k]);          // not certainly inside either: provisional
+        m = __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other);   // two plain compares: no mask round trip
       }
-      const u64 m = __builtin_amdgcn_ballot_w64(hit);
       const u32 at = count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
       if constexpr (!PUSH) {
         if (hit && fits) {
           // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
           *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_frame[k]) + (at << 2)) = fr;
           *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_g[k]) + (at << 2)) = gg[u];
-          if (DIAG) { B.rec_cell[(size_t)slab.next[k] + at] = (unsigned char)(c4v[u] >> 3); B.rec_dis[(size_t)slab.next[k] + at] = dis; }
+          if (DIAG) { B.rec_cell[(size_t)slab.next[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)slab.next[k] + at] = dis; }
         }
-        if (!DIAG) amb_any |= __builtin_amdgcn_ballot_w64(amb);
+        if (!DIAG) amb_any |= m & __builtin_amdgcn_ballot_w64(!(d2 < lo2[k]));
       } else {
         if (amb && fits) {
           const u32 qa = atomicAdd(B.amb_count, 1u);
@@ -510,32 +553,44 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
     };
 #pragma unroll
     for (int u = 0; u < NW; u++) {
+      float d2[K];
+      if (!DIAG) dist2(u, d2);
 #pragma unroll
-      for (int k = 0; k < K; k++) test(std::false_type{}, u, k, matches[k]);
+      for (int k = 0; k < K; k++) test(std::false_type{}, u, k, DIAG ? 0.0f : d2[k], matches[k]);
     }
     if (!DIAG && amb_any) {   // rare: about one in 10^4 matches
 #pragma unroll
       for (int u = 0; u < NW; u++) {
+        float d2[K];
+        dist2(u, d2);
 #pragma unroll
-        for (int k = 0; k < K; k++) test(std::true_type{}, u, k, m_start[k]);
+        for (int k = 0; k < K; k++) test(std::true_type{}, u, k, d2[k], m_start[k]);
       }
     }
     PH_ADD(3, ph_t);
   };
-  // full groups of SGTD_PROBE_UNROLL words, then what is left in groups of 2 and 1
-  {
+  // full groups of SGTD_PROBE_UNROLL words, window after window, then what is left in groups
+  // of 2 and 1 (inside the last window)
+  if (n_words) {
     u32 w0 = 0;
-    for (; w0 + SGTD_PROBE_UNROLL <= n_words; w0 += SGTD_PROBE_UNROLL) {
-      group(std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
-      if (w0 == 0) pending.touch();
+    bool touched = false;
+    while (true) {
+      window(w0);
+      const u32 w_stop = min(n_words, w0 + 64u);
+      for (; w0 + SGTD_PROBE_UNROLL <= w_stop; w0 += SGTD_PROBE_UNROLL) {
+        group(std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
+        if (!touched) { pending.touch(); touched = true; }
+      }
+      if (w_stop == n_words) break;
     }
-    const bool touched = w0 != 0;
     const u32 left = n_words - w0;   // wave-uniform
     if (left & 2u) { group(std::integral_constant<int, 2>{}, w0); w0 += 2; }
     if (left & 1u) { group(std::integral_constant<int, 1>{}, w0); w0 += 1; }
     if (!touched) pending.touch();   // every path through the sweep leaves them complete
+  } else {
+    pending.touch();
   }
-  static_assert(SGTD_PROBE_UNROLL == 4, "remainder groups cover 2 and 1 words");
+  static_assert(SGTD_PROBE_UNROLL == 4, "remainder groups cover 2 and 1 words; a window is a whole number of groups");
 #pragma unroll
   for (int k = 0; k < K; k++) {
     if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches[k]);
@@ -587,6 +642,7 @@ template <bool DIAG, bool WIDE>
 __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorted_kernel(
     TableView T, ProbeBuffers B, const unsigned char *rows, const QueryRec *sorted, double rough,
     const u32 *n_valid_p, u32 *xcd_heads /*[8 * 1024]*/, u32 chunk /* 1..SGTD_TICKET_MAX */) {
+  __shared__ u64 s_bits[SGTD_PROBE_THREADS / SGTD_WAVE][64];   // per wave: range starts of the current 4096 positions
   const int lane = lane_id();
   const u32 n_valid = *n_valid_p;
   // Every WAVE dequeues `chunk` consecutive sorted positions at a time (no workgroup
@@ -667,7 +723,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
       if (!DIAG)
         while (run < (u32)SGTD_PAIR && i + run < n &&
                (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * (i + run) + 2)) == g_cur) run++;
-      const u32 step = run >= 4 ? 4u : (run >= 2 ? 2u : 1u);
+      const u32 step = run >= 2 ? 2u : 1u;
       const uint4 row = row_next;
       if (i + step < n) {   // the GroupRow after this step (often the same one)
         const u32 g1 = (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * (i + step) + 2));
@@ -691,12 +747,11 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
 #pragma unroll
         for (int k = 0; k < KK; k++) unpack(f, k, i + (u32)k);
         DescResult res[KK];
-        sweep_descriptors<DIAG, WIDE, KK>(T, B, rough, f, plan_from_group_row<KK>(f), slab, res, pend);
+        sweep_descriptors<DIAG, WIDE, KK>(T, B, rough, f, plan_from_group_row<KK>(f, T.n_entries), s_bits[threadIdx.x >> 6], slab, res, pend);
 #pragma unroll
         for (int k = 0; k < KK; k++)
           if ((u32)lane == i + (u32)k) { r_ptr = res[k].ptr; r_visit = res[k].visit; r_match = res[k].match; }
       };
-      if constexpr (!DIAG && SGTD_PAIR >= 4) { if (step == 4) pass(std::integral_constant<int, 4>{}); }
       if constexpr (!DIAG && SGTD_PAIR >= 2) { if (step == 2) pass(std::integral_constant<int, 2>{}); }
       if (step == 1) pass(std::integral_constant<int, 1>{});
       i += step;

@@ -455,14 +455,14 @@ int build_segment(sgtd_engine *e, sgtd_engine::Segment &S, long long g0, long lo
                                                                  S.bucket_key.as<u64>(), E);
   HIPCHK(hipGetLastError());
   // probe order: every bucket partitioned by slice, insertion order inside a slice
-  CHK(ensure(e, S.perm, (size_t)E * sizeof(u32)));
+  CHK(ensure(e, S.perm, (size_t)(E + SGTD_SENTINELS) * sizeof(u32)));
   CHK(ensure(e, S.dir, (size_t)U * sizeof(BucketDir)));
   slice_partition_kernel<<<e->n_cus * 8, 256, 0, e->stream>>>(S.bucket_start.as<u32>(), U, (u32)E, vin,
                                                                e->slice_of.as<unsigned char>(), S.perm.as<u32>(),
                                                                S.dir.as<BucketDir>());
   HIPCHK(hipGetLastError());
-  CHK(ensure(e, S.hot, (size_t)E * sizeof(HotEntry)));
-  gather_hot_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(S.perm.as<u32>(), side, frame, S.hot.as<HotEntry>(), E, (u32)g0);
+  CHK(ensure(e, S.hot, (size_t)(E + SGTD_SENTINELS) * sizeof(HotEntry)));
+  gather_hot_kernel<<<grid_for(E + SGTD_SENTINELS, 256), 256, 0, e->stream>>>(S.perm.as<u32>(), side, frame, S.hot.as<HotEntry>(), E, (u32)g0);
   HIPCHK(hipGetLastError());
   u32 cap = 1024;
   while (cap < 2ull * U) cap <<= 1;
@@ -493,7 +493,7 @@ int build_segment(sgtd_engine *e, sgtd_engine::Segment &S, long long g0, long lo
 int do_finalize(sgtd_engine *e, bool force_merge = false) {
   if (e->finalized && !(force_merge && e->n_seg > 1)) return SGTD_OK;
   const long long E = e->n_entries;
-  if (E >= (1ll << 32) - 2) return SGTD_ERR_UNSUPPORTED;
+  if (E >= (1ll << 32) - 2 - SGTD_SENTINELS) return SGTD_ERR_UNSUPPORTED;
   const auto t0 = std::chrono::steady_clock::now();
   sgtd_engine::Segment &M = e->seg[0], &T = e->seg[1];
   const long long tail_max = e->tail_max > 0 ? (long long)e->tail_max : std::max<long long>(262144, (M.g1 - M.g0) / 8);
@@ -674,7 +674,7 @@ int launch_select(sgtd_engine *e) {
       if (sg == 0 && e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));   // ms_probe = the sweep(s) from here
       // 32-bit byte offsets into the probe layout while it stays below 4 GB (record addresses
       // are a wave-uniform base + a 32-bit lane offset either way)
-      const bool narrow = (unsigned long long)vs.T.n_entries * sizeof(HotEntry) < (1ull << 32);
+      const bool narrow = ((unsigned long long)vs.T.n_entries + SGTD_SENTINELS) * sizeof(HotEntry) < (1ull << 32);
 #define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
   probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
       vs.T, vs.B, rows, e->sdesc.as<QueryRec>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)

@@ -203,7 +203,18 @@ __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
 __global__ void gather_hot_kernel(u32 *perm, const double *side, const u32 *frame,
                                   HotEntry *ent, long long n, u32 g0) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
+  if (p >= n) {
+    // SGTD_SENTINELS entries behind the last one: where the sweep's lanes beyond a visit list
+    // read (sides +inf: the f32 test rejects them)
+    if (p < n + SGTD_SENTINELS) {
+      HotEntry h;
+      h.s0 = h.s1 = h.s2 = __builtin_inff();
+      h.frame = 0xFFFFFFFFu;
+      ent[p] = h;
+      perm[p] = 0;
+    }
+    return;
+  }
   const u32 g = perm[p];
   perm[p] = g + g0;
   HotEntry h;
