@@ -328,8 +328,8 @@ def main():
     # descriptor, 8 B per match record
     algo_bytes = 28 * P + 64 * D + 8 * M
     algo_gbs = algo_bytes / t_probe / 1e9 if t_probe > 0 else 0.0
-    # What can bound the sweep: (a) the bytes its waves really load and store through L2 — 20 B per
-    # entry it loads (after slice pruning and pair sharing; sgtd_stats.last_P_swept) + 8 B per match
+    # What can bound the sweep: (a) the bytes its waves really load and store through L2 — 16 B per
+    # entry it loads (after slice pruning and pair sharing; sgtd_stats.last_P_swept) + 4 B per match
     # record — against the aggregate L2 rate; (b) the HBM bytes the PMC counters saw (2 x FETCH_SIZE
     # + WRITE_SIZE, separate rocprofv3 passes, profiles/r02_traffic.json) against the HBM peak.
     # `frac` is the larger of the two fractions and can never exceed 1; the algorithmic rate of
@@ -337,7 +337,7 @@ def main():
     # peak because pruned slices are never loaded and the rest is mostly served from L2.
     entry_bytes = st["hbm_bytes_table"] // max(st["n_entries"], 1)   # probe-layout bytes per loaded entry
     P_swept = st.get("last_P_swept") or P
-    l2_gbs = (entry_bytes * P_swept + 8 * M) / t_probe / 1e9 if t_probe > 0 else 0.0
+    l2_gbs = (entry_bytes * P_swept + 4 * M) / t_probe / 1e9 if t_probe > 0 else 0.0
     tr = load_traffic(F, N, Q, world)
     traffic = tr.get("bytes_per_launch") if tr else None
     hbm_gbs = traffic / t_probe / 1e9 if (traffic and t_probe > 0) else None
@@ -354,8 +354,8 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_gbs,
                 "algorithmic_over_hbm_peak": algo_gbs / HBM_PEAK_GBS,
                 "reference_visits_per_s": P / t_probe if t_probe > 0 else 0.0,
-                "note": "bound = the level whose fraction is larger: L2->CU bytes the sweep really moves (20 B x entries loaded "
-                        "+ 8 B x records) vs 34.5 TB/s, or PMC HBM bytes vs 8 TB/s; algorithmic bytes (28 B x reference visits) "
+                "note": "bound = the level whose fraction is larger: L2->CU bytes the sweep really moves (16 B x entries loaded "
+                        "+ 4 B x records) vs 34.5 TB/s, or PMC HBM bytes vs 8 TB/s; algorithmic bytes (28 B x reference visits) "
                         "exceed the HBM peak because pruned z-slices are never loaded and buckets are re-read from L2 (DESIGN.md §3)",
                 "P_visited": P, "P_swept_after_slice_pruning": st.get("last_P_swept"), "M_matches": M,
                 "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],

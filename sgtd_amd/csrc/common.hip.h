@@ -65,17 +65,36 @@ __host__ __device__ __forceinline__ u32 hash_key(u64 k) {
   return h;
 }
 
-// One table entry in the probe layout: 16 bytes — the three sides rounded to f32 and the frame
+// One table entry in the probe layout: 16 bytes — the three sides rounded to f32 and the entry's
 // id.  The sweep decides almost every entry on these (f32_bounds below gives squared thresholds
 // that make the f32 test conservative on both sides); the few entries that fall between them are
 // decided on the exact f64 sides of the cold table, so every decision equals the reference's.
-// The insertion index of entry p is perm[p] (a second, 4-byte array: one 1-KB and one 256-B load
-// per 64 entries instead of two 1-KB loads).
+//
+// id = (frame - frame_lo) << bits | i, i = rank of the entry among the entries of its frame in
+// insertion order (IdMap): ONE 32-bit word names the frame (votes, candidate lookup: a shift) and
+// the entry (only the candidates' pairs are ever translated back to the insertion index), so a
+// match record is 4 bytes and the sweep reads nothing but the 16-B entries.
 struct __attribute__((aligned(16))) HotEntry {
   float s0, s1, s2;   // (float)side_length_ (scaled)
-  u32 frame;          // frame_id_
+  u32 id;             // frame_id_ and entry (IdMap)
 };
-#define SGTD_HOT_BYTES 20   // per entry: HotEntry + its perm word
+#define SGTD_HOT_BYTES 16   // per entry
+// id -> frame, insertion index.  Frames whose entries are contiguous in insertion order (maps
+// built frame by frame): by_frame == nullptr and frame_first[f] is the insertion index of the
+// frame's first entry; otherwise by_frame lists the insertion indices grouped by frame (stable)
+// and frame_first[f] is the frame's first position in that list.
+struct IdMap {
+  const u32 *frame_first;   // [frame span]
+  const u32 *by_frame;      // [n_entries] or nullptr
+  u32 bits;                 // of i
+  u32 frame_lo;
+};
+#define SGTD_DEAD_ID 0xFFFFFFFFu     // a record that turned out not to match; the sentinel entries' id
+__device__ __forceinline__ u32 id_local_frame(const IdMap &m, u32 id) { return id >> m.bits; }
+__device__ __forceinline__ u32 id_entry(const IdMap &m, u32 id) {
+  const u32 p = m.frame_first[id >> m.bits] + (id & ((1u << m.bits) - 1u));
+  return m.by_frame ? m.by_frame[p] : p;
+}
 // behind the last entry of a probe layout: entries with sides +inf that match nothing; the lanes of
 // a sweep's last 64-entry word beyond the visit list read them (no validity test per entry)
 #define SGTD_SENTINELS 64

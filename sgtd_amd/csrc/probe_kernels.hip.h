@@ -42,7 +42,7 @@
 
 struct TableView {
   const HotEntry *ent;         // [E] probe order: by key, by slice inside a bucket, insertion order inside a slice
-  const u32 *perm;             // [E] probe position -> insertion index g
+  IdMap map;                   // entry id -> frame, insertion index
   const double *cold_side;     // [E*3] exact sides in insertion order (undecided f32 tests, diagnostic build)
   const BucketDir *dir;        // [U] bucket directory
   const HashSlot *hash;
@@ -63,8 +63,7 @@ struct QueryView {
 };
 
 struct ProbeBuffers {
-  u32 *rec_frame;       // [rec_cap] match record, frame id (votes and counting read only this half)
-  u32 *rec_g;           // [rec_cap] match record, insertion index of the entry
+  u32 *rec;             // [rec_cap] match records: the entry's id (frame and entry in one word, common.hip.h IdMap)
   unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
@@ -80,13 +79,13 @@ struct ProbeBuffers {
   int n_seg;            // table segments swept (main, tail)
   u32 *votes;           // [n_queries * frame_span]
   int *overflow;        // [2]: 0 match records, 1 candidate pairs
+  u32 id_bits;          // a record's local frame (frame - table frame_lo) is rec >> id_bits
   // records whose f32 test fell between the two thresholds: stored provisionally as matches,
   // queued here and decided on the exact sides by resolve_undecided_kernel right after the sweep
   uint2 *amb_queue;     // [amb_cap] (record index, descriptor slot)
   u32 *amb_count;
   u32 amb_cap;
 };
-#define SGTD_DEAD_FRAME 0xFFFFFFFFu   // frame of a provisional record that turned out not to match
 
 #define SGTD_PROBE_THREADS 256
 #define SGTD_PROBE_CHUNK 128    // query descriptors per assemble block
@@ -394,8 +393,11 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
   for (int k = 0; k < K; k++) {
     q0f[k] = (float)f.q0[k]; q1f[k] = (float)f.q1[k]; q2f[k] = (float)f.q2[k];
     lo2[k] = f.lo2[k]; hi2[k] = f.hi2[k];
-    qframe[k] = f.qframe[k];
+    // the query's frame as the ids name it; a frame the table does not hold equals no entry's
+    const u32 ql = f.qframe[k] - T.map.frame_lo;
+    qframe[k] = ql < T.frame_span ? ql : 0xFFFFFFFFu;
   }
+  const u32 id_bits = T.map.bits;
   const double thr = DIAG ? norm3(f.q0[0], f.q1[0], f.q2[0]) * rough : 0.0;   // :356-357
   const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_WAVE - 1);
   u64 ph_t = PH_T(); (void)ph_t;
@@ -422,12 +424,11 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
   PH_ADD(0, ph_t);
 
   u32 matches[K];
-  u32 *list_frame[K], *list_g[K];   // wave-uniform
+  u32 *list[K];   // wave-uniform
 #pragma unroll
   for (int k = 0; k < K; k++) {
     matches[k] = 0;
-    list_frame[k] = B.rec_frame + slab.next[k];
-    list_g[k] = B.rec_g + slab.next[k];
+    list[k] = B.rec + slab.next[k];
   }
   const u32 n_words = (total + 63u) >> 6;
   slab.swept += total;
@@ -457,7 +458,6 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
   auto group = [&](auto nw_tag, u32 w0) {
     constexpr int NW = decltype(nw_tag)::value;
     float4 v[NW];
-    u32 gg[NW];
     u32 cellv[NW];    // cell (0..26) of the lane's entry (diagnostic sweep)
     f32x2 pen[NW];    // pair: 0 / +inf per descriptor (the entry's cell passes its gate or not)
     bool valid[NW];   // diagnostic sweep (the exact test reads the cold table, not the sentinel's sides)
@@ -478,9 +478,7 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
       const u32 e = pos + dsel;       // beyond the list: the sentinel entries
       const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + e)
                               : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(T.ent) + (e << 4));
-      const u32 *pg = WIDE ? T.perm + e : reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(T.perm) + (e << 2));
-      v[u] = *pa;             // s0, s1, s2 (f32), frame
-      gg[u] = *pg;            // insertion index
+      v[u] = *pa;             // s0, s1, s2 (f32), id
     }
 #ifdef SGTD_EXP_PHASE
     PH_ADD(1, ph_t);
@@ -511,16 +509,16 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
     // that only queues the provisional records (rare)
     auto test = [&](auto push_tag, int u, int k, float d2, u32 &count) {
       constexpr bool PUSH = decltype(push_tag)::value;
-      const u32 fr = __float_as_uint(v[u].w);
-      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  ids differ (:373)
-      const bool other = qframe[k] != fr;
+      const u32 id = __float_as_uint(v[u].w);
+      // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  frame ids differ (:373)
+      const bool other = qframe[k] != (id >> id_bits);
       bool hit, amb = false;
       u64 m;
       double dis = 0.0;
       if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
         hit = false;
         if (valid[u] && other) {
-          const double *sp = T.cold_side + (size_t)gg[u] * 3;
+          const double *sp = T.cold_side + (size_t)id_entry(T.map, id) * 3;
           const double ex = f.q0[k] - sp[0], ey = f.q1[k] - sp[1], ez = f.q2[k] - sp[2];
           dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
           hit = dis < thr;
@@ -537,8 +535,7 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
       if constexpr (!PUSH) {
         if (hit && fits) {
           // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
-          *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_frame[k]) + (at << 2)) = fr;
-          *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list_g[k]) + (at << 2)) = gg[u];
+          *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list[k]) + (at << 2)) = id;
           if (DIAG) { B.rec_cell[(size_t)slab.next[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)slab.next[k] + at] = dis; }
         }
         if (!DIAG) amb_any |= m & __builtin_amdgcn_ballot_w64(!(d2 < lo2[k]));
@@ -786,17 +783,17 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
 
 // The provisional records of the sweep, decided exactly (STDesc.cpp:374-378 in the squared,
 // comparison-exact form): a record whose entry does not match after all gets the frame
-// SGTD_DEAD_FRAME (no vote, no candidate) and leaves the query's match count.
+// of no frame (SGTD_DEAD_ID: no vote, no candidate) and leaves the query's match count.
 __global__ void resolve_undecided_kernel(TableView T, QueryView Q, ProbeBuffers B, u32 *q_M) {
   const u32 n = min(*B.amb_count, B.amb_cap);
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint2 it = B.amb_queue[i];
     const QueryRec &r = Q.qrec[it.y];
-    const double *sp = T.cold_side + (size_t)B.rec_g[it.x] * 3;
+    const double *sp = T.cold_side + (size_t)id_entry(T.map, B.rec[it.x]) * 3;
     const double dx = r.q0 - sp[0], dy = r.q1 - sp[1], dz = r.q2 - sp[2];
     const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
     if (!(d2 < r.thr2)) {
-      B.rec_frame[it.x] = SGTD_DEAD_FRAME;
+      B.rec[it.x] = SGTD_DEAD_ID;
       atomicSub(&q_M[(u32)((long long)it.y / Q.stride)], 1u);
     }
   }
@@ -1022,7 +1019,7 @@ __device__ __forceinline__ u32 cand_slot(const u64 *s_tab, u32 frame) {
 }
 
 // the match lists of one 128-descriptor block counted into a vote histogram (LDS or global)
-// (bins [frame_lo, frame_lo + limit): records of other frames — another tile's, or dead ones — are skipped)
+// (bins = local frames [frame_lo, frame_lo + limit): records of other frames — another tile's, or dead ones — are skipped)
 template <bool LDS_VOTES>
 __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBuffers &B, int q, u32 d_first, u32 cnt,
                                                u32 frame_lo, u32 limit, u32 *s_hist, u32 *votes, u32 *s_pre, u32 *s_ptr,
@@ -1040,7 +1037,7 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
         const u32 r = r0 + u * SGTD_WAVE + lane;
         u32 dd, addr;
         sub_locate(s_pre, s_ptr, r < R ? r : 0u, dd, addr);
-        nfr[u] = B.rec_frame[addr];
+        nfr[u] = B.rec[addr] >> B.id_bits;     // local frame (a dead record's is beyond every span)
       }
     };
     if (R) load4(0);
@@ -1082,7 +1079,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (id.valid && d_first < cnt) {
     u32 visits = 0, total = 0;
-    votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, frame_lo, frame_span, s_hist, votes, s_pre[wid], s_ptr[wid], visits, total);
+    votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, 0u, frame_span, s_hist, votes, s_pre[wid], s_ptr[wid], visits, total);
     if (lane == 0) {
       atomicAdd(&q_M[q], total);
       atomicAdd(&q_P[q], (unsigned long long)visits);
@@ -1126,7 +1123,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
     for (int blk = wid; blk < blocks_per_query; blk += NW) {
       const u32 d_first = (u32)blk * SGTD_PROBE_CHUNK;
       if (d_first >= cnt) break;
-      votes_of_block<true>(Q, B, q, d_first, cnt, frame_lo + tile_lo, n_bins, s_hist, nullptr, s_pre[wid], s_ptr[wid], visits, total);
+      votes_of_block<true>(Q, B, q, d_first, cnt, tile_lo, n_bins, s_hist, nullptr, s_pre[wid], s_ptr[wid], visits, total);
     }
     if (lane == 0 && blockIdx.y == 0) {
       atomicAdd(&s_M, total);
@@ -1148,7 +1145,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
 // (q_idx << 32 | g) of the records whose frame made the candidate list, and their slots.
 // Written by block_count_kernel, consumed by block_write_kernel (no second record walk).
 struct CompactLists {
-  u64 *pair;             // [cap] slot << 58 | q_idx << 32 | g
+  u64 *pair;             // [cap] slot << 58 | q_idx << 32 | entry id
   u32 *blk_start;        // [nq * blocks_per_query] first entry of the block's list
   u32 *blk_n;            // [nq * blocks_per_query] entries of the block's list
   u32 *cursor;           // global allocation cursor
@@ -1209,29 +1206,29 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
     const u32 R = sub_open(Q, B, sg, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
     total += R;
     // the records of the next four words are loaded while the current four are looked up
-    u32 nfr[4], ngg[4], ndd[4];
+    u32 nid[4], ndd[4];
     auto load4 = [&](u32 r0) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const u32 r = r0 + u * SGTD_WAVE + lane;
         u32 ad;
         sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, ndd[u], ad);
-        nfr[u] = B.rec_frame[ad];
-        ngg[u] = B.rec_g[ad];     // with the frame, not after the slot lookup: no dependent load
+        nid[u] = B.rec[ad];
       }
     };
     if (R) load4(0);
     for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
-      u32 fr[4], gg[4], dd[4];
+      u32 rid[4], dd[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { fr[u] = nfr[u]; gg[u] = ngg[u]; dd[u] = ndd[u]; }
+      for (int u = 0; u < 4; u++) { rid[u] = nid[u]; dd[u] = ndd[u]; }
       if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const bool ok = r0 + u * SGTD_WAVE + lane < R;
         u32 sl = 0xFFu;
-        if (SLOT_TABLE) { if (ok && fr[u] - frame_lo < frame_span) sl = s_slot8[fr[u] - frame_lo]; }   // a dead record's frame is out of range
-        else if (ok) sl = cand_slot(s_cand, fr[u]);
+        const u32 lf = rid[u] >> B.id_bits;                               // local frame
+        if (SLOT_TABLE) { if (ok && lf < frame_span) sl = s_slot8[lf]; }   // a dead record's frame is out of range
+        else if (ok && lf < frame_span) sl = cand_slot(s_cand, lf + frame_lo);
         const bool valid = sl != 0xFFu;
         const u64 m = __builtin_amdgcn_ballot_w64(valid);
         if (valid) {
@@ -1239,7 +1236,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
           if (fits) {
             const u32 pos = start + running + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
             // slot rides in the top 6 bits of the q_idx half (q_idx < 36 * 65535 < 2^26)
-            L.pair[pos] = ((u64)((sl << 26) | (d0 + dd[u])) << 32) | (u64)gg[u];
+            L.pair[pos] = ((u64)((sl << 26) | (d0 + dd[u])) << 32) | (u64)rid[u];
           }
         }
         running += (u32)__builtin_popcountll(m);
@@ -1321,7 +1318,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
                                                           int blocks_per_query,
                                                           const u32 *blk_excl, int cand_num,
                                                           const long long *pair_off, const u32 *q_pair_base,
-                                                          u64 *pairs) {
+                                                          u64 *pairs, IdMap map) {
   constexpr int NW = 256 / SGTD_WAVE;
   constexpr int CAP = SGTD_WRITE_CAP;   // staged pairs per slot = one 128-B (16) or 64-B (8) line
   __shared__ u64 s_mask[NW][64];         // per wave and slot: lanes of the current word that carry the slot
@@ -1367,13 +1364,22 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   load2(0);
   for (u32 r0 = 0; r0 < nv; r0 += 2 * SGTD_WAVE) {
     u64 pr[2]; u32 sl[2];
+    u32 first[2];      // the entry ids become insertion indices here: first entry of the id's frame, fetched
+                       // before the next words (loads return in order: it is waited for alone)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const bool ok = r0 + u * SGTD_WAVE + lane < nv;
       pr[u] = nraw[u] & 0x03FFFFFFFFFFFFFFull;
       sl[u] = ok ? (u32)(nraw[u] >> 58) : 0xFFu;
+      first[u] = map.frame_first[(u32)nraw[u] >> map.bits];
     }
     if (r0 + 2 * SGTD_WAVE < nv) load2(r0 + 2 * SGTD_WAVE);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      u32 g = first[u] + ((u32)pr[u] & ((1u << map.bits) - 1u));
+      if (map.by_frame) g = map.by_frame[g];
+      pr[u] = (pr[u] & 0xFFFFFFFF00000000ull) | (u64)g;
+    }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const bool valid = sl[u] != 0xFFu;
@@ -1411,7 +1417,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
 // slice; the reference's bucket order is insertion order, so the descriptor's matches are put
 // out by ascending (cell, entry id) — tail entries have larger ids than main entries — with a
 // selection sort per descriptor (diagnostic path: lists are short).
-__global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuffers B, int q,
+__global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuffers B, IdMap map, int q,
                                                            u32 *out_qi, u32 *out_entry, u32 *out_frame,
                                                            unsigned char *out_cell, double *out_dis) {
   __shared__ u32 lds[256 / SGTD_WAVE + 1];
@@ -1433,15 +1439,15 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
         for (int sg = 0; sg < B.n_seg; sg++) {
           const u32 p0 = B.list_ptr[(long long)sg * B.seg_stride + d], m = B.n_match[(long long)sg * B.seg_stride + d];
           for (u32 j = 0; j < m; j++) {
-            const long long key = ((long long)B.rec_cell[p0 + j] << 32) | (long long)B.rec_g[p0 + j];
+            const long long key = ((long long)B.rec_cell[p0 + j] << 32) | (long long)id_entry(map, B.rec[p0 + j]);
             if (key > last && key < best) { best = key; at = p0 + j; }
           }
         }
         last = best;
         const u32 o = carry + ex + k;
         out_qi[o] = i;
-        out_entry[o] = B.rec_g[at];
-        out_frame[o] = B.rec_frame[at];
+        out_entry[o] = id_entry(map, B.rec[at]);
+        out_frame[o] = id_local_frame(map, B.rec[at]) + map.frame_lo;
         if (out_cell) out_cell[o] = B.rec_cell[at];
         if (out_dis) out_dis[o] = B.rec_dis[at];
       }

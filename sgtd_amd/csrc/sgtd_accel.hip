@@ -86,6 +86,10 @@ struct sgtd_engine {
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
   int tail_batches = 0;                  // query batches swept with the current tail (it is merged after a few: see settle_tail)
   DevBuf slice_of, sq_sum;
+  // entry ids of the probe layout (common.hip.h IdMap), rebuilt over the whole table by every finalize
+  DevBuf frame_first, by_frame, id_of_g, longest;
+  u32 id_bits = 0;                       // bits of the in-frame rank the built segments' ids use (0: none built)
+  bool id_by_frame = false;              // frames out of insertion order: by_frame / id_of_g are in use
   // sort scratch
   DevBuf keyA, keyB, valA, valB, hist, digit_tot, flags, bad_flag;
   std::vector<DevBuf> scan_lvl;
@@ -380,6 +384,15 @@ int radix_sort_pairs(sgtd_engine *e, u64 *&kin, u64 *&kout, u32 *&vin, u32 *&vou
   return SGTD_OK;
 }
 
+IdMap id_map(const sgtd_engine *e, u32 bits) {
+  IdMap m;
+  m.frame_first = e->frame_first.as<u32>();
+  m.by_frame = e->id_by_frame ? e->by_frame.as<u32>() : nullptr;
+  m.bits = bits;
+  m.frame_lo = e->have_frames ? e->frame_lo : 0;
+  return m;
+}
+
 // probe layout of the entries [g0, g1) into segment S: sort by key, slices, directory, hash
 int build_segment(sgtd_engine *e, sgtd_engine::Segment &S, long long g0, long long g1) {
   const long long E = g1 - g0;
@@ -462,7 +475,8 @@ int build_segment(sgtd_engine *e, sgtd_engine::Segment &S, long long g0, long lo
                                                                S.dir.as<BucketDir>());
   HIPCHK(hipGetLastError());
   CHK(ensure(e, S.hot, (size_t)(E + SGTD_SENTINELS) * sizeof(HotEntry)));
-  gather_hot_kernel<<<grid_for(E + SGTD_SENTINELS, 256), 256, 0, e->stream>>>(S.perm.as<u32>(), side, frame, S.hot.as<HotEntry>(), E, (u32)g0);
+  gather_hot_kernel<<<grid_for(E + SGTD_SENTINELS, 256), 256, 0, e->stream>>>(
+      S.perm.as<u32>(), side, frame, e->id_by_frame ? e->id_of_g.as<u32>() : nullptr, id_map(e, e->id_bits), S.hot.as<HotEntry>(), E, (u32)g0);
   HIPCHK(hipGetLastError());
   u32 cap = 1024;
   while (cap < 2ull * U) cap <<= 1;
@@ -483,6 +497,70 @@ int build_segment(sgtd_engine *e, sgtd_engine::Segment &S, long long g0, long lo
   return SGTD_OK;
 }
 
+// The entry ids (IdMap) of the whole table: frame_first (+ by_frame, id_of_g when frame ids are out
+// of insertion order) and the number of bits the in-frame rank needs.  `bits` is what the ids of
+// the segments built from now on use; a change invalidates segments built with another value.
+int build_idmap(sgtd_engine *e, u32 &bits) {
+  const long long E = e->n_entries;
+  bits = e->id_bits ? e->id_bits : 13;
+  if (E == 0 || !e->have_frames) return SGTD_OK;
+  const u32 lo = e->frame_lo, span = e->frame_hi - e->frame_lo + 1;
+  const u32 *frame = e->tab.frame.as<u32>();
+  CHK(ensure(e, e->frame_first, (size_t)span * sizeof(u32)));
+  CHK(ensure(e, e->longest, 2 * sizeof(u32)));
+  HIPCHK(hipMemsetAsync(e->longest.p, 0, 2 * sizeof(u32), e->stream));
+  frame_monotone_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(frame, E, reinterpret_cast<int *>(e->longest.as<u32>() + 1));
+  HIPCHK(hipGetLastError());
+  u32 h[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h, e->longest.p, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->id_by_frame = h[1] != 0;
+  const u32 *key = frame;
+  if (e->id_by_frame) {
+    CHK(ensure(e, e->keyA, (size_t)E * sizeof(u64)));
+    CHK(ensure(e, e->keyB, (size_t)E * sizeof(u64)));
+    CHK(ensure(e, e->valA, (size_t)E * sizeof(u32)));
+    CHK(ensure(e, e->valB, (size_t)E * sizeof(u32)));
+    u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
+    u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
+    frame_keys_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(frame, kin, vin, E);
+    HIPCHK(hipGetLastError());
+    CHK(radix_sort_pairs(e, kin, kout, vin, vout, E, 32, true));     // stable: insertion order inside a frame
+    CHK(ensure(e, e->by_frame, (size_t)E * sizeof(u32)));
+    CHK(ensure(e, e->id_of_g, (size_t)E * sizeof(u32)));
+    HIPCHK(hipMemcpyAsync(e->by_frame.p, vin, (size_t)E * sizeof(u32), hipMemcpyDeviceToDevice, e->stream));
+    // the sorted frame ids, compacted to 32 bits, in id_of_g's buffer until the ids are written... they
+    // are needed together: use valB's partner buffer (the sort is over)
+    low_words_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, E, vout);
+    HIPCHK(hipGetLastError());
+    key = vout;
+  }
+  frame_first_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(key, E, lo, e->frame_first.as<u32>());
+  HIPCHK(hipGetLastError());
+  frame_longest_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(key, E, lo, e->frame_first.as<u32>(), e->longest.as<u32>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h, e->longest.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  u32 need = 1;
+  while (need < 32 && (1ull << need) < (unsigned long long)h[0]) need++;
+  // the local frame 2^(32 - bits) - 1 is the dead record's: span must stay below it
+  auto fits = [&](u32 b) { return b < 32 && (unsigned long long)span < (1ull << (32 - b)) - 1ull; };
+  if (bits < need || !fits(bits)) {
+    bits = std::max<u32>(need, 13);
+    if (!fits(bits)) bits = need;
+    if (!fits(bits)) {
+      e->err = "a 32-bit entry id cannot hold this table's frame span and its largest frame";
+      return SGTD_ERR_UNSUPPORTED;
+    }
+  }
+  if (e->id_by_frame) {
+    id_of_sorted_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(key, e->by_frame.as<u32>(), E, lo, e->frame_first.as<u32>(), bits,
+                                                                 e->id_of_g.as<u32>());
+    HIPCHK(hipGetLastError());
+  }
+  return SGTD_OK;
+}
+
 // AddSTDescs only ever appends (STDesc.cpp:149-172).  After an append to a finalized table only
 // the appended entries are sorted, into the tail segment (cost proportional to the tail); the
 // query sweeps both segments — inside a bucket the reference's order is insertion order, i.e.
@@ -497,8 +575,13 @@ int do_finalize(sgtd_engine *e, bool force_merge = false) {
   const auto t0 = std::chrono::steady_clock::now();
   sgtd_engine::Segment &M = e->seg[0], &T = e->seg[1];
   const long long tail_max = e->tail_max > 0 ? (long long)e->tail_max : std::max<long long>(262144, (M.g1 - M.g0) / 8);
+  u32 bits = 0;
+  CHK(build_idmap(e, bits));
+  // (an appended frame older than the main segment's newest, a frame that outgrew the ids' rank
+  // bits, or frame ids that just went out of insertion order: everything is rebuilt)
   const bool can_tail = !force_merge && M.built && M.g0 == 0 && M.g1 > 0 && M.g1 <= E && E - M.g1 <= tail_max &&
-                        (E == M.g1 || e->append_min_frame > M.frame_hi);
+                        bits == e->id_bits && !e->id_by_frame && (E == M.g1 || e->append_min_frame > M.frame_hi);
+  e->id_bits = bits;
   if (can_tail) {
     if (E > M.g1) { CHK(build_segment(e, T, M.g1, E)); e->n_seg = 2; }
     else { T.built = false; e->n_seg = 1; }
@@ -517,7 +600,7 @@ int do_finalize(sgtd_engine *e, bool force_merge = false) {
 // the query pipeline on descriptors already in e->qd (strided)
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e) {
-  CHK(ensure(e, e->rec, e->rec_cap * sizeof(u64)));
+  CHK(ensure(e, e->rec, e->rec_cap * sizeof(u32)));
   CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));   // every block reserves room for all of its records
   if (e->diag) {
     CHK(ensure(e, e->rec_cell, e->rec_cap));
@@ -541,7 +624,7 @@ Views make_views(sgtd_engine *e, int sgi = 0) {
   v.span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   TableView &T = v.T;
   const sgtd_engine::Segment &S = e->seg[sgi];
-  T.ent = S.hot.as<HotEntry>(); T.perm = S.perm.as<u32>(); T.cold_side = e->tab.side.as<double>();
+  T.ent = S.hot.as<HotEntry>(); T.map = id_map(e, e->id_bits ? e->id_bits : 13); T.cold_side = e->tab.side.as<double>();
   T.dir = S.dir.as<BucketDir>();
   T.hash = S.hash.as<HashSlot>(); T.hash_mask = S.hash_mask;
   T.n_entries = (u32)(S.g1 - S.g0); T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
@@ -552,7 +635,7 @@ Views make_views(sgtd_engine *e, int sgi = 0) {
   ProbeBuffers &B = v.B;
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
-  B.rec_frame = e->rec.as<u32>(); B.rec_g = e->rec.as<u32>() + e->rec_cap;   // two halves of one allocation
+  B.rec = e->rec.as<u32>(); B.id_bits = e->id_bits ? e->id_bits : 13;
   B.rec_cursor = e->cursors.as<unsigned long long>();
   B.rec_need = e->cursors.as<unsigned long long>() + 2;
   B.swept = e->cursors.as<unsigned long long>() + 3;
@@ -803,7 +886,7 @@ int launch_select(sgtd_engine *e) {
   block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL,
                                                     blocks, e->blk_count.as<u32>(), cn,
                                                     e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
-                                                    e->pairs.as<u64>());
+                                                    e->pairs.as<u64>(), v.T.map);
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
   e->batch_valid = true;
@@ -846,7 +929,7 @@ int rerun_write(sgtd_engine *e) {
                                                (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
   HIPCHK(hipGetLastError());
   block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL, blocks, e->blk_count.as<u32>(), cn,
-                                                    e->pair_off.as<long long>(), e->q_pair_base.as<u32>(), e->pairs.as<u64>());
+                                                    e->pair_off.as<long long>(), e->q_pair_base.as<u32>(), e->pairs.as<u64>(), v.T.map);
   HIPCHK(hipGetLastError());
   return SGTD_OK;
 }
@@ -1281,7 +1364,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const double want = 1.3 * est_matches_per_query(e, max_n) * (double)n_queries;
-    const double cap_mem = (double)free_b / 4.0 / 20.0;    // records + compact list + pairs, a quarter of what is free
+    const double cap_mem = (double)free_b / 4.0 / 16.0;    // records + compact list + pairs, a quarter of what is free
     const size_t cap = (size_t)std::min(std::min(want, cap_mem), (double)0xFFFFFFF0ull);
     if (cap > e->rec_cap) e->rec_cap = cap;
     if (cap / 2 > e->pair_cap) e->pair_cap = cap / 2;   // candidate pairs: 0.2 .. 0.5 of the matches
@@ -1321,8 +1404,8 @@ int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
   const double per_query = std::max(1.0, est_matches_per_query(e, n_keypoints)) * 2.0;   // margin: slab slack, variation
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  // 20 B per record (records 8, compact list 8, candidate pairs ~4) on top of what the buffers already hold
-  const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->pairs.bytes) / 20.0;
+  // 16 B per record (records 4, compact list 8, candidate pairs ~4) on top of what the buffers already hold
+  const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->pairs.bytes) / 16.0;
   const double lim = std::min((double)0xFFFFFFF0ull, mem_records);
   *max_queries = (int64_t)std::max(1.0, std::floor(lim / per_query));
   return SGTD_OK;
@@ -1454,7 +1537,7 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
     CHK(ensure(e, e->rough_dis, n * sizeof(double)));
   }
   Views v = make_views(e);
-  rough_gather_kernel<<<1, 256, 0, e->stream>>>(v.Q, v.B, q, e->rough_qi.as<u32>(), e->rough_entry.as<u32>(),
+  rough_gather_kernel<<<1, 256, 0, e->stream>>>(v.Q, v.B, v.T.map, q, e->rough_qi.as<u32>(), e->rough_entry.as<u32>(),
                                                  e->rough_frame.as<u32>(),
                                                  e->diag ? e->rough_cell.as<unsigned char>() : nullptr,
                                                  e->diag ? e->rough_dis.as<double>() : nullptr);

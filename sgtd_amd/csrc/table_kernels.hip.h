@@ -200,7 +200,7 @@ __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
 // ---------------------------------------------------------------------------
 // side / frame are the arrays of the segment's range (indexed from its first entry g0); perm
 // comes in with positions inside the range and leaves with insertion indices
-__global__ void gather_hot_kernel(u32 *perm, const double *side, const u32 *frame,
+__global__ void gather_hot_kernel(u32 *perm, const double *side, const u32 *frame, const u32 *id_of_g, IdMap map,
                                   HotEntry *ent, long long n, u32 g0) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) {
@@ -209,20 +209,50 @@ __global__ void gather_hot_kernel(u32 *perm, const double *side, const u32 *fram
     if (p < n + SGTD_SENTINELS) {
       HotEntry h;
       h.s0 = h.s1 = h.s2 = __builtin_inff();
-      h.frame = 0xFFFFFFFFu;
+      h.id = SGTD_DEAD_ID;
       ent[p] = h;
       perm[p] = 0;
     }
     return;
   }
-  const u32 g = perm[p];
+  const u32 g = perm[p];         // position inside the segment's range of entries
   perm[p] = g + g0;
   HotEntry h;
   h.s0 = (float)side[(size_t)g * 3 + 0];   // round to nearest: the bound in f32_bounds assumes it
   h.s1 = (float)side[(size_t)g * 3 + 1];
   h.s2 = (float)side[(size_t)g * 3 + 2];
-  h.frame = frame[g];
+  if (id_of_g) h.id = id_of_g[g + g0];
+  else {
+    const u32 f = frame[g] - map.frame_lo;
+    h.id = (f << map.bits) | ((g + g0) - map.frame_first[f]);
+  }
   ent[p] = h;
+}
+
+// the frame runs of `key` (frame ids: in insertion order when they are monotone, else sorted):
+// first[f - lo] = first position of frame f ...
+__global__ void frame_first_kernel(const u32 *key, long long n, u32 lo, u32 *first) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  if (p == 0 || key[p - 1] != key[p]) first[key[p] - lo] = (u32)p;
+}
+// ... and the longest run (the largest number of entries of one frame)
+__global__ void frame_longest_kernel(const u32 *key, long long n, u32 lo, const u32 *first, u32 *longest) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  if (p == n - 1 || key[p + 1] != key[p]) atomicMax(longest, (u32)(p + 1) - first[key[p] - lo]);
+}
+// frames out of insertion order: id of every entry from its position in the frame-major list
+__global__ void id_of_sorted_kernel(const u32 *key, const u32 *by_frame, long long n, u32 lo, const u32 *first,
+                                    u32 bits, u32 *id_of_g) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const u32 f = key[p] - lo;
+  id_of_g[by_frame[p]] = (f << bits) | ((u32)p - first[f]);
+}
+__global__ void low_words_kernel(const u64 *keys, long long n, u32 *out) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) out[g] = (u32)keys[g];
 }
 
 // frame ids non-decreasing in insertion order?  (true for maps built frame by frame; then the
