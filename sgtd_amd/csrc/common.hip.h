@@ -100,24 +100,28 @@ __device__ __forceinline__ u32 id_entry(const IdMap &m, u32 id) {
 #define SGTD_SENTINELS 64
 
 // Inside a bucket (one reference cell + label code) the entries are partitioned into
-// SGTD_ZSLICES slices of the longest side's cell interval plus one overflow slice, each in
-// insertion order.  A query descriptor only visits the slices its threshold ball reaches
-// (|side2 - q2| <= thr) and the overflow slice.  All entries of one map frame in one bucket
-// that could match the same query descriptor lie in ONE slice (table_kernels.hip.h,
-// slice_assign_kernel), so the matches of any (query descriptor, cell, frame) still come out in
-// insertion order — the order of the reference's bucket scan restricted to a frame, which is
-// all that votes and per-candidate match lists depend on.
-#define SGTD_ZSLICES 4
-#define SGTD_NSLICE (SGTD_ZSLICES + 1)     // + overflow slice (always visited)
+// SGTD_YSLICES x SGTD_ZSLICES sub-cells — halves of the second side's cell interval, each cut
+// into thirds of the third side's — plus one overflow slice, each in insertion order; sub-cell
+// s = yh * SGTD_ZSLICES + zt, the thirds of one half are adjacent.  A query descriptor only
+// visits the sub-cells its threshold box reaches (|side1 - q1| <= thr and |side2 - q2| <= thr:
+// per half one contiguous run of thirds) and the overflow slice.  All entries of one map frame
+// in one bucket that could match the same query descriptor lie in ONE slice
+// (table_kernels.hip.h, slice_assign_kernel), so the matches of any (query descriptor, cell,
+// frame) still come out in insertion order — the order of the reference's bucket scan
+// restricted to a frame, which is all that votes and per-candidate match lists depend on.
+#define SGTD_YSLICES 2
+#define SGTD_ZSLICES 3
+#define SGTD_NSUB (SGTD_YSLICES * SGTD_ZSLICES)
+#define SGTD_NSLICE (SGTD_NSUB + 1)        // + overflow slice (always visited)
 // one bucket of the directory, 32 B: cum[k] = entries of the bucket in slices 0..k
-// (cum[SGTD_ZSLICES] = all of them, the reference's bucket length)
+// (cum[SGTD_NSUB] = all of them, the reference's bucket length)
 struct __attribute__((aligned(32))) BucketDir {
   u32 start;
   u32 cum[SGTD_NSLICE];
-  u32 pad[2];
 };
-static_assert(sizeof(BucketDir) == 32 && SGTD_ZSLICES == 4, "the sweep unpacks {start, cum[0..4]} from two 16-B halves");
-#define SGTD_NRANGE (2 * SGTD_NCELL)       // visit ranges of one descriptor: (cell, regular | overflow)
+static_assert(sizeof(BucketDir) == 32 && SGTD_YSLICES == 2 && SGTD_ZSLICES == 3,
+              "the sweep unpacks {start, cum[0..2]} and {cum[3..6]} from the two 16-B halves of a row");
+#define SGTD_NRANGE (2 * SGTD_NCELL)       // lanes of a plan round: (cell, half) — or (cell, overflow) on the odd ones
 #define SGTD_GROUP_ROW_BYTES 1024          // 27 BucketDir rows (864 B), padded
 
 // What the sweep needs about ONE query descriptor, 64 B: written per descriptor slot by the

@@ -153,21 +153,21 @@ struct DescSet {
   u32 slot[K];          // descriptor slot d
 };
 
-// the visit list as the sweep walks it: lane r < 54 holds the exclusive offset off[r] of range
-// r = 2 * cell + (0 regular slices | 1 overflow slice), lanes >= 54 the total.  For a pair it
-// is the union of the two descriptors' lists.  Lane 54 stands for one more range that starts at
-// `total` and maps onto the 64 sentinel entries behind the table's last entry (sides +inf: no
-// match), so the lanes of the last 64-entry word beyond the list need no special case.
-// The non-empty ranges, numbered in order, are what the sweep addresses: lane j holds for the
-// j-th one dlc = start - off, its cell (diagnostic sweep) and, for a pair, per descriptor the
-// penalty 0 / +inf that starts the squared-distance sum (+inf: the cell fails that descriptor's
-// gate); `ne` marks the lanes r whose range r is not empty.
+// The visit list as the sweep walks it: the non-empty ranges of table entries, in the order of
+// the reference's cells (inside a cell: lower half, upper half, overflow slice), numbered
+// j = 0..n-1 and held one per lane: offc = exclusive offset of range j in the list,
+// dlc = start - offc, its cell (diagnostic sweep) and, for a pair, per descriptor the penalty
+// 0 / +inf that starts the squared-distance sum (+inf: the cell fails that descriptor's gate).
+// For a pair the list is the union of the two descriptors' lists.  Lane n stands for one more
+// range that starts at `total` and maps onto the sentinel entries behind the table's last entry
+// (sides +inf: no match), so the lanes of the last 64-entry word beyond the list need no special
+// case; lanes beyond n hold offc = 0xFFFFFFFF.
 template <int K>
 struct DescPlan {
-  u32 off;
+  u32 offc;
   u32 dlc, cellc;
   float penc[K];
-  u64 ne;               // wave-uniform
+  u32 n, total;         // wave-uniform
   u32 ref_visits[K];    // wave-uniform: entries the reference's loop visits (all slices of the gated cells)
 };
 
@@ -299,77 +299,111 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
     }
     uint4 *out = reinterpret_cast<uint4 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES) + 2 * c;
     out[0] = lo;     // start, cum[0..2]
-    out[1] = hi;     // cum[3], cum[4], 0, 0
+    out[1] = hi;     // cum[3..6]
   }
 }
 
-// GroupRow + the descriptors' gate masks (:366-369) + their thresholds: per range the gated,
-// slice-pruned length and start, and the exclusive scan of the lengths.
-// Lane r = 2 c + k: even lanes hold {start, cum0, cum1, cum2} of cell c, odd lanes
-// {cum3, cum4, 0, 0}.  Regular range (k = 0): the slices that hold entries with
-// |side2 - q2| <= thr' — an entry outside cannot match: its squared distance, as the reference
-// computes it, is at least fl(dz * dz) >= thr2.  Overflow range (k = 1): all of that slice.
+// GroupRow + the descriptors' gate masks (:366-369) + their thresholds -> the visit list.
+// Lane 2 c + h holds one 16-B half of cell c's directory row: even lanes {start, cum0, cum1,
+// cum2}, odd lanes {cum3, cum4, cum5, cum6}, and stands for half h of the cell: the thirds of
+// that half which hold entries with |side1 - q1| <= thr' and |side2 - q2| <= thr' — an entry
+// outside cannot match: its squared distance, as the reference computes it, is at least
+// fl(d * d) >= thr2 for that axis.  The odd lanes also stand for the cell's overflow slice
+// (all of it; most buckets have none).  The non-empty ranges are compacted, in cell order, by
+// two forward permutes (a lane nobody writes receives 0: the two results are OR-ed), and the
+// offsets are the scan of the compacted lengths.
 // K = 2: the union of the two descriptors' ranges; the sweep tests every loaded entry against
-// both and masks each with its own gate (a slice too many is harmless, a cell too many is not).
+// both and starts each sum from the descriptor's own gate penalty (a slice too many is harmless,
+// a cell too many is not).
+__device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int &lo, int &hi) {
+  // slices of the cell interval reached by [q - t, q + t]; slice s holds the entries with
+  // (side + 0.5 - cell) * n in [s, s + 1).  q - cell is below 2.5 in magnitude for every gated
+  // cell: the bounds are computed in f32 from it (error < 1e-6) with a margin of 1e-4 slice on
+  // top of the threshold's own upward rounding; visiting a slice too many is harmless.
+  const float a = ((dq - t_up) + 0.5f) * (float)n - 1e-4f;
+  const float b = ((dq + t_up) + 0.5f) * (float)n + 1e-4f;
+  lo = !(a > 0.0f) ? 0 : (a >= (float)n ? n : (int)a);          // floor, clamped to [0, n]; NaN -> 0
+  hi = b < 0.0f ? -1 : (!(b < (float)n) ? n - 1 : (int)b);      // floor, clamped to [-1, n - 1]; NaN -> n - 1
+}
+
 template <int K>
 __device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f, u32 n_entries) {
   const int lane = lane_id();
   const int c = lane >> 1;
   const bool odd = lane & 1;
-  // neighbour lane of the pair: even lanes receive cum3 / cum4, odd lanes start / cum0
-  const u32 nx = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-  const u32 ny = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.y, 0xB1, 0xf, 0xf, false);
-  const int iz = c % 3 - 1;
+  const int half = lane & 1;
+  // neighbour lane of the pair (quad_perm [1,0,3,2]): the other half of the cell's row
+  const u32 px = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.x, 0xB1, 0xf, 0xf, false);
+  const u32 pz = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.z, 0xB1, 0xf, 0xf, false);
+  const u32 pw = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.w, 0xB1, 0xf, 0xf, false);
+  // cumulative counts around this lane's half: before its first third, after each third
+  const u32 cm1 = odd ? pw : 0u, c0 = odd ? f.row.x : f.row.y, c1 = odd ? f.row.y : f.row.z, c2 = odd ? f.row.z : f.row.w;
+  const u32 bstart = odd ? px : f.row.x;
+  const int iy = (c / 3) % 3 - 1, iz = c % 3 - 1;
   int s_lo = SGTD_ZSLICES, s_hi = -1;
   bool live = false;
   DescPlan<K> pl;
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const bool lv = lane < SGTD_NRANGE && ((f.gate[k] >> c) & 1u);
-    // slices of cell z = (int)(q2 + iz) reached by [q2 - t, q2 + t]; slice s holds the entries with
-    // (side2 + 0.5 - z) * 4 in [s, s + 1).  q2 - z is below 2.5 in magnitude for every gated cell:
-    // the bounds are computed in f32 from it (error < 1e-6) with a margin of 1e-4 slice on top of
-    // the threshold's own upward rounding; visiting a slice too many is harmless.
-    const float dq = (float)(f.q2[k] - (double)(int)(f.q2[k] + (double)iz));
-    const float a = ((dq - f.t_up[k]) + 0.5f) * (float)SGTD_ZSLICES - 1e-4f;
-    const float b = ((dq + f.t_up[k]) + 0.5f) * (float)SGTD_ZSLICES + 1e-4f;
-    const int lo_k = !(a > 0.0f) ? 0 : (a >= (float)SGTD_ZSLICES ? SGTD_ZSLICES : (int)a);          // floor, clamped to [0, 4]; NaN -> 0
-    const int hi_k = b < 0.0f ? -1 : (!(b < (float)SGTD_ZSLICES) ? SGTD_ZSLICES - 1 : (int)b);      // floor, clamped to [-1, 3]; NaN -> 3
-    if (lv && hi_k >= lo_k) { s_lo = min(s_lo, lo_k); s_hi = max(s_hi, hi_k); }
+    int y_lo, y_hi, z_lo, z_hi;
+    reached_slices((float)(f.q1[k] - (double)(int)(f.q1[k] + (double)iy)), f.t_up[k], SGTD_YSLICES, y_lo, y_hi);
+    reached_slices((float)(f.q2[k] - (double)(int)(f.q2[k] + (double)iz)), f.t_up[k], SGTD_ZSLICES, z_lo, z_hi);
+    if (lv && half >= y_lo && half <= y_hi && z_hi >= z_lo) { s_lo = min(s_lo, z_lo); s_hi = max(s_hi, z_hi); }
     live |= lv;
-    // the reference's loop visits every entry of every gated cell: cum4 of the even lanes
-    pl.ref_visits[k] = wave_sum((lv && !odd) ? ny : 0u);
+    // the reference's loop visits every entry of every gated cell: cum6 of the odd lanes
+    pl.ref_visits[k] = wave_sum((lv && odd) ? f.row.w : 0u);
   }
-  // cum before slice s (s = 0..4): 0, cum0, cum1, cum2, cum3; even lanes only
-  const u32 cum3 = nx;
-  const u32 before_lo = s_lo == 0 ? 0u : (s_lo == 1 ? f.row.y : (s_lo == 2 ? f.row.z : (s_lo == 3 ? f.row.w : cum3)));
-  const u32 upto_hi = s_hi < 0 ? 0u : (s_hi == 0 ? f.row.y : (s_hi == 1 ? f.row.z : (s_hi == 2 ? f.row.w : cum3)));
-  u32 start, len;
-  if (!odd) {
-    start = f.row.x + before_lo;
-    len = (s_hi >= s_lo) ? upto_hi - before_lo : 0u;
-  } else {
-    start = nx + f.row.x;            // bucket start + cum3
-    len = f.row.y - f.row.x;         // cum4 - cum3
+  const u32 before = s_lo == 0 ? cm1 : (s_lo == 1 ? c0 : c1);
+  const u32 upto = s_hi == 0 ? c0 : (s_hi == 1 ? c1 : c2);
+  u32 start_a = bstart + before;
+  u32 len_a = (s_hi >= s_lo) ? upto - before : 0u;            // (s_hi >= s_lo only for a live lane)
+  const u32 start_b = px + f.row.z;                           // odd lanes: bucket start + cum5
+  const u32 len_b = (odd && live) ? f.row.w - f.row.z : 0u;   // cum6 - cum5
+  u64 keep_a = __builtin_amdgcn_ballot_w64(len_a != 0u);
+  const u64 keep_b = __builtin_amdgcn_ballot_w64(len_b != 0u);
+  if (__builtin_popcountll(keep_a) + __builtin_popcountll(keep_b) > 62) {
+    // more ranges than lanes (only with many overflow slices): the halves of a cell as ONE
+    // unpruned range, all six sub-cells — a superset of what the descriptors reach
+    start_a = f.row.x;
+    len_a = (!odd && live) ? pz : 0u;                         // cum5 of the even lane's cell
+    keep_a = __builtin_amdgcn_ballot_w64(len_a != 0u);
   }
-  len = live ? len : 0u;
-  const u32 inc = wave_incl_scan(len);
-  pl.off = inc - len;          // lanes >= 54 add nothing: they hold the total
-  // compaction of the non-empty ranges (and the sentinel range, lane 54) to lanes 0..n-1 by a
-  // forward permute; the empty ones all write lane 63, which no ordinal reaches (at most 55)
-  const bool sentinel = lane == SGTD_NRANGE;
-  if (sentinel) start = n_entries;
-  const bool keep = len != 0u || sentinel;
-  pl.ne = __builtin_amdgcn_ballot_w64(keep);
-  const u32 ord = __builtin_amdgcn_mbcnt_hi((u32)(pl.ne >> 32), __builtin_amdgcn_mbcnt_lo((u32)pl.ne, 0u));
-  const u32 dst = (keep ? ord : 63u) << 2;
-  pl.dlc = (u32)__builtin_amdgcn_ds_permute((int)dst, (int)(start - pl.off));   // start[r] - off[r]
-  pl.cellc = (u32)__builtin_amdgcn_ds_permute((int)dst, c);
+  const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(keep_a >> 32), __builtin_amdgcn_mbcnt_lo((u32)keep_a, 0u)) +
+                    __builtin_amdgcn_mbcnt_hi((u32)(keep_b >> 32), __builtin_amdgcn_mbcnt_lo((u32)keep_b, 0u));
+  const u32 n = (u32)(__builtin_popcountll(keep_a) + __builtin_popcountll(keep_b));
+  // forward permutes: range -> its number; an empty one writes lane 63, which no number reaches
+  const u32 dst_a = (len_a != 0u ? below : 63u) << 2;
+  u32 startc = (u32)__builtin_amdgcn_ds_permute((int)dst_a, (int)start_a);
+  u32 lenc = (u32)__builtin_amdgcn_ds_permute((int)dst_a, (int)len_a);
+  u32 cellc = (u32)__builtin_amdgcn_ds_permute((int)dst_a, c);
+  u32 penb[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const bool open = lane < SGTD_NRANGE && ((f.gate[k] >> c) & 1u);
-    pl.penc[k] = __uint_as_float((u32)__builtin_amdgcn_ds_permute((int)dst, open ? 0 : 0x7F800000));
+    penb[k] = open ? 0u : 0x7F800000u;
   }
+  u32 pencu[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) pencu[k] = (u32)__builtin_amdgcn_ds_permute((int)dst_a, (int)penb[k]);
+  if (keep_b) {     // the overflow slice of cell c follows both of its halves
+    const u32 dst_b = (len_b != 0u ? below + (u32)((keep_a >> lane) & 1ull) : 63u) << 2;
+    startc |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, (int)start_b);
+    lenc |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, (int)len_b);
+    cellc |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, c);
+#pragma unroll
+    for (int k = 0; k < K; k++) pencu[k] |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, (int)penb[k]);
+  }
+  lenc = (u32)lane < n ? lenc : 0u;
+  const u32 inc = wave_incl_scan(lenc);
+  const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
+  pl.n = n;
+  pl.total = total;
+  pl.offc = (u32)lane < n ? inc - lenc : ((u32)lane == n ? total : 0xFFFFFFFFu);
+  pl.dlc = (u32)lane < n ? startc - pl.offc : n_entries - total;       // lane n: the sentinel entries
+  pl.cellc = cellc;
+#pragma unroll
+  for (int k = 0; k < K; k++) pl.penc[k] = __uint_as_float((u32)lane < n ? pencu[k] : 0x7F800000u);
   return pl;
 }
 
@@ -399,7 +433,7 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
   }
   const u32 id_bits = T.map.bits;
   const double thr = DIAG ? norm3(f.q0[0], f.q1[0], f.q2[0]) * rough : 0.0;   // :356-357
-  const u32 total = (u32)__builtin_amdgcn_readlane((int)pl.off, SGTD_WAVE - 1);
+  const u32 total = pl.total;
   u64 ph_t = PH_T(); (void)ph_t;
   // records of one descriptor are contiguous: make sure its stream's slab can take the worst
   // case (every visited entry matches)
@@ -448,11 +482,11 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
   // one load group: NW words located, their loads issued back to back, then tested.  NW is a
   // compile-time count: each group size is straight-line code (branches around loads would
   // make the compiler wait for earlier loads before every later one).
-  const bool marks = ((pl.ne >> lane) & 1ull) && pl.off != 0u;
+  const bool marks = (u32)lane <= pl.n && pl.offc != 0u;
   auto window = [&](u32 w_first) {     // w_first: a multiple of 64 words
     bits[lane] = 0;
-    const u32 wr = ((pl.off - 1u) >> 6) - w_first;
-    if (marks && wr < 64u) atomicOr(reinterpret_cast<unsigned long long *>(bits + wr), 1ull << ((pl.off - 1u) & 63u));
+    const u32 wr = ((pl.offc - 1u) >> 6) - w_first;
+    if (marks && wr < 64u) atomicOr(reinterpret_cast<unsigned long long *>(bits + wr), 1ull << ((pl.offc - 1u) & 63u));
     __builtin_amdgcn_wave_barrier();
   };
   auto group = [&](auto nw_tag, u32 w0) {
@@ -467,7 +501,7 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
       const u32 pos = w_lo + lane;
       valid[u] = pos < total;
       const u64 bm = bits[(w0 + u) & 63u];      // marks of positions w_lo + 1 .. w_lo + 64
-      const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pl.off <= w_lo) & pl.ne) - 1u;
+      const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pl.offc <= w_lo)) - 1u;
       const u32 j4 = __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, before)) << 2;
       const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)pl.dlc);
       if (DIAG) cellv[u] = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)pl.cellc);

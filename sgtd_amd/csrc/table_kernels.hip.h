@@ -9,11 +9,11 @@
 //   sort       stable LSD radix sort of (key, g) by key, 8-bit digits, passes
 //              whose digit is constant are skipped; stable => inside a bucket
 //              entries stay in insertion order == the reference's index j
-//   slices     every bucket is partitioned (stably) into SGTD_ZSLICES slices of the
-//              third side's cell interval + an overflow slice; entries of one frame
+//   slices     every bucket is partitioned (stably) into 2 x 3 sub-cells (halves of the
+//              second side's cell interval x thirds of the third side's) + an overflow slice; entries of one frame
 //              that could match the same query descriptor never straddle slices
 //              (slice_assign_kernel), so per-frame match order stays the reference's
-//   gather     probe layout in that order p: HotEntry {f32 sides, frame} 16 B + perm[p] = g
+//   gather     probe layout in that order p: HotEntry {f32 sides, entry id} 16 B (+ perm[p] = g for the table dump)
 //   csr+hash   bucket directory (start + slice counts) and open-addressing table key -> bucket
 #pragma once
 #include "common.hip.h"
@@ -262,19 +262,25 @@ __global__ void frame_monotone_kernel(const u32 *frame, long long n, int *flag) 
   if (g + 1 < n && frame[g + 1] < frame[g]) *flag = 1;
 }
 
-// z-slice of an entry inside its cell: the cell is (int)(s2 + 0.5) (STDesc.cpp:157), the
-// slice the quarter of [cell, cell + 1) that s2 + 0.5 falls into (exact: a power-of-two scale)
-__device__ __forceinline__ u32 z_slice(double s2) {
-  const double y = s2 + 0.5;
+// sub-cell of an entry inside its cell: per axis the cell is (int)(s + 0.5) (STDesc.cpp:156-157),
+// the slice the half / third of [cell, cell + 1) that s + 0.5 falls into.  (The product with 3
+// is rounded: an entry within an ulp of a third's boundary may land on either side — the plan's
+// slice bounds carry a margin of 1e-4 slice, table_kernels and sweep only have to agree on
+// where the entry IS, which they do by construction: both read slice_of / the directory.)
+__device__ __forceinline__ u32 axis_slice(double s, int n) {
+  const double y = s + 0.5;
   const int cell = (int)y;
-  const int sl = (int)(y * (double)SGTD_ZSLICES) - cell * SGTD_ZSLICES;
-  return (u32)min(max(sl, 0), SGTD_ZSLICES - 1);
+  const int sl = (int)(y * (double)n) - cell * n;
+  return (u32)min(max(sl, 0), n - 1);
+}
+__device__ __forceinline__ u32 sub_cell(double s1, double s2) {
+  return axis_slice(s1, SGTD_YSLICES) * SGTD_ZSLICES + axis_slice(s2, SGTD_ZSLICES);
 }
 
 // Slice assignment.  Input: entries sorted by (key, frame, g) (order[p] = g, keys[p]).  One
 // thread per position; the head of every (key, frame) run decides for the run: if two of its
-// members lie in different z-slices AND could both match one query descriptor, the whole run
-// goes to the overflow slice, otherwise every member keeps its z-slice.  Two entries a, b can
+// members lie in different sub-cells AND could both match one query descriptor, the whole run
+// goes to the overflow slice, otherwise every member keeps its sub-cell.  Two entries a, b can
 // both match a query q only if ||a - b|| < 2 thr(q) and thr(q) = rough ||q|| <=
 // rough (||a|| + thr(q)), i.e. thr(q) <= rough ||a|| / (1 - rough): the test below uses the
 // larger norm and a relative margin.  Runs longer than SGTD_RUN_MAX members go to the
@@ -291,7 +297,7 @@ __global__ void slice_assign_kernel(const u64 *keys, const u32 *order, const dou
   long long e = p + 1;
   while (e < n && e - p <= SGTD_RUN_MAX && keys[e] == key && frame[order[e]] == fr) e++;
   const int len = (int)(e - p);
-  if (len == 1) { slice_of[g0] = (unsigned char)z_slice(side[(size_t)g0 * 3 + 2]); return; }
+  if (len == 1) { slice_of[g0] = (unsigned char)sub_cell(side[(size_t)g0 * 3 + 1], side[(size_t)g0 * 3 + 2]); return; }
   bool overflow = len > SGTD_RUN_MAX;
   if (overflow) {   // mark the rest of the long run as well
     while (e < n && keys[e] == key && frame[order[e]] == fr) e++;
@@ -300,12 +306,12 @@ __global__ void slice_assign_kernel(const u64 *keys, const u32 *order, const dou
     for (int i = 0; i < len && !overflow; i++) {
       const u32 ga = order[p + i];
       const double a0 = side[(size_t)ga * 3], a1 = side[(size_t)ga * 3 + 1], a2 = side[(size_t)ga * 3 + 2];
-      const u32 sa = z_slice(a2);
+      const u32 sa = sub_cell(a1, a2);
       const double na = norm3(a0, a1, a2);
       for (int j = i + 1; j < len; j++) {
         const u32 gb = order[p + j];
         const double b0 = side[(size_t)gb * 3], b1 = side[(size_t)gb * 3 + 1], b2 = side[(size_t)gb * 3 + 2];
-        if (z_slice(b2) == sa) continue;
+        if (sub_cell(b1, b2) == sa) continue;
         const double nb = norm3(b0, b1, b2);
         const double lim = f * fmax(na, nb) + 1e-9;
         if (!(norm3(a0 - b0, a1 - b1, a2 - b2) > lim)) { overflow = true; break; }   // NaN counts as close
@@ -314,7 +320,7 @@ __global__ void slice_assign_kernel(const u64 *keys, const u32 *order, const dou
   }
   for (long long q = p; q < e; q++) {
     const u32 g = order[q];
-    slice_of[g] = overflow ? (unsigned char)SGTD_ZSLICES : (unsigned char)z_slice(side[(size_t)g * 3 + 2]);
+    slice_of[g] = overflow ? (unsigned char)SGTD_NSUB : (unsigned char)sub_cell(side[(size_t)g * 3 + 1], side[(size_t)g * 3 + 2]);
   }
 }
 
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256) void slice_partition_kernel(const u32 *bucket_
     }
     u32 base[SGTD_NSLICE], acc = 0;
     BucketDir row;
-    row.start = start; row.pad[0] = 0; row.pad[1] = 0;
+    row.start = start;
 #pragma unroll
     for (int s = 0; s < SGTD_NSLICE; s++) {
       base[s] = start + acc;
