@@ -50,6 +50,7 @@ struct TableView {
   u32 n_entries;
   u32 frame_lo;                // votes are indexed by frame - frame_lo
   u32 frame_span;              // number of vote bins per query
+  u32 coarse_at;               // a visit list of more ranges than this is planned without slice pruning (62; SGTD_COARSE_AT: test hook)
 };
 
 struct QueryView {
@@ -327,7 +328,7 @@ __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int 
 }
 
 template <int K>
-__device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f, u32 n_entries) {
+__device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f, u32 n_entries, u32 coarse_at) {
   const int lane = lane_id();
   const int c = lane >> 1;
   const bool odd = lane & 1;
@@ -362,7 +363,7 @@ __device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f, 
   const u32 len_b = (odd && live) ? f.row.w - f.row.z : 0u;   // cum6 - cum5
   u64 keep_a = __builtin_amdgcn_ballot_w64(len_a != 0u);
   const u64 keep_b = __builtin_amdgcn_ballot_w64(len_b != 0u);
-  if (__builtin_popcountll(keep_a) + __builtin_popcountll(keep_b) > 62) {
+  if ((u32)(__builtin_popcountll(keep_a) + __builtin_popcountll(keep_b)) > coarse_at) {
     // more ranges than lanes (only with many overflow slices): the halves of a cell as ONE
     // unpruned range, all six sub-cells — a superset of what the descriptors reach
     start_a = f.row.x;
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorte
 #pragma unroll
         for (int k = 0; k < KK; k++) unpack(f, k, i + (u32)k);
         DescResult res[KK];
-        sweep_descriptors<DIAG, WIDE, KK>(T, B, rough, f, plan_from_group_row<KK>(f, T.n_entries), s_bits[threadIdx.x >> 6], slab, res, pend);
+        sweep_descriptors<DIAG, WIDE, KK>(T, B, rough, f, plan_from_group_row<KK>(f, T.n_entries, T.coarse_at), s_bits[threadIdx.x >> 6], slab, res, pend);
 #pragma unroll
         for (int k = 0; k < KK; k++)
           if ((u32)lane == i + (u32)k) { r_ptr = res[k].ptr; r_visit = res[k].visit; r_match = res[k].match; }

@@ -84,6 +84,7 @@ struct sgtd_engine {
   u32 append_min_frame = 0xFFFFFFFFu;    // smallest frame id appended since the main segment was built
   int64_t tail_max = 0;                  // SGTD_TAIL_MAX: entries the tail may hold before a merge (0 = an eighth of the main segment)
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
+  u32 coarse_at = 62;                    // SGTD_COARSE_AT: see TableView
   int tail_batches = 0;                  // query batches swept with the current tail (it is merged after a few: see settle_tail)
   DevBuf slice_of, sq_sum;
   // entry ids of the probe layout (common.hip.h IdMap), rebuilt over the whole table by every finalize
@@ -627,6 +628,7 @@ Views make_views(sgtd_engine *e, int sgi = 0) {
   T.ent = S.hot.as<HotEntry>(); T.map = id_map(e, e->id_bits ? e->id_bits : 13); T.cold_side = e->tab.side.as<double>();
   T.dir = S.dir.as<BucketDir>();
   T.hash = S.hash.as<HashSlot>(); T.hash_mask = S.hash_mask;
+  T.coarse_at = e->coarse_at;
   T.n_entries = (u32)(S.g1 - S.g0); T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
   QueryView &Q = v.Q;
   Q.side = e->qd.side.as<double>(); Q.qrec = e->qd.qrec.as<QueryRec>();
@@ -1167,6 +1169,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   e->qd.with_thr2 = true;
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
   if (const char *o = getenv("SGTD_TAIL_MAX")) e->tail_max = atoll(o);
+  if (const char *o = getenv("SGTD_COARSE_AT")) e->coarse_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }
   if (const char *o = getenv("SGTD_PAIR_CAP")) { e->pair_cap = (size_t)std::max(64ll, atoll(o)); e->rec_cap_fixed = true; }

@@ -665,8 +665,13 @@ def _random_descs(oracle_mod, manager_mod, rng, n, frame, small):
     return out
 
 
+@pytest.mark.parametrize("coarse_at", [None, "0", "6"])
 @pytest.mark.parametrize("monotone", [True, False])
-def test_bucket_slices_keep_the_reference_order_per_frame(mods, monotone):
+def test_bucket_slices_keep_the_reference_order_per_frame(mods, monotone, coarse_at, monkeypatch):
+    # coarse_at: the plan of a visit list with more ranges than this falls back to unpruned cells
+    # (62 in production, where it needs dozens of overflow slices): 0 = every list, 6 = a mix
+    if coarse_at is not None:
+        monkeypatch.setenv("SGTD_COARSE_AT", coarse_at)
     oracle, manager, _ = mods
     rng = np.random.default_rng(77 if monotone else 78)
     g, o = _pair(mods, rough_dis_threshold=0.04, candidate_num=20)
