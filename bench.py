@@ -350,6 +350,9 @@ def main():
     roofline = {"bound": bound, "kernel": "probe_sorted_kernel (sweep)", "achieved": achieved, "peak": peak, "unit": "GB/s",
                 "frac": min(frac, 1.0), "traffic": traffic, "traffic_profile": tr.get("profile_tag") if tr else None,
                 "hbm_frac": hbm_frac, "l2_frac": l2_frac,
+                # what really limits the sweep: wave64 VALU instructions x 4 cycles over the 1024 SIMDs' cycles,
+                # from the SQ counter pass of the same profile (not measurable live)
+                "valu_issue_frac": tr.get("valu_issue_frac") if tr else None,
                 "avg_launch_ms": kern_ms["ms_probe"], "probe_layout_bytes_per_loaded_entry": entry_bytes,
                 "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_gbs,
                 "algorithmic_over_hbm_peak": algo_gbs / HBM_PEAK_GBS,

@@ -16,6 +16,6 @@ if [ "$TESTS" = "tests" ]; then
 fi
 timeout 900 python3 bench.py $EXTRA > $OUT/bench.json 2> $OUT/bench.err
 echo "bench rc=$?"; tail -c 600 $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --cpu-baseline off --verify off --boundary off --sweep "" $EXTRA > $OUT/bench_under_stats.json 2> $OUT/stats.err
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --cpu-baseline off --verify off --boundary off --sweep "" $EXTRA > $OUT/bench_under_stats.json 2> $OUT/stats.err
 python3 profiles/summarize.py $OUT $TAG > $OUT/summarize.log 2>&1
 tail -3 $OUT/summarize.log
