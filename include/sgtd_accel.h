@@ -80,14 +80,14 @@ typedef struct sgtd_stats {
   int64_t last_P;          /* table entries visited (STDesc.cpp:372 iterations)*/
   int64_t last_M;          /* rough matches (STDesc.cpp:378)                   */
   int64_t last_cand_pairs; /* pairs in all candidate match lists               */
-  int64_t hbm_bytes_table; /* bytes of the hot (probed) table arrays (20 B/entry) */
+  int64_t hbm_bytes_table; /* bytes of the hot (probed) table array (16 B/entry) */
   /* per-kernel device time of the last batch, ms (only when timing is enabled
    * with sgtd_set_timing; measured with hipEvents on the handle's stream)     */
   float ms_build, ms_sort, ms_probe, ms_votes, ms_topk, ms_count, ms_scan, ms_write, ms_total;
   int32_t overflowed;      /* last batch outgrew a work buffer and was re-run  */
   int32_t reserved;
   int64_t last_P_swept;    /* table entries the sweep really loaded: last_P minus the
-                              z-slices of the visited buckets that no match can lie in */
+                              sub-cells of the visited buckets that no match can lie in */
   double bucket_len_sq_over_E; /* sum over buckets of len^2 / E: the bucket length a table entry
                               sees on average (sizes the first batch's work buffers)        */
   int64_t tail_entries;    /* entries in the tail segment (appended after the last full build
@@ -154,7 +154,7 @@ int sgtd_add(sgtd_handle h, const sgtd_desc_soa *d, int64_t n);
 int sgtd_add_frames(sgtd_handle h, const float *xyz, const uint32_t *label,
                     const int64_t *kp_off, int n_frames, int device_ptrs);
 
-/* Sorts the appended entries into the probe layout (by key, z-slices inside a bucket, bucket
+/* Sorts the appended entries into the probe layout (by key, sub-cells inside a bucket, bucket
  * directory + key hash).  Idempotent; called implicitly by the first query after an add.
  * Appending to a finalized table (AddSTDescs only ever appends, STDesc.cpp:149-172) sorts only
  * the appended entries, into a tail segment that every query sweeps after the main one; the
