@@ -359,7 +359,7 @@ def main():
                 "reference_visits_per_s": P / t_probe if t_probe > 0 else 0.0,
                 "note": "bound = the level whose fraction is larger: L2->CU bytes the sweep really moves (16 B x entries loaded "
                         "+ 4 B x records) vs 34.5 TB/s, or PMC HBM bytes vs 8 TB/s; algorithmic bytes (28 B x reference visits) "
-                        "exceed the HBM peak because pruned z-slices are never loaded and buckets are re-read from L2 (DESIGN.md §3)",
+                        "exceed the HBM peak because pruned sub-cells are never loaded and buckets are re-read from L2; the kernel itself is VALU-issue bound (valu_issue_frac, DESIGN.md §3)",
                 "P_visited": P, "P_swept_after_slice_pruning": st.get("last_P_swept"), "M_matches": M,
                 "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
                 "kernel_ms": kern_ms}
