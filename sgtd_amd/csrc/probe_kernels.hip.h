@@ -1,20 +1,21 @@
 // probe_kernels.hip.h — candidate_selector (src/sgtd/src/STDesc.cpp:318-460)
 //
-//   probe     (:351-400) one wavefront per query descriptor: its 27 cells
-//             (truncating (int)(side+inc), gate ||side-centre|| < 1.5, hash
-//             lookup key -> bucket) become one concatenated visit list of up to 54
-//             ranges — per cell the z-slices of the bucket that the descriptor's
-//             threshold ball reaches, and the bucket's overflow slice
-//             (common.hip.h, table_kernels.hip.h) — that all 64 lanes stream from
-//             the 16-B/entry probe layout (one 16-B and one 4-B load per lane and
-//             64 entries, 4 x 64 entries in flight).  The distance test runs in
-//             f32 against two squared thresholds that make it conservative on
-//             both sides (common.hip.h f32_bounds); the few entries between them
-//             are decided on the exact f64 sides with the exact squared threshold
-//             (sq_threshold) — every decision is the reference's.  Matches are
-//             compacted in visit order by __ballot/popcount prefix into a
-//             per-descriptor list of (frame, entry) records; restricted to any one
-//             map frame that order is the reference's (cell, j) order.
+//   probe     (:351-400) one wavefront per pair of query descriptors of one home
+//             cell: the 27 cells (truncating (int)(side+inc), gate ||side-centre||
+//             < 1.5, hash lookup key -> bucket) become one concatenated visit list
+//             of non-empty ranges — per cell and half of the second side's
+//             interval the thirds of the third side's that a descriptor's threshold
+//             box reaches, and the bucket's overflow slice (common.hip.h,
+//             table_kernels.hip.h) — that all 64 lanes stream from the 16-B/entry
+//             probe layout (one 16-B load per lane and 64 entries, 4 x 64 entries
+//             in flight).  The distance test runs in f32 against two squared
+//             thresholds that make it conservative on both sides (common.hip.h
+//             f32_bounds); the few entries between them are decided on the exact
+//             f64 sides with the exact squared threshold (sq_threshold) — every
+//             decision is the reference's.  Matches are compacted in visit order
+//             by ballot/popcount prefix into a per-descriptor list of 4-byte entry
+//             ids (frame and entry in one word, IdMap); restricted to any one map
+//             frame that order is the reference's (cell, j) order.
 //             Schedule (probe_sorted_kernel): the batch's descriptors are
 //             radix-sorted by home cell, descriptors of one home cell share ONE
 //             set of 27 bucket lookups (GroupRow), per-XCD ticket queues hand

@@ -67,7 +67,7 @@ struct sgtd_engine {
   bool finalized = false;  // the first query builds the (possibly empty) bucket directory
 
   // ---- table, probe layout (hot): a main segment and, after appends to a finalized table, a
-  // tail segment — each a complete probe layout (HotEntry[n] 16 B + perm[n], bucket directory,
+  // tail segment — each a complete probe layout (HotEntry[n] 16 B, perm[n] for the table dump, bucket directory,
   // key hash) over a contiguous range of insertion indices.  Appending re-sorts only the tail;
   // the tail is merged into the main segment when it outgrows an eighth of it.
   struct Segment {

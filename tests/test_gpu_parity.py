@@ -644,7 +644,7 @@ def test_overflowed_batch_is_resolved_before_the_sharded_export(mods, monkeypatc
 
 
 # ---------------------------------------------------------------------------
-# probe layout: z-slices + overflow slice inside a bucket, f32 pre-test with exact fallback
+# probe layout: sub-cells + overflow slice inside a bucket, f32 pre-test with exact fallback
 # ---------------------------------------------------------------------------
 def _random_descs(oracle_mod, manager_mod, rng, n, frame, small):
     """caller-made descriptors (AddSTDescs path) concentrated in a few cells: many entries of
