@@ -231,6 +231,8 @@ __device__ __forceinline__ void write_query_rec(QueryRec *out, double s0, double
   reinterpret_cast<uint4 *>(qr)[3] = make_uint4(__float_as_uint(lo2), __float_as_uint(hi2), __float_as_uint(t_up), 0u);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // operands of v_pk_*_f32
+
 struct HashSlot {  // 16 bytes
   u64 key;
   u32 bucket;   // index into the bucket directory

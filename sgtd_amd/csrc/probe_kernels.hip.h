@@ -122,7 +122,6 @@ struct PendingLoads {
 #define SGTD_PAIR 2
 #endif
 static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2, "the pair sweep computes both distances with packed f32 math");
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WaveSlab {
   u32 next[SGTD_PAIR], end[SGTD_PAIR];   // this wave's private ranges of match records: one bump stream per

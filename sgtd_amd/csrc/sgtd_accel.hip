@@ -1581,7 +1581,12 @@ int sgtd_verify(sgtd_handle e) {
   P.q_vertex = e->qd.vertex.as<float>(); P.q_center = e->qd.center.as<double>();
   P.t_vertex = e->tab.vertex.as<float>(); P.t_center = e->tab.center.as<double>();
   P.score = e->v_score.as<double>(); P.pose = e->v_pose.as<double>(); P.inlier = e->v_inlier.as<unsigned char>();
+  // per-pair vote masks between the kernel's two passes: the compact candidate lists of the assemble
+  // passes are dead once the pairs are final (sync_batch above), and hold a word per record
+  CHK(ensure(e, e->c_pair, (size_t)std::max<int64_t>(total, 1) * sizeof(u64)));
+  P.passed = e->c_pair.as<u64>();
   P.thr2 = 9.0;   // sqrt_rn(y) < 3.0 <=> y < 9.0 (sqrt(9) = 3, sqrt(pred(9)) rounds to pred(3)); dis_threshold :469
+  { const char *o = getenv("SGTD_VERIFY_EXACT"); P.exact_only = (o && atoi(o)) ? 1 : 0; }
   verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
   e->verified = true;

@@ -5,9 +5,14 @@
 // pair range written by block_write_kernel, in the reference's order.
 //   hypotheses  (:467-468,481-487) every skip_len-th pair, use_size <= 50 of them: one thread
 //               each solves the 3x3 Kabsch problem of its triangle pair (triangle_solver)
-//   votes       (:488-505) every thread owns one pair of the current 256-pair tile and
-//               tests it against all hypotheses (R, t broadcast from LDS); the per-hypothesis
-//               counts are wave ballots accumulated in lane h
+//   votes       (:488-505) every thread owns two pairs of the current 512-pair tile and
+//               tests them against all hypotheses (R, t broadcast from LDS); the per-hypothesis
+//               counts are wave ballots accumulated in lane h.  A vertex is pre-tested in
+//               packed f32 (both pairs in one v_pk_fma_f32 chain) against two squared
+//               thresholds that make the f32 result conservative on both sides (bound
+//               below); what falls between them is decided in f64 exactly as the reference
+//               computes it.  Vertex A fails for nearly every (pair, hypothesis): B and C
+//               are only looked at where it passes
 //   best        (:507-514) first maximum; needs >= 4 votes (:515)
 //   inliers     (:516-539) second pass with the best hypothesis: one flag byte per pair of
 //               the list (sucess_match_vec = the flagged pairs in list order), score = count
@@ -21,9 +26,7 @@
 
 #define SGTD_VERIFY_THREADS 256
 #define SGTD_VERIFY_MAX_HYP 64     // use_size <= 50 (:467-468)
-#ifndef SGTD_VERIFY_PPT
-#define SGTD_VERIFY_PPT 1         // pairs per thread per step of the vote pass (2 measured equal: VALU-bound)
-#endif
+#define SGTD_VERIFY_PPT 2          // pairs per thread per step of the vote pass: the halves of the packed f32 operations
 
 struct VerifyParams {
   // candidate lists of the batch
@@ -42,7 +45,9 @@ struct VerifyParams {
   double *score;               // [nq][cand_num]   verify_score (-1: fewer than 4 votes)
   double *pose;                // [nq][cand_num][12]  rot row-major (9) then t (3)
   unsigned char *inlier;       // [total pairs] flag per pair of every list
+  u64 *passed;                 // [total pairs] scratch: bit h = the pair votes for hypothesis h of its candidate
   double thr2;                 // smallest y with sqrt_rn(y) >= 3.0 (dis_threshold, :469)
+  int exact_only;              // test hook (SGTD_VERIFY_EXACT=1): no f32 pre-test, every vertex A test in f64
 };
 
 // One-sided (Hestenes) Jacobi SVD of a 3x3, H = U diag(s) V^T; columns of (near) zero
@@ -158,8 +163,9 @@ __device__ __forceinline__ bool vertex_close(const double *Rt, const double v[3]
 
 __global__ __launch_bounds__(SGTD_VERIFY_THREADS) void verify_kernel(VerifyParams P) {
   __shared__ double s_Rt[SGTD_VERIFY_MAX_HYP][12];
+  __shared__ __attribute__((aligned(16))) float s_Rtf[SGTD_VERIFY_MAX_HYP][12];   // the same rounded to f32 (pre-test)
   __shared__ u32 s_votes[SGTD_VERIFY_MAX_HYP];
-  __shared__ u32 s_best, s_count;
+  __shared__ u32 s_best, s_count, s_rmax, s_tmax;
   const int tid = threadIdx.x, lane = lane_id();
   const int q = blockIdx.x / P.cand_num, c = blockIdx.x % P.cand_num;
   double *score = P.score + (size_t)q * P.cand_num + c;
@@ -179,49 +185,104 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) void verify_kernel(VerifyParam
   };
 
   if (tid < SGTD_VERIFY_MAX_HYP) s_votes[tid] = 0;
-  if (tid == 0) s_count = 0;
+  if (tid == 0) { s_count = 0; s_rmax = P.exact_only ? 0x7FC00000u : 0u; s_tmax = 0; }   // NaN bound: every pre-test undecided
+  __syncthreads();
   if (tid < use_size) {
     double qv[9], ev[9], qc[3], ec[3], out[12];
     size_t qd, g;
     load_pair((long long)tid * skip_len, qv, ev, qd, g);
     for (int k = 0; k < 3; k++) { qc[k] = P.q_center[qd * 3 + k]; ec[k] = P.t_center[g * 3 + k]; }
     solve_triangle_dev(qv, qc, ev, ec, out);
-    for (int k = 0; k < 12; k++) s_Rt[tid][k] = out[k];
+    for (int k = 0; k < 12; k++) { s_Rt[tid][k] = out[k]; s_Rtf[tid][k] = (float)out[k]; }
+    // largest |rot entry| and |t|_1 over the hypotheses, rounded up, as float bit patterns
+    // (non-negative floats order like their bits; a NaN beats everything and makes every
+    // f32 pre-test undecided)
+    double rm = 0, tm = fabs(out[9]) + fabs(out[10]) + fabs(out[11]);
+    for (int k = 0; k < 9; k++) rm = fmax(rm, fabs(out[k]));
+    if (!(rm == rm)) rm = __builtin_nan("");
+    atomicMax(&s_rmax, __float_as_uint((float)(rm * 1.000001)));
+    atomicMax(&s_tmax, __float_as_uint((float)(tm * 1.000001)));
   }
   __syncthreads();
 
-  // ---- votes of every hypothesis (:488-505): SGTD_VERIFY_PPT pairs per thread and step, so
-  // that one LDS read of a hypothesis serves that many tests
+  // ---- votes of every hypothesis (:488-505).  f32 pre-test of a vertex, both pairs of a thread
+  // in the halves of packed operations (vertex B only where A passed, C only where B passed): p^ = fma chain of the f32-rounded (R, t) on the exact f32
+  // vertices.  With u = 2^-24, |p^_i - p_i| <= 4 u (Rmax |v|_1 + |t|_1) (one rounding of R and t,
+  // three fused operations), the difference and the sum of squares add relative errors of a
+  // few u, so | ||d^|| - ||d|| | <= E = 16 u (Rmax |v|_1 + tmax + thr) with room to spare (the
+  // f64 evaluation of the reference is within 1e-15 relative of the exact value):
+  //   d2^ < (thr - E)^2 (1 - 8u)  ==>  the reference's test passes
+  //   d2^ > (thr + E)^2 (1 + 8u)  ==>  it fails;  anything else (NaN included) is decided in f64.
   u32 acc = 0;   // lane h of every wave: votes of hypothesis h seen by this wave
   constexpr int PPT = SGTD_VERIFY_PPT;
+  static_assert(PPT == 2, "two pairs per thread: the halves of v_pk_*_f32");
+  const float uf = 5.9604644775390625e-08f;
+  const float rmaxf = __uint_as_float(s_rmax), tmaxf = __uint_as_float(s_tmax);
+  const float thrf = (float)(sqrt(P.thr2) * 1.000001);
   for (long long j0 = 0; j0 < n; j0 += (long long)PPT * SGTD_VERIFY_THREADS) {
-    double qv[PPT][9], ev[PPT][9];
     bool valid[PPT];
+    float lo2[PPT], hi2[PPT];
+    f32x2 vx, vy, vz, wx, wy, wz;          // vertex A of the two pairs (f32 as stored)
+    float qbc[PPT][6], ebc[PPT][6];        // vertices B, C
+    u64 passed[PPT] = {0ull, 0ull};        // bit h: the pair votes for hypothesis h
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
       const long long j = j0 + (long long)u * SGTD_VERIFY_THREADS + tid;
       valid[u] = j < n;
-      size_t qd, g;
-      load_pair(valid[u] ? j : 0, qv[u], ev[u], qd, g);
+      const u64 pr = P.pairs[base + (valid[u] ? j : 0)];
+      const float *qp = P.q_vertex + (qslot0 + (size_t)(pr >> 32)) * 9, *ep = P.t_vertex + (size_t)(pr & 0xFFFFFFFFull) * 9;
+      const float a0 = qp[0], a1 = qp[1], a2 = qp[2], b0 = ep[0], b1 = ep[1], b2 = ep[2];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { qbc[u][k] = qp[3 + k]; ebc[u][k] = ep[3 + k]; }
+      if (u == 0) { vx.x = a0; vy.x = a1; vz.x = a2; wx.x = b0; wy.x = b1; wz.x = b2; }
+      else { vx.y = a0; vy.y = a1; vz.y = a2; wx.y = b0; wy.y = b1; wz.y = b2; }
+      const float E = 16.0f * uf * (rmaxf * ((fabsf(a0) + fabsf(a1)) + fabsf(a2)) + tmaxf + thrf);
+      const float lo = thrf * 0.999998f - E, hi = thrf + E;     // (thrf was rounded up by 1e-6: take it back for lo)
+      lo2[u] = lo > 0.0f ? lo * lo * (1.0f - 8.0f * uf) : 0.0f;  // NaN E: lo2 = 0 (never certainly in) ...
+      hi2[u] = hi * hi * (1.0f + 8.0f * uf);                     // ... and hi2 = NaN (never certainly out)
     }
     for (int h = 0; h < use_size; h++) {
-      const double *Rt = s_Rt[h];
-      bool in[PPT];
-      bool any = false;
+      const float4 r0 = reinterpret_cast<const float4 *>(s_Rtf[h])[0];   // R00 R01 R02 R10
+      const float4 r1 = reinterpret_cast<const float4 *>(s_Rtf[h])[1];   // R11 R12 R20 R21
+      const float4 r2 = reinterpret_cast<const float4 *>(s_Rtf[h])[2];   // R22 t0 t1 t2
+      auto bc = [](float x) { f32x2 r = {x, x}; return r; };
+      const f32x2 px = __builtin_elementwise_fma(bc(r0.x), vx, __builtin_elementwise_fma(bc(r0.y), vy, __builtin_elementwise_fma(bc(r0.z), vz, bc(r2.y))));
+      const f32x2 py = __builtin_elementwise_fma(bc(r0.w), vx, __builtin_elementwise_fma(bc(r1.x), vy, __builtin_elementwise_fma(bc(r1.y), vz, bc(r2.z))));
+      const f32x2 pz = __builtin_elementwise_fma(bc(r1.z), vx, __builtin_elementwise_fma(bc(r1.w), vy, __builtin_elementwise_fma(bc(r2.x), vz, bc(r2.w))));
+      const f32x2 dx = px - wx, dy = py - wy, dz = pz - wz;
+      const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      bool in[PPT], amb[PPT];
+      in[0] = valid[0] && d2.x < lo2[0]; amb[0] = valid[0] && !(d2.x < lo2[0]) && !(d2.x > hi2[0]);
+      in[1] = valid[1] && d2.y < lo2[1]; amb[1] = valid[1] && !(d2.y < lo2[1]) && !(d2.y > hi2[1]);
+      if (__ballot(amb[0] || amb[1])) {     // rare: vertex A exactly
 #pragma unroll
-      for (int u = 0; u < PPT; u++) {
-        in[u] = valid[u] && vertex_close(Rt, qv[u], ev[u], P.thr2);
-        any = any || in[u];
+        for (int u = 0; u < PPT; u++)
+          if (amb[u]) {
+            const double qa[3] = {(double)(u ? vx.y : vx.x), (double)(u ? vy.y : vy.x), (double)(u ? vz.y : vz.x)};
+            const double ea[3] = {(double)(u ? wx.y : wx.x), (double)(u ? wy.y : wy.x), (double)(u ? wz.y : wz.x)};
+            in[u] = vertex_close(s_Rt[h], qa, ea, P.thr2);
+          }
       }
-      if (__ballot(any)) {         // most hypotheses fail at vertex A for the whole wave
+      if (__ballot(in[0] || in[1])) {       // most hypotheses fail at vertex A for the whole wave
         u32 cnt = 0;
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
-          in[u] = in[u] && vertex_close(Rt, qv[u] + 3, ev[u] + 3, P.thr2) && vertex_close(Rt, qv[u] + 6, ev[u] + 6, P.thr2);
+          if (in[u]) {
+            double qv[6], ev[6];
+            for (int k = 0; k < 6; k++) { qv[k] = (double)qbc[u][k]; ev[k] = (double)ebc[u][k]; }
+            in[u] = vertex_close(s_Rt[h], qv, ev, P.thr2) && vertex_close(s_Rt[h], qv + 3, ev + 3, P.thr2);
+          }
+          if (in[u]) passed[u] |= 1ull << h;
           cnt += (u32)__popcll(__ballot(in[u]));
         }
         if (lane == h) acc += cnt;
       }
+    }
+    // what the inlier pass needs of this pair: no second walk over the vertices
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+      const long long j = j0 + (long long)u * SGTD_VERIFY_THREADS + tid;
+      if (j < n) P.passed[base + j] = passed[u];
     }
   }
   if (lane < use_size && acc) atomicAdd(&s_votes[lane], acc);
@@ -242,20 +303,13 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) void verify_kernel(VerifyParam
     for (long long j = tid; j < n; j += SGTD_VERIFY_THREADS) P.inlier[base + j] = 0;
     return;
   }
-  // ---- inliers of the best hypothesis (:516-539)
+  // ---- inliers of the best hypothesis (:516-539): the pairs that voted for it
   const double *Rt = s_Rt[best];
   u32 mine = 0;
-  for (long long j0 = 0; j0 < n; j0 += SGTD_VERIFY_THREADS) {
-    const long long j = j0 + tid;
-    if (j < n) {
-      double qv[9], ev[9];
-      size_t qd, g;
-      load_pair(j, qv, ev, qd, g);
-      const bool in = vertex_close(Rt, qv, ev, P.thr2) && vertex_close(Rt, qv + 3, ev + 3, P.thr2) &&
-                      vertex_close(Rt, qv + 6, ev + 6, P.thr2);
-      P.inlier[base + j] = in ? 1 : 0;
-      mine += in ? 1u : 0u;
-    }
+  for (long long j = tid; j < n; j += SGTD_VERIFY_THREADS) {
+    const bool in = (P.passed[base + j] >> best) & 1ull;
+    P.inlier[base + j] = in ? 1 : 0;
+    mine += in ? 1u : 0u;
   }
   mine = wave_sum(mine);
   if (lane == 0 && mine) atomicAdd(&s_count, mine);

@@ -384,6 +384,40 @@ def test_verify_parity(mods, n_kp, n_frames):
     mgr.close()
 
 
+def test_verify_f32_pretest_equals_the_all_f64_path_at_size(mods, monkeypatch):
+    """vertex A is pre-tested in packed f32 with a conservative bound and decided in f64 when in
+    doubt: scores, poses and inlier flags of 64 queries x 50 candidates on a 600-frame map must
+    equal the run with the pre-test switched off (SGTD_VERIFY_EXACT=1)"""
+    _, manager, synth = mods
+    smap = synth.make_map(600, 200, stream=41)
+    qs = synth.make_queries(smap, 64, stream=41)
+    out = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("SGTD_VERIFY_EXACT", exact)
+        g = manager.STDescManager()
+        g.add_frames(smap.xyz, smap.label)
+        res = g.query_frames(qs.xyz, qs.label)
+        g.verify()
+        rows = []
+        for q in range(64):
+            score, rot, t = g.result_verify(q)
+            nc = int(res.n_cand[q])
+            inl = [g.result_inliers(q, k, int(res.pair_off[q, k + 1] - res.pair_off[q, k])) for k in range(nc) if score[k] >= 0]
+            rows.append((score.copy(), rot.copy(), t.copy(), inl))
+        out.append(rows)
+        g.close()
+    n_inl = 0
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+        assert len(a[3]) == len(b[3])
+        for x, y in zip(a[3], b[3]):
+            np.testing.assert_array_equal(x, y)
+            n_inl += len(x)
+    assert n_inl > 1000
+
+
 # ---------------------------------------------------------------------------
 # SURVEY §8f row 4: saved table == rebuilt table, and appending after a load
 # ---------------------------------------------------------------------------
