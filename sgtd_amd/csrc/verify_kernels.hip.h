@@ -161,7 +161,8 @@ __device__ __forceinline__ bool vertex_close(const double *Rt, const double v[3]
   return ((dx * dx + dy * dy) + dz * dz) < thr2;
 }
 
-__global__ __launch_bounds__(SGTD_VERIFY_THREADS) void verify_kernel(VerifyParams P) {
+// (four waves per SIMD: the solver's f64 temporaries must not set the register budget of the vote loop)
+__global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void verify_kernel(VerifyParams P) {
   __shared__ double s_Rt[SGTD_VERIFY_MAX_HYP][12];
   __shared__ __attribute__((aligned(16))) float s_Rtf[SGTD_VERIFY_MAX_HYP][12];   // the same rounded to f32 (pre-test)
   __shared__ u32 s_votes[SGTD_VERIFY_MAX_HYP];
@@ -221,9 +222,8 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) void verify_kernel(VerifyParam
   const float thrf = (float)(sqrt(P.thr2) * 1.000001);
   for (long long j0 = 0; j0 < n; j0 += (long long)PPT * SGTD_VERIFY_THREADS) {
     bool valid[PPT];
-    float lo2[PPT], hi2[PPT];
-    f32x2 vx, vy, vz, wx, wy, wz;          // vertex A of the two pairs (f32 as stored)
-    float qbc[PPT][6], ebc[PPT][6];        // vertices B, C
+    f32x2 v[3][3], w[3][3];        // [vertex A, B, C][x, y, z], the two pairs in the halves (f32 as stored)
+    f32x2 lo2[3], hi2[3];          // per vertex: the two squared f32 thresholds of each pair
     u64 passed[PPT] = {0ull, 0ull};        // bit h: the pair votes for hypothesis h
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
@@ -231,50 +231,52 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) void verify_kernel(VerifyParam
       valid[u] = j < n;
       const u64 pr = P.pairs[base + (valid[u] ? j : 0)];
       const float *qp = P.q_vertex + (qslot0 + (size_t)(pr >> 32)) * 9, *ep = P.t_vertex + (size_t)(pr & 0xFFFFFFFFull) * 9;
-      const float a0 = qp[0], a1 = qp[1], a2 = qp[2], b0 = ep[0], b1 = ep[1], b2 = ep[2];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { qbc[u][k] = qp[3 + k]; ebc[u][k] = ep[3 + k]; }
-      if (u == 0) { vx.x = a0; vy.x = a1; vz.x = a2; wx.x = b0; wy.x = b1; wz.x = b2; }
-      else { vx.y = a0; vy.y = a1; vz.y = a2; wx.y = b0; wy.y = b1; wz.y = b2; }
-      const float E = 16.0f * uf * (rmaxf * ((fabsf(a0) + fabsf(a1)) + fabsf(a2)) + tmaxf + thrf);
-      const float lo = thrf * 0.999998f - E, hi = thrf + E;     // (thrf was rounded up by 1e-6: take it back for lo)
-      lo2[u] = lo > 0.0f ? lo * lo * (1.0f - 8.0f * uf) : 0.0f;  // NaN E: lo2 = 0 (never certainly in) ...
-      hi2[u] = hi * hi * (1.0f + 8.0f * uf);                     // ... and hi2 = NaN (never certainly out)
+      for (int m = 0; m < 3; m++) {
+        const float a0 = qp[3 * m], a1 = qp[3 * m + 1], a2 = qp[3 * m + 2];
+        const float b0 = ep[3 * m], b1 = ep[3 * m + 1], b2 = ep[3 * m + 2];
+        const float E = 16.0f * uf * (rmaxf * ((fabsf(a0) + fabsf(a1)) + fabsf(a2)) + tmaxf + thrf);
+        const float lo = thrf * 0.999998f - E, hi = thrf + E;     // (thrf was rounded up by 1e-6: take it back for lo)
+        const float l2 = lo > 0.0f ? lo * lo * (1.0f - 8.0f * uf) : 0.0f;  // NaN E: lo2 = 0 (never certainly in) ...
+        const float h2 = hi * hi * (1.0f + 8.0f * uf);                     // ... and hi2 = NaN (never certainly out)
+        if (u == 0) { v[m][0].x = a0; v[m][1].x = a1; v[m][2].x = a2; w[m][0].x = b0; w[m][1].x = b1; w[m][2].x = b2; lo2[m].x = l2; hi2[m].x = h2; }
+        else { v[m][0].y = a0; v[m][1].y = a1; v[m][2].y = a2; w[m][0].y = b0; w[m][1].y = b1; w[m][2].y = b2; lo2[m].y = l2; hi2[m].y = h2; }
+      }
     }
     for (int h = 0; h < use_size; h++) {
       const float4 r0 = reinterpret_cast<const float4 *>(s_Rtf[h])[0];   // R00 R01 R02 R10
       const float4 r1 = reinterpret_cast<const float4 *>(s_Rtf[h])[1];   // R11 R12 R20 R21
       const float4 r2 = reinterpret_cast<const float4 *>(s_Rtf[h])[2];   // R22 t0 t1 t2
       auto bc = [](float x) { f32x2 r = {x, x}; return r; };
-      const f32x2 px = __builtin_elementwise_fma(bc(r0.x), vx, __builtin_elementwise_fma(bc(r0.y), vy, __builtin_elementwise_fma(bc(r0.z), vz, bc(r2.y))));
-      const f32x2 py = __builtin_elementwise_fma(bc(r0.w), vx, __builtin_elementwise_fma(bc(r1.x), vy, __builtin_elementwise_fma(bc(r1.y), vz, bc(r2.z))));
-      const f32x2 pz = __builtin_elementwise_fma(bc(r1.z), vx, __builtin_elementwise_fma(bc(r1.w), vy, __builtin_elementwise_fma(bc(r2.x), vz, bc(r2.w))));
-      const f32x2 dx = px - wx, dy = py - wy, dz = pz - wz;
-      const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      bool in[PPT], amb[PPT];
-      in[0] = valid[0] && d2.x < lo2[0]; amb[0] = valid[0] && !(d2.x < lo2[0]) && !(d2.x > hi2[0]);
-      in[1] = valid[1] && d2.y < lo2[1]; amb[1] = valid[1] && !(d2.y < lo2[1]) && !(d2.y > hi2[1]);
-      if (__ballot(amb[0] || amb[1])) {     // rare: vertex A exactly
+      // vertex m of both pairs: certainly close (stays in), certainly far (leaves), or undecided in
+      // f32 — then decided exactly, as the reference computes it
+      auto vertex = [&](int m, bool (&in)[PPT]) {
+        const f32x2 px = __builtin_elementwise_fma(bc(r0.x), v[m][0], __builtin_elementwise_fma(bc(r0.y), v[m][1], __builtin_elementwise_fma(bc(r0.z), v[m][2], bc(r2.y))));
+        const f32x2 py = __builtin_elementwise_fma(bc(r0.w), v[m][0], __builtin_elementwise_fma(bc(r1.x), v[m][1], __builtin_elementwise_fma(bc(r1.y), v[m][2], bc(r2.z))));
+        const f32x2 pz = __builtin_elementwise_fma(bc(r1.z), v[m][0], __builtin_elementwise_fma(bc(r1.w), v[m][1], __builtin_elementwise_fma(bc(r2.x), v[m][2], bc(r2.w))));
+        const f32x2 dx = px - w[m][0], dy = py - w[m][1], dz = pz - w[m][2];
+        const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        bool amb[PPT];
+        amb[0] = in[0] && !(d2.x < lo2[m].x) && !(d2.x > hi2[m].x); in[0] = in[0] && d2.x < lo2[m].x;
+        amb[1] = in[1] && !(d2.y < lo2[m].y) && !(d2.y > hi2[m].y); in[1] = in[1] && d2.y < lo2[m].y;
+        if (__ballot(amb[0] || amb[1])) {     // rare
 #pragma unroll
-        for (int u = 0; u < PPT; u++)
-          if (amb[u]) {
-            const double qa[3] = {(double)(u ? vx.y : vx.x), (double)(u ? vy.y : vy.x), (double)(u ? vz.y : vz.x)};
-            const double ea[3] = {(double)(u ? wx.y : wx.x), (double)(u ? wy.y : wy.x), (double)(u ? wz.y : wz.x)};
-            in[u] = vertex_close(s_Rt[h], qa, ea, P.thr2);
-          }
-      }
-      if (__ballot(in[0] || in[1])) {       // most hypotheses fail at vertex A for the whole wave
-        u32 cnt = 0;
-#pragma unroll
-        for (int u = 0; u < PPT; u++) {
-          if (in[u]) {
-            double qv[6], ev[6];
-            for (int k = 0; k < 6; k++) { qv[k] = (double)qbc[u][k]; ev[k] = (double)ebc[u][k]; }
-            in[u] = vertex_close(s_Rt[h], qv, ev, P.thr2) && vertex_close(s_Rt[h], qv + 3, ev + 3, P.thr2);
-          }
-          if (in[u]) passed[u] |= 1ull << h;
-          cnt += (u32)__popcll(__ballot(in[u]));
+          for (int u = 0; u < PPT; u++)
+            if (amb[u]) {
+              const double qa[3] = {(double)(u ? v[m][0].y : v[m][0].x), (double)(u ? v[m][1].y : v[m][1].x), (double)(u ? v[m][2].y : v[m][2].x)};
+              const double ea[3] = {(double)(u ? w[m][0].y : w[m][0].x), (double)(u ? w[m][1].y : w[m][1].x), (double)(u ? w[m][2].y : w[m][2].x)};
+              in[u] = vertex_close(s_Rt[h], qa, ea, P.thr2);
+            }
         }
+      };
+      bool in[PPT] = {valid[0], valid[1]};
+      vertex(0, in);
+      if (__ballot(in[0] || in[1])) {       // wrong hypotheses fail at vertex A for the whole wave
+        vertex(1, in);
+        if (__ballot(in[0] || in[1])) vertex(2, in);
+        if (in[0]) passed[0] |= 1ull << h;
+        if (in[1]) passed[1] |= 1ull << h;
+        const u32 cnt = (u32)__popcll(__ballot(in[0])) + (u32)__popcll(__ballot(in[1]));
         if (lane == h) acc += cnt;
       }
     }
