@@ -223,7 +223,7 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
   for (long long j0 = 0; j0 < n; j0 += (long long)PPT * SGTD_VERIFY_THREADS) {
     bool valid[PPT];
     f32x2 v[3][3], w[3][3];        // [vertex A, B, C][x, y, z], the two pairs in the halves (f32 as stored)
-    f32x2 lo2[3], hi2[3];          // per vertex: the two squared f32 thresholds of each pair
+    f32x2 lo2, hi2;                // the two squared f32 thresholds of each pair (from its largest vertex)
     u64 passed[PPT] = {0ull, 0ull};        // bit h: the pair votes for hypothesis h
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
@@ -231,17 +231,21 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
       valid[u] = j < n;
       const u64 pr = P.pairs[base + (valid[u] ? j : 0)];
       const float *qp = P.q_vertex + (qslot0 + (size_t)(pr >> 32)) * 9, *ep = P.t_vertex + (size_t)(pr & 0xFFFFFFFFull) * 9;
+      float vmax = 0.0f;
 #pragma unroll
       for (int m = 0; m < 3; m++) {
         const float a0 = qp[3 * m], a1 = qp[3 * m + 1], a2 = qp[3 * m + 2];
         const float b0 = ep[3 * m], b1 = ep[3 * m + 1], b2 = ep[3 * m + 2];
-        const float E = 16.0f * uf * (rmaxf * ((fabsf(a0) + fabsf(a1)) + fabsf(a2)) + tmaxf + thrf);
-        const float lo = thrf * 0.999998f - E, hi = thrf + E;     // (thrf was rounded up by 1e-6: take it back for lo)
-        const float l2 = lo > 0.0f ? lo * lo * (1.0f - 8.0f * uf) : 0.0f;  // NaN E: lo2 = 0 (never certainly in) ...
-        const float h2 = hi * hi * (1.0f + 8.0f * uf);                     // ... and hi2 = NaN (never certainly out)
-        if (u == 0) { v[m][0].x = a0; v[m][1].x = a1; v[m][2].x = a2; w[m][0].x = b0; w[m][1].x = b1; w[m][2].x = b2; lo2[m].x = l2; hi2[m].x = h2; }
-        else { v[m][0].y = a0; v[m][1].y = a1; v[m][2].y = a2; w[m][0].y = b0; w[m][1].y = b1; w[m][2].y = b2; lo2[m].y = l2; hi2[m].y = h2; }
+        const float s1 = (fabsf(a0) + fabsf(a1)) + fabsf(a2);
+        vmax = !(s1 <= vmax) ? s1 : vmax;                           // max that keeps a NaN
+        if (u == 0) { v[m][0].x = a0; v[m][1].x = a1; v[m][2].x = a2; w[m][0].x = b0; w[m][1].x = b1; w[m][2].x = b2; }
+        else { v[m][0].y = a0; v[m][1].y = a1; v[m][2].y = a2; w[m][0].y = b0; w[m][1].y = b1; w[m][2].y = b2; }
       }
+      const float E = 16.0f * uf * (rmaxf * vmax + tmaxf + thrf);
+      const float lo = thrf * 0.999998f - E, hi = thrf + E;     // (thrf was rounded up by 1e-6: take it back for lo)
+      const float l2 = lo > 0.0f ? lo * lo * (1.0f - 8.0f * uf) : 0.0f;  // NaN E: lo2 = 0 (never certainly in) ...
+      const float h2 = hi * hi * (1.0f + 8.0f * uf);                     // ... and hi2 = NaN (never certainly out)
+      if (u == 0) { lo2.x = l2; hi2.x = h2; } else { lo2.y = l2; hi2.y = h2; }
     }
     for (int h = 0; h < use_size; h++) {
       const float4 r0 = reinterpret_cast<const float4 *>(s_Rtf[h])[0];   // R00 R01 R02 R10
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
         const f32x2 dx = px - w[m][0], dy = py - w[m][1], dz = pz - w[m][2];
         const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
         bool amb[PPT];
-        amb[0] = in[0] && !(d2.x < lo2[m].x) && !(d2.x > hi2[m].x); in[0] = in[0] && d2.x < lo2[m].x;
-        amb[1] = in[1] && !(d2.y < lo2[m].y) && !(d2.y > hi2[m].y); in[1] = in[1] && d2.y < lo2[m].y;
+        amb[0] = in[0] && !(d2.x < lo2.x) && !(d2.x > hi2.x); in[0] = in[0] && d2.x < lo2.x;
+        amb[1] = in[1] && !(d2.y < lo2.y) && !(d2.y > hi2.y); in[1] = in[1] && d2.y < lo2.y;
         if (__ballot(amb[0] || amb[1])) {     // rare
 #pragma unroll
           for (int u = 0; u < PPT; u++)
