@@ -530,8 +530,8 @@ int build_idmap(sgtd_engine *e, u32 &bits) {
     CHK(ensure(e, e->by_frame, (size_t)E * sizeof(u32)));
     CHK(ensure(e, e->id_of_g, (size_t)E * sizeof(u32)));
     HIPCHK(hipMemcpyAsync(e->by_frame.p, vin, (size_t)E * sizeof(u32), hipMemcpyDeviceToDevice, e->stream));
-    // the sorted frame ids, compacted to 32 bits, in id_of_g's buffer until the ids are written... they
-    // are needed together: use valB's partner buffer (the sort is over)
+    // the sorted frame ids as 32-bit words in the sort's spare value buffer (the sort is over; the
+    // kernels below run before build_segment reuses the scratch)
     low_words_kernel<<<grid_for(E, 256), 256, 0, e->stream>>>(kin, E, vout);
     HIPCHK(hipGetLastError());
     key = vout;
