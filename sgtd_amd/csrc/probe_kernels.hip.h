@@ -1023,6 +1023,45 @@ __device__ __forceinline__ void sub_locate(const u32 *s_pre, const u32 *s_ptr, u
   addr = s_ptr[c] + (r - s_pre[c]);
 }
 
+// The same sub-block as a stream of QUADS — four consecutive records of one list, the last quad
+// of a list possibly short: one list search serves four records (the record buffer has room
+// for the reads past a list's end).  s_pre: exclusive quad offsets, s_ptr: list starts, s_cnt:
+// list lengths; returns the number of quads, `records` the number of records.
+__device__ __forceinline__ u32 sub_open_quads(const QueryView &Q, const ProbeBuffers &B, int sg, int q, u32 d0, u32 cnt,
+                                              u32 *s_pre /*[32]*/, u32 *s_ptr /*[32]*/, u32 *s_cnt /*[32]*/,
+                                              u32 &visits, u32 &records) {
+  const int lane = lane_id();
+  u32 n = 0, p = 0, v = 0;
+  if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
+    const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
+    n = B.n_match[d]; p = B.list_ptr[d]; v = B.n_visit[d];
+  }
+  const u32 nq = (n + 3u) >> 2;
+  const u32 inc = wave_incl_scan(nq);
+  const u32 RQ = __shfl(inc, SGTD_WAVE - 1);
+  visits += wave_sum(v);
+  records = wave_sum(n);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 32) { s_pre[lane] = inc - nq; s_ptr[lane] = p; s_cnt[lane] = n; }
+  __builtin_amdgcn_wave_barrier();
+  return RQ;
+}
+
+// quad r of the sub-block -> (descriptor index inside it, address of its first record, records in it)
+__device__ __forceinline__ void sub_locate_quad(const u32 *s_pre, const u32 *s_ptr, const u32 *s_cnt, u32 r, u32 &dd,
+                                                u32 &addr, u32 &k) {
+  u32 c = 0;
+  if (s_pre[16] <= r) c = 16;
+  if (s_pre[c + 8] <= r) c += 8;
+  if (s_pre[c + 4] <= r) c += 4;
+  if (s_pre[c + 2] <= r) c += 2;
+  if (s_pre[c + 1] <= r) c += 1;
+  dd = c;
+  const u32 first = (r - s_pre[c]) << 2;      // record index of the quad inside its list
+  addr = s_ptr[c] + first;
+  k = min(4u, s_cnt[c] - first);
+}
+
 // frame -> candidate slot of one query as an LDS open-addressing table (cand_num <= 64
 // frames in 256 slots): the assemble kernels look every match record up here instead of in
 // the per-frame slot_of array in global memory — no dependent global load per record, and
@@ -1058,35 +1097,44 @@ __device__ __forceinline__ u32 cand_slot(const u64 *s_tab, u32 frame) {
 template <bool LDS_VOTES>
 __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBuffers &B, int q, u32 d_first, u32 cnt,
                                                u32 frame_lo, u32 limit, u32 *s_hist, u32 *votes, u32 *s_pre, u32 *s_ptr,
-                                               u32 &visits, u32 &total) {
+                                               u32 *s_cnt, u32 &visits, u32 &total) {
   const int lane = lane_id();
   for (int sg = 0; sg < B.n_seg; sg++)
   for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
-    const u32 R = sub_open(Q, B, sg, q, d0, cnt, s_pre, s_ptr, visits);
-    total += R;
-    // the frames of the next four words are loaded while the current four are counted
-    u32 nfr[4];
-    auto load4 = [&](u32 r0) {
+    u32 records;
+    const u32 RQ = sub_open_quads(Q, B, sg, q, d0, cnt, s_pre, s_ptr, s_cnt, visits, records);
+    total += records;
+    // the quads of the next two words are loaded while the current two are counted
+    uint4 nrec[2];
+    u32 nk[2];
+    auto load2 = [&](u32 r0) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 2; u++) {
         const u32 r = r0 + u * SGTD_WAVE + lane;
-        u32 dd, addr;
-        sub_locate(s_pre, s_ptr, r < R ? r : 0u, dd, addr);
-        nfr[u] = B.rec[addr] >> B.id_bits;     // local frame (a dead record's is beyond every span)
+        u32 dd, addr, k;
+        sub_locate_quad(s_pre, s_ptr, s_cnt, r < RQ ? r : 0u, dd, addr, k);
+        nk[u] = r < RQ ? k : 0u;
+        const u32 *src = B.rec + addr;      // 4-byte aligned
+        nrec[u] = make_uint4(src[0], src[1], src[2], src[3]);
       }
     };
-    if (R) load4(0);
-    for (u32 r0 = 0; r0 < R; r0 += 4 * SGTD_WAVE) {
-      u32 fr[4];
+    if (RQ) load2(0);
+    for (u32 r0 = 0; r0 < RQ; r0 += 2 * SGTD_WAVE) {
+      uint4 rc[2];
+      u32 kk[2];
 #pragma unroll
-      for (int u = 0; u < 4; u++) fr[u] = nfr[u];
-      if (r0 + 4 * SGTD_WAVE < R) load4(r0 + 4 * SGTD_WAVE);
+      for (int u = 0; u < 2; u++) { rc[u] = nrec[u]; kk[u] = nk[u]; }
+      if (r0 + 2 * SGTD_WAVE < RQ) load2(r0 + 2 * SGTD_WAVE);
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const u32 bin = fr[u] - frame_lo;
-        if (r0 + u * SGTD_WAVE + lane < R && bin < limit) {
-          if (LDS_VOTES) atomicAdd(&s_hist[bin], 1u);
-          else atomicAdd(&votes[bin], 1u);
+      for (int u = 0; u < 2; u++) {
+        const u32 w4[4] = {rc[u].x, rc[u].y, rc[u].z, rc[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const u32 bin = (w4[i] >> B.id_bits) - frame_lo;     // local frame (a dead record's is beyond every span)
+          if ((u32)i < kk[u] && bin < limit) {
+            if (LDS_VOTES) atomicAdd(&s_hist[bin], 1u);
+            else atomicAdd(&votes[bin], 1u);
+          }
         }
       }
     }
@@ -1100,6 +1148,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   extern __shared__ u32 s_hist[];   // [frame_span] when LDS_VOTES
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
+  __shared__ u32 s_cnt[NW][32];
   if (B.overflow[0]) return;
   const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
@@ -1114,7 +1163,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   if (id.valid && d_first < cnt) {
     u32 visits = 0, total = 0;
-    votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, 0u, frame_span, s_hist, votes, s_pre[wid], s_ptr[wid], visits, total);
+    votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, 0u, frame_span, s_hist, votes, s_pre[wid], s_ptr[wid], s_cnt[wid], visits, total);
     if (lane == 0) {
       atomicAdd(&q_M[q], total);
       atomicAdd(&q_P[q], (unsigned long long)visits);
@@ -1142,6 +1191,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
   extern __shared__ u32 s_hist[];   // [tile_span]
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
+  __shared__ u32 s_cnt[NW][32];
   __shared__ u32 s_M;
   __shared__ unsigned long long s_P;
   const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
@@ -1158,7 +1208,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
     for (int blk = wid; blk < blocks_per_query; blk += NW) {
       const u32 d_first = (u32)blk * SGTD_PROBE_CHUNK;
       if (d_first >= cnt) break;
-      votes_of_block<true>(Q, B, q, d_first, cnt, tile_lo, n_bins, s_hist, nullptr, s_pre[wid], s_ptr[wid], visits, total);
+      votes_of_block<true>(Q, B, q, d_first, cnt, tile_lo, n_bins, s_hist, nullptr, s_pre[wid], s_ptr[wid], s_cnt[wid], visits, total);
     }
     if (lane == 0 && blockIdx.y == 0) {
       atomicAdd(&s_M, total);

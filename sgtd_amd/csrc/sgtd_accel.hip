@@ -601,7 +601,7 @@ int do_finalize(sgtd_engine *e, bool force_merge = false) {
 // the query pipeline on descriptors already in e->qd (strided)
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e) {
-  CHK(ensure(e, e->rec, e->rec_cap * sizeof(u32)));
+  CHK(ensure(e, e->rec, (e->rec_cap + 4) * sizeof(u32)));      // + a quad: the vote pass reads four records at the last list's tail
   CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));   // every block reserves room for all of its records
   if (e->diag) {
     CHK(ensure(e, e->rec_cell, e->rec_cap));
