@@ -505,11 +505,20 @@ def main():
     incremental = None
     if mode == "single" and args.sweep != "none":
         try:
-            g3 = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 200))
-            g3.set_stream(stream.cuda_stream)
-            g3.add_frames(*to_dev(smap.xyz, smap.label))
-            g3.finalize()
-            full_ms = g3.stats()["ms_finalize"]
+            # (ms_finalize is wall time and includes the device allocations of a handle's first build:
+            # after the host-pointer legs above those have been seen to stall for seconds once, so
+            # a throw-away handle takes that hit and the second one is timed)
+            full_ms = None
+            for attempt in range(2):
+                g3 = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 200))
+                g3.set_stream(stream.cuda_stream)
+                g3.add_frames(*to_dev(smap.xyz, smap.label))
+                g3.sync()
+                g3.finalize()
+                ms = g3.stats()["ms_finalize"]
+                full_ms = ms if full_ms is None else min(full_ms, ms)
+                if attempt == 0:
+                    g3.close()
 
             def s3():
                 g3.query_frames(d_qxyz, d_qlab, fetch=False)
