@@ -699,6 +699,42 @@ def _random_descs(oracle_mod, manager_mod, rng, n, frame, small):
     return out
 
 
+def test_entry_ids_grow_with_the_largest_frame(mods):
+    """an entry id holds the rank of the entry inside its frame in 13 bits until a frame needs more:
+    appending a frame of 9 000 descriptors to a finalized table re-ids (and rebuilds) the table;
+    candidates, votes and ordered match lists stay the reference's before and after"""
+    oracle, manager, _ = mods
+    rng = np.random.default_rng(91)
+    g, o = _pair(mods, rough_dis_threshold=0.04, candidate_num=20)
+
+    def check():
+        for small in (True, False):
+            gq, oq = _random_descs(oracle, manager, rng, 200, 99, small)
+            g.candidate_selector(gq)
+            res = g.results()
+            r = o.select(oq)
+            nc = int(res.n_cand[0])
+            np.testing.assert_array_equal(res.cand_frame[0, :nc], r["cand_frame"])
+            np.testing.assert_array_equal(res.cand_votes[0, :nc], r["cand_votes"])
+            qi, de = g.result_pairs(0, res)
+            np.testing.assert_array_equal(qi, r["q_idx"])
+            np.testing.assert_array_equal(de, r["db_entry"])
+        return g.stats()
+
+    for f in range(6):
+        gd, od = _random_descs(oracle, manager, rng, 700, f, small=(f % 2 == 0))
+        g.AddSTDescs(gd); o.add(od)
+    check()
+    gd, od = _random_descs(oracle, manager, rng, 9000, 6, small=True)      # > 8192 entries in one frame
+    g.AddSTDescs(gd); o.add(od)
+    st = check()
+    assert st["tail_entries"] == 0                                          # a change of the id width cannot live in a tail
+    gd, od = _random_descs(oracle, manager, rng, 300, 7, small=False)       # and the next small append can again
+    g.AddSTDescs(gd); o.add(od)
+    st = check()
+    assert st["tail_entries"] == 300
+
+
 @pytest.mark.parametrize("coarse_at", [None, "0", "6"])
 @pytest.mark.parametrize("monotone", [True, False])
 def test_bucket_slices_keep_the_reference_order_per_frame(mods, monotone, coarse_at, monkeypatch):
