@@ -735,6 +735,32 @@ def test_entry_ids_grow_with_the_largest_frame(mods):
     assert st["tail_entries"] == 300
 
 
+def test_entry_id_envelope_is_refused_loudly(mods):
+    """frame span x largest frame beyond a 32-bit entry id: SGTD_ERR_UNSUPPORTED with a message, not
+    a wrong answer (600 001 frames need 20 bits, a 5 000-entry frame 13)"""
+    oracle, manager, _ = mods
+    from sgtd_amd._lib import SgtdError
+    rng = np.random.default_rng(92)
+    g = manager.STDescManager(max_frame_n=700000)
+    gd, _ = _random_descs(oracle, manager, rng, 5000, 0, small=True)
+    g.AddSTDescs(gd)
+    gd, _ = _random_descs(oracle, manager, rng, 100, 600000, small=True)
+    g.AddSTDescs(gd)
+    gq, _ = _random_descs(oracle, manager, rng, 50, 650000, small=True)
+    with pytest.raises(SgtdError) as ei:
+        g.candidate_selector(gq)
+    assert ei.value.status == -6 and "entry id" in str(ei.value)
+    g.close()
+    # the same two frames 1 000 ids apart fit
+    g = manager.STDescManager(max_frame_n=700000)
+    gd, _ = _random_descs(oracle, manager, rng, 5000, 0, small=True)
+    g.AddSTDescs(gd)
+    gd, _ = _random_descs(oracle, manager, rng, 100, 1000, small=True)
+    g.AddSTDescs(gd)
+    g.candidate_selector(gq)
+    g.close()
+
+
 @pytest.mark.parametrize("coarse_at", [None, "0", "6"])
 @pytest.mark.parametrize("monotone", [True, False])
 def test_bucket_slices_keep_the_reference_order_per_frame(mods, monotone, coarse_at, monkeypatch):
