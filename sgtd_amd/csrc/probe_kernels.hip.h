@@ -93,6 +93,12 @@ struct ProbeBuffers {
 #define SGTD_PROBE_CHUNK 128    // query descriptors per assemble block
 #define SGTD_REC_SLAB 8192u     // match records a wave takes from the global cursor at once
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
+#ifndef SGTD_VOTE_WORDS
+#define SGTD_VOTE_WORDS 2        // 64-quad words of records in flight per wave in the vote pass
+#endif
+#ifndef SGTD_WRITE_WORDS
+#define SGTD_WRITE_WORDS 2       // 64-pair words of the compact list in flight per wave in block_write
+#endif
 #ifndef SGTD_PROBE_UNROLL
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
 #endif
@@ -1105,11 +1111,11 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
     const u32 RQ = sub_open_quads(Q, B, sg, q, d0, cnt, s_pre, s_ptr, s_cnt, visits, records);
     total += records;
     // the quads of the next two words are loaded while the current two are counted
-    uint4 nrec[2];
-    u32 nk[2];
+    uint4 nrec[SGTD_VOTE_WORDS];
+    u32 nk[SGTD_VOTE_WORDS];
     auto load2 = [&](u32 r0) {
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < SGTD_VOTE_WORDS; u++) {
         const u32 r = r0 + u * SGTD_WAVE + lane;
         u32 dd, addr, k;
         sub_locate_quad(s_pre, s_ptr, s_cnt, r < RQ ? r : 0u, dd, addr, k);
@@ -1119,14 +1125,14 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
       }
     };
     if (RQ) load2(0);
-    for (u32 r0 = 0; r0 < RQ; r0 += 2 * SGTD_WAVE) {
-      uint4 rc[2];
-      u32 kk[2];
+    for (u32 r0 = 0; r0 < RQ; r0 += SGTD_VOTE_WORDS * SGTD_WAVE) {
+      uint4 rc[SGTD_VOTE_WORDS];
+      u32 kk[SGTD_VOTE_WORDS];
 #pragma unroll
-      for (int u = 0; u < 2; u++) { rc[u] = nrec[u]; kk[u] = nk[u]; }
-      if (r0 + 2 * SGTD_WAVE < RQ) load2(r0 + 2 * SGTD_WAVE);
+      for (int u = 0; u < SGTD_VOTE_WORDS; u++) { rc[u] = nrec[u]; kk[u] = nk[u]; }
+      if (r0 + SGTD_VOTE_WORDS * SGTD_WAVE < RQ) load2(r0 + SGTD_VOTE_WORDS * SGTD_WAVE);
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < SGTD_VOTE_WORDS; u++) {
         const u32 w4[4] = {rc[u].x, rc[u].y, rc[u].z, rc[u].w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -1438,35 +1444,35 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   };
   // the next two words of the compact list are loaded while the current two are split (the
   // raw words are only unpacked at the top of the next step: touching them earlier would wait)
-  u64 nraw[2];
+  u64 nraw[SGTD_WRITE_WORDS];
   auto load2 = [&](u32 r0) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
       const u32 r = r0 + u * SGTD_WAVE + lane;
       nraw[u] = cp[r < nv ? r : 0u];
     }
   };
   load2(0);
-  for (u32 r0 = 0; r0 < nv; r0 += 2 * SGTD_WAVE) {
-    u64 pr[2]; u32 sl[2];
-    u32 first[2];      // the entry ids become insertion indices here: first entry of the id's frame, fetched
+  for (u32 r0 = 0; r0 < nv; r0 += SGTD_WRITE_WORDS * SGTD_WAVE) {
+    u64 pr[SGTD_WRITE_WORDS]; u32 sl[SGTD_WRITE_WORDS];
+    u32 first[SGTD_WRITE_WORDS];      // the entry ids become insertion indices here: first entry of the id's frame, fetched
                        // before the next words (loads return in order: it is waited for alone)
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
       const bool ok = r0 + u * SGTD_WAVE + lane < nv;
       pr[u] = nraw[u] & 0x03FFFFFFFFFFFFFFull;
       sl[u] = ok ? (u32)(nraw[u] >> 58) : 0xFFu;
       first[u] = map.frame_first[(u32)nraw[u] >> map.bits];
     }
-    if (r0 + 2 * SGTD_WAVE < nv) load2(r0 + 2 * SGTD_WAVE);
+    if (r0 + SGTD_WRITE_WORDS * SGTD_WAVE < nv) load2(r0 + SGTD_WRITE_WORDS * SGTD_WAVE);
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
       u32 g = first[u] + ((u32)pr[u] & ((1u << map.bits) - 1u));
       if (map.by_frame) g = map.by_frame[g];
       pr[u] = (pr[u] & 0xFFFFFFFF00000000ull) | (u64)g;
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
       const bool valid = sl[u] != 0xFFu;
       const int s = (int)(sl[u] & 63u);
       // lanes with equal slot, by commutative LDS ORs (the result does not depend on the
