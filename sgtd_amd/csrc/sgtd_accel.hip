@@ -730,12 +730,13 @@ int launch_select(sgtd_engine *e) {
     sorted_desc_kernel<<<grid_for(n_slots * 4, 256), 256, 0, e->stream>>>(v.Q, vin, e->gid.as<u32>(), nv, e->sdesc.as<QueryRec>(),
                                                                         e->group_first.as<u32>(), e->n_groups.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
-    // descriptors per wave ticket: about 2k entry visits, from the visits per descriptor the
-    // previous batch measured (4 until there is one); SGTD_SORTED_CHUNK overrides
+    // descriptors per wave ticket: about 3k entry visits, from the visits per descriptor the
+    // previous batch measured (4 until there is one; F = 10 k: tickets of 2 / 4 / 8 / 16
+    // descriptors sweep in 9.0 / 7.8 / 7.5 / 7.5 ms); SGTD_SORTED_CHUNK overrides
     u32 chunk = 4;
     if (e->stats.last_D > 0 && e->stats.last_P_swept > 0) {
       const double per_desc = (double)e->stats.last_P_swept / (double)e->stats.last_D;
-      chunk = (u32)std::min(8.0, std::max(1.0, std::floor(2048.0 / per_desc + 0.5)));
+      chunk = (u32)std::min(8.0, std::max(1.0, std::floor(3072.0 / per_desc + 0.5)));
       // descriptors of a home cell are swept together up to SGTD_PAIR at a time: a ticket must
       // hold whole runs
       chunk = std::max<u32>(chunk, SGTD_PAIR);
