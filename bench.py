@@ -13,14 +13,20 @@ KITTI-00 length).
 
 N > 1: `python bench.py --gpus N` starts N ranks itself (child processes under
 torch.distributed.run, before anything touches a GPU); when it is already
-running under a launcher (RANK/WORLD_SIZE set) it is one rank.  Modes (--shard):
-  query  (default when the map fits one GPU) the map is replicated, every rank
-         serves its own Q query frames per step — weak scaling, no data-path
-         collective, one RCCL all_gather of the result tables per step;
-  table  the map's hash table is sharded by frame range over the ranks, every
-         rank sweeps its shard with the same Q queries, the local top-50 tables
-         are all-gathered with RCCL and merged (sgtd_amd/dist.py::ShardedMap) —
-         strong scaling; also measured (as `table_sharded`) beside the default.
+running under a launcher (RANK/WORLD_SIZE set) it is one rank.  The headline
+`value` for N > 1 is the form BASELINE.json's north_star names:
+  table  (default) the map's hash table is sharded by frame range over the ranks,
+         every rank sweeps its shard with the same Q queries, the local top-50
+         tables are all-gathered (RCCL) and merged with the reference's rule
+         (STDesc.cpp:423-433; sgtd_amd/dist.py::ShardedMap) — strong scaling: the
+         same F-frame map and Q queries per step whatever N is;
+  query  (--shard query; also measured beside the headline as `replicated` when the
+         map fits one GPU) the map is replicated, every rank serves its own Q query
+         frames per step — weak scaling, no data-path collective, one all_gather of
+         the result tables per step.
+Beside them, N > 1: `multi_device_handle` — ONE process (rank 0) driving all N
+devices through sgtd_create_multi, the form the reference's C++ caller uses; and,
+at N = 8, `cfg4`: BASELINE configs[3]'s 100 000-frame map sharded the same way.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -51,9 +57,14 @@ def parse():
     ap.add_argument("--keypoints", type=int, default=200, help="keypoints per frame N")
     ap.add_argument("--queries", type=int, default=2048,
                     help="query frames per step (per rank in query mode); 512 / 1024 / 2048 / 4096 give 81 / 92 / 98 / 101 k frames/s at F = 10 k")
-    ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto")
-    ap.add_argument("--also-table", choices=["on", "off"], default="on",
-                    help="N>1, query mode: also measure the table-sharded mode in the same run")
+    ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto",
+                    help="N>1: what `value` measures; auto = table (the map's hash table sharded by frame range)")
+    ap.add_argument("--also-replicated", choices=["on", "off"], default="on",
+                    help="N>1, table mode: also measure the replicated-map / sharded-queries mode (and check that both give the same lists)")
+    ap.add_argument("--multi-handle", choices=["auto", "on", "off"], default="auto",
+                    help="N>1: also drive all N devices from ONE process through sgtd_create_multi (auto: when N real devices exist)")
+    ap.add_argument("--cfg4", choices=["auto", "on", "off"], default="auto",
+                    help="N>1: also measure BASELINE configs[3] (100 000-frame map, table-sharded); auto = at N == 8")
     ap.add_argument("--sweep", default="1000,4541",
                     help="other map sizes measured for map_size_sweep ('' = no other sizes, 'none' = also skip the incremental-insert leg)")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
@@ -155,9 +166,10 @@ def recall(smap, queries, top1):
     exact frame, and map pose within 5 m of the query's true pose (the reference's
     success radius, semantic_graph_localization.cpp:750)"""
     ok = top1 >= 0
+    n = top1.shape[0]            # (the first n queries of the set)
     pose = smap.pose[np.clip(top1, 0, smap.pose.shape[0] - 1), :2]
-    dist = np.linalg.norm(pose - queries.pose[:, :2], axis=1)
-    return {"top1_is_gt_frame": float(np.mean(ok & (top1 == queries.gt_frame))),
+    dist = np.linalg.norm(pose - queries.pose[:n, :2], axis=1)
+    return {"top1_is_gt_frame": float(np.mean(ok & (top1 == queries.gt_frame[:n]))),
             "top1_pose_within_5m": float(np.mean(ok & (dist < 5.0)))}
 
 
@@ -226,9 +238,12 @@ def main():
     table_bytes = 155.0 * 36 * N * F
     mode = "single"
     if world > 1:
-        mode = args.shard if args.shard != "auto" else ("query" if table_bytes < HBM_BYTES / 4 else "table")
-    n_q_total = Q * world if mode == "query" else Q
+        mode = args.shard if args.shard != "auto" else "table"
+    fits_one_gpu = table_bytes < HBM_BYTES / 4
+    # the replicated leg serves Q queries per rank: the first Q of them are the table mode's batch
+    n_q_total = Q * world if (mode == "query" or (mode == "table" and args.also_replicated == "on" and fits_one_gpu)) else Q
     queries = synth.make_queries(smap, n_q_total, stream=1)
+    n_q_value = Q * world if mode == "query" else Q     # query frames one step of the headline mode serves
 
     def to_dev(xyz, label):
         return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
@@ -291,7 +306,7 @@ def main():
         mgr.set_stream(stream.cuda_stream)
         lo, hi = shard_range(F, world, rank)
         sm.add_shard_frames(*to_dev(smap.xyz[lo:hi], smap.label[lo:hi]))
-        d_qxyz, d_qlab = to_dev(queries.xyz, queries.label)
+        d_qxyz, d_qlab = to_dev(queries.xyz[:Q], queries.label[:Q])
         q_lo, q_hi = 0, Q
 
         def step():
@@ -308,6 +323,8 @@ def main():
             merged["out"] = rm.query(d_qxyz, d_qlab, n_q_total)
 
     elapsed = timed(step, mgr)
+    backend_ran = dist.get_backend() if world > 1 else None
+    collective = {"nccl": "RCCL (torch.distributed backend nccl)", "gloo": "gloo (NOT RCCL: test fallback)"}.get(backend_ran, backend_ran)
     st = mgr.stats()
 
     # ---- per-kernel timing for the roofline (HIP events on the handle's stream)
@@ -440,10 +457,17 @@ def main():
         step(); mgr.sync()   # leave the handle on the headline batch
         res = mgr.results()
 
-    # ---- N > 1, query mode: the table-sharded form of the same map beside it (strong scaling:
-    # the same Q queries on every rank, each rank sweeps its frame range, RCCL gather + merge)
-    table_sharded = None
-    if mode == "query" and args.also_table == "on":
+    # ---- N > 1: the other multi-GPU form of the same map beside the headline, and the check that
+    # the table-sharded merged list IS the single-table list (every replica holds the whole table)
+    table_sharded, replicated = None, None
+
+    def entries_of(m):
+        ent = torch.tensor([m.stats()["n_entries"]], dtype=torch.int64, device=dev)
+        ents = [torch.zeros_like(ent) for _ in range(world)]
+        dist.all_gather(ents, ent)
+        return [int(e.item()) for e in ents]
+
+    if mode == "query" and fits_one_gpu:
         sm = ShardedMap(F, rank, world, device_id=local_rank)
         sm.mgr.set_stream(stream.cuda_stream)
         lo, hi = shard_range(F, world, rank)
@@ -454,18 +478,92 @@ def main():
         def tstep():
             tmerged["out"] = sm.query(tq_xyz, tq_lab)
         t_el = timed(tstep, sm.mgr)
-        ent = torch.tensor([sm.mgr.stats()["n_entries"]], dtype=torch.int64, device=dev)
-        ents = [torch.zeros_like(ent) for _ in range(world)]
-        dist.all_gather(ents, ent)
-        # the merged list of the sharded map must be the replicated map's list, query by query
         ref_f, ref_v = merged["out"]
         tf, tv_, _ = tmerged["out"]
         same = bool(torch.equal(tf, ref_f[:Q]) and torch.equal(tv_, ref_v[:Q]))
         table_sharded = {"value": Q * args.steps / t_el, "unit": "frames/s", "ms_per_step": 1000.0 * t_el / args.steps,
                          "queries_per_step": Q, "scaling": "strong", "ranks_in_collective": dist.get_world_size(),
-                         "table_entries_per_rank": [int(e.item()) for e in ents],
-                         "merged_list_equals_replicated_map": same}
+                         "collective": collective, "table_entries_per_rank": entries_of(sm.mgr),
+                         "merged_list_equals_single_table": same}
         del sm
+    elif mode == "table" and args.also_replicated == "on" and fits_one_gpu:
+        rm = ReplicatedMap(F, rank, world, device_id=local_rank)
+        rm.mgr.set_stream(stream.cuda_stream)
+        rm.add_frames(*to_dev(smap.xyz, smap.label))
+        rq_xyz, rq_lab = to_dev(queries.xyz[rank * Q:(rank + 1) * Q], queries.label[rank * Q:(rank + 1) * Q])
+        rmerged = {}
+
+        def rstep():
+            rmerged["out"] = rm.query(rq_xyz, rq_lab, Q * world)
+        r_el = timed(rstep, rm.mgr)
+        tf, tv_ = merged["out"]
+        rf, rv = rmerged["out"]
+        same = bool(torch.equal(tf, rf[:Q]) and torch.equal(tv_, rv[:Q]))     # rank 0's replica served the table mode's Q queries
+        replicated = {"value": Q * world * args.steps / r_el, "unit": "frames/s", "ms_per_step": 1000.0 * r_el / args.steps,
+                      "queries_per_step": Q * world, "queries_per_rank": Q, "scaling": "weak",
+                      "ranks_in_collective": dist.get_world_size(), "collective": collective,
+                      "table_entries_per_rank": entries_of(rm.mgr), "equals_table_sharded_list": same}
+        replicated["recall"] = recall(smap, queries, rf[:, 0].cpu().numpy())
+        del rm
+    merged_equal = (replicated or {}).get("equals_table_sharded_list", (table_sharded or {}).get("merged_list_equals_single_table"))
+
+    # ---- N > 1: BASELINE configs[3], the 100 000-frame map sharded by frame range the same way
+    # (the reference itself cannot hold it: MAX_FRAME_N = 20 000, STDesc.h:33)
+    cfg4 = None
+    if world > 1 and (args.cfg4 == "on" or (args.cfg4 == "auto" and world == 8)) and F != 100000:
+        try:
+            F4, Q4 = 100000, 256
+            lo4, hi4 = shard_range(F4, world, rank)
+            m4 = synth.make_map(F4, N, stream=4)          # every rank generates the world, keeps its frames
+            q4 = synth.make_queries(m4, Q4, stream=4)
+            s4 = ShardedMap(F4, rank, world, device_id=local_rank)
+            s4.mgr.set_stream(stream.cuda_stream)
+            s4.add_shard_frames(*to_dev(m4.xyz[lo4:hi4], m4.label[lo4:hi4]))
+            x4, l4 = to_dev(q4.xyz, q4.label)
+            out4 = {}
+
+            def step4():
+                out4["out"] = s4.query(x4, l4)
+            e4 = timed(step4, s4.mgr)
+            top1 = out4["out"][0][:, 0].cpu().numpy()
+            cfg4 = {"workload": "synthetic %d keypoints/frame, %d-frame map hash-sharded by frame range over %d GPUs, candidate gather" % (N, F4, world),
+                    "value": Q4 * args.steps / e4, "unit": "frames/s", "ms_per_step": 1000.0 * e4 / args.steps,
+                    "queries_per_step": Q4, "table_entries_per_rank": entries_of(s4.mgr), "collective": collective,
+                    "recall": recall(m4, q4, top1)}
+            del s4, m4, q4, x4, l4
+        except Exception as exc:
+            cfg4 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    # ---- N > 1: ONE process over all N devices (sgtd_create_multi: frame blocks dealt to the devices,
+    # concurrent sweeps, host-side merge with the same rule) — the form the reference's C++ caller uses.
+    # Rank 0 drives it while the other ranks wait at the barrier behind it.
+    multi_handle = None
+    want_multi = world > 1 and (args.multi_handle == "on" or (args.multi_handle == "auto" and torch.cuda.device_count() >= world))
+    if want_multi:
+        if rank == 0:
+            try:
+                gm = STDescManager(devices=list(range(world)), max_frame_n=max(20000, F + 1))
+                gm.add_frames(smap.xyz, smap.label)            # host pointers (the multi-device handle's contract)
+                gm.finalize()
+                hq_xyz, hq_lab = np.ascontiguousarray(queries.xyz[:Q]), np.ascontiguousarray(queries.label[:Q])
+                for _ in range(2):
+                    gm.query_frames(hq_xyz, hq_lab, fetch=False); gm.sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    gm.query_frames(hq_xyz, hq_lab, fetch=False)
+                    gm.sync()
+                tm = time.perf_counter() - t0
+                rg = gm.results()
+                ref_f = merged["out"][0][:Q].cpu().numpy() if mode != "single" else None
+                same = bool(ref_f is not None and np.array_equal(rg.cand_frame[:, :ref_f.shape[1]], ref_f))
+                multi_handle = {"value": Q * args.steps / tm, "unit": "frames/s", "ms_per_step": 1000.0 * tm / args.steps,
+                                "devices": gm.device_count, "queries_per_step": Q,
+                                "note": "one process, host pointers in (PCIe inside the timed region), per-device sweeps concurrent, host merge",
+                                "candidates_equal_headline_list": same}
+                gm.close()
+            except Exception as exc:
+                multi_handle = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        barrier()
 
     # ---- other map sizes (same batch, same pipeline), N = 1 only
     sweep = None
@@ -556,10 +654,10 @@ def main():
 
     out = None
     if rank == 0:
-        value = n_q_total * args.steps / elapsed
+        value = n_q_value * args.steps / elapsed
         sharding = {"single": "none",
-                    "table": "map frames range-sharded over %d GPUs, every rank sweeps all queries, RCCL all_gather + merge of top-50" % world,
-                    "query": "map replicated on %d GPUs, %d query frames per rank and step, RCCL all_gather of the result tables" % (world, Q)}[mode]
+                    "table": "map frames range-sharded over %d GPUs, every rank sweeps all queries, all_gather + merge of top-50 over %s" % (world, collective),
+                    "query": "map replicated on %d GPUs, %d query frames per rank and step, all_gather of the result tables over %s" % (world, Q, collective)}[mode]
         out = {
             "metric": "query frames/sec vs map size (descriptor build + candidate selection)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -570,8 +668,8 @@ def main():
                           "conservative thresholds and decides the few entries between them on the exact f64 sides",
             "config": {"workload": "synthetic %d keypoints/frame, %d-frame map, descriptor build+match (BASELINE north-star point: 10k-frame map, 1 GPU)" % (N, F)
                        if F == 10000 else "synthetic %d keypoints/frame, %d-frame map, descriptor build+match" % (N, F),
-                       "map_frames": F, "keypoints_per_frame": N, "queries_per_step": n_q_total,
-                       "sharding": sharding, "queries_this_rank": q_hi - q_lo,
+                       "map_frames": F, "keypoints_per_frame": N, "queries_per_step": n_q_value,
+                       "sharding": sharding, "mode": mode, "collective_backend": backend_ran, "queries_this_rank": q_hi - q_lo,
                        "ranks_in_collective": ranks_seen, "table_entries_per_rank": entries_per_rank,
                        "table_entries_this_rank": st["n_entries"], "table_buckets_this_rank": st["n_buckets"]},
             "roofline": roofline,
@@ -588,11 +686,18 @@ def main():
             out["incremental_insert"] = incremental
         if table_sharded is not None:
             out["table_sharded"] = table_sharded
+        if replicated is not None:
+            out["replicated"] = replicated
+        if merged_equal is not None:
+            out["merged_list_equals_single_table"] = merged_equal
+        if cfg4 is not None:
+            out["cfg4"] = cfg4
+        if multi_handle is not None:
+            out["multi_device_handle"] = multi_handle
         if mode == "single":
             out["recall"] = recall(smap, queries, res.top1())
         else:
-            f = merged["out"][0]
-            out["recall"] = recall(smap, queries, f[:, 0].cpu().numpy())
+            out["recall"] = recall(smap, queries, merged["out"][0][:, 0].cpu().numpy())
         want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and F <= 12000)
         if mode == "single" and want_cpu:
             try:

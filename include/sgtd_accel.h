@@ -128,6 +128,17 @@ int sgtd_set_stream(sgtd_handle h, void *hip_stream);
 /* enable per-kernel hipEvent timing (costs a few microseconds per launch) */
 int sgtd_set_timing(sgtd_handle h, int enabled);
 
+/* ---- key helpers: the pure functions the kernels derive their keys with (the same inline
+ * code, instantiated on the host; no device needed) — pinned by the CPU tests against the
+ * reference's own Combinatorial_Binary_Encoding (STDesc.cpp:3-16), STDesc_LOC equality
+ * (STDesc.h:229-236: x, y, z, a only) and VOXEL_LOC equality (STDesc.h:133-135).
+ * sgtd_table_key: cell coordinates below 65 536 and a 12-bit code; sgtd_dedup_key: millimetre
+ * coordinates below 2^21 (the envelope check_cfg enforces).  Inside those envelopes two keys
+ * are equal words exactly when the reference's operator== holds. */
+uint32_t sgtd_label_code(int a, int b, int c);
+uint64_t sgtd_table_key(uint32_t code, uint32_t x, uint32_t y, uint32_t z);
+uint64_t sgtd_dedup_key(uint64_t mx, uint64_t my, uint64_t mz);
+
 /* STDescManager::current_frame_id_ (STDesc.h:350) */
 int sgtd_current_frame_id(sgtd_handle h, uint32_t *out);
 

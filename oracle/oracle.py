@@ -76,6 +76,12 @@ def lib():
         L.orc_set_num_threads.argtypes = [vp, C.c_int]
         L.orc_label_code.restype = C.c_int
         L.orc_label_code.argtypes = [C.c_int] * 3
+        for f in ("orc_cell_key_eq", "orc_milli_key_eq"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [vp, vp]
+        for f in ("orc_cell_key_hash", "orc_milli_key_hash"):
+            getattr(L, f).restype = i64
+            getattr(L, f).argtypes = [vp]
         L.orc_build.restype = i64
         L.orc_build.argtypes = [vp, vp, vp, C.c_int]
         L.orc_last_export.argtypes = [vp, C.POINTER(OrcSoa)]
@@ -251,3 +257,26 @@ class OracleManager:
 
 def label_code(a, b, c):
     return lib().orc_label_code(a, b, c)
+
+
+REF_PIN_PATH = os.path.join(_HERE, "_ref", "libsgtd_ref_pin.so")
+
+
+def ref_pin():
+    """oracle/_ref/libsgtd_ref_pin.so — the pieces of the reference itself that compile with
+    standard headers (oracle/ref_pin.cpp, built by `make -C oracle` where /root/reference
+    exists; the built library travels to the GPU box).  None if it was never built."""
+    if not os.path.exists(REF_PIN_PATH):
+        return None
+    L = C.CDLL(REF_PIN_PATH)
+    L.ref_label_code.restype = C.c_int
+    L.ref_label_code.argtypes = [C.c_int] * 3
+    for f in ("ref_hash_p", "ref_max_n", "ref_max_frame_n"):
+        getattr(L, f).restype = C.c_int64
+    for f in ("ref_voxel_eq", "ref_loc_eq"):
+        getattr(L, f).restype = C.c_int
+        getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+    for f in ("ref_voxel_hash", "ref_loc_hash"):
+        getattr(L, f).restype = C.c_int64
+        getattr(L, f).argtypes = [C.c_void_p]
+    return L

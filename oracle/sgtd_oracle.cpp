@@ -582,6 +582,20 @@ void orc_set_current_frame_id(orc_manager *m, uint32_t id) { m->current_frame_id
 // timing protocol of BASELINE.md §2: the same table timed at several OpenMP thread settings
 void orc_set_num_threads(orc_manager *m, int n) { m->cfg.num_threads = n > 0 ? n : 1; }
 int orc_label_code(int a, int b, int c) { return label_code(a, b, c); }
+// the restated key types, for the pin against the reference's own (oracle/ref_pin.cpp)
+int orc_cell_key_eq(const int64_t *p, const int64_t *q) {
+  CellKey a, b;
+  a.x = p[0]; a.y = p[1]; a.z = p[2]; a.a = p[3]; a.b = p[4]; a.c = p[5];
+  b.x = q[0]; b.y = q[1]; b.z = q[2]; b.a = q[3]; b.b = q[4]; b.c = q[5];
+  return a == b;
+}
+int64_t orc_cell_key_hash(const int64_t *p) {
+  CellKey a;
+  a.x = p[0]; a.y = p[1]; a.z = p[2]; a.a = p[3]; a.b = p[4]; a.c = p[5];
+  return CellKeyHash()(a);
+}
+int orc_milli_key_eq(const int64_t *p, const int64_t *q) { return MilliKey{p[0], p[1], p[2]} == MilliKey{q[0], q[1], q[2]}; }
+int64_t orc_milli_key_hash(const int64_t *p) { return MilliKeyHash()(MilliKey{p[0], p[1], p[2]}); }
 
 int64_t orc_build(orc_manager *m, const float *xyz, const uint32_t *label, int n) {
   std::vector<P4> pc(n);

@@ -66,6 +66,12 @@ void orc_set_num_threads(orc_manager *m, int n);
 
 /* Combinatorial_Binary_Encoding — STDesc.cpp:3-16 */
 int orc_label_code(int a, int b, int c);
+/* the restated key types: STDesc_LOC (x, y, z, a, b, c; STDesc.h:217-250) and VOXEL_LOC
+ * (x, y, z; STDesc.h:126-154) — equality and std::hash value */
+int orc_cell_key_eq(const int64_t *p, const int64_t *q);
+int64_t orc_cell_key_hash(const int64_t *p);
+int orc_milli_key_eq(const int64_t *p, const int64_t *q);
+int64_t orc_milli_key_hash(const int64_t *p);
 
 /* BuildSingleScanSTD (STDesc.cpp:174-315) on keypoints xyz[n*3] f32 + label[n].
  * The result is kept inside the manager ("last built"); returns its size. */

@@ -18,7 +18,7 @@ ERRORS = {-8: "IO", -1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY",
 
 # every symbol include/sgtd_accel.h declares
 SYMBOLS = [
-    "sgtd_default_config", "sgtd_create", "sgtd_create_multi", "sgtd_device_count", "sgtd_device_handle", "sgtd_destroy", "sgtd_strerror", "sgtd_last_error",
+    "sgtd_default_config", "sgtd_create", "sgtd_create_multi", "sgtd_device_count", "sgtd_device_handle", "sgtd_destroy", "sgtd_strerror", "sgtd_last_error", "sgtd_label_code", "sgtd_table_key", "sgtd_dedup_key",
     "sgtd_set_stream", "sgtd_set_timing", "sgtd_current_frame_id", "sgtd_max_descs", "sgtd_build",
     "sgtd_add", "sgtd_add_frames", "sgtd_finalize", "sgtd_query_frames", "sgtd_query_descs", "sgtd_max_batch",
     "sgtd_result_candidates", "sgtd_export_candidates_dev", "sgtd_result_query_desc_count", "sgtd_result_pairs",
@@ -116,6 +116,12 @@ def lib():
     L.sgtd_strerror.restype = C.c_char_p
     L.sgtd_last_error.argtypes = [vp]
     L.sgtd_last_error.restype = C.c_char_p
+    L.sgtd_label_code.argtypes = [C.c_int] * 3
+    L.sgtd_label_code.restype = C.c_uint32
+    L.sgtd_table_key.argtypes = [C.c_uint32] * 4
+    L.sgtd_table_key.restype = C.c_uint64
+    L.sgtd_dedup_key.argtypes = [C.c_uint64] * 3
+    L.sgtd_dedup_key.restype = C.c_uint64
     L.sgtd_set_stream.argtypes = [vp, vp]
     L.sgtd_set_timing.argtypes = [vp, C.c_int]
     L.sgtd_current_frame_id.argtypes = [vp, C.POINTER(C.c_uint32)]

@@ -67,10 +67,11 @@ __device__ __forceinline__ Tri make_triangle(const float4 &p1, const float4 &p2,
 }
 
 // millimetre dedup key: (int64_t)(float)(side*1000) per side (:244-248), 21 bits each
+__host__ __device__ __forceinline__ u64 pack_milli_key(u64 x, u64 y, u64 z) { return (x << 42) | (y << 21) | z; }
 __device__ __forceinline__ u64 milli_key(const Tri &t) {
   float kx = (float)(t.a * 1000.0), ky = (float)(t.b * 1000.0), kz = (float)(t.c * 1000.0);
   u64 x = (u64)(long long)kx, y = (u64)(long long)ky, z = (u64)(long long)kz;
-  return (x << 42) | (y << 21) | z;
+  return pack_milli_key(x, y, z);
 }
 
 struct BuildParams {

@@ -73,9 +73,13 @@ int add(sgtd_engine *e, const sgtd_desc_soa *d, int64_t n) {
     if (d->frame[i] != gid) { e->err = "multi-device tables take descriptors stamped with the current frame id"; return SGTD_ERR_UNSUPPORTED; }
     lf[(size_t)i] = local_of(gid, g->n);
   }
-  sgtd_desc_soa t = *d;
-  t.frame = lf.data();
-  MCHK(sgtd_add(c, &t, n));
+  if (n == 0) {   // an empty frame (d may be NULL): the owner only advances its frame counter
+    MCHK(sgtd_add(c, nullptr, 0));
+  } else {
+    sgtd_desc_soa t = *d;
+    t.frame = lf.data();
+    MCHK(sgtd_add(c, &t, n));
+  }
   g->current_frame_id++;
   g->batch_valid = false;
   return SGTD_OK;

@@ -1,26 +1,29 @@
 // probe_kernels.hip.h — candidate_selector (src/sgtd/src/STDesc.cpp:318-460)
 //
-//   probe     (:351-400) one wavefront per pair of query descriptors of one home
-//             cell: the 27 cells (truncating (int)(side+inc), gate ||side-centre||
-//             < 1.5, hash lookup key -> bucket) become one concatenated visit list
-//             of non-empty ranges — per cell and half of the second side's
-//             interval the thirds of the third side's that a descriptor's threshold
-//             box reaches, and the bucket's overflow slice (common.hip.h,
-//             table_kernels.hip.h) — that all 64 lanes stream from the 16-B/entry
-//             probe layout (one 16-B load per lane and 64 entries, 4 x 64 entries
-//             in flight).  The distance test runs in f32 against two squared
-//             thresholds that make it conservative on both sides (common.hip.h
-//             f32_bounds); the few entries between them are decided on the exact
-//             f64 sides with the exact squared threshold (sq_threshold) — every
-//             decision is the reference's.  Matches are compacted in visit order
-//             by ballot/popcount prefix into a per-descriptor list of 4-byte entry
-//             ids (frame and entry in one word, IdMap); restricted to any one map
-//             frame that order is the reference's (cell, j) order.
-//             Schedule (probe_sorted_kernel): the batch's descriptors are
-//             radix-sorted by home cell, descriptors of one home cell share ONE
-//             set of 27 bucket lookups (GroupRow), per-XCD ticket queues hand
-//             neighbouring cells to waves of one XCD so that the buckets stay in
-//             that XCD's L2; votes_kernel counts votes from the lists afterwards.
+//   probe     (:351-400) one wavefront per PASS — one query descriptor, or two
+//             of one home cell: the 27 cells (truncating (int)(side+inc), gate
+//             ||side-centre|| < 1.5, hash lookup key -> bucket) become one
+//             concatenated visit list of non-empty ranges — per cell and half of
+//             the second side's interval the thirds of the third side's that a
+//             descriptor's threshold box reaches, and the bucket's overflow slice
+//             (common.hip.h, table_kernels.hip.h).  plan_passes_kernel derives the
+//             list of every pass, one LANE per pass, and leaves it as a record in
+//             HBM; the sweep (probe_sorted_kernel) prefetches the next pass's record
+//             while it streams the current list with all 64 lanes from the
+//             16-B/entry probe layout (one 16-B load per lane and 64 entries,
+//             4 x 64 entries in flight).  The distance test runs in f32 against two
+//             squared thresholds that make it conservative on both sides
+//             (common.hip.h f32_bounds); the few entries between them are decided on
+//             the exact f64 sides with the exact squared threshold (sq_threshold) —
+//             every decision is the reference's.  Matches are compacted in visit
+//             order by ballot/popcount prefix into a per-descriptor list of 4-byte
+//             entry ids (frame and entry in one word, IdMap); restricted to any one
+//             map frame that order is the reference's (cell, j) order.
+//             Schedule: the batch's descriptors are radix-sorted by home cell,
+//             descriptors of one home cell share ONE set of 27 bucket lookups
+//             (GroupRow), per-XCD ticket queues hand neighbouring cells to waves of
+//             one XCD so that the buckets stay in that XCD's L2; votes_kernel counts
+//             votes from the lists afterwards.
 //   topk      (:423-433) candidate_num rounds of arg-max over the votes:
 //             votes desc, frame id asc, stop below 5 votes
 //   assemble  (:434-449) one wavefront per 128-descriptor block walks the
@@ -33,10 +36,6 @@
 //             commutative LDS ORs, running positions in lane registers — and
 //             writes each candidate's match_list_ in the reference's (i, cell, j)
 //             order through per-slot 128-B staging lines
-//
-// Diagnostics (never in the shipped build): -DSGTD_EXP_PHASE adds in-kernel phase
-// clocks and counters printed by the host after a few launches; -DSGTD_EXP_TRACE
-// records per-wave start/end times of the sweep.
 #pragma once
 #include "common.hip.h"
 #include <type_traits>
@@ -69,23 +68,33 @@ struct ProbeBuffers {
   unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
-  unsigned long long *rec_cursor;   // global slab cursor (64-bit: requests can add up beyond 2^32)
-  unsigned long long *rec_need;     // matches that found no room (sizes the regrown buffer)
-  unsigned long long *swept;        // table entries the sweep really loaded (after slice pruning)
+  // the batch's counters live in ONE buffer (a single base address in the kernels' scalar
+  // registers): words 0-1 the global slab cursor of the match records (64-bit: requests can
+  // add up beyond 2^32), 2 the undecided-record queue's fill, 3 the compact lists' cursor,
+  // 4-5 matches that found no room (sizes the regrown buffer), 6-7 table entries the sweep
+  // really loaded (after slice pruning), 8 the pass pool's cursor, 10-11 the overflow flags
+  // (0: match records / pass pool / undecided queue, 1: candidate pairs), from word 1024 the
+  // sweep's eight ticket-queue heads, 1024 words (4 KB: own L2 channel) apart
+  u32 *ctr;
+  __host__ __device__ __forceinline__ unsigned long long *rec_cursor() const { return reinterpret_cast<unsigned long long *>(ctr); }
+  __host__ __device__ __forceinline__ u32 *amb_count() const { return ctr + 2; }
+  __host__ __device__ __forceinline__ u32 *compact_cursor() const { return ctr + 3; }
+  __host__ __device__ __forceinline__ unsigned long long *rec_need() const { return reinterpret_cast<unsigned long long *>(ctr + 4); }
+  __host__ __device__ __forceinline__ unsigned long long *swept() const { return reinterpret_cast<unsigned long long *>(ctr + 6); }
+  __host__ __device__ __forceinline__ u32 *pool_cursor() const { return ctr + 8; }
+  __host__ __device__ __forceinline__ int *overflow() const { return reinterpret_cast<int *>(ctr + 10); }
+  __host__ __device__ __forceinline__ u32 *xcd_heads() const { return ctr + 1024; }
   // per table segment sg and descriptor slot d, at [sg * seg_stride + d] (the sweep of segment sg
-  // gets the three pointers advanced to its part):
-  u32 *list_ptr;        // first record of the descriptor's list from that segment
+  // gets the pointers advanced to its part):
+  uint2 *list;          // {first record of the descriptor's list from that segment, matches of the descriptor there}
   u32 *n_visit;         // entries the reference's loop visits for the descriptor there (STDesc.cpp:372)
-  u32 *n_match;         // matches of the descriptor there
   long long seg_stride; // descriptor slots of the batch
   int n_seg;            // table segments swept (main, tail)
   u32 *votes;           // [n_queries * frame_span]
-  int *overflow;        // [2]: 0 match records, 1 candidate pairs
   u32 id_bits;          // a record's local frame (frame - table frame_lo) is rec >> id_bits
   // records whose f32 test fell between the two thresholds: stored provisionally as matches,
   // queued here and decided on the exact sides by resolve_undecided_kernel right after the sweep
   uint2 *amb_queue;     // [amb_cap] (record index, descriptor slot)
-  u32 *amb_count;
   u32 amb_cap;
 };
 
@@ -103,28 +112,20 @@ struct ProbeBuffers {
 #define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
 #endif
 
-// per-descriptor results of the sweep (stored once per ticket by the caller)
-struct DescResult {
-  u32 ptr, visit, match;
-};
-
-// Loads that were issued before a descriptor's sweep and are first used after it (the next
-// descriptor's GroupRow, the next ticket's records): the sweep "touches" them once its first
-// load group has returned — vector loads return in order, so they are complete by then —
-// otherwise the compiler, which cannot count the stores of the loops in between, would wait
-// for every outstanding store (vmcnt(0)) at their first use.
+// Loads that were issued before a pass's sweep and are first used after it (the next pass's
+// ranges): the sweep "touches" them once its first load group has returned — vector loads
+// return in order, so they are complete by then — otherwise the compiler, which cannot count
+// the stores of the loops in between, would wait for every outstanding store (vmcnt(0)) at
+// their first use.
 struct PendingLoads {
-  uint4 *row = nullptr;
-  uint4 *rec = nullptr;
+  u32 *h = nullptr, *a = nullptr, *b = nullptr, *c = nullptr;
   __device__ __forceinline__ void touch() const {
-    if (row) asm volatile("" : "+v"(row->x), "+v"(row->y), "+v"(row->z), "+v"(row->w));
-    if (rec) asm volatile("" : "+v"(rec->x), "+v"(rec->y), "+v"(rec->z), "+v"(rec->w));
+    if (a) asm volatile("" : "+v"(*h), "+v"(*a), "+v"(*b), "+v"(*c));
   }
 };
 
 #ifndef SGTD_PAIR
-// descriptors of one home cell swept together by a wave (shared plan, locate and loads): 1 or 2.
-// (4 at a time halves the loads again but needs 129 VGPRs — 3 waves per SIMD: measured slower)
+// descriptors of one home cell swept together by a wave (shared visit list, locate and loads): 1 or 2.
 #define SGTD_PAIR 2
 #endif
 static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2, "the pair sweep computes both distances with packed f32 math");
@@ -133,49 +134,6 @@ struct WaveSlab {
   u32 next[SGTD_PAIR], end[SGTD_PAIR];   // this wave's private ranges of match records: one bump stream per
                                          // descriptor of a pair, so that every descriptor's list stays contiguous
   u64 swept;                             // entries this wave loaded
-#ifdef SGTD_EXP_PHASE
-  u64 ph[8];
-#endif
-};
-#ifdef SGTD_EXP_PHASE
-__device__ unsigned long long g_phase[8];
-__device__ unsigned long long g_words[2];   // 64-entry words swept, load groups (trips) issued
-#define PH_T() __builtin_readcyclecounter()
-#define PH_ADD(i, t0) do { const u64 _n = PH_T(); slab.ph[i] += _n - (t0); (t0) = _n; } while (0)
-#else
-#define PH_T() 0ull
-#define PH_ADD(i, t0) do { } while (0)
-#endif
-
-// what the sweep needs about K query descriptors of ONE home cell (they share the GroupRow); the
-// loads are issued one step ahead, the per-lane plan is derived right before the sweep
-template <int K>
-struct DescSet {
-  uint4 row;            // lane l < 54: 16-B quarter l of the group's 27 directory rows
-  double q0[K], q1[K], q2[K], thr2[K];
-  float lo2[K], hi2[K]; // conservative f32 thresholds (f32_bounds)
-  float t_up[K];        // f32 upper bound of the match threshold
-  u32 qframe[K];
-  u32 gate[K];          // the descriptor's 27-bit gate mask
-  u32 slot[K];          // descriptor slot d
-};
-
-// The visit list as the sweep walks it: the non-empty ranges of table entries, in the order of
-// the reference's cells (inside a cell: lower half, upper half, overflow slice), numbered
-// j = 0..n-1 and held one per lane: offc = exclusive offset of range j in the list,
-// dlc = start - offc, its cell (diagnostic sweep) and, for a pair, per descriptor the penalty
-// 0 / +inf that starts the squared-distance sum (+inf: the cell fails that descriptor's gate).
-// For a pair the list is the union of the two descriptors' lists.  Lane n stands for one more
-// range that starts at `total` and maps onto the sentinel entries behind the table's last entry
-// (sides +inf: no match), so the lanes of the last 64-entry word beyond the list need no special
-// case; lanes beyond n hold offc = 0xFFFFFFFF.
-template <int K>
-struct DescPlan {
-  u32 offc;
-  u32 dlc, cellc;
-  float penc[K];
-  u32 n, total;         // wave-uniform
-  u32 ref_visits[K];    // wave-uniform: entries the reference's loop visits (all slices of the gated cells)
 };
 
 // ---------------------------------------------------------------------------
@@ -242,24 +200,14 @@ __global__ void group_heads_kernel(const u64 *keys, const u32 *n_valid_p, u32 *f
   flags[p] = head;
 }
 
-// sorted records + first sorted position of every group + the number of groups; four
-// threads per position, one 16-B quarter of the record each (coalesced 64-B reads, 1-KB writes)
-__global__ void sorted_desc_kernel(QueryView Q, const u32 *order, const u32 *gid, const u32 *n_valid_p,
-                                   QueryRec *out, u32 *group_first, u32 *n_groups, long long n) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long p = t >> 2;
-  const int qtr = (int)(t & 3);
+// first sorted position of every group + the number of groups
+__global__ void group_first_kernel(const u32 *gid, const u32 *n_valid_p, u32 *group_first, u32 *n_groups, long long n) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long nv = (long long)*n_valid_p;
   if (p >= n || p >= nv) return;
   const u32 g = gid[p];
-  const u32 d = order[p];
-  uint4 v = reinterpret_cast<const uint4 *>(Q.qrec + d)[qtr];
-  if (qtr == 2) {
-    v.z = g; v.w = d;
-    if (p == 0 || gid[p - 1] != g) group_first[g] = (u32)p;
-    if (p == nv - 1) *n_groups = g + 1;
-  }
-  reinterpret_cast<uint4 *>(out + p)[qtr] = v;
+  if (p == 0 || gid[p - 1] != g) group_first[g] = (u32)p;
+  if (p == nv - 1) *n_groups = g + 1;
 }
 
 // One GroupRow per home cell of the batch: the 27 ungated bucket lookups (STDesc.cpp:358-371
@@ -273,7 +221,7 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 5;
   const long long n_groups = (*n_valid_p) ? (long long)*n_groups_p : 0;
   for (long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; g < n_groups; g += stride) {
-    if (c >= SGTD_NCELL) continue;
+    if (c >= SGTD_NCELL) continue;      // (the ballots below only look at lanes c < 27 of either half)
     const long long d = (long long)order[group_first[g]];
     uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
     const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
@@ -290,7 +238,11 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
     const int x = nonneg ? max((int)q0 + ix, 0) : (int)(q0 + (double)ix);
     const int y = nonneg ? max((int)q1 + iy, 0) : (int)(q1 + (double)iy);
     const int z = nonneg ? max((int)q2 + iz, 0) : (int)(q2 + (double)iz);
-    if (x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
+    // a side so small that side - 1 rounds to -1.0 (|side| below 2^-53): the reference probes the
+    // empty cell -1, the clamp above would sweep cell 0 a second time — that slot stays empty
+    const bool minus_one = nonneg && ((ix < 0 && (int)(q0 + (double)ix) < 0) || (iy < 0 && (int)(q1 + (double)iy) < 0) ||
+                                      (iz < 0 && (int)(q2 + (double)iz) < 0));
+    if (!minus_one && x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
       const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
       u32 h = hash_key(key) & T.hash_mask;
       while (true) {
@@ -307,21 +259,78 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
     uint4 *out = reinterpret_cast<uint4 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES) + 2 * c;
     out[0] = lo;     // start, cum[0..2]
     out[1] = hi;     // cum[3..6]
+    // behind the 27 rows: which cells have a bucket at all, and which of those an overflow slice
+    // (plan_passes_kernel bounds a pass's number of ranges with them before it walks the rows)
+    const u64 ex = __builtin_amdgcn_ballot_w64(hi.w != 0u), ov = __builtin_amdgcn_ballot_w64(hi.w != hi.z);
+    const int sh = (int)(threadIdx.x & 32);
+    if (c == 0) out[2 * SGTD_NCELL] = make_uint4((u32)(ex >> sh) & 0x7FFFFFFu, (u32)(ov >> sh) & 0x7FFFFFFu, 0u, 0u);
   }
 }
 
-// GroupRow + the descriptors' gate masks (:366-369) + their thresholds -> the visit list.
-// Lane 2 c + h holds one 16-B half of cell c's directory row: even lanes {start, cum0, cum1,
-// cum2}, odd lanes {cum3, cum4, cum5, cum6}, and stands for half h of the cell: the thirds of
-// that half which hold entries with |side1 - q1| <= thr' and |side2 - q2| <= thr' — an entry
-// outside cannot match: its squared distance, as the reference computes it, is at least
-// fl(d * d) >= thr2 for that axis.  The odd lanes also stand for the cell's overflow slice
-// (all of it; most buckets have none).  The non-empty ranges are compacted, in cell order, by
-// two forward permutes (a lane nobody writes receives 0: the two results are OR-ed), and the
-// offsets are the scan of the compacted lengths.
-// K = 2: the union of the two descriptors' ranges; the sweep tests every loaded entry against
-// both and starts each sum from the descriptor's own gate penalty (a slice too many is harmless,
-// a cell too many is not).
+// ---------------------------------------------------------------------------
+// Passes.  A PASS is what one wavefront sweeps at a time: one query descriptor, or two
+// consecutive descriptors of one home cell (sorted positions first + 2 i, first + 2 i + 1 of
+// the group — they share the GroupRow, so one visit list, one locate and one 16-B load per 64
+// entries serve both).  plan_passes_kernel turns every pass into a RECORD in HBM, one lane per
+// pass, so that the sweep starts from a ready visit list instead of deriving it per wave:
+//
+//   header, 64 B (one 4-B load per lane i < 16, in flight during the pass before; v_readlane at the pass's start):
+//     w0 = n | K << 8     n = non-empty ranges of the visit list (<= 62), K = descriptors (1, 2)
+//     w1 = total          entries in the visit list
+//     w2, w3              descriptor slots d
+//     w4, w5              the descriptors' frames as the entry ids name them (frame - frame_lo,
+//                         0xFFFFFFFF for a frame the table does not hold)
+//     w6..w15             q0, q1, q2 (f32), lo2, hi2 (f32_bounds), each for descriptor 0 and 1
+//   ranges, 12 B each, n + 1 of them (lane j of the sweep loads range j):
+//     offc   exclusive offset of range j in the visit list
+//     dlc    start - offc (entry index of list position p in range j = p + dlc)
+//     meta   cell (0..26) | bit 8: the cell fails descriptor 0's gate | bit 9: descriptor 1's
+//   Range n is the sentinel: it starts at `total` and maps onto the 64 entries with sides +inf
+//   behind the table's last entry, so the lanes of the last 64-entry word beyond the list need
+//   no special case.
+//
+// The visit list: the non-empty ranges of table entries in the order of the reference's cells
+// (voxel_round, :327-333; inside a cell: lower half, upper half, overflow slice) — per cell
+// and half of the second side's interval the thirds of the third side's that hold entries with
+// |side1 - q1| <= thr' and |side2 - q2| <= thr' (an entry outside cannot match: its squared
+// distance, as the reference computes it, is at least fl(d * d) >= thr2 for that axis), and the
+// bucket's overflow slice (all of it; most buckets have none).  For a pair the list is the
+// union of the two descriptors' lists; the sweep tests every loaded entry against both and
+// starts each sum from the descriptor's own gate penalty (a slice too many is harmless, a cell
+// too many is not).
+//
+// Pass slots: leader position p of group g (first position f) owns slot g + ((p + (f & 1)) >> 1)
+// — injective and increasing in p, at most n_groups + (n_valid + 1) / 2 + 1 slots, the unused
+// ones (at most one per group) hold SGTD_NO_PASS; the sweep's tickets are ranges of slots.
+// ---------------------------------------------------------------------------
+#define SGTD_NO_PASS 0xFFFFFFFFu
+#define SGTD_PASS_HDR_UNITS 4          // 64-B header in 16-B units
+#define SGTD_PASS_SLACK_UNITS 64       // behind the pool: the sweep's 64 lanes load 12 B each whatever n is
+
+struct __attribute__((packed, aligned(4))) RangeWords { u32 offc, dlc, meta; };
+
+struct PassPool {
+  uint4 *pool;          // [cap + slack] pass records, 16-B units
+  u32 *rec_off;         // [pass slots] first unit of the slot's record, SGTD_NO_PASS: nothing to sweep
+  u32 *cursor;          // units handed out (keeps counting when the pool is full: sizes the regrown pool)
+  u32 cap;              // units
+};
+
+__host__ __device__ __forceinline__ u32 pass_slot_count(u32 n_valid, u32 n_groups, bool pair) {
+  if (!n_valid) return 0u;
+  return pair ? n_groups + ((n_valid + 1u) >> 1) + 1u : n_valid;
+}
+
+// pos_of_slot[s] = sorted position of the leader of pass slot s (the array is pre-set to SGTD_NO_PASS)
+__global__ void pass_slots_kernel(const u32 *gid, const u32 *group_first, const u32 *n_valid_p, u32 *pos_of_slot,
+                                  long long n, int pair) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n || p >= (long long)*n_valid_p) return;
+  if (!pair) { pos_of_slot[p] = (u32)p; return; }
+  const u32 g = gid[p], f = group_first[g];
+  if ((((u32)p - f) & 1u) == 0u) pos_of_slot[g + (((u32)p + (f & 1u)) >> 1)] = (u32)p;
+}
+
 __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int &lo, int &hi) {
   // slices of the cell interval reached by [q - t, q + t]; slice s holds the entries with
   // (side + 0.5 - cell) * n in [s, s + 1).  q - cell is below 2.5 in magnitude for every gated
@@ -333,115 +342,225 @@ __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int 
   hi = b < 0.0f ? -1 : (!(b < (float)n) ? n - 1 : (int)b);      // floor, clamped to [-1, n - 1]; NaN -> n - 1
 }
 
-template <int K>
-__device__ __forceinline__ DescPlan<K> plan_from_group_row(const DescSet<K> &f, u32 n_entries, u32 coarse_at) {
+// One lane per pass slot.  The lanes of a wave hold consecutive slots, i.e. passes of consecutive
+// groups: the wave stages the GroupRows of SGTD_PLAN_GROUPS groups at a time in LDS (coalesced
+// copies instead of 64 scattered 16-B loads per lane and cell) and the lanes of those groups
+// walk their group's 27 directory rows there ONCE, writing the ranges as they go: a record's room
+// is taken from the pool beforehand (one atomic per wave) for an upper bound of its ranges — two
+// per gated cell that has a bucket, one more where the bucket has an overflow slice (the masks
+// group_resolve_kernel left behind the rows).  n_visit / list point at this table segment's
+// part; a pass without a single entry to visit gets no record and its (empty) results are
+// written here.
+#define SGTD_PLAN_GROUPS 12
+#define SGTD_ROW_QUADS (2 * SGTD_NCELL + 1)     // 16-B quarters of one GroupRow: 27 rows + the masks
+template <bool PAIR>
+__global__ __launch_bounds__(256) void plan_passes_kernel(TableView T, QueryView Q, const u32 *order, const u32 *gid,
+                                                          const u32 *pos_of_slot, const u32 *n_valid_p,
+                                                          const u32 *n_groups_p, const unsigned char *rows, PassPool P,
+                                                          u32 *n_visit, uint2 *list, int *overflow) {
+  __shared__ uint4 s_rows[256 / SGTD_WAVE][SGTD_PLAN_GROUPS * SGTD_ROW_QUADS];
   const int lane = lane_id();
-  const int c = lane >> 1;
-  const bool odd = lane & 1;
-  const int half = lane & 1;
-  // neighbour lane of the pair (quad_perm [1,0,3,2]): the other half of the cell's row
-  const u32 px = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.x, 0xB1, 0xf, 0xf, false);
-  const u32 pz = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.z, 0xB1, 0xf, 0xf, false);
-  const u32 pw = (u32)__builtin_amdgcn_update_dpp(0, (int)f.row.w, 0xB1, 0xf, 0xf, false);
-  // cumulative counts around this lane's half: before its first third, after each third
-  const u32 cm1 = odd ? pw : 0u, c0 = odd ? f.row.x : f.row.y, c1 = odd ? f.row.y : f.row.z, c2 = odd ? f.row.z : f.row.w;
-  const u32 bstart = odd ? px : f.row.x;
-  const int iy = (c / 3) % 3 - 1, iz = c % 3 - 1;
-  int s_lo = SGTD_ZSLICES, s_hi = -1;
-  bool live = false;
-  DescPlan<K> pl;
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    const bool lv = lane < SGTD_NRANGE && ((f.gate[k] >> c) & 1u);
-    int y_lo, y_hi, z_lo, z_hi;
-    reached_slices((float)(f.q1[k] - (double)(int)(f.q1[k] + (double)iy)), f.t_up[k], SGTD_YSLICES, y_lo, y_hi);
-    reached_slices((float)(f.q2[k] - (double)(int)(f.q2[k] + (double)iz)), f.t_up[k], SGTD_ZSLICES, z_lo, z_hi);
-    if (lv && half >= y_lo && half <= y_hi && z_hi >= z_lo) { s_lo = min(s_lo, z_lo); s_hi = max(s_hi, z_hi); }
-    live |= lv;
-    // the reference's loop visits every entry of every gated cell: cum6 of the odd lanes
-    pl.ref_visits[k] = wave_sum((lv && odd) ? f.row.w : 0u);
+  uint4 *my_rows = s_rows[threadIdx.x >> 6];
+  const u32 nv = *n_valid_p;
+  const u32 n_pass = pass_slot_count(nv, *n_groups_p, PAIR);
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((s & ~63u) >= n_pass) return;                 // the whole wave
+  const u32 p = s < n_pass ? pos_of_slot[s] : SGTD_NO_PASS;
+  const bool act = p != SGTD_NO_PASS;
+  int K = 0;
+  u32 g = 0, d[2] = {0, 0};
+  if (act) {
+    g = gid[p];
+    K = (PAIR && p + 1 < nv && gid[p + 1] == g) ? 2 : 1;
+    d[0] = order[p];
+    d[1] = K == 2 ? order[p + 1] : d[0];
   }
-  const u32 before = s_lo == 0 ? cm1 : (s_lo == 1 ? c0 : c1);
-  const u32 upto = s_hi == 0 ? c0 : (s_hi == 1 ? c1 : c2);
-  u32 start_a = bstart + before;
-  u32 len_a = (s_hi >= s_lo) ? upto - before : 0u;            // (s_hi >= s_lo only for a live lane)
-  const u32 start_b = px + f.row.z;                           // odd lanes: bucket start + cum5
-  const u32 len_b = (odd && live) ? f.row.w - f.row.z : 0u;   // cum6 - cum5
-  u64 keep_a = __builtin_amdgcn_ballot_w64(len_a != 0u);
-  const u64 keep_b = __builtin_amdgcn_ballot_w64(len_b != 0u);
-  if ((u32)(__builtin_popcountll(keep_a) + __builtin_popcountll(keep_b)) > coarse_at) {
-    // more ranges than lanes (only with many overflow slices): the halves of a cell as ONE
-    // unpruned range, all six sub-cells — a superset of what the descriptors reach
-    start_a = f.row.x;
-    len_a = (!odd && live) ? pz : 0u;                         // cum5 of the even lane's cell
-    keep_a = __builtin_amdgcn_ballot_w64(len_a != 0u);
+  u32 hq[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};   // q0, q1, q2 (f32), lo2, hi2 as words
+  u32 qfr[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gate[2] = {0, 0};
+  // per descriptor and offset -1, 0, +1: the halves (second side) and thirds (third side) its
+  // threshold box reaches as bit masks: halves in bits 2 o .. 2 o + 1, thirds in bits 8 + 3 o .. 8 + 3 o + 2
+  u32 reach[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    if (k < K) {
+      const uint4 *r = reinterpret_cast<const uint4 *>(Q.qrec + d[k]);
+      const uint4 a = r[0], b = r[1], c = r[2], e = r[3];
+      const double q0 = __hiloint2double((int)a.y, (int)a.x), q1 = __hiloint2double((int)a.w, (int)a.z),
+                   q2 = __hiloint2double((int)b.y, (int)b.x);
+      hq[k][0] = __float_as_uint((float)q0); hq[k][1] = __float_as_uint((float)q1); hq[k][2] = __float_as_uint((float)q2);
+      hq[k][3] = e.x; hq[k][4] = e.y;
+      const u32 ql = c.x - T.map.frame_lo;
+      qfr[k] = ql < T.frame_span ? ql : 0xFFFFFFFFu;
+      gate[k] = c.y;
+      const float t_up = __uint_as_float(e.z);
+#pragma unroll
+      for (int o = 0; o < 3; o++) {
+        int lo, hi;
+        reached_slices((float)(q1 - (double)(int)(q1 + (double)(o - 1))), t_up, SGTD_YSLICES, lo, hi);
+        reach[k] |= (((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u)) << (2 * o);           // (hi < lo: no bit)
+        reached_slices((float)(q2 - (double)(int)(q2 + (double)(o - 1))), t_up, SGTD_ZSLICES, lo, hi);
+        reach[k] |= (((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u)) << (8 + 3 * o);
+      }
+    }
   }
-  const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(keep_a >> 32), __builtin_amdgcn_mbcnt_lo((u32)keep_a, 0u)) +
-                    __builtin_amdgcn_mbcnt_hi((u32)(keep_b >> 32), __builtin_amdgcn_mbcnt_lo((u32)keep_b, 0u));
-  const u32 n = (u32)(__builtin_popcountll(keep_a) + __builtin_popcountll(keep_b));
-  // forward permutes: range -> its number; an empty one writes lane 63, which no number reaches
-  const u32 dst_a = (len_a != 0u ? below : 63u) << 2;
-  u32 startc = (u32)__builtin_amdgcn_ds_permute((int)dst_a, (int)start_a);
-  u32 lenc = (u32)__builtin_amdgcn_ds_permute((int)dst_a, (int)len_a);
-  u32 cellc = (u32)__builtin_amdgcn_ds_permute((int)dst_a, c);
-  u32 penb[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    const bool open = lane < SGTD_NRANGE && ((f.gate[k] >> c) & 1u);
-    penb[k] = open ? 0u : 0x7F800000u;
+  const u32 gate_any = gate[0] | gate[1];
+  // the wave's groups are consecutive ids (slots grow with the sorted position): first and last active lane
+  const u64 act_mask = __builtin_amdgcn_ballot_w64(act);
+  if (!act_mask) {
+    if (s < n_pass) P.rec_off[s] = SGTD_NO_PASS;
+    return;
   }
-  u32 pencu[K];
+  const u32 g_lo = (u32)__builtin_amdgcn_readlane((int)g, __builtin_ctzll(act_mask));
+  const u32 g_hi = (u32)__builtin_amdgcn_readlane((int)g, 63 - __builtin_clzll(act_mask));
+  u32 my_off = SGTD_NO_PASS;
+  for (u32 gc = g_lo; gc <= g_hi; gc += SGTD_PLAN_GROUPS) {
+    const u32 ng = min((u32)SGTD_PLAN_GROUPS, g_hi - gc + 1u);
+    __builtin_amdgcn_wave_barrier();
+    {   // flat copy of ng x 55 quarters, four loads in flight per lane
+      const u32 n_quads = ng * SGTD_ROW_QUADS;
+      for (u32 i0 = 0; i0 < n_quads; i0 += 4 * SGTD_WAVE) {
+        uint4 t[4];
 #pragma unroll
-  for (int k = 0; k < K; k++) pencu[k] = (u32)__builtin_amdgcn_ds_permute((int)dst_a, (int)penb[k]);
-  if (keep_b) {     // the overflow slice of cell c follows both of its halves
-    const u32 dst_b = (len_b != 0u ? below + (u32)((keep_a >> lane) & 1ull) : 63u) << 2;
-    startc |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, (int)start_b);
-    lenc |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, (int)len_b);
-    cellc |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, c);
+        for (int u = 0; u < 4; u++) {
+          const u32 i = min(i0 + u * SGTD_WAVE + lane, n_quads - 1u);
+          const u32 gg = i / SGTD_ROW_QUADS, q = i - gg * SGTD_ROW_QUADS;
+          t[u] = reinterpret_cast<const uint4 *>(rows + (size_t)(gc + gg) * SGTD_GROUP_ROW_BYTES)[q];
+        }
 #pragma unroll
-    for (int k = 0; k < K; k++) pencu[k] |= (u32)__builtin_amdgcn_ds_permute((int)dst_b, (int)penb[k]);
+        for (int u = 0; u < 4; u++) {
+          const u32 i = i0 + u * SGTD_WAVE + lane;
+          if (i < n_quads) my_rows[i] = t[u];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool mine = act && g - gc < (u32)SGTD_PLAN_GROUPS;      // (g >= gc for every lane not yet served)
+    const u32 *row = reinterpret_cast<const u32 *>(my_rows + (mine ? g - gc : 0u) * SGTD_ROW_QUADS);
+    // room for the record: an upper bound of the ranges
+    const u32 m_exist = row[8 * SGTD_NCELL], m_ovf = row[8 * SGTD_NCELL + 1];
+    u32 ub = mine ? 2u * (u32)__builtin_popcount(gate_any & m_exist) + (u32)__builtin_popcount(gate_any & m_ovf) : 0u;
+    // more ranges than the sweep has lanes (only with many overflow slices): the halves of a cell as
+    // ONE unpruned range, all six sub-cells — a superset of what the descriptors reach
+    const bool coarse = ub > T.coarse_at;
+    if (coarse) ub = (u32)__builtin_popcount(gate_any & m_exist) + (u32)__builtin_popcount(gate_any & m_ovf);
+    const u32 units = ub ? SGTD_PASS_HDR_UNITS + ((ub + 1u) * 12u + 15u) / 16u : 0u;
+    const u32 inc = wave_incl_scan(units);
+    const u32 wave_units = (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
+    u32 base = 0;
+    if (wave_units) {
+      if (lane == 0) base = atomicAdd(P.cursor, wave_units);
+      base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+    }
+    const bool room = (u64)base + wave_units <= (u64)P.cap;
+    if (!room && lane == 0) overflow[0] = 1;                 // the host grows the pool and re-runs the batch
+    const u32 off = base + inc - units;
+    u32 n = 0, total = 0, visits[2] = {0, 0};
+    if (mine) {
+      RangeWords *wp = reinterpret_cast<RangeWords *>(P.pool + off + SGTD_PASS_HDR_UNITS);   // next range of the record
+      const bool emit = ub != 0u && room;
+      auto put = [&](u32 start, u32 len, u32 meta) {
+        if (len) {
+          if (emit) *wp++ = RangeWords{total, start - total, meta};     // one 12-B store
+          total += len;
+          n++;
+        }
+      };
+#pragma unroll 1
+      for (int c = 0; c < SGTD_NCELL; c++) {     // (unrolled, the compiler keeps 54 gate predicates in scalar registers)
+        const int oy = (c / 3) % 3, oz = c % 3;
+        const u32 *rc = row + 8 * c;             // {start, cum0 .. cum6}
+        const u32 cum6 = rc[7], cum5 = rc[6], start = rc[0];
+        // sub-cells reached by any gated descriptor: bits 0..2 the thirds of the lower half, 3..5 of the upper
+        u32 sub = 0, meta = (u32)c;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const bool lv = (gate[k] >> c) & 1u;     // (gate[k] = 0 for k >= K)
+          const u32 zk = (reach[k] >> (8 + 3 * oz)) & 7u, yk = (reach[k] >> (2 * oy)) & 3u;
+          const u32 sk = ((yk & 1u) ? zk : 0u) | ((yk & 2u) ? zk << 3 : 0u);
+          sub |= lv ? sk : 0u;
+          visits[k] += lv ? cum6 : 0u;           // the reference's loop visits every entry of every gated cell
+          meta |= lv ? 0u : 0x100u << k;
+        }
+        const bool live = (gate_any >> c) & 1u;
+        sub |= (sub & (sub >> 2) & 0x9u) << 1;   // per half the thirds from the first to the last reached one
+        if (!coarse) {
+          // half h: entries before its first reached third (cum[i - 1], 0 for i = 0) and up to its last
+          const u32 m0 = sub & 7u, m1 = sub & 0x38u;
+          const u32 lo0 = (u32)__builtin_ctz(m0 | 0x40u), hi0 = 31u - (u32)__builtin_clz(m0 | 1u);
+          const u32 lo1 = (u32)__builtin_ctz(m1 | 0x40u), hi1 = 31u - (u32)__builtin_clz(m1 | 1u);
+          const u32 before0 = lo0 ? rc[lo0] : 0u, upto0 = rc[hi0 + 1];
+          const u32 before1 = rc[lo1], upto1 = rc[hi1 + 1];
+          put(start + before0, m0 ? upto0 - before0 : 0u, meta);
+          put(start + before1, m1 ? upto1 - before1 : 0u, meta);
+        } else {
+          put(start, live ? cum5 : 0u, meta);                   // both halves
+        }
+        put(start + cum5, live ? cum6 - cum5 : 0u, meta);         // the overflow slice follows both halves
+      }
+      const bool rec = emit && n != 0u;
+      if (rec) {
+        my_off = off;
+        *wp = RangeWords{total, T.n_entries - total, 0x300u};   // the sentinel range
+        uint4 *h = P.pool + off;
+        h[0] = make_uint4(n | ((u32)K << 8), total, d[0], d[1]);
+        h[1] = make_uint4(qfr[0], qfr[1], hq[0][0], hq[1][0]);
+        h[2] = make_uint4(hq[0][1], hq[1][1], hq[0][2], hq[1][2]);
+        h[3] = make_uint4(hq[0][3], hq[1][3], hq[0][4], hq[1][4]);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (k < K) {
+          n_visit[d[k]] = visits[k];
+          if (!rec) list[d[k]] = make_uint2(0u, 0u);
+        }
+    }
   }
-  lenc = (u32)lane < n ? lenc : 0u;
-  const u32 inc = wave_incl_scan(lenc);
-  const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
-  pl.n = n;
-  pl.total = total;
-  pl.offc = (u32)lane < n ? inc - lenc : ((u32)lane == n ? total : 0xFFFFFFFFu);
-  pl.dlc = (u32)lane < n ? startc - pl.offc : n_entries - total;       // lane n: the sentinel entries
-  pl.cellc = cellc;
-#pragma unroll
-  for (int k = 0; k < K; k++) pl.penc[k] = __uint_as_float((u32)lane < n ? pencu[k] : 0x7F800000u);
-  return pl;
+  if (s < n_pass) P.rec_off[s] = my_off;
 }
 
-// STDesc.cpp:372-399 for K query descriptors of one home cell by one wavefront: streams the
+// What the sweep holds about the pass it is working on
+template <int K>
+struct PassView {
+  // wave-uniform, from the header
+  float q0f[K], q1f[K], q2f[K], lo2[K], hi2[K];
+  u32 qframe[K], slot[K];
+  u32 n, total;
+  // lane j: range j (lanes beyond the sentinel: offc = 0xFFFFFFFF)
+  u32 offc, dlc, meta;
+};
+
+// STDesc.cpp:372-399 for the K query descriptors of one pass by one wavefront: streams the
 // (union) visit list once, tests every entry against each descriptor, compacts each
 // descriptor's matches in visit order into its own list.
 // WIDE = false: the probe layout is below 4 GB, so entry addresses are a uniform base + a
 // 32-bit byte offset (no quarter-rate 64-bit VALU address arithmetic per entry); the host
 // picks the variant from the table size.  Record addresses are a wave-uniform list base + a
 // 32-bit lane offset either way.
-template <bool DIAG, bool WIDE, int K>
-__device__ __forceinline__ void sweep_descriptors(const TableView &T, const ProbeBuffers &B, double rough,
-                                                  const DescSet<K> &f, const DescPlan<K> &pl, u64 *bits,
-                                                  WaveSlab &slab, DescResult (&result)[K], PendingLoads pending) {
+// FRAMES = false: no descriptor of the batch carries a frame id the table holds (the reference
+// stamps every query descriptor with current_frame_id_, one beyond the map's last frame, quirk 1
+// of SURVEY §8a), so the frame test of :373 is true for every entry and is not evaluated.
+template <bool DIAG, bool WIDE, bool FRAMES, int K>
+__device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffers &B, const QueryView &Q, double rough,
+                                           const PassView<K> &pv, u64 *bits, WaveSlab &slab, PendingLoads pending) {
   static_assert(!DIAG || K == 1, "the diagnostic sweep takes one descriptor at a time");
   const int lane = lane_id();
-  // per-descriptor constants of the test (wave-uniform)
-  float q0f[K], q1f[K], q2f[K], lo2[K], hi2[K];
-  u32 qframe[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    q0f[k] = (float)f.q0[k]; q1f[k] = (float)f.q1[k]; q2f[k] = (float)f.q2[k];
-    lo2[k] = f.lo2[k]; hi2[k] = f.hi2[k];
-    // the query's frame as the ids name it; a frame the table does not hold equals no entry's
-    const u32 ql = f.qframe[k] - T.map.frame_lo;
-    qframe[k] = ql < T.frame_span ? ql : 0xFFFFFFFFu;
-  }
   const u32 id_bits = T.map.bits;
-  const double thr = DIAG ? norm3(f.q0[0], f.q1[0], f.q2[0]) * rough : 0.0;   // :356-357
-  const u32 total = pl.total;
-  u64 ph_t = PH_T(); (void)ph_t;
+  const u32 total = pv.total;
+  // the diagnostic sweep evaluates the reference's form verbatim on the exact f64 sides, :356-357
+  double dq0 = 0.0, dq1 = 0.0, dq2 = 0.0, thr = 0.0;
+  if constexpr (DIAG) {
+    const QueryRec &r = Q.qrec[pv.slot[0]];
+    dq0 = r.q0; dq1 = r.q1; dq2 = r.q2;
+    thr = norm3(dq0, dq1, dq2) * rough;
+  }
+  // per lane: the gate penalties of its range (0 / +inf per descriptor) and its cell
+  float penc[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) penc[k] = __uint_as_float((pv.meta >> (8 + k)) & 1u ? 0x7F800000u : 0u);
+  const u32 cellc = pv.meta & 0xFFu;
+  // narrow layout: the address delta in bytes, so that an entry's byte offset is ONE three-operand add
+  const u32 dlc_sel = WIDE ? pv.dlc : pv.dlc << 4;
+  const u32 lane16 = (u32)lane << 4;
   // records of one descriptor are contiguous: make sure its stream's slab can take the worst
   // case (every visited entry matches)
   bool fits = true;
@@ -453,16 +572,15 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
       // abandoned at a slab's end to about an eighth however long the visit lists are
       const u32 take = total > (1u << 28) ? total : max(SGTD_REC_SLAB, 8u * total);
       u64 got = 0;
-      if (lane == 0) got = atomicAdd(B.rec_cursor, (unsigned long long)take);
+      if (lane == 0) got = atomicAdd(B.rec_cursor(), (unsigned long long)take);
       got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
       if (got + take <= (u64)B.rec_cap) { slab.next[k] = (u32)got; slab.end[k] = (u32)got + take; }
       else { slab.next[k] = 0; slab.end[k] = 0; }      // the buffer is exhausted: nothing of this stream fits any more
     }
     fits = fits && ((u64)slab.next[k] + total <= (u64)slab.end[k]);
   }
-  if (!fits && lane == 0) B.overflow[0] = 1;
+  if (!fits && lane == 0) B.overflow()[0] = 1;
   __builtin_amdgcn_wave_barrier();
-  PH_ADD(0, ph_t);
 
   u32 matches[K];
   u32 *list[K];   // wave-uniform
@@ -473,12 +591,6 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
   }
   const u32 n_words = (total + 63u) >> 6;
   slab.swept += total;
-#ifdef SGTD_EXP_PHASE
-  if (lane == 0 && n_words) {
-    atomicAdd(&g_words[0], (unsigned long long)n_words);
-    atomicAdd(&g_words[1], (unsigned long long)((n_words + SGTD_PROBE_UNROLL - 1) / SGTD_PROBE_UNROLL));
-  }
-#endif
   // position -> range.  The starts of the non-empty ranges are marked in a bit array over the
   // positions of the visit list (this wave's 64 x 64-bit LDS window, rebuilt every 4096
   // positions; the mark of a range that starts at position p > 0 is bit p - 1): the range of
@@ -489,11 +601,11 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
   // one load group: NW words located, their loads issued back to back, then tested.  NW is a
   // compile-time count: each group size is straight-line code (branches around loads would
   // make the compiler wait for earlier loads before every later one).
-  const bool marks = (u32)lane <= pl.n && pl.offc != 0u;
+  const bool marks = (u32)lane <= pv.n && pv.offc != 0u;
   auto window = [&](u32 w_first) {     // w_first: a multiple of 64 words
     bits[lane] = 0;
-    const u32 wr = ((pl.offc - 1u) >> 6) - w_first;
-    if (marks && wr < 64u) atomicOr(reinterpret_cast<unsigned long long *>(bits + wr), 1ull << ((pl.offc - 1u) & 63u));
+    const u32 wr = ((pv.offc - 1u) >> 6) - w_first;
+    if (marks && wr < 64u) atomicOr(reinterpret_cast<unsigned long long *>(bits + wr), 1ull << ((pv.offc - 1u) & 63u));
     __builtin_amdgcn_wave_barrier();
   };
   auto group = [&](auto nw_tag, u32 w0) {
@@ -502,30 +614,28 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
     u32 cellv[NW];    // cell (0..26) of the lane's entry (diagnostic sweep)
     f32x2 pen[NW];    // pair: 0 / +inf per descriptor (the entry's cell passes its gate or not)
     bool valid[NW];   // diagnostic sweep (the exact test reads the cold table, not the sentinel's sides)
+    const u64 *bits_w = bits + (w0 & 63u);      // (a group never straddles the window: w0 is a multiple of its size)
 #pragma unroll
     for (int u = 0; u < NW; u++) {
       const u32 w_lo = (w0 + u) << 6;
-      const u32 pos = w_lo + lane;
-      valid[u] = pos < total;
-      const u64 bm = bits[(w0 + u) & 63u];      // marks of positions w_lo + 1 .. w_lo + 64
-      const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pl.offc <= w_lo)) - 1u;
+      valid[u] = w_lo + lane < total;
+      const u64 bm = bits_w[u];                 // marks of positions w_lo + 1 .. w_lo + 64
+      const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pv.offc <= w_lo)) - 1u;
       const u32 j4 = __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, before)) << 2;
-      const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)pl.dlc);
-      if (DIAG) cellv[u] = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)pl.cellc);
+      const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)dlc_sel);
+      if (DIAG) cellv[u] = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)cellc);
       if constexpr (K == 2) {
-        pen[u].x = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(pl.penc[0])));
-        pen[u].y = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(pl.penc[1])));
+        pen[u].x = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(penc[0])));
+        pen[u].y = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(penc[1])));
       }
-      const u32 e = pos + dsel;       // beyond the list: the sentinel entries
-      const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + e)
-                              : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(T.ent) + (e << 4));
+      // entry = position + the range's delta; beyond the list: the sentinel entries
+      const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + (w_lo + lane + dsel))
+                              : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(T.ent) + (dsel + lane16 + (w_lo << 4)));
+#ifdef SGTD_EXP_L1
+      pa = reinterpret_cast<const float4 *>(T.ent) + lane;     // experiment: every load hits the same L1-resident KB
+#endif
       v[u] = *pa;             // s0, s1, s2 (f32), id
     }
-#ifdef SGTD_EXP_PHASE
-    PH_ADD(1, ph_t);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    PH_ADD(2, ph_t);
-#endif
     u32 m_start[K];
 #pragma unroll
     for (int k = 0; k < K; k++) m_start[k] = matches[k];
@@ -534,7 +644,7 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
     // in the halves of packed f32 operations and start from the gate penalties
     auto dist2 = [&](int u, float (&d2)[K]) {
       if constexpr (K == 2) {
-        const f32x2 qx = {q0f[0], q0f[1]}, qy = {q1f[0], q1f[1]}, qz = {q2f[0], q2f[1]};
+        const f32x2 qx = {pv.q0f[0], pv.q0f[1]}, qy = {pv.q1f[0], pv.q1f[1]}, qz = {pv.q2f[0], pv.q2f[1]};
         const f32x2 sx = {v[u].x, v[u].x}, sy = {v[u].y, v[u].y}, sz = {v[u].z, v[u].z};
         const f32x2 dx = qx - sx, dy = qy - sy, dz = qz - sz;
         f32x2 acc = __builtin_elementwise_fma(dx, dx, pen[u]);      // pen 0: fl(dx * dx) as in f32_bounds
@@ -542,17 +652,19 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
         acc = __builtin_elementwise_fma(dz, dz, acc);
         d2[0] = acc.x; d2[1] = acc.y;
       } else {
-        const float dx = q0f[0] - v[u].x, dy = q1f[0] - v[u].y, dz = q2f[0] - v[u].z;
+        const float dx = pv.q0f[0] - v[u].x, dy = pv.q1f[0] - v[u].y, dz = pv.q2f[0] - v[u].z;
         d2[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
       }
     };
     // one (word, descriptor) test; PUSH = false: store the matches, true: replay of the group
     // that only queues the provisional records (rare)
-    auto test = [&](auto push_tag, int u, int k, float d2, u32 &count) {
+    auto test = [&](auto push_tag, int u, int k, float d2, u32 &count) mutable {
       constexpr bool PUSH = decltype(push_tag)::value;
-      const u32 id = __float_as_uint(v[u].w);
+      u32 id = __float_as_uint(v[u].w);
+      // (the replay shares nothing with the first evaluation: no mask of the hot loop stays alive for it)
+      if constexpr (PUSH) asm volatile("" : "+v"(id), "+v"(d2));
       // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  frame ids differ (:373)
-      const bool other = qframe[k] != (id >> id_bits);
+      const bool other = !(FRAMES || DIAG) || pv.qframe[k] != (id >> id_bits);
       bool hit, amb = false;
       u64 m;
       double dis = 0.0;
@@ -560,31 +672,40 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
         hit = false;
         if (valid[u] && other) {
           const double *sp = T.cold_side + (size_t)id_entry(T.map, id) * 3;
-          const double ex = f.q0[k] - sp[0], ey = f.q1[k] - sp[1], ez = f.q2[k] - sp[2];
+          const double ex = dq0 - sp[0], ey = dq1 - sp[1], ez = dq2 - sp[2];
           dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
           hit = dis < thr;
         }
         m = __builtin_amdgcn_ballot_w64(hit);
       } else {
         // (sentinel entries and gated-out cells: d2 = +inf, above every hi2 — f32_bounds keeps it finite)
-        const bool near = !(d2 > hi2[k]);     // not certainly outside (NaN stays in)
+        const bool near = !(d2 > pv.hi2[k]);     // not certainly outside (NaN stays in)
         hit = near && other;
-        amb = hit && !(d2 < lo2[k]);          // not certainly inside either: provisional
-        m = __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other);   // two plain compares: no mask round trip
+        amb = hit && !(d2 < pv.lo2[k]);          // not certainly inside either: provisional
+        m = FRAMES ? __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other)   // two plain compares: no mask round trip
+                   : __builtin_amdgcn_ballot_w64(near);
       }
       const u32 at = count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
       if constexpr (!PUSH) {
+#ifdef SGTD_EXP_NOSTORE
+        if (hit && fits && at == 0xFFFFFFF0u) {                 // experiment: no record stores
+#else
         if (hit && fits) {
+#endif
           // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
           *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list[k]) + (at << 2)) = id;
           if (DIAG) { B.rec_cell[(size_t)slab.next[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)slab.next[k] + at] = dis; }
         }
-        if (!DIAG) amb_any |= m & __builtin_amdgcn_ballot_w64(!(d2 < lo2[k]));
+        // amb_any |= m & ballot(!(d2 < lo2)) — as one unit, so that no hit mask outlives its test
+        // (left to the scheduler, sixteen masks of a group wait in scalar registers for this)
+        if (!DIAG)
+          asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n\ts_and_b64 vcc, vcc, %3\n\ts_or_b64 %0, %0, vcc"
+                       : "+s"(amb_any) : "s"(__float_as_uint(pv.lo2[k])), "v"(d2), "s"(m) : "vcc");
       } else {
         if (amb && fits) {
-          const u32 qa = atomicAdd(B.amb_count, 1u);
-          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.next[k] + at, f.slot[k]);
-          else B.overflow[0] = 1;    // re-run with a larger queue (grows with the record buffer)
+          const u32 qa = atomicAdd(B.amb_count(), 1u);
+          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.next[k] + at, pv.slot[k]);
+          else B.overflow()[0] = 1;    // re-run with a larger queue (grows with the record buffer)
         }
       }
       count += (u32)__builtin_popcountll(m);
@@ -605,7 +726,6 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
         for (int k = 0; k < K; k++) test(std::true_type{}, u, k, d2[k], m_start[k]);
       }
     }
-    PH_ADD(3, ph_t);
   };
   // full groups of SGTD_PROBE_UNROLL words, window after window, then what is left in groups
   // of 2 and 1 (inside the last window)
@@ -629,20 +749,23 @@ __device__ __forceinline__ void sweep_descriptors(const TableView &T, const Prob
     pending.touch();
   }
   static_assert(SGTD_PROBE_UNROLL == 4, "remainder groups cover 2 and 1 words; a window is a whole number of groups");
+  // the pass's results: lane k stores for descriptor k
+  {
+    u32 r_slot = pv.slot[0], r_ptr = slab.next[0], r_match = matches[0];
+    if constexpr (K == 2) {
+      if (lane == 1) { r_slot = pv.slot[1]; r_ptr = slab.next[1]; r_match = matches[1]; }
+    }
+    if (lane < K) B.list[r_slot] = make_uint2(r_ptr, fits ? r_match : 0u);
+  }
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    if (!fits && lane == 0) atomicAdd(B.rec_need, (unsigned long long)matches[k]);
-    result[k].ptr = slab.next[k]; result[k].visit = pl.ref_visits[k]; result[k].match = fits ? matches[k] : 0;
+    if (!fits && lane == 0) atomicAdd(B.rec_need(), (unsigned long long)matches[k]);
     if (fits) slab.next[k] += matches[k];
   }
   __builtin_amdgcn_wave_barrier();
-  PH_ADD(4, ph_t);
 }
 
-#ifndef SGTD_SWEEP_OCC
-#define SGTD_SWEEP_OCC
-#endif
-#define SGTD_TICKET_MAX 16   // descriptors per ticket: 4 lanes each in one 64-lane load
+#define SGTD_TICKET_MAX 64   // pass slots per ticket: one lane each in the ticket's offset load
 #define SGTD_NO_CHUNK 0xFFFFFFFFu
 
 // The per-XCD ticket queues of the sweep: chunk ids [c_lo, c_hi) of queue x belong
@@ -676,157 +799,106 @@ struct TicketQueue {
   }
 };
 
-template <bool DIAG, bool WIDE>
-__global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_OCC void probe_sorted_kernel(
-    TableView T, ProbeBuffers B, const unsigned char *rows, const QueryRec *sorted, double rough,
-    const u32 *n_valid_p, u32 *xcd_heads /*[8 * 1024]*/, u32 chunk /* 1..SGTD_TICKET_MAX */) {
+
+template <bool DIAG, bool WIDE, bool FRAMES>
+__global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(
+    TableView T, ProbeBuffers B, QueryView Q, PassPool P, double rough, const u32 *n_valid_p, const u32 *n_groups_p,
+    u32 chunk /* 1..SGTD_TICKET_MAX */) {
   __shared__ u64 s_bits[SGTD_PROBE_THREADS / SGTD_WAVE][64];   // per wave: range starts of the current 4096 positions
   const int lane = lane_id();
-  const u32 n_valid = *n_valid_p;
-  // Every WAVE dequeues `chunk` consecutive sorted positions at a time (no workgroup
-  // barrier).  Small chunks keep the descriptors in flight on one XCD — and with them the
-  // buckets it is reading — within that XCD's 4 MB L2; the host sizes a ticket to about 2k
-  // entry visits.  Software pipeline per wave: the ticket after next is in flight, the next
-  // ticket's descriptor records are in flight, the next descriptor's GroupRow is in flight
-  // while the current descriptor is swept.
+  const u32 n_slots = pass_slot_count(*n_valid_p, *n_groups_p, !DIAG && SGTD_PAIR >= 2);
+  // Every WAVE dequeues `chunk` consecutive pass slots at a time (no workgroup barrier).
+  // Small chunks keep the passes in flight on one XCD — and with them the buckets it is
+  // reading — within that XCD's 4 MB L2; the host sizes a ticket to about 3k entry visits.
+  // Software pipeline per wave: the ticket after next is in flight, the next ticket's record
+  // offsets are in flight, the next pass's header and ranges are in flight while the current
+  // pass is swept.
   TicketQueue tq;
-  tq.heads = xcd_heads;
-  tq.n_chunks = (n_valid + chunk - 1) / chunk;
+  tq.heads = B.xcd_heads();
+  tq.n_chunks = (n_slots + chunk - 1) / chunk;
   u32 xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   tq.xcc = xcc & 7u;
   tq.select(0);
   WaveSlab slab{};
-#ifdef SGTD_EXP_PHASE
-  for (int i = 0; i < 8; i++) slab.ph[i] = 0;
-  const u64 ph_start = PH_T();
-#endif
-#ifdef SGTD_EXP_TRACE
-  const u64 tr_t0 = wall_clock64();
-  u64 tr_own = 0; u32 tr_n_own = 0, tr_n_st = 0;
-#endif
-  // lane j loads quarter j & 3 of descriptor j >> 2 of the chunk
-  auto load_chunk = [&](u32 c) {
-    const u32 p = c * chunk + ((u32)lane >> 2);
-    uint4 r = make_uint4(0, 0, 0, 0);
-    if (c != SGTD_NO_CHUNK && ((u32)lane >> 2) < chunk && p < n_valid)
-      r = reinterpret_cast<const uint4 *>(sorted + p)[lane & 3];
+  // lane i: record offset of pass slot i of ticket c
+  auto load_offs = [&](u32 c) {
+    u32 r = SGTD_NO_PASS;
+    if (c != SGTD_NO_CHUNK && (u32)lane < chunk && c * chunk + (u32)lane < n_slots) r = P.rec_off[c * chunk + (u32)lane];
     return r;
   };
-  // lane l < 54 loads 16-B quarter l of the group's 27 directory rows
-  auto load_row = [&](u32 g) {
-    uint4 r = make_uint4(0, 0, 0, 0);
-    if (lane < SGTD_NRANGE) r = reinterpret_cast<const uint4 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES)[lane];
-    return r;
-  };
-
-  u32 cur_c = tq.resolve(tq.issue());
-  uint4 rec = load_chunk(cur_c);
-  asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));   // same for the ticket loop
+  u32 ov = load_offs(tq.resolve(tq.issue()));
   u32 tk_next = tq.issue();
-  while (cur_c != SGTD_NO_CHUNK) {
-    const u32 nxt_c = tq.resolve(tk_next);        // requested one whole chunk ago
-    tk_next = tq.issue();                         // in flight during this chunk
-    uint4 rec_next = load_chunk(nxt_c);           // in flight during this chunk
-    const u32 p_first = cur_c * chunk;
-    const u32 n = min(chunk, n_valid - p_first);
-#ifdef SGTD_EXP_TRACE
-    if (tq.t == 0) tr_n_own += n; else { if (!tr_own) tr_own = wall_clock64(); tr_n_st += n; }
-#endif
-    u32 g_cur = (u32)__builtin_amdgcn_readlane((int)rec.z, 2);
-    uint4 row_next = load_row(g_cur);
-    // waited for here, once per ticket: the loop below then carries no pending load into its
-    // header on either edge (the next rows are touched inside the sweep)
-    asm volatile("" : "+v"(row_next.x), "+v"(row_next.y), "+v"(row_next.z), "+v"(row_next.w));
-    u32 r_ptr = 0, r_visit = 0, r_match = 0;   // lane i: results of descriptor i of the chunk
-    // descriptor i of the chunk -> its fields (records are 4 lanes each)
-    auto unpack = [&](auto &f, int k, u32 i) {
-      const int l0 = (int)(4 * i);
-      f.q0[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0), __builtin_amdgcn_readlane((int)rec.x, l0));
-      f.q1[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0), __builtin_amdgcn_readlane((int)rec.z, l0));
-      f.q2[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.y, l0 + 1), __builtin_amdgcn_readlane((int)rec.x, l0 + 1));
-      f.thr2[k] = __hiloint2double(__builtin_amdgcn_readlane((int)rec.w, l0 + 1), __builtin_amdgcn_readlane((int)rec.z, l0 + 1));
-      f.qframe[k] = (u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 2);
-      f.gate[k] = (u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 2);
-      f.slot[k] = (u32)__builtin_amdgcn_readlane((int)rec.w, l0 + 2);
-      f.lo2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.x, l0 + 3));
-      f.hi2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.y, l0 + 3));
-      f.t_up[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)rec.z, l0 + 3));
+  u32 nxt_c = tq.resolve(tk_next);
+  tk_next = tq.issue();
+  u32 ov_n = load_offs(nxt_c);
+  u64 todo = __builtin_amdgcn_ballot_w64(ov != SGTD_NO_PASS);
+  // the next pass of this wave's stream of tickets: its record offset, SGTD_NO_PASS at the end
+  auto next_pass = [&]() -> u32 {
+    while (!todo) {
+      if (nxt_c == SGTD_NO_CHUNK) return SGTD_NO_PASS;
+      ov = ov_n;
+      nxt_c = tq.resolve(tk_next);      // requested one whole ticket ago
+      tk_next = tq.issue();             // in flight during this ticket
+      ov_n = load_offs(nxt_c);          // in flight during this ticket
+      todo = __builtin_amdgcn_ballot_w64(ov != SGTD_NO_PASS);
+    }
+    const int i = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    return (u32)__builtin_amdgcn_readlane((int)ov, i);
+  };
+  // header (lane i < 16: word i) and ranges (lane j: range j) of the current and the next pass
+  u32 hv = 0, r_off = 0xFFFFFFFFu, r_dl = 0, r_meta = 0x300u, hv_n = 0, rn_off = 0xFFFFFFFFu, rn_dl = 0, rn_meta = 0x300u;
+  auto fetch = [&](u32 off, u32 &h, u32 &a, u32 &b, u32 &c) {
+    if (off == SGTD_NO_PASS) return;
+    h = reinterpret_cast<const u32 *>(P.pool + off)[lane & 15];
+    // every lane loads 12 B whatever n is (no wait for the header): the lanes beyond the
+    // sentinel read into the following records or the pool's slack and are masked below
+    const RangeWords rw = reinterpret_cast<const RangeWords *>(P.pool + off + SGTD_PASS_HDR_UNITS)[lane];
+    a = rw.offc; b = rw.dlc; c = rw.meta;
+  };
+  u32 off_c = next_pass();
+  fetch(off_c, hv, r_off, r_dl, r_meta);
+  while (off_c != SGTD_NO_PASS) {
+    const u32 off_n = next_pass();
+    fetch(off_n, hv_n, rn_off, rn_dl, rn_meta);          // in flight during this pass
+    PendingLoads pend;
+    pend.h = &hv_n; pend.a = &rn_off; pend.b = &rn_dl; pend.c = &rn_meta;
+    const u32 w0 = (u32)__builtin_amdgcn_readlane((int)hv, 0);
+    const u32 n = w0 & 0xFFu, kk = w0 >> 8;
+    auto pass = [&](auto k_tag) {
+      constexpr int KK = decltype(k_tag)::value;
+      PassView<KK> pv;
+      pv.n = n; pv.total = (u32)__builtin_amdgcn_readlane((int)hv, 1);
+#pragma unroll
+      for (int k = 0; k < KK; k++) {
+        pv.slot[k] = (u32)__builtin_amdgcn_readlane((int)hv, 2 + k);
+        pv.qframe[k] = (u32)__builtin_amdgcn_readlane((int)hv, 4 + k);
+        pv.q0f[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 6 + k));
+        pv.q1f[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 8 + k));
+        pv.q2f[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 10 + k));
+        pv.lo2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 12 + k));
+        pv.hi2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 14 + k));
+      }
+      const bool mine = (u32)lane <= n;
+      pv.offc = mine ? r_off : 0xFFFFFFFFu;
+      pv.dlc = r_dl;
+      pv.meta = mine ? r_meta : 0x300u;
+      sweep_pass<DIAG, WIDE, FRAMES, KK>(T, B, Q, rough, pv, s_bits[threadIdx.x >> 6], slab, pend);
     };
-    for (u32 i = 0; i < n;) {
-      // consecutive descriptors of one home cell are swept together, 4 or 2 at a time (one plan,
-      // one locate and one load per 64 entries for all of them); the diagnostic build takes them
-      // one by one
-      u32 run = 1;
-      if (!DIAG)
-        while (run < (u32)SGTD_PAIR && i + run < n &&
-               (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * (i + run) + 2)) == g_cur) run++;
-      const u32 step = run >= 2 ? 2u : 1u;
-      const uint4 row = row_next;
-      if (i + step < n) {   // the GroupRow after this step (often the same one)
-        const u32 g1 = (u32)__builtin_amdgcn_readlane((int)rec.z, (int)(4 * (i + step) + 2));
-        if (g1 != g_cur) row_next = load_row(g1);
-        g_cur = g1;
-      }
-      PendingLoads pend;
-      pend.row = &row_next;
-      pend.rec = &rec_next;
-      // a home cell none of whose 27 buckets exists in this table segment (common for the small
-      // tail segment of an appended map): nothing to plan or sweep
-      if (!__builtin_amdgcn_ballot_w64((row.x | row.y | row.z | row.w) != 0u)) {
-        pend.touch();
-        i += step;
-        continue;
-      }
-      auto pass = [&](auto k_tag) {
-        constexpr int KK = decltype(k_tag)::value;
-        DescSet<KK> f;
-        f.row = row;
-#pragma unroll
-        for (int k = 0; k < KK; k++) unpack(f, k, i + (u32)k);
-        DescResult res[KK];
-        sweep_descriptors<DIAG, WIDE, KK>(T, B, rough, f, plan_from_group_row<KK>(f, T.n_entries, T.coarse_at), s_bits[threadIdx.x >> 6], slab, res, pend);
-#pragma unroll
-        for (int k = 0; k < KK; k++)
-          if ((u32)lane == i + (u32)k) { r_ptr = res[k].ptr; r_visit = res[k].visit; r_match = res[k].match; }
-      };
-      if constexpr (!DIAG && SGTD_PAIR >= 2) { if (step == 2) pass(std::integral_constant<int, 2>{}); }
-      if (step == 1) pass(std::integral_constant<int, 1>{});
-      i += step;
-    }
-    {   // the chunk's results: lane i < n stores for its descriptor (slot d in quarter 2 of record i)
-      const u32 d_mine = (u32)__shfl((int)rec.w, (4 * lane + 2) & 63);
-      if ((u32)lane < n) {
-        B.list_ptr[d_mine] = r_ptr;
-        B.n_visit[d_mine] = r_visit;
-        B.n_match[d_mine] = r_match;
-      }
-    }
-    cur_c = nxt_c;
-    rec = rec_next;
+    if constexpr (!DIAG && SGTD_PAIR >= 2) { if (kk == 2) pass(std::integral_constant<int, 2>{}); }
+    if (kk == 1) pass(std::integral_constant<int, 1>{});
+    off_c = off_n;
+    hv = hv_n; r_off = rn_off; r_dl = rn_dl; r_meta = rn_meta;
   }
-  if (lane == 0 && slab.swept) atomicAdd(B.swept, (unsigned long long)slab.swept);
-#ifdef SGTD_EXP_PHASE
-  if (lane == 0) {
-    for (int i = 0; i < 6; i++) atomicAdd(&g_phase[i], slab.ph[i]);
-    atomicAdd(&g_phase[7], PH_T() - ph_start);
-    atomicAdd(&g_phase[6], 1ull);
-  }
-#endif
-#ifdef SGTD_EXP_TRACE
-  if (lane == 0) {
-    u64 *tr = reinterpret_cast<u64 *>(xcd_heads + 8 * 1024) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    tr[0] = tr_t0; tr[1] = tr_own; tr[2] = wall_clock64();
-    tr[3] = ((u64)tq.xcc << 56) | ((u64)tr_n_own << 28) | (u64)tr_n_st;
-  }
-#endif
+  if (lane == 0 && slab.swept) atomicAdd(B.swept(), (unsigned long long)slab.swept);
 }
 
 // The provisional records of the sweep, decided exactly (STDesc.cpp:374-378 in the squared,
 // comparison-exact form): a record whose entry does not match after all gets the frame
 // of no frame (SGTD_DEAD_ID: no vote, no candidate) and leaves the query's match count.
 __global__ void resolve_undecided_kernel(TableView T, QueryView Q, ProbeBuffers B, u32 *q_M) {
-  const u32 n = min(*B.amb_count, B.amb_cap);
+  const u32 n = min(*B.amb_count(), B.amb_cap);
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint2 it = B.amb_queue[i];
     const QueryRec &r = Q.qrec[it.y];
@@ -1005,7 +1077,8 @@ __device__ __forceinline__ u32 sub_open(const QueryView &Q, const ProbeBuffers &
   u32 n = 0, p = 0, v = 0;
   if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
     const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
-    n = B.n_match[d]; p = B.list_ptr[d]; v = B.n_visit[d];
+    const uint2 lp = B.list[d];
+    n = lp.y; p = lp.x; v = B.n_visit[d];
   }
   const u32 inc = wave_incl_scan(n);
   const u32 R = __shfl(inc, SGTD_WAVE - 1);
@@ -1040,7 +1113,8 @@ __device__ __forceinline__ u32 sub_open_quads(const QueryView &Q, const ProbeBuf
   u32 n = 0, p = 0, v = 0;
   if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
     const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
-    n = B.n_match[d]; p = B.list_ptr[d]; v = B.n_visit[d];
+    const uint2 lp = B.list[d];
+    n = lp.y; p = lp.x; v = B.n_visit[d];
   }
   const u32 nq = (n + 3u) >> 2;
   const u32 inc = wave_incl_scan(nq);
@@ -1155,7 +1229,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   __shared__ u32 s_pre[NW][32];
   __shared__ u32 s_ptr[NW][32];
   __shared__ u32 s_cnt[NW][32];
-  if (B.overflow[0]) return;
+  if (B.overflow()[0]) return;
   const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
   if (id.q >= Q.n_queries) return;   // workgroup-uniform: all 4 waves share the query
@@ -1204,7 +1278,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
   const int q = blockIdx.x;
   const u32 tile_lo = blockIdx.y * tile_span;
   const u32 n_bins = min(tile_span, frame_span - tile_lo);
-  const bool dead = B.overflow[0] != 0;     // the batch is re-run: leave zeros
+  const bool dead = B.overflow()[0] != 0;     // the batch is re-run: leave zeros
   for (u32 f = tid; f < n_bins; f += SGTD_VOTES_Q_THREADS) s_hist[f] = 0;
   if (tid == 0) { s_M = 0; s_P = 0; }
   __syncthreads();
@@ -1258,7 +1332,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   __shared__ u32 s_ptr[NW][32];
   __shared__ u32 s_hist[NW][64];
   __shared__ u64 s_cand[SGTD_CAND_HASH];
-  if (B.overflow[0]) return;
+  if (B.overflow()[0]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
   const int q = id.q;
@@ -1281,13 +1355,13 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   // room for the block's compact list: at most every record of the block
   u32 nm = 0;
   for (int sg = 0; sg < B.n_seg; sg++)
-    for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.n_match[(long long)sg * B.seg_stride + (long long)q * Q.stride + dd];
+    for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.list[(long long)sg * B.seg_stride + (long long)q * Q.stride + dd].y;
   const u32 r_blk = wave_sum(nm);
   u32 start = 0;
   if (lane == 0) start = atomicAdd(L.cursor, r_blk);
   start = (u32)__builtin_amdgcn_readfirstlane((int)start);
   const bool fits = (unsigned long long)start + r_blk <= (unsigned long long)L.cap;
-  if (!fits && lane == 0) B.overflow[0] = 1;     // sized like the record buffer: grown and re-run with it
+  if (!fits && lane == 0) B.overflow()[0] = 1;     // sized like the record buffer: grown and re-run with it
   s_hist[wid][lane] = 0;
   u32 visits = 0, total = 0, running = 0;
   // segment by segment: a candidate frame lives in one segment, so its matches still arrive in
@@ -1415,7 +1489,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   __shared__ u64 s_mask[NW][64];         // per wave and slot: lanes of the current word that carry the slot
   __shared__ u64 s_stage[NW][64][CAP + 1];   // per wave and slot: pairs waiting for a full-line store (rows padded by one
                                              // word: a 128-byte row stride put every slot's k-th pair on the same banks)
-  if (B.overflow[0] || B.overflow[1]) return;
+  if (B.overflow()[0] || B.overflow()[1]) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const BlockId id = assemble_block(Q.n_queries, blocks_per_query);
   if (!id.valid) return;
@@ -1519,7 +1593,7 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
     const long long d = (long long)q * Q.stride + i;
     u32 n = 0;
     if (i < cnt)
-      for (int sg = 0; sg < B.n_seg; sg++) n += B.n_match[(long long)sg * B.seg_stride + d];
+      for (int sg = 0; sg < B.n_seg; sg++) n += B.list[(long long)sg * B.seg_stride + d].y;
     u32 tot;
     const u32 ex = block_excl_scan(n, lds, tot);
     if (i < cnt) {
@@ -1528,7 +1602,8 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
         long long best = 0x7FFFFFFFFFFFFFFFll;
         u32 at = 0;
         for (int sg = 0; sg < B.n_seg; sg++) {
-          const u32 p0 = B.list_ptr[(long long)sg * B.seg_stride + d], m = B.n_match[(long long)sg * B.seg_stride + d];
+          const uint2 lp = B.list[(long long)sg * B.seg_stride + d];
+          const u32 p0 = lp.x, m = lp.y;
           for (u32 j = 0; j < m; j++) {
             const long long key = ((long long)B.rec_cell[p0 + j] << 32) | (long long)id_entry(map, B.rec[p0 + j]);
             if (key > last && key < best) { best = key; at = p0 + j; }

@@ -41,6 +41,7 @@ struct DescStore {
   }
 };
 
+constexpr size_t kCtrWords = 1024 + 8 * 1024;   // ProbeBuffers::ctr: counters + the sweep's ticket-queue heads
 enum { EV_START = 0, EV_BUILD, EV_SORT, EV_PROBE, EV_VOTES, EV_TOPK, EV_COUNT_T, EV_SCAN, EV_WRITE, EV_COUNT };
 
 }  // namespace
@@ -97,6 +98,7 @@ struct sgtd_engine {
 
   // ---- build scratch
   DevBuf kp_off_dev, xyz_dev, label_dev, ws_keys, ws_slots, cnt_scan;
+  DevBuf b_kp_off_dev, b_xyz_dev, b_label_dev;   // sgtd_build's own staging (never the pending batch's inputs)
   DescStore tmp;        // strided build output for map construction
   DescStore fetch;      // sgtd_fetch_entries staging
   DevBuf fetch_idx;
@@ -115,7 +117,7 @@ struct sgtd_engine {
   std::vector<long long> last_kp_off;
   int last_max_n = 0;
   u32 last_qframe = 0;  // current_frame_id_ when the batch was enqueued (a re-run stamps the same id)
-  DevBuf cursors, list_ptr, n_visit, n_match, votes, slot_of, overflow;
+  DevBuf cursors, list, n_visit, votes, slot_of;   // cursors: the batch's counters, overflow flags and ticket heads (ProbeBuffers::ctr)
   DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
   DevBuf c_pair, c_blk;           // compact candidate-match lists between block_count and block_write
   DevBuf amb_queue;               // provisional records awaiting the exact test
@@ -126,7 +128,9 @@ struct sgtd_engine {
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   bool rec_cap_fixed = false;          // SGTD_REC_CAP given: no pre-sizing from the table statistics
   size_t pair_cap = (size_t)1 << 24;   // candidate pairs (grown on overflow)
-  DevBuf n_valid, xcd_heads, cell_rows, gid, q_prefix, group_first, n_groups, sdesc;
+  DevBuf n_valid, cell_rows, gid, q_prefix, group_first, n_groups;
+  DevBuf pos_of_slot, rec_off, pass_pool;   // pass slots and records (probe_kernels.hip.h)
+  size_t pool_units = 0;                    // pass pool capacity in 16-B units (0: sized by the first batch; grown on overflow)
   int sorted_chunk = 0;                // > 0: fixed descriptors per ticket (SGTD_SORTED_CHUNK), else adaptive
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
   // host copies after sync
@@ -275,9 +279,14 @@ int launch_build(sgtd_engine *e, const float *d_xyz, const u32 *d_label, const l
 }
 
 // uploads keypoints (or takes device pointers) and the offsets; returns views
+// own_set: sgtd_build stages into buffers of its own — a synced query batch may still be re-run
+// from the batch's staging buffers (sgtd_result_rough's diagnostic pass)
 int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64_t *kp_off,
                  int n_frames, int device_ptrs, const float **d_xyz, const u32 **d_label,
-                 int *max_n) {
+                 int *max_n, bool own_set = false) {
+  DevBuf &kp_buf = own_set ? e->b_kp_off_dev : e->kp_off_dev;
+  DevBuf &xyz_buf = own_set ? e->b_xyz_dev : e->xyz_dev;
+  DevBuf &label_buf = own_set ? e->b_label_dev : e->label_dev;
   std::vector<long long> off(n_frames + 1);
   int mx = 0;
   for (int f = 0; f <= n_frames; f++) off[f] = kp_off[f];
@@ -287,8 +296,8 @@ int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64
     mx = std::max(mx, (int)n);
   }
   *max_n = mx;
-  CHK(ensure(e, e->kp_off_dev, (size_t)(n_frames + 1) * sizeof(long long)));
-  HIPCHK(hipMemcpyAsync(e->kp_off_dev.p, off.data(), (size_t)(n_frames + 1) * sizeof(long long),
+  CHK(ensure(e, kp_buf, (size_t)(n_frames + 1) * sizeof(long long)));
+  HIPCHK(hipMemcpyAsync(kp_buf.p, off.data(), (size_t)(n_frames + 1) * sizeof(long long),
                         hipMemcpyHostToDevice, e->stream));
   // the staging vector dies at return: make the copy complete first
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -297,16 +306,16 @@ int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64
     *d_xyz = xyz;
     *d_label = label;
   } else {
-    CHK(ensure(e, e->xyz_dev, (size_t)std::max<long long>(total + off[0], 1) * 3 * sizeof(float)));
-    CHK(ensure(e, e->label_dev, (size_t)std::max<long long>(total + off[0], 1) * sizeof(u32)));
+    CHK(ensure(e, xyz_buf, (size_t)std::max<long long>(total + off[0], 1) * 3 * sizeof(float)));
+    CHK(ensure(e, label_buf, (size_t)std::max<long long>(total + off[0], 1) * sizeof(u32)));
     if (total > 0) {
-      HIPCHK(hipMemcpyAsync(e->xyz_dev.as<float>() + off[0] * 3, xyz + off[0] * 3,
+      HIPCHK(hipMemcpyAsync(xyz_buf.as<float>() + off[0] * 3, xyz + off[0] * 3,
                             (size_t)total * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipMemcpyAsync(e->label_dev.as<u32>() + off[0], label + off[0], (size_t)total * sizeof(u32),
+      HIPCHK(hipMemcpyAsync(label_buf.as<u32>() + off[0], label + off[0], (size_t)total * sizeof(u32),
                             hipMemcpyHostToDevice, e->stream));
     }
-    *d_xyz = e->xyz_dev.as<float>();
-    *d_label = e->label_dev.as<u32>();
+    *d_xyz = xyz_buf.as<float>();
+    *d_label = label_buf.as<u32>();
   }
   return SGTD_OK;
 }
@@ -638,14 +647,12 @@ Views make_views(sgtd_engine *e, int sgi = 0) {
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
   B.rec = e->rec.as<u32>(); B.id_bits = e->id_bits ? e->id_bits : 13;
-  B.rec_cursor = e->cursors.as<unsigned long long>();
-  B.rec_need = e->cursors.as<unsigned long long>() + 2;
-  B.swept = e->cursors.as<unsigned long long>() + 3;
-  B.amb_queue = e->amb_queue.as<uint2>(); B.amb_count = e->cursors.as<u32>() + 2;
+  B.ctr = e->cursors.as<u32>();
+  B.amb_queue = e->amb_queue.as<uint2>();
   B.amb_cap = (u32)std::min<size_t>(e->amb_queue.bytes / sizeof(uint2), 0xFFFFFFF0u);
-  B.list_ptr = e->list_ptr.as<u32>(); B.n_visit = e->n_visit.as<u32>(); B.n_match = e->n_match.as<u32>();
+  B.list = e->list.as<uint2>(); B.n_visit = e->n_visit.as<u32>();
   B.seg_stride = (long long)e->nq * e->q_stride; B.n_seg = e->n_seg;
-  B.votes = e->votes.as<u32>(); B.overflow = e->overflow.as<int>();
+  B.votes = e->votes.as<u32>();
   v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   return v;
 }
@@ -656,11 +663,9 @@ int launch_select(sgtd_engine *e) {
   const int cn = e->dc.cand_num;
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
-  CHK(ensure(e, e->cursors, 8 * sizeof(u32)));
-  CHK(ensure(e, e->overflow, 2 * sizeof(int)));
-  CHK(ensure(e, e->list_ptr, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(u32)));
+  CHK(ensure(e, e->cursors, kCtrWords * sizeof(u32)));
+  CHK(ensure(e, e->list, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(uint2)));
   CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(u32)));
-  CHK(ensure(e, e->n_match, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(u32)));
   CHK(ensure(e, e->votes, (size_t)nq * span * sizeof(u32)));
   CHK(ensure(e, e->slot_of, (size_t)nq * span));
   CHK(ensure(e, e->q_M, (size_t)nq * sizeof(u32)));
@@ -675,8 +680,7 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->pair_off, (size_t)nq * (cn + 1) * sizeof(long long)));
   CHK(rec_alloc(e));
 
-  HIPCHK(hipMemsetAsync(e->cursors.p, 0, 8 * sizeof(u32), e->stream));
-  HIPCHK(hipMemsetAsync(e->overflow.p, 0, 2 * sizeof(int), e->stream));
+  HIPCHK(hipMemsetAsync(e->cursors.p, 0, kCtrWords * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
   HIPCHK(hipMemsetAsync(e->cand_frame.p, 0xFF, (size_t)nq * cn * sizeof(int), e->stream));
@@ -702,11 +706,6 @@ int launch_select(sgtd_engine *e) {
     CHK(ensure(e, e->valB, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->gid, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->n_valid, sizeof(u32)));
-#ifdef SGTD_EXP_TRACE
-    CHK(ensure(e, e->xcd_heads, 8 * 1024 * sizeof(u32) + (size_t)e->n_cus * 8 * 4 * 32));
-#else
-    CHK(ensure(e, e->xcd_heads, 8 * 1024 * sizeof(u32)));
-#endif
     u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
     u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
     // bits per cell coordinate of the sort key: the largest cell a built descriptor can have
@@ -716,121 +715,86 @@ int launch_select(sgtd_engine *e) {
     CHK(ensure(e, e->q_prefix, (size_t)nq * sizeof(u32)));
     CHK(ensure(e, e->group_first, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->n_groups, sizeof(u32)));
+    // pass slots: at most one per group and one per two descriptors (probe_kernels.hip.h)
+    const bool pair = !e->diag && SGTD_PAIR >= 2;
+    const size_t max_pass_slots = (size_t)pass_slot_count((u32)n_slots, (u32)n_slots, pair) + 64;
+    CHK(ensure(e, e->pos_of_slot, max_pass_slots * sizeof(u32)));
+    CHK(ensure(e, e->rec_off, max_pass_slots * sizeof(u32)));
+    if (e->pool_units == 0) e->pool_units = std::max<size_t>(65536, (size_t)n_slots * 10);   // 160 B per descriptor slot, grown on overflow
+    CHK(ensure(e, e->pass_pool, (e->pool_units + SGTD_PASS_SLACK_UNITS) * sizeof(uint4)));
     const u32 *nv = e->n_valid.as<u32>();
     query_prefix_kernel<<<1, 256, 0, e->stream>>>(e->q_count.as<u32>(), e->q_prefix.as<u32>(), nq, e->n_valid.as<u32>());
     HIPCHK(hipGetLastError());
     home_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), kin, vin, n_slots, cbits);
     HIPCHK(hipGetLastError());
     CHK(radix_sort_pairs(e, kin, kout, vin, vout, n_slots, key_bits, false, nv));   // only the n_valid compact elements are live
-    HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * 1024 * sizeof(u32), e->stream));
     group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits);
     HIPCHK(hipGetLastError());
     CHK(device_scan(e, e->gid.as<u32>(), e->gid.as<u32>(), n_slots));
-    CHK(ensure(e, e->sdesc, (size_t)n_slots * sizeof(QueryRec)));
-    sorted_desc_kernel<<<grid_for(n_slots * 4, 256), 256, 0, e->stream>>>(v.Q, vin, e->gid.as<u32>(), nv, e->sdesc.as<QueryRec>(),
-                                                                        e->group_first.as<u32>(), e->n_groups.as<u32>(), n_slots);
+    group_first_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), nv, e->group_first.as<u32>(),
+                                                                        e->n_groups.as<u32>(), n_slots);
     HIPCHK(hipGetLastError());
-    // descriptors per wave ticket: about 3k entry visits, from the visits per descriptor the
-    // previous batch measured (4 until there is one; F = 10 k: tickets of 2 / 4 / 8 / 16
-    // descriptors sweep in 9.0 / 7.8 / 7.5 / 7.5 ms); SGTD_SORTED_CHUNK overrides
-    u32 chunk = 4;
+    HIPCHK(hipMemsetAsync(e->pos_of_slot.p, 0xFF, max_pass_slots * sizeof(u32), e->stream));
+    pass_slots_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), e->group_first.as<u32>(), nv,
+                                                                       e->pos_of_slot.as<u32>(), n_slots, pair ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    // pass slots per wave ticket: about 3k entry visits, from the visits per descriptor the
+    // previous batch measured (2 until there is one); SGTD_SORTED_CHUNK overrides
+    u32 chunk = 2;
     if (e->stats.last_D > 0 && e->stats.last_P_swept > 0) {
-      const double per_desc = (double)e->stats.last_P_swept / (double)e->stats.last_D;
-      chunk = (u32)std::min(8.0, std::max(1.0, std::floor(3072.0 / per_desc + 0.5)));
-      // descriptors of a home cell are swept together up to SGTD_PAIR at a time: a ticket must
-      // hold whole runs
-      chunk = std::max<u32>(chunk, SGTD_PAIR);
-      chunk = (chunk + SGTD_PAIR - 1) / SGTD_PAIR * SGTD_PAIR;
+      // last_P_swept counts a pair's shared list once: visits per pass ~ P_swept / (D / 1.9)
+      const double per_pass = (double)e->stats.last_P_swept / ((double)e->stats.last_D / (pair ? 1.9 : 1.0));
+      chunk = (u32)std::min(8.0, std::max(1.0, std::floor(3072.0 / per_pass + 0.5)));
     }
     if (e->sorted_chunk > 0) chunk = (u32)std::min(SGTD_TICKET_MAX, e->sorted_chunk);
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
-    const int sgrid = e->n_cus * 8;
+    int sgrid = e->n_cus * 8;
+    if (const char *o = getenv("SGTD_SWEEP_BLOCKS_PER_CU")) sgrid = e->n_cus * std::max(1, atoi(o));   // experiment knob
+    PassPool PP;
+    PP.pool = e->pass_pool.as<uint4>(); PP.rec_off = e->rec_off.as<u32>();
+    PP.cursor = v.B.pool_cursor(); PP.cap = (u32)std::min<size_t>(e->pool_units, 0xFFFFFF00u);
     for (int sg = 0; sg < e->n_seg; sg++) {
-      // one GroupRow per home cell against this segment's directory, then its sweep; the
-      // descriptors' lists from segment sg are recorded in part sg of list_ptr / n_visit / n_match
+      // one GroupRow per home cell against this segment's directory, the passes' visit lists
+      // from it, then the sweep; the descriptors' lists from segment sg are recorded in part sg
+      // of list / n_visit (the pass pool takes the records of all segments, one after the other)
       Views vs = make_views(e, sg);
-      vs.B.list_ptr += (size_t)sg * n_slots; vs.B.n_visit += (size_t)sg * n_slots; vs.B.n_match += (size_t)sg * n_slots;
+      vs.B.list += (size_t)sg * n_slots; vs.B.n_visit += (size_t)sg * n_slots;
       if (sg > 0) {
-        HIPCHK(hipMemsetAsync(e->xcd_heads.p, 0, 8 * 1024 * sizeof(u32), e->stream));
-        HIPCHK(hipMemsetAsync(e->cursors.as<u32>() + 2, 0, sizeof(u32), e->stream));   // the undecided-record queue
+        HIPCHK(hipMemsetAsync(vs.B.xcd_heads(), 0, 8 * 1024 * sizeof(u32), e->stream));
+        HIPCHK(hipMemsetAsync(vs.B.amb_count(), 0, sizeof(u32), e->stream));   // the undecided-record queue
       }
       group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->group_first.as<u32>(),
                                                                   e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>());
+      HIPCHK(hipGetLastError());
+      const int pgrid = grid_for((long long)max_pass_slots, 256);
+#define SGTD_LAUNCH_PLAN(PR)                                                                                   \
+  plan_passes_kernel<PR><<<pgrid, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->gid.as<u32>(), e->pos_of_slot.as<u32>(), nv, \
+                                                       e->n_groups.as<u32>(), rows, PP, vs.B.n_visit, vs.B.list,          \
+                                                       vs.B.overflow())
+      if (pair) SGTD_LAUNCH_PLAN(true); else SGTD_LAUNCH_PLAN(false);
+#undef SGTD_LAUNCH_PLAN
       HIPCHK(hipGetLastError());
       if (sg == 0 && e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));   // ms_probe = the sweep(s) from here
       // 32-bit byte offsets into the probe layout while it stays below 4 GB (record addresses
       // are a wave-uniform base + a 32-bit lane offset either way)
       const bool narrow = ((unsigned long long)vs.T.n_entries + SGTD_SENTINELS) * sizeof(HotEntry) < (1ull << 32);
-#define SGTD_LAUNCH_SORTED(DG, WD)                                                                              \
-  probe_sorted_kernel<DG, WD><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                     \
-      vs.T, vs.B, rows, e->sdesc.as<QueryRec>(), e->dc.rough, e->n_valid.as<u32>(), e->xcd_heads.as<u32>(), chunk)
-      if (e->diag) SGTD_LAUNCH_SORTED(true, true);
-      else if (narrow) SGTD_LAUNCH_SORTED(false, false);
-      else SGTD_LAUNCH_SORTED(false, true);
+      // can a descriptor of the batch carry a frame id the table holds?  Frames built by
+      // sgtd_query_frames are stamped with the current frame id (one beyond the newest map frame
+      // in the reference's use); descriptors handed in by the caller carry whatever they carry
+      const bool frames = e->last_kind != 1 || (e->have_frames && e->last_qframe >= e->frame_lo && e->last_qframe <= e->frame_hi);
+#define SGTD_LAUNCH_SORTED(DG, WD, FR)                                                                          \
+  probe_sorted_kernel<DG, WD, FR><<<sgrid, SGTD_PROBE_THREADS, 0, e->stream>>>(                                 \
+      vs.T, vs.B, vs.Q, PP, e->dc.rough, e->n_valid.as<u32>(), e->n_groups.as<u32>(), chunk)
+      if (e->diag) SGTD_LAUNCH_SORTED(true, true, true);
+      else if (narrow && frames) SGTD_LAUNCH_SORTED(false, false, true);
+      else if (narrow) SGTD_LAUNCH_SORTED(false, false, false);
+      else if (frames) SGTD_LAUNCH_SORTED(false, true, true);
+      else SGTD_LAUNCH_SORTED(false, true, false);
 #undef SGTD_LAUNCH_SORTED
       HIPCHK(hipGetLastError());
       resolve_undecided_kernel<<<64, 256, 0, e->stream>>>(vs.T, vs.Q, vs.B, e->q_M.as<u32>());
       HIPCHK(hipGetLastError());
     }
-#ifdef SGTD_EXP_PHASE
-    {
-      static int bcalls = 0;
-      if (++bcalls == 6) {
-        HIPCHK(hipStreamSynchronize(e->stream));
-        unsigned long long bp[8];
-        HIPCHK(hipMemcpyFromSymbol(bp, HIP_SYMBOL(g_bphase), sizeof(bp)));
-        const double tot = (double)(bp[0] + bp[1] + bp[2] + bp[3] + bp[4]);
-        fprintf(stderr, "BPHASE: load %.3f knn %.3f keys %.3f dedup+prefix %.3f fill %.3f\n", bp[0] / tot, bp[1] / tot, bp[2] / tot, bp[3] / tot, bp[4] / tot);
-      }
-    }
-    {
-      static int pcalls = 0;
-      if (++pcalls == 6) {
-        HIPCHK(hipStreamSynchronize(e->stream));
-        unsigned long long ph[8];
-        HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)));
-        unsigned long long wd[2];
-        HIPCHK(hipMemcpyFromSymbol(wd, HIP_SYMBOL(g_words), sizeof(wd)));
-        fprintf(stderr, "WORDS: %llu words in %llu load groups of %d: %.1f%% of the slots filled\n", wd[0], wd[1], SGTD_PROBE_UNROLL,
-                100.0 * (double)wd[0] / ((double)wd[1] * SGTD_PROBE_UNROLL));
-        const double tot = (double)ph[7];
-        fprintf(stderr, "PHASE: slab %.3f (unused %.3f) locate+issue %.3f wait %.3f compute %.3f tail %.3f outer %.3f (fractions of wave life)\n",
-                ph[0] / tot, ph[5] / tot, ph[1] / tot, ph[2] / tot, ph[3] / tot, ph[4] / tot,
-                (tot - ph[0] - ph[1] - ph[2] - ph[3] - ph[4] - ph[5]) / tot);
-      }
-    }
-#endif
-#ifdef SGTD_EXP_TRACE
-    {
-      static int calls = 0;
-      if (++calls == 3) {
-        HIPCHK(hipStreamSynchronize(e->stream));
-        const size_t nw = (size_t)sgrid * 4;
-        std::vector<u64> tr(nw * 4);
-        HIPCHK(hipMemcpy(tr.data(), (char *)e->xcd_heads.p + 8 * 1024 * sizeof(u32), nw * 32, hipMemcpyDeviceToHost));
-        u64 t0 = ~0ull, t1 = 0;
-        for (size_t w = 0; w < nw; w++) { t0 = std::min(t0, tr[w * 4]); t1 = std::max(t1, tr[w * 4 + 2]); }
-        fprintf(stderr, "TRACE kernel span %.1f us (100 MHz ticks), chunk %u\n", (t1 - t0) / 100.0, chunk);
-        for (int x = 0; x < 8; x++) {
-          double own_max = 0, own_min = 1e30, end_max = 0, end_min = 1e30, start_max = 0; u64 n_own = 0, n_st = 0; int cnt = 0, late = 0;
-          double busy = 0;
-          for (size_t w = 0; w < nw; w++) {
-            if ((int)(tr[w * 4 + 3] >> 56) != x) continue;
-            cnt++;
-            const double s = (tr[w * 4] - t0) / 100.0, o = (tr[w * 4 + 1] - t0) / 100.0, en = (tr[w * 4 + 2] - t0) / 100.0;
-            if (s > 100.0) late++;
-            start_max = std::max(start_max, s);
-            if (s <= 100.0) { own_max = std::max(own_max, o); own_min = std::min(own_min, o); }
-            end_max = std::max(end_max, en); end_min = std::min(end_min, en);
-            n_own += (tr[w * 4 + 3] >> 28) & 0xFFFFFFF; n_st += tr[w * 4 + 3] & 0xFFFFFFF;
-            busy += en - s;
-          }
-          fprintf(stderr, "  xcd %d: waves %d (late %d, last start %.0f us) own-queue done %.0f..%.0f us, end %.0f..%.0f us, descs own %llu stolen %llu, mean wave life %.0f us\n",
-                  x, cnt, late, start_max, own_min, own_max, end_min, end_max, (unsigned long long)n_own, (unsigned long long)n_st, busy / std::max(cnt, 1));
-        }
-      }
-    }
-#endif
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
     // one 16-wave workgroup per (query, frame tile) when that fills the chip: the tile's LDS
@@ -863,7 +827,7 @@ int launch_select(sgtd_engine *e) {
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
-  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
+  CL.cursor = v.B.compact_cursor(); CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
   if (span <= 48 * 1024) {
     const int sl_bytes = (int)((span + 15) & ~15u);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_count_kernel<true>),
@@ -880,10 +844,10 @@ int launch_select(sgtd_engine *e) {
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
   block_scan_kernel<<<nq, 64, 0, e->stream>>>(e->blk_count.as<u32>(), blocks, cn, e->n_cand.as<int>(),
                                                e->pair_off.as<long long>(), e->q_pairs.as<u32>(),
-                                               e->overflow.as<int>());
+                                               v.B.overflow());
   HIPCHK(hipGetLastError());
   query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
-                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
+                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
   block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL,
@@ -922,14 +886,14 @@ int rerun_write(sgtd_engine *e) {
   const int groups = (blocks + 3) / 4;
   const int agrid = ((nq + 7) / 8) * groups * 8;
   CHK(ensure(e, e->pairs, e->pair_cap * sizeof(u64)));
-  HIPCHK(hipMemsetAsync(e->overflow.as<int>() + 1, 0, sizeof(int), e->stream));
   Views v = make_views(e);
+  HIPCHK(hipMemsetAsync(v.B.overflow() + 1, 0, sizeof(int), e->stream));
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
-  CL.cursor = e->cursors.as<u32>() + 3; CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
+  CL.cursor = v.B.compact_cursor(); CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
   query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
-                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), e->overflow.as<int>());
+                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
   HIPCHK(hipGetLastError());
   block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL, blocks, e->blk_count.as<u32>(), cn,
                                                     e->pair_off.as<long long>(), e->q_pair_base.as<u32>(), e->pairs.as<u64>(), v.T.map);
@@ -946,13 +910,13 @@ int sync_batch(sgtd_engine *e) {
     int ovf[2] = {0, 0};
     unsigned long long cursor = 0, need = 0;
     swept = 0;
-    u32 total = 0;
-    HIPCHK(hipMemcpyAsync(ovf, e->overflow.p, sizeof(ovf), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&cursor, e->cursors.p, sizeof(cursor), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&need, e->cursors.as<unsigned long long>() + 2, sizeof(need), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&swept, e->cursors.as<unsigned long long>() + 3, sizeof(swept), hipMemcpyDeviceToHost, e->stream));
+    u32 total = 0, pool_used = 0;
+    u32 ctr[12];     // ProbeBuffers::ctr, one copy
+    HIPCHK(hipMemcpyAsync(ctr, e->cursors.p, sizeof(ctr), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    std::memcpy(&cursor, ctr, 8); std::memcpy(&need, ctr + 4, 8); std::memcpy(&swept, ctr + 6, 8);
+    pool_used = ctr[8]; ovf[0] = (int)ctr[10]; ovf[1] = (int)ctr[11];
     if (!ovf[0] && !ovf[1]) {
       // slab use varies a little from run to run (which wave sweeps what): when a batch comes within
       // a tenth of the capacity, make room for half as much again (reallocated at the next launch)
@@ -964,7 +928,11 @@ int sync_batch(sgtd_engine *e) {
     if (attempt == 7) return SGTD_ERR_CAPACITY;
     // grow towards the u32 index limit; a batch that does not fit even there must be split
     const size_t lim = 0xFFFFFFF0ull;
-    if (ovf[0]) {
+    if (ovf[0] && (size_t)pool_used > e->pool_units) {
+      // the pass records did not fit (the cursor kept counting: pool_used is what the batch needs)
+      if (e->pool_units >= 0xFFFFFF00ull) return SGTD_ERR_CAPACITY;
+      e->pool_units = std::min<size_t>(0xFFFFFF00ull, (size_t)pool_used + (size_t)pool_used / 4 + 65536);
+    } else if (ovf[0]) {
       if (e->rec_cap >= lim) return SGTD_ERR_CAPACITY;
       // what was stored fits rec_cap, `need` matches did not; slabs leave about an eighth unused,
       // every wave strands part of its last slab
@@ -1144,6 +1112,10 @@ const char *sgtd_strerror(int status) {
 
 const char *sgtd_last_error(sgtd_handle h) { return h ? h->err.c_str() : ""; }
 
+uint32_t sgtd_label_code(int a, int b, int c) { return label_code(a, b, c); }
+uint64_t sgtd_table_key(uint32_t code, uint32_t x, uint32_t y, uint32_t z) { return pack_key(code, x, y, z); }
+uint64_t sgtd_dedup_key(uint64_t mx, uint64_t my, uint64_t mz) { return pack_milli_key(mx, my, mz); }
+
 int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (!cfg || !out) return SGTD_ERR_INVALID;
   *out = nullptr;
@@ -1206,9 +1178,9 @@ int sgtd_destroy(sgtd_handle e) {
   DevBuf *bufs[] = {&e->seg[0].hot, &e->seg[0].perm, &e->seg[0].hash, &e->seg[0].bucket_start, &e->seg[0].bucket_key, &e->seg[0].dir,
                     &e->seg[1].hot, &e->seg[1].perm, &e->seg[1].hash, &e->seg[1].bucket_start, &e->seg[1].bucket_key, &e->seg[1].dir, &e->slice_of, &e->sq_sum,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
-                    &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->n_valid, &e->xcd_heads, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->sdesc, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list_ptr, &e->n_visit,
-                    &e->n_match, &e->votes, &e->slot_of, &e->overflow, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
+                    &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->b_kp_off_dev, &e->b_xyz_dev, &e->b_label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->pos_of_slot, &e->rec_off, &e->pass_pool, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list, &e->n_visit,
+                    &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
                     &e->cand_votes, &e->pair_off, &e->pairs};
@@ -1257,11 +1229,11 @@ int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sg
   CHK(settle_pending(e));
   int64_t off[2] = {0, n};
   const float *dx; const u32 *dl; int max_n;
-  CHK(stage_inputs(e, xyz, label, off, 1, 0, &dx, &dl, &max_n));
+  CHK(stage_inputs(e, xyz, label, off, 1, 0, &dx, &dl, &max_n, /*own_set=*/true));
   const long long stride = (long long)n * e->dc.tpi;
   CHK(ensure_store(e, e->tmp, (size_t)std::max<long long>(stride, 1)));
   CHK(ensure(e, e->tmp_count, sizeof(u32)));
-  CHK(launch_build(e, dx, dl, e->kp_off_dev.as<long long>(), 1, max_n, e->current_frame_id, 0,
+  CHK(launch_build(e, dx, dl, e->b_kp_off_dev.as<long long>(), 1, max_n, e->current_frame_id, 0,
                    e->tmp.view(), stride, e->tmp_count.as<u32>()));
   u32 cnt = 0;
   HIPCHK(hipMemcpyAsync(&cnt, e->tmp_count.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));

@@ -30,13 +30,24 @@ def test_two_rank_bench_shards_and_replicas_agree():
     if torch.cuda.device_count() < 2:
         env.update(SGTD_BENCH_BACKEND="gloo", SGTD_BENCH_SHARE_GPU="1")
     two = _bench(["--gpus", "2"], env)
-    assert two["n_gpus"] == 2 and two["config"]["ranks_in_collective"] == 2
-    assert two["scaling"] == "weak" and two["config"]["queries_per_step"] == 48
-    assert len(two["config"]["table_entries_per_rank"]) == 2
-    ts = two["table_sharded"]
-    assert ts["ranks_in_collective"] == 2 and ts["merged_list_equals_replicated_map"] is True
-    assert sum(ts["table_entries_per_rank"]) == two["config"]["table_entries_per_rank"][0]   # shards add up to the replica
+    # the headline for N > 1 is the form the north_star names: the map's table sharded by frame range,
+    # the same Q queries on every rank, all_gather + merge of the per-shard top-50 (strong scaling)
+    cfg = two["config"]
+    assert two["n_gpus"] == 2 and cfg["ranks_in_collective"] == 2 and cfg["mode"] == "table"
+    assert two["scaling"] == "strong" and cfg["queries_per_step"] == 24
+    assert len(cfg["table_entries_per_rank"]) == 2
+    assert cfg["collective_backend"] == ("gloo" if "SGTD_BENCH_BACKEND" in env else "nccl")
+    assert ("NOT RCCL" in cfg["sharding"]) == (cfg["collective_backend"] == "gloo")      # the line says what really ran
+    assert two["merged_list_equals_single_table"] is True
+    rp = two["replicated"]        # beside it: every rank a full replica, 24 queries each (weak scaling)
+    assert rp["ranks_in_collective"] == 2 and rp["scaling"] == "weak" and rp["queries_per_step"] == 48
+    assert rp["equals_table_sharded_list"] is True
+    assert sum(cfg["table_entries_per_rank"]) == rp["table_entries_per_rank"][0]   # shards add up to the replica
     one = _bench(["--gpus", "1", "--queries", "48"], dict(os.environ))
-    assert one["n_gpus"] == 1 and one["recall"] == two["recall"]      # same 48 queries, same answers
-    tbl = _bench(["--gpus", "2", "--shard", "table"], env)
-    assert tbl["scaling"] == "strong" and tbl["config"]["queries_per_step"] == 24
+    assert one["n_gpus"] == 1 and one["recall"] == rp["recall"]      # same 48 queries, same answers
+    qm = _bench(["--gpus", "2", "--shard", "query"], env)
+    assert qm["scaling"] == "weak" and qm["config"]["queries_per_step"] == 48 and qm["recall"] == one["recall"]
+    assert qm["table_sharded"]["merged_list_equals_single_table"] is True and qm["merged_list_equals_single_table"] is True
+    if torch.cuda.device_count() >= 2:     # one process over both devices (sgtd_create_multi)
+        mh = two["multi_device_handle"]
+        assert mh["devices"] == 2 and mh["candidates_equal_headline_list"] is True
