@@ -108,9 +108,6 @@ struct ProbeBuffers {
 #ifndef SGTD_WRITE_WORDS
 #define SGTD_WRITE_WORDS 2       // 64-pair words of the compact list in flight per wave in block_write
 #endif
-#ifndef SGTD_PROBE_UNROLL
-#define SGTD_PROBE_UNROLL 4     // 64-entry words whose loads are in flight together
-#endif
 
 // Loads that were issued before a pass's sweep and are first used after it (the next pass's
 // ranges): the sweep "touches" them once its first load group has returned — vector loads
@@ -131,10 +128,22 @@ struct PendingLoads {
 static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2, "the pair sweep computes both distances with packed f32 math");
 
 struct WaveSlab {
+  u32 start[SGTD_PAIR];                  // first record of the stream's slab
   u32 next[SGTD_PAIR], end[SGTD_PAIR];   // this wave's private ranges of match records: one bump stream per
                                          // descriptor of a pair, so that every descriptor's list stays contiguous
   u64 swept;                             // entries this wave loaded
+#ifdef SGTD_EXP_PHASE
+  u64 ph[8], t;                          // experiment build: cycles per phase of the wave's life
+#endif
 };
+#ifdef SGTD_EXP_PHASE
+// Experiment build (never shipped): in-kernel phase clocks of the sweep, summed over the waves
+// and printed by the host after a few launches.
+__device__ unsigned long long g_phase[8];
+#define PH_ADD(i) do { const u64 _n = __builtin_readcyclecounter(); slab.ph[i] += _n - slab.t; slab.t = _n; } while (0)
+#else
+#define PH_ADD(i) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // sweep: the batch's descriptors are visited in the order of a locality key
@@ -351,7 +360,9 @@ __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int 
 // group_resolve_kernel left behind the rows).  n_visit / list point at this table segment's
 // part; a pass without a single entry to visit gets no record and its (empty) results are
 // written here.
+#ifndef SGTD_PLAN_GROUPS
 #define SGTD_PLAN_GROUPS 12
+#endif
 #define SGTD_ROW_QUADS (2 * SGTD_NCELL + 1)     // 16-B quarters of one GroupRow: 27 rows + the masks
 template <bool PAIR>
 __global__ __launch_bounds__(256) void plan_passes_kernel(TableView T, QueryView Q, const u32 *order, const u32 *gid,
@@ -574,8 +585,8 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
       u64 got = 0;
       if (lane == 0) got = atomicAdd(B.rec_cursor(), (unsigned long long)take);
       got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
-      if (got + take <= (u64)B.rec_cap) { slab.next[k] = (u32)got; slab.end[k] = (u32)got + take; }
-      else { slab.next[k] = 0; slab.end[k] = 0; }      // the buffer is exhausted: nothing of this stream fits any more
+      if (got + take <= (u64)B.rec_cap) { slab.start[k] = (u32)got; slab.next[k] = (u32)got; slab.end[k] = (u32)got + take; }
+      else { slab.start[k] = 0; slab.next[k] = 0; slab.end[k] = 0; }   // the buffer is exhausted: nothing of this stream fits any more
     }
     fits = fits && ((u64)slab.next[k] + total <= (u64)slab.end[k]);
   }
@@ -583,11 +594,13 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   __builtin_amdgcn_wave_barrier();
 
   u32 matches[K];
-  u32 *list[K];   // wave-uniform
+  char *slab_base[K];   // wave-uniform: the slab's first record; record r of the slab is at byte 4 r
+  u32 rel[K];           // the descriptor's list starts at record rel of its slab
 #pragma unroll
   for (int k = 0; k < K; k++) {
     matches[k] = 0;
-    list[k] = B.rec + slab.next[k];
+    slab_base[k] = reinterpret_cast<char *>(B.rec + slab.start[k]);
+    rel[k] = slab.next[k] - slab.start[k];
   }
   const u32 n_words = (total + 63u) >> 6;
   slab.swept += total;
@@ -598,9 +611,6 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   // the per-lane offsets + popcount, scalar) plus the marks of positions 64 w + 1 .. 64 w + l
   // (v_mbcnt over the window word) — one LDS read and one ds_bpermute per 64 entries (three for
   // a pair: the two gate penalties), whatever the number of ranges.
-  // one load group: NW words located, their loads issued back to back, then tested.  NW is a
-  // compile-time count: each group size is straight-line code (branches around loads would
-  // make the compiler wait for earlier loads before every later one).
   const bool marks = (u32)lane <= pv.n && pv.offc != 0u;
   auto window = [&](u32 w_first) {     // w_first: a multiple of 64 words
     bits[lane] = 0;
@@ -608,17 +618,19 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     if (marks && wr < 64u) atomicOr(reinterpret_cast<unsigned long long *>(bits + wr), 1ull << ((pv.offc - 1u) & 63u));
     __builtin_amdgcn_wave_barrier();
   };
-  auto group = [&](auto nw_tag, u32 w0) {
-    constexpr int NW = decltype(nw_tag)::value;
-    float4 v[NW];
-    u32 cellv[NW];    // cell (0..26) of the lane's entry (diagnostic sweep)
-    f32x2 pen[NW];    // pair: 0 / +inf per descriptor (the entry's cell passes its gate or not)
-    bool valid[NW];   // diagnostic sweep (the exact test reads the cold table, not the sentinel's sides)
-    const u64 *bits_w = bits + (w0 & 63u);      // (a group never straddles the window: w0 is a multiple of its size)
+  // one load group = NW consecutive words: located and their loads issued back to back (issue),
+  // tested later (tests).  NW is a compile-time count: straight-line code.
+  //   v      s0, s1, s2 (f32), id of the lane's entry per word
+  //   pen    pair: 0 / +inf per descriptor (the entry's cell passes its gate or not)
+  //   cellv  cell (0..26) of the lane's entry (diagnostic sweep)
+  auto issue = [&](auto &v, auto &pen, auto &cellv, u32 w0) {
+    constexpr int NW = (int)(sizeof(v) / sizeof(v[0]));
+    if ((w0 & 63u) == 0u) window(w0);           // (a group never straddles the window: w0 is a multiple of its size)
+    PH_ADD(0);
+    const u64 *bits_w = bits + (w0 & 63u);
 #pragma unroll
     for (int u = 0; u < NW; u++) {
       const u32 w_lo = (w0 + u) << 6;
-      valid[u] = w_lo + lane < total;
       const u64 bm = bits_w[u];                 // marks of positions w_lo + 1 .. w_lo + 64
       const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pv.offc <= w_lo)) - 1u;
       const u32 j4 = __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, before)) << 2;
@@ -634,8 +646,12 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
 #ifdef SGTD_EXP_L1
       pa = reinterpret_cast<const float4 *>(T.ent) + lane;     // experiment: every load hits the same L1-resident KB
 #endif
-      v[u] = *pa;             // s0, s1, s2 (f32), id
+      v[u] = *pa;
     }
+    PH_ADD(1);
+  };
+  auto tests = [&](auto &v, auto &pen, auto &cellv, u32 w0) {
+    constexpr int NW = (int)(sizeof(v) / sizeof(v[0]));
     u32 m_start[K];
 #pragma unroll
     for (int k = 0; k < K; k++) m_start[k] = matches[k];
@@ -670,7 +686,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
       double dis = 0.0;
       if constexpr (DIAG) {   // the reference's form verbatim on the exact sides, :374-378
         hit = false;
-        if (valid[u] && other) {
+        if ((w0 + u) * 64u + (u32)lane < total && other) {      // (not the sentinel entries: the exact test reads the cold table)
           const double *sp = T.cold_side + (size_t)id_entry(T.map, id) * 3;
           const double ex = dq0 - sp[0], ey = dq1 - sp[1], ez = dq2 - sp[2];
           dis = sqrt((ex * ex + ey * ey) + ez * ez);   // Eigen norm() association
@@ -685,31 +701,32 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         m = FRAMES ? __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other)   // two plain compares: no mask round trip
                    : __builtin_amdgcn_ballot_w64(near);
       }
-      const u32 at = count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+      // record index inside the slab
+      const u32 at = rel[k] + count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
       if constexpr (!PUSH) {
+        // wave-uniform base (the slab) + a 32-bit lane offset: no 64-bit VALU address math
 #ifdef SGTD_EXP_NOSTORE
-        if (hit && fits && at == 0xFFFFFFF0u) {                 // experiment: no record stores
-#else
-        if (hit && fits) {
+        if (at == 0xFFFFFFF0u)
 #endif
-          // wave-uniform base (the descriptor's list) + a 32-bit lane offset: no 64-bit VALU address math
-          *reinterpret_cast<u32 *>(reinterpret_cast<char *>(list[k]) + (at << 2)) = id;
-          if (DIAG) { B.rec_cell[(size_t)slab.next[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)slab.next[k] + at] = dis; }
+        if (hit && fits) *reinterpret_cast<u32 *>(slab_base[k] + (at << 2)) = id;
+        if constexpr (DIAG) {
+          if (hit && fits) { B.rec_cell[(size_t)slab.start[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)slab.start[k] + at] = dis; }
         }
         // amb_any |= m & ballot(!(d2 < lo2)) — as one unit, so that no hit mask outlives its test
-        // (left to the scheduler, sixteen masks of a group wait in scalar registers for this)
+        // (left to the scheduler, the masks of a whole group wait in scalar registers for this)
         if (!DIAG)
           asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n\ts_and_b64 vcc, vcc, %3\n\ts_or_b64 %0, %0, vcc"
                        : "+s"(amb_any) : "s"(__float_as_uint(pv.lo2[k])), "v"(d2), "s"(m) : "vcc");
       } else {
         if (amb && fits) {
           const u32 qa = atomicAdd(B.amb_count(), 1u);
-          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.next[k] + at, pv.slot[k]);
+          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.start[k] + at, pv.slot[k]);
           else B.overflow()[0] = 1;    // re-run with a larger queue (grows with the record buffer)
         }
       }
       count += (u32)__builtin_popcountll(m);
     };
+    PH_ADD(2);
 #pragma unroll
     for (int u = 0; u < NW; u++) {
       float d2[K];
@@ -726,20 +743,32 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         for (int k = 0; k < K; k++) test(std::true_type{}, u, k, d2[k], m_start[k]);
       }
     }
+    PH_ADD(3);
   };
-  // full groups of SGTD_PROBE_UNROLL words, window after window, then what is left in groups
-  // of 2 and 1 (inside the last window)
   if (n_words) {
+    // Groups of four words, window after window, then what is left in groups of 2 and 1 (inside the
+    // last window).  ALL of a group's loads are waited for before its first record store: vmcnt
+    // counts loads and stores in issue order, and the stores sit in branches the compiler cannot
+    // count — left to itself it waits "all but the last 3 / 2 / 1 / 0 operations" before word
+    // 0 / 1 / 2 / 3, which, once the stores of the words before are in the queue, means waiting for
+    // their acknowledgements from L2.  (Measured and rejected: two-word groups double-buffered —
+    // the wait for a group's loads then falls behind the stores of the group tested in between, whose
+    // number the compiler cannot know either: 6.3 ms against 5.85; with unconditional stores into a
+    // dump word, which it can count: 6.9 ms, three times the store instructions.)
+    auto group = [&](auto nw_tag, u32 w0) {
+      constexpr int NW = decltype(nw_tag)::value;
+      float4 v[NW];
+      f32x2 pen[NW];
+      u32 cellv[NW];
+      issue(v, pen, cellv, w0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+      tests(v, pen, cellv, w0);
+    };
     u32 w0 = 0;
     bool touched = false;
-    while (true) {
-      window(w0);
-      const u32 w_stop = min(n_words, w0 + 64u);
-      for (; w0 + SGTD_PROBE_UNROLL <= w_stop; w0 += SGTD_PROBE_UNROLL) {
-        group(std::integral_constant<int, SGTD_PROBE_UNROLL>{}, w0);
-        if (!touched) { pending.touch(); touched = true; }
-      }
-      if (w_stop == n_words) break;
+    for (; w0 + 4u <= n_words; w0 += 4u) {
+      group(std::integral_constant<int, 4>{}, w0);
+      if (!touched) { pending.touch(); touched = true; }
     }
     const u32 left = n_words - w0;   // wave-uniform
     if (left & 2u) { group(std::integral_constant<int, 2>{}, w0); w0 += 2; }
@@ -748,7 +777,6 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   } else {
     pending.touch();
   }
-  static_assert(SGTD_PROBE_UNROLL == 4, "remainder groups cover 2 and 1 words; a window is a whole number of groups");
   // the pass's results: lane k stores for descriptor k
   {
     u32 r_slot = pv.slot[0], r_ptr = slab.next[0], r_match = matches[0];
@@ -763,6 +791,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     if (fits) slab.next[k] += matches[k];
   }
   __builtin_amdgcn_wave_barrier();
+  PH_ADD(4);
 }
 
 #define SGTD_TICKET_MAX 64   // pass slots per ticket: one lane each in the ticket's offset load
@@ -800,8 +829,13 @@ struct TicketQueue {
 };
 
 
+#ifndef SGTD_SWEEP_WAVES
+// at least five waves per SIMD (96 vector registers): the double-buffered groups hide the load latency
+// of one wave, the other waves cover the LDS round trips of the locate step
+#define SGTD_SWEEP_WAVES
+#endif
 template <bool DIAG, bool WIDE, bool FRAMES>
-__global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(
+__global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_WAVES void probe_sorted_kernel(
     TableView T, ProbeBuffers B, QueryView Q, PassPool P, double rough, const u32 *n_valid_p, const u32 *n_groups_p,
     u32 chunk /* 1..SGTD_TICKET_MAX */) {
   __shared__ u64 s_bits[SGTD_PROBE_THREADS / SGTD_WAVE][64];   // per wave: range starts of the current 4096 positions
@@ -821,6 +855,11 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(
   tq.xcc = xcc & 7u;
   tq.select(0);
   WaveSlab slab{};
+#ifdef SGTD_EXP_PHASE
+  for (int i = 0; i < 8; i++) slab.ph[i] = 0;
+  slab.t = __builtin_readcyclecounter();
+  const u64 ph_start = slab.t;
+#endif
   // lane i: record offset of pass slot i of ticket c
   auto load_offs = [&](u32 c) {
     u32 r = SGTD_NO_PASS;
@@ -864,6 +903,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(
     fetch(off_n, hv_n, rn_off, rn_dl, rn_meta);          // in flight during this pass
     PendingLoads pend;
     pend.h = &hv_n; pend.a = &rn_off; pend.b = &rn_dl; pend.c = &rn_meta;
+    PH_ADD(5);      // between passes: tickets, the next record's fetch
     const u32 w0 = (u32)__builtin_amdgcn_readlane((int)hv, 0);
     const u32 n = w0 & 0xFFu, kk = w0 >> 8;
     auto pass = [&](auto k_tag) {
@@ -892,6 +932,13 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) void probe_sorted_kernel(
     hv = hv_n; r_off = rn_off; r_dl = rn_dl; r_meta = rn_meta;
   }
   if (lane == 0 && slab.swept) atomicAdd(B.swept(), (unsigned long long)slab.swept);
+#ifdef SGTD_EXP_PHASE
+  if (lane == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(&g_phase[i], slab.ph[i]);
+    atomicAdd(&g_phase[6], 1ull);
+    atomicAdd(&g_phase[7], __builtin_readcyclecounter() - ph_start);
+  }
+#endif
 }
 
 // The provisional records of the sweep, decided exactly (STDesc.cpp:374-378 in the squared,

@@ -796,6 +796,20 @@ int launch_select(sgtd_engine *e) {
       HIPCHK(hipGetLastError());
     }
     HIPCHK(hipGetLastError());
+#ifdef SGTD_EXP_PHASE
+    {
+      static int pcalls = 0;
+      if (++pcalls == 6) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        unsigned long long ph[8];
+        HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)));
+        const double tot = (double)ph[7];
+        fprintf(stderr, "PHASE (fractions of wave life, %llu waves): prologue %.3f locate+issue %.3f wait-loads %.3f test %.3f epilogue %.3f between-passes %.3f rest %.3f\n",
+                ph[6], ph[0] / tot, ph[1] / tot, ph[2] / tot, ph[3] / tot, ph[4] / tot, ph[5] / tot,
+                (tot - ph[0] - ph[1] - ph[2] - ph[3] - ph[4] - ph[5]) / tot);
+      }
+    }
+#endif
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
     // one 16-wave workgroup per (query, frame tile) when that fills the chip: the tile's LDS
     // histogram is final (no flush atomics); spans beyond LDS take several tiles of 36 Ki frames
