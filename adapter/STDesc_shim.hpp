@@ -42,14 +42,20 @@
 // here returns the sgtd_status of the first failing call (SGTD_OK otherwise) for the caller to
 // log.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <thread>
 #include <utility>
 #include <vector>
 
 #ifndef SGTD_ACCEL_H
 #include "sgtd_accel.h"   // include/sgtd_accel.h of this repository (add its directory to the include path)
+#endif
+
+#ifndef SGTD_SHIM_FILL_THREADS
+#define SGTD_SHIM_FILL_THREADS 6u   // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call
 #endif
 
 namespace sgtd_shim {
@@ -88,6 +94,10 @@ void to_soa(const std::vector<Desc> &in, SoaBuf &b) {
   }
 }
 
+// (Filled by the calling thread.  The reference links OpenMP (CMakeLists.txt:22-44), but a parallel
+// fill does not pay here: with a team of 8 the call got SLOWER — 38.7 ms per frame against 27.9 — and
+// with a team of all 256 hardware threads 180 ms: the idle team spins after every region and takes
+// the cores the HIP runtime's own threads need for the copies and launches that follow.)
 template <class Desc>
 void from_soa(const SoaBuf &b, size_t n, std::vector<Desc> &out) {
   out.resize(n);
@@ -175,8 +185,10 @@ struct Selection {
   std::vector<int64_t> off, entry;
 };
 
+// with_pairs = false: candidates, votes and list offsets only (SearchLoop verifies on the device and
+// fetches just the inlier pairs)
 template <class Desc>
-int select(sgtd_handle h, const std::vector<Desc> &stds_vec, int candidate_num, Selection &s) {
+int select(sgtd_handle h, const std::vector<Desc> &stds_vec, int candidate_num, Selection &s, bool with_pairs = true) {
   SoaBuf q(stds_vec.size());
   to_soa(stds_vec, q);
   int st = sgtd_query_descs(h, &q.v, (int64_t)stds_vec.size());
@@ -184,7 +196,7 @@ int select(sgtd_handle h, const std::vector<Desc> &stds_vec, int candidate_num, 
   const int cn = candidate_num;
   s.frame.assign(cn, -1); s.votes.assign(cn, 0); s.off.assign(cn + 1, 0);
   st = sgtd_result_candidates(h, &s.n_cand, s.frame.data(), s.votes.data(), s.off.data());
-  if (st != SGTD_OK) return st;
+  if (st != SGTD_OK || !with_pairs) return st;
   const int64_t total = s.off[s.n_cand];
   s.q_idx.resize((size_t)total); s.entry.resize((size_t)total);
   int64_t got = 0;
@@ -220,8 +232,9 @@ int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::ve
 // ---- STDesc.cpp:84-147 with candidate_verify (:462-547) on the device ---------------------
 // Vec3 / Mat3 = Eigen::Vector3d / Eigen::Matrix3d (operator[] and operator()(row, col)).
 // The match lists stay on the device: only the inlier pairs of every candidate
-// (sucess_match_vec, what LOOP_RESULT::loop_std_pair holds) are fetched, a few thousand
-// descriptors instead of the ~10^5 of the full lists.
+// (sucess_match_vec, what LOOP_RESULT::loop_std_pair holds) are fetched — one device compaction
+// (sgtd_result_inlier_pairs), one gather of the table entries they name — instead of the ~10^5
+// pairs of the full lists.
 template <class Desc, class Vec3, class Mat3, class LoopResult>
 int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, double> &loop_result,
                std::pair<Vec3, Mat3> &loop_transform, std::vector<std::pair<Desc, Desc>> &loop_std_pair,
@@ -244,7 +257,7 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
 #define SGTD_LAP(x) do { } while (0)
 #endif
   Selection s;
-  int st = select(h, stds_vec, candidate_num, s);  // :98
+  int st = select(h, stds_vec, candidate_num, s, /*with_pairs=*/false);  // :98
   if (st != SGTD_OK) return st;
   CS1 = (int)(std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count() * 1000);
   SGTD_LAP("select");
@@ -255,42 +268,79 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   st = sgtd_result_verify(h, 0, score.data(), pose.data());
   if (st != SGTD_OK) return st;
   SGTD_LAP("verify");
-  // inlier positions of every accepted candidate, then ONE fetch of the table entries they name
-  std::vector<std::vector<int32_t>> inl((size_t)s.n_cand);
-  std::vector<int64_t> want;
-  for (int k = 0; k < s.n_cand; k++) {
-    if (!(score[k] >= 0)) continue;                // sucess_match_vec, :516-539
-    inl[k].resize((size_t)(s.off[k + 1] - s.off[k]));
-    int64_t n = 0;
-    st = sgtd_result_inliers(h, 0, k, inl[k].data(), (int64_t)inl[k].size(), &n);
+  // the inlier pairs of every candidate (sucess_match_vec, :516-539) in one call, then ONE fetch of
+  // the table entries they name
+  std::vector<int64_t> ioff((size_t)cn + 1, 0);
+  int64_t n_inl = 0;
+  st = sgtd_result_inlier_pairs(h, 0, ioff.data(), nullptr, nullptr, 0, &n_inl);
+  if (st != SGTD_OK && st != SGTD_ERR_CAPACITY) return st;
+  std::vector<int32_t> iq((size_t)n_inl);
+  std::vector<int64_t> want((size_t)n_inl);
+  if (n_inl) {
+    st = sgtd_result_inlier_pairs(h, 0, ioff.data(), iq.data(), want.data(), n_inl, &n_inl);
     if (st != SGTD_OK) return st;
-    inl[k].resize((size_t)n);
-    for (int32_t p : inl[k]) want.push_back(s.entry[(size_t)(s.off[k] + p)]);
   }
   SGTD_LAP("inliers");
   SoaBuf ent(want.size());
   st = sgtd_fetch_entries(h, want.data(), (int64_t)want.size(), &ent.v);
   if (st != SGTD_OK) return st;
   SGTD_LAP("fetch");
-  std::vector<Desc> db;
-  from_soa(ent, want.size(), db);
-  SGTD_LAP("from_soa");
   double best_score = 0;
   int best = -1;
   const size_t first = match_result_list.size();
-  size_t w = 0;
+  match_result_list.resize(first + (size_t)s.n_cand);
   for (int k = 0; k < s.n_cand; k++) {             // :105-131
-    LoopResult r;
+    LoopResult &r = match_result_list[first + (size_t)k];
     r.match_id = s.frame[k];
     r.match_fitness = score[k];                    // an int member in the reference: truncates like :119
     for (int a = 0; a < 3; a++) {
       for (int b = 0; b < 3; b++) r.loop_transform.second(a, b) = pose[(size_t)k * 12 + a * 3 + b];
       r.loop_transform.first[a] = pose[(size_t)k * 12 + 9 + a];
     }
-    r.loop_std_pair.reserve(inl[k].size());
-    for (int32_t p : inl[k]) r.loop_std_pair.emplace_back(stds_vec[s.q_idx[(size_t)(s.off[k] + p)]], std::move(db[w++]));
+    // a candidate that failed verification (score -1) has no sucess_match_vec
+    r.loop_std_pair.resize(score[k] >= 0 ? (size_t)(ioff[(size_t)k + 1] - ioff[(size_t)k]) : 0);
     if (score[k] > best_score) { best_score = score[k]; best = k; }   // :125-131
-    match_result_list.push_back(std::move(r));
+  }
+  // LOOP_RESULT::loop_std_pair of EVERY candidate is filled: the caller copies the list of whichever
+  // candidate its registration step prefers (semantic_graph_localization.cpp:622,672-718), and the
+  // member is a plain std::vector — nothing can be deferred.
+  // The ~10^5 descriptors (416 bytes and a heap-allocated node_id each) are written by a few
+  // short-lived threads, every candidate's list by one of them: threads that exit, not an OpenMP team —
+  // an idle team spins after its region and slowed the HIP calls that follow (8 threads: 38.7 ms per
+  // frame against 27.9 single-threaded, 256 threads: 180 ms).
+  auto fill = [&](int k0, int k1) {
+    for (int k = k0; k < k1; k++) {
+      if (!(score[k] >= 0)) continue;
+      std::vector<std::pair<Desc, Desc>> &lp = match_result_list[first + (size_t)k].loop_std_pair;
+      for (int64_t j = ioff[(size_t)k]; j < ioff[(size_t)k + 1]; j++) {
+        std::pair<Desc, Desc> &pr = lp[(size_t)(j - ioff[(size_t)k])];
+        pr.first = stds_vec[(size_t)iq[(size_t)j]];
+        Desc &d = pr.second;
+        const size_t i = (size_t)j;
+        for (int c = 0; c < 3; c++) {
+          d.side_length_[c] = ent.side[3 * i + c]; d.angle_[c] = ent.angle[3 * i + c]; d.center_[c] = ent.center[3 * i + c];
+          d.vertex_A_[c] = ent.vertex[9 * i + c]; d.vertex_B_[c] = ent.vertex[9 * i + 3 + c]; d.vertex_C_[c] = ent.vertex[9 * i + 6 + c];
+          d.vertex_attached_[c] = (double)ent.label[3 * i + c];
+        }
+        d.frame_id_ = ent.frame[i];
+        d.node_id = {ent.node_id[3 * i], ent.node_id[3 * i + 1], ent.node_id[3 * i + 2]};
+      }
+    }
+  };
+  {
+    // candidates dealt to the threads in runs of about equal numbers of pairs
+    const int n_thr = n_inl > 8192 ? (int)std::min<unsigned>(SGTD_SHIM_FILL_THREADS, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::thread> team;
+    int k0 = 0;
+    for (int t = 0; t < n_thr; t++) {
+      int k1 = k0;
+      const int64_t until = n_inl * (t + 1) / n_thr;
+      while (k1 < s.n_cand && (t == n_thr - 1 || ioff[(size_t)k1 + 1] <= until)) k1++;
+      if (t == n_thr - 1) fill(k0, s.n_cand);
+      else if (k1 > k0) team.emplace_back(fill, k0, k1);
+      k0 = k1;
+    }
+    for (auto &th : team) th.join();
   }
   SGTD_LAP("pairs");
   if (best >= 0 && best_score > icp_threshold) {   // :138-146

@@ -102,13 +102,16 @@ def cpu_baseline(smap, queries, gpu_results, mgr, budget_s, protocol):
     F = smap.xyz.shape[0]
     o = OracleManager(num_threads=ref_threads, max_frame_n=max(20000, F + 1))
     t0 = time.time()
-    for f in range(F):
-        o.build(smap.xyz[f], smap.label[f], export=False)
-        o.add_last()
+    o.add_frames(smap.xyz, smap.label)       # = F x (build, add_last); builds on all host threads, untimed
     t_map = time.time() - t0
     nq_all = queries.xyz.shape[0]
     settings = [("ref_rule_nproc_minus_4", ref_threads), ("all_cores", ncpu), ("one_thread", 1)]
     share = {"ref_rule_nproc_minus_4": 0.5, "all_cores": 0.25, "one_thread": 0.25}
+    from sgtd_amd.synth import effective_cpus
+    quota = effective_cpus()        # a container may show all hardware threads and be allowed far fewer CPUs' worth of time
+    if quota < ncpu:
+        settings.insert(2, ("cgroup_quota_cpus", quota))
+        share = {"ref_rule_nproc_minus_4": 0.4, "all_cores": 0.2, "cgroup_quota_cpus": 0.2, "one_thread": 0.2}
     out_settings, parity = {}, None
     q_next = 0
     for name, thr in settings:
@@ -155,10 +158,45 @@ def cpu_baseline(smap, queries, gpu_results, mgr, budget_s, protocol):
               sample="%d (nproc-4 threads) + %d (all cores) + %d (1 thread) of the step's query frames, same %d-frame map; "
                      "oracle map build %.1f s untimed; protocol %s"
                      % (prim["queries_timed"], out_settings["all_cores"]["queries_timed"],
-                        out_settings["one_thread"]["queries_timed"], F, t_map, protocol),
-              ms_per_query=prim["ms_per_query"]["median"], host_cpus=ncpu, best_setting_frames_per_s=best,
+                        out_settings["one_thread"]["queries_timed"], F, t_map, protocol)
+                     + ("; %d more on the %d CPUs of the cgroup quota" % (out_settings["cgroup_quota_cpus"]["queries_timed"], quota) if quota < ncpu else "")
+                     + ("; queries_timed < 200 per setting (BASELINE.md §2 asks 200: --cpu-protocol full)" if protocol != "full" else ""),
+              ms_per_query=prim["ms_per_query"]["median"], host_cpus=ncpu, host_cpu_quota=quota, best_setting_frames_per_s=best,
               thread_settings=out_settings)
     return cb, parity
+
+
+def cpp_adapter_leg(smap, queries, n_frames):
+    """examples/localize with LOCALIZE_PER_FRAME: the reference's one-frame-per-call pattern through the
+    C++ adapter, as a child process (its own handle on the same GPU; started after this process's
+    kernels are idle).  Compiled here with g++ -O2."""
+    import re
+    import tempfile
+    from sgtd_amd import evaluate as ev, ingest
+    exe = os.path.join(ROOT, "examples", "localize")
+    src = os.path.join(ROOT, "examples", "localize.cpp")
+    lib_dir = os.path.join(ROOT, "sgtd_amd")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "adapter", "STDesc_shim.hpp"))):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+                               "-L" + lib_dir, "-lsgtd_accel", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
+    with tempfile.TemporaryDirectory() as tmp:
+        mp, qp = os.path.join(tmp, "map.cache"), os.path.join(tmp, "query.cache")
+        ingest.write_cache(mp, smap.xyz, smap.label, np.stack([ev.pose_row(*p) for p in smap.pose]))
+        nq = min(n_frames, queries.xyz.shape[0])
+        ingest.write_cache(qp, queries.xyz[:nq], queries.label[:nq], np.stack([ev.pose_row(*p) for p in queries.pose[:nq]]))
+        out = subprocess.run([exe, mp, qp, str(nq)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, LOCALIZE_PER_FRAME=str(nq)))
+    if out.returncode != 0:
+        raise RuntimeError(out.stdout[-500:] + out.stderr[-500:])
+    m = re.search(r"per-frame calls through STDescManager \((\d+) frames\): ([0-9.]+) ms per frame = BuildSingleScanSTD ([0-9.]+) \+ SearchLoop ([0-9.]+); "
+                  r"(\d+)/(\d+) agree with the batched run, ([0-9.]+) inlier pairs per loop", out.stdout)
+    if not m:
+        raise RuntimeError("unexpected output: " + out.stdout[-500:])
+    return {"cpp_adapter_ms_per_frame": float(m.group(2)), "cpp_adapter_ms_build": float(m.group(3)),
+            "cpp_adapter_ms_search_loop": float(m.group(4)), "cpp_adapter_frames": int(m.group(1)),
+            "cpp_adapter_agree_with_batched": "%s/%s" % (m.group(5), m.group(6)), "cpp_adapter_inlier_pairs_per_loop": float(m.group(7)),
+            "cpp_adapter_note": "examples/localize LOCALIZE_PER_FRAME: BuildSingleScanSTD + SearchLoop (device verification, every "
+                                "LOOP_RESULT::loop_std_pair filled) per frame through adapter/STDesc_shim.hpp, g++ -O2"}
 
 
 def recall(smap, queries, top1):
@@ -174,15 +212,16 @@ def recall(smap, queries, top1):
 
 
 def load_traffic(F, N, Q, world):
-    """HBM bytes per sweep launch from the committed PMC passes (profiles/r02_traffic.json,
-    written by profiles/collect_r02.sh for exactly this configuration), else None"""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    try:
-        for row in json.load(open(path)):
-            if (row.get("frames"), row.get("keypoints"), row.get("queries"), row.get("gpus", 1)) == (F, N, Q, world):
-                return row
-    except Exception:
-        pass
+    """HBM bytes per sweep launch from the committed PMC passes (profiles/r<NN>_traffic.json, written by
+    profiles/collect_r<NN>.sh for exactly this configuration; the newest round that has the row), else None"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True):
+        try:
+            for row in json.load(open(path)):
+                if (row.get("frames"), row.get("keypoints"), row.get("queries"), row.get("gpus", 1)) == (F, N, Q, world):
+                    return row
+        except Exception:
+            pass
     return None
 
 
@@ -454,6 +493,14 @@ def main():
                         "note": "python ctypes adapter (sgtd_amd/manager.py); value above excludes PCIe and list fetches"}
         except Exception as exc:
             boundary = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        # ... and the same call pattern through the reference-typed C++ adapter (adapter/STDesc_shim.hpp
+        # behind include/sgtd/STDescManager.hpp): examples/localize replays BuildSingleScanSTD + SearchLoop
+        # frame by frame (semantic_graph_localization.cpp:590-603) as a child process of its own
+        try:
+            boundary = boundary or {}
+            boundary.update(cpp_adapter_leg(smap, queries, min(Q, 64)))
+        except Exception as exc:
+            boundary["cpp_adapter_error"] = "%s: %s" % (type(exc).__name__, exc)
         step(); mgr.sync()   # leave the handle on the headline batch
         res = mgr.results()
 

@@ -3,7 +3,7 @@
 // on the C ABI alone: graph-JSON directories in, localization statistics out.  No ROS, no PCL,
 // no GICP (enable_gicp = false); BASE2OUSTER = identity.
 //
-//   localize <map_dir> <query_dir> [batch=256] [icp_threshold=0.4]
+//   localize <map_dir | map.cache> <query_dir | query.cache> [batch=256] [icp_threshold=0.4]
 //   LOCALIZE_PER_FRAME=n: additionally run the first n queries the way the reference node does —
 //   one BuildSingleScanSTD + SearchLoop call per frame through the STDescManager adapter
 //   (semantic_graph_localization.cpp:590-601) — and report the time per frame
@@ -88,6 +88,8 @@ struct Graphs {
   const uint32_t *label = nullptr;
   const int64_t *off = nullptr;
 };
+// a directory of graph-JSON files, or ONE graph-batch cache file (sgtd_graphs_save_cache, sgtd_amd/ingest.py write_cache)
+static int load_any(const char *path, Graphs &g);
 static int load(const std::vector<std::string> &files, Graphs &g) {
   std::vector<const char *> p;
   for (auto &s : files) p.push_back(s.c_str());
@@ -99,17 +101,29 @@ static int load(const std::vector<std::string> &files, Graphs &g) {
   return sgtd_graphs_view(g.b, &g.n, nullptr, &g.xyz, &g.label, &g.off, &g.poses);
 }
 
+static int load_any(const char *path, Graphs &g) {
+  if (fs::is_regular_file(path)) {
+    const int st = sgtd_graphs_load_cache(path, &g.b);
+    if (st != SGTD_OK) {
+      std::fprintf(stderr, "%s\n", sgtd_graphs_error(g.b));
+      return st;
+    }
+    return sgtd_graphs_view(g.b, &g.n, nullptr, &g.xyz, &g.label, &g.off, &g.poses);
+  }
+  return load(list_json(path), g);
+}
+
 int main(int argc, char **argv) {
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s <map_dir> <query_dir> [batch] [icp_threshold]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <map_dir | map.cache> <query_dir | query.cache> [batch] [icp_threshold]\n", argv[0]);
     return 2;
   }
   const int batch = argc > 3 ? std::atoi(argv[3]) : 256;
   const double icp_threshold = argc > 4 ? std::atof(argv[4]) : 0.4;   // SG_localization.yaml:89
   auto t0 = std::chrono::steady_clock::now();
   Graphs map, qs;
-  OK(load(list_json(argv[1]), map));
-  OK(load(list_json(argv[2]), qs));
+  OK(load_any(argv[1], map));
+  OK(load_any(argv[2], qs));
   auto t1 = std::chrono::steady_clock::now();
 
   sgtd_config cfg;

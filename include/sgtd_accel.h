@@ -244,6 +244,12 @@ int sgtd_export_verify_dev(sgtd_handle h, double *d_score, double *d_pose);
 /* sucess_match_vec of (query q, candidate cand) as positions into that candidate's
  * match_list_ (ascending = list order); capacity in elements, *n = needed */
 int sgtd_result_inliers(sgtd_handle h, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n);
+/* The inlier pairs of EVERY candidate of query q in one call (one device compaction, one copy):
+ * candidate k's pairs are [cand_off[k], cand_off[k+1]) of q_idx / db_entry, in match-list order;
+ * cand_off holds candidate_num + 1 offsets.  What SearchLoop needs to fill
+ * LOOP_RESULT::loop_std_pair (STDesc.cpp:119-124) without fetching the full match lists. */
+int sgtd_result_inlier_pairs(sgtd_handle h, int q, int64_t *cand_off, int32_t *q_idx, int64_t *db_entry,
+                             int64_t capacity, int64_t *n_pairs);
 /* STDescManager::SearchLoop's choice (STDesc.cpp:105-146) for every query of the batch:
  * the first candidate with the strictly largest verify_score, accepted if it exceeds
  * icp_threshold; best_frame = -1 and best_score = 0 otherwise (loop_result (-1, 0)).

@@ -58,6 +58,10 @@ def build_library(force=False):
     return _LIB_PATH
 
 
+# an idle OpenMP team must sleep, not spin: the GPU tests and the bench alternate between the oracle
+# and HIP calls / torch CPU kernels on hosts whose CPU quota is far below their thread count
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 _lib = None
 
 
@@ -86,6 +90,7 @@ def lib():
         L.orc_build.argtypes = [vp, vp, vp, C.c_int]
         L.orc_last_export.argtypes = [vp, C.POINTER(OrcSoa)]
         L.orc_add_last.argtypes = [vp]
+        L.orc_add_frames.argtypes = [vp, vp, vp, C.c_int, C.c_int]
         L.orc_add.argtypes = [vp, C.POINTER(OrcSoa), i64]
         L.orc_select.restype = C.c_int
         L.orc_select.argtypes = [vp, C.c_int, C.POINTER(OrcSoa), i64, vp, vp, vp, vp]
@@ -184,6 +189,12 @@ class OracleManager:
 
     def add_last(self):
         lib().orc_add_last(self._h)
+
+    def add_frames(self, xyz, label):
+        """xyz (F, N, 3), label (F, N): what F build + add_last pairs give (builds on all host threads)"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        label = np.ascontiguousarray(label, dtype=np.uint32)
+        lib().orc_add_frames(self._h, _p(xyz), _p(label), xyz.shape[0], xyz.shape[1])
 
     def add(self, d):
         s = d.soa()

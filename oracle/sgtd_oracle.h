@@ -80,6 +80,8 @@ int64_t orc_build(orc_manager *m, const float *xyz, const uint32_t *label, int n
 void orc_last_export(const orc_manager *m, orc_desc_soa *out);
 /* AddSTDescs (STDesc.cpp:149-172) of the last built descriptors */
 void orc_add_last(orc_manager *m);
+/* n_frames x (orc_build, orc_add_last) on uniform frames of n keypoints; builds in parallel, inserts in order */
+void orc_add_frames(orc_manager *m, const float *xyz, const uint32_t *label, int n_frames, int n);
 /* AddSTDescs of caller-provided descriptors */
 void orc_add(orc_manager *m, const orc_desc_soa *d, int64_t n);
 

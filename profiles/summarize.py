@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 output of profiles/collect_r02.sh into the small files that
 are committed under profiles/: per-kernel duration stats, per-kernel PMC means,
-<tag>_probe_traffic.json and a row of r02_traffic.json (HBM bytes per sweep launch, read by bench.py).
+<tag>_probe_traffic.json and a row of <round>_traffic.json (HBM bytes per sweep launch, read by bench.py).
 
 HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md §HBM:
 FETCH_SIZE (KB) counts 128-B requests as 64 B for wide coalesced reads (the
@@ -41,7 +41,7 @@ def main():
         for k, cs in pmc_means(os.path.join(src, name, "*", "*_counter_collection.csv")).items():
             pmc.setdefault(k, {}).update(cs)
     keep = {k: v for k, v in pmc.items() if any(s in k for s in
-            ("probe", "resolve", "block_", "votes", "topk", "build_frames", "locality", "radix", "query_base"))}
+            ("probe", "plan_passes", "resolve", "block_", "votes", "topk", "build_frames", "locality", "radix", "query_base"))}
     json.dump(keep, open(os.path.join(here, "%s_pmc_means.json" % tag), "w"), indent=1, sort_keys=True)
     med = {}
     for name in ("fetch", "write", "tcc"):
@@ -61,8 +61,8 @@ def main():
                    "bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
                    "TCC_HIT_sum": p.get("TCC_HIT_sum"), "TCC_MISS_sum": p.get("TCC_MISS_sum")}
         json.dump(traffic, open(os.path.join(here, "%s_probe_traffic.json" % tag), "w"), indent=1, sort_keys=True)
-        # bench.py reads the rows of r02_traffic.json (one per measured configuration)
-        rows_path = os.path.join(here, "r02_traffic.json")
+        # bench.py reads the rows of <round>_traffic.json (one per measured configuration), newest round first
+        rows_path = os.path.join(here, "%s_traffic.json" % tag[:3])
         rows = []
         if os.path.exists(rows_path):
             try:

@@ -24,7 +24,7 @@ SYMBOLS = [
     "sgtd_result_candidates", "sgtd_export_candidates_dev", "sgtd_result_query_desc_count", "sgtd_result_pairs",
     "sgtd_result_query_descs", "sgtd_result_votes", "sgtd_result_rough", "sgtd_fetch_entries",
     "sgtd_table_dump", "sgtd_sync", "sgtd_get_stats",
-    "sgtd_verify", "sgtd_export_verify_dev", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_search_loop",
+    "sgtd_verify", "sgtd_export_verify_dev", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_result_inlier_pairs", "sgtd_search_loop",
     "sgtd_graphs_load", "sgtd_graphs_save_cache", "sgtd_graphs_load_cache", "sgtd_graphs_view",
     "sgtd_graphs_error", "sgtd_graphs_free", "sgtd_save_table", "sgtd_load_table",
 ]

@@ -53,6 +53,7 @@ int result_votes(sgtd_engine *e, int q, uint32_t *votes, int64_t capacity, uint3
 int verify(sgtd_engine *e);
 int result_verify(sgtd_engine *e, int q, double *score, double *pose);
 int result_inliers(sgtd_engine *e, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n);
+int result_inlier_pairs(sgtd_engine *e, int q, int64_t *cand_off, int32_t *q_idx, int64_t *db_entry, int64_t capacity, int64_t *n_pairs);
 int search_loop(sgtd_engine *e, double icp_threshold, int32_t *best_cand, int32_t *best_frame, double *best_score);
 int sync(sgtd_engine *e);
 int get_stats(sgtd_engine *e, sgtd_stats *out);

@@ -336,6 +336,43 @@ int result_inliers(sgtd_engine *e, int q, int cand, int32_t *idx, int64_t capaci
   return SGTD_OK;
 }
 
+// inlier pairs of every merged candidate of query q: each candidate's from its owner, entry ids with the owner in the upper bits
+int result_inlier_pairs(sgtd_engine *e, int q, int64_t *cand_off, int32_t *q_idx, int64_t *db_entry, int64_t capacity, int64_t *n_pairs) {
+  Group *g = G(e);
+  if (!n_pairs || !cand_off || !g->verified || q < 0 || q >= g->nq) return SGTD_ERR_INVALID;
+  const int cn = e->cfg.candidate_num;
+  std::vector<std::vector<int32_t>> qi(g->n);
+  std::vector<std::vector<int64_t>> en(g->n), off(g->n);
+  std::vector<bool> have(g->n, false);
+  int64_t o = 0;
+  bool fits = true;
+  for (int k = 0; k <= cn; k++) cand_off[k] = 0;
+  for (int k = 0; k < g->n_cand[q]; k++) {
+    const size_t i = (size_t)q * cn + k;
+    const int s = g->owner[i], ks = g->owner_slot[i];
+    if (!have[s]) {   // the owner's inlier pairs of this query, once
+      sgtd_engine *c = g->dev[s];
+      off[s].resize((size_t)cn + 1);
+      int64_t ns = 0;
+      int st = sgtd_result_inlier_pairs(c, q, off[s].data(), nullptr, nullptr, 0, &ns);
+      if (st != SGTD_OK && st != SGTD_ERR_CAPACITY) MCHK(st);
+      qi[s].resize((size_t)std::max<int64_t>(ns, 1)); en[s].resize((size_t)std::max<int64_t>(ns, 1));
+      MCHK(sgtd_result_inlier_pairs(c, q, off[s].data(), qi[s].data(), en[s].data(), ns, &ns));
+      have[s] = true;
+    }
+    cand_off[k] = o;
+    for (int64_t r = off[s][(size_t)ks]; r < off[s][(size_t)ks + 1]; r++, o++) {
+      if (o < capacity) {
+        if (q_idx) q_idx[o] = qi[s][(size_t)r];
+        if (db_entry) db_entry[o] = ((int64_t)s << SGTD_ENTRY_SHARD_SHIFT) | en[s][(size_t)r];
+      } else fits = false;
+    }
+  }
+  for (int k = g->n_cand[q]; k <= cn; k++) cand_off[k] = o;
+  *n_pairs = o;
+  return fits ? SGTD_OK : SGTD_ERR_CAPACITY;
+}
+
 // SearchLoop's choice on the merged list (STDesc.cpp:105-146)
 int search_loop(sgtd_engine *e, double icp_threshold, int32_t *best_cand, int32_t *best_frame, double *best_score) {
   Group *g = G(e);

@@ -123,6 +123,7 @@ struct sgtd_engine {
   DevBuf amb_queue;               // provisional records awaiting the exact test
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
+  DevBuf inl_pairs, inl_off;                  // sgtd_result_inlier_pairs staging
   bool verified = false;
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
@@ -139,6 +140,11 @@ struct sgtd_engine {
   std::vector<int> h_n_cand, h_cand_frame, h_cand_votes;
   std::vector<long long> h_pair_off;
   sgtd_stats stats{};
+  // pinned host staging of the small transfers (see d2h / h2d below)
+  char *pin = nullptr;
+  size_t pin_cap = 0, pin_used = 0;
+  struct PinCopy { void *dst; size_t off, bytes; };
+  std::vector<PinCopy> pin_pending;
 };
 
 #include "multi.hip.h"
@@ -161,7 +167,9 @@ namespace {
 
 int ensure(sgtd_engine *e, DevBuf &b, size_t bytes, bool keep = false) {
   if (bytes <= b.bytes) return SGTD_OK;
-  size_t want = keep ? std::max(bytes, b.bytes + b.bytes / 2) : bytes;
+  // (a buffer that grows again gets a quarter more than asked for: the one-frame-per-call pattern would
+  // otherwise free and allocate a dozen work buffers on every frame that is a little larger than the last)
+  size_t want = keep ? std::max(bytes, b.bytes + b.bytes / 2) : (b.p ? bytes + bytes / 4 : bytes);
   void *np = nullptr;
   HIPCHK(hipMalloc(&np, want));
   if (keep && b.p && b.bytes) {
@@ -198,6 +206,65 @@ void free_store(DescStore &s) {
   free_buf(s.side); free_buf(s.angle); free_buf(s.center); free_buf(s.vertex);
   free_buf(s.label); free_buf(s.frame); free_buf(s.node_id); free_buf(s.qrec);
   s.cap = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Small host <-> device transfers go through ONE pinned staging buffer per handle: a
+// hipMemcpyAsync on pageable memory costs ~150 us each on this runtime (the reference's
+// one-frame-per-call pattern issues ~60 of them per frame), on pinned memory a few.
+// d2h: queue a copy device -> pinned and remember where the caller wants it; xfer_sync: wait for
+// the stream, then move the queued results to the caller's (pageable) buffers.  h2d: copy the
+// caller's data into pinned memory at once, queue pinned -> device; the pinned bytes are reused
+// only after the next xfer_sync.  Transfers beyond kPinMax take the direct path (bandwidth-bound).
+// ---------------------------------------------------------------------------
+constexpr size_t kPinMax = (size_t)4 << 20, kPinCap = (size_t)16 << 20;
+
+int xfer_sync(sgtd_engine *e) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (const auto &c : e->pin_pending) std::memcpy(c.dst, e->pin + c.off, c.bytes);
+  e->pin_pending.clear();
+  e->pin_used = 0;
+  return SGTD_OK;
+}
+
+int pin_room(sgtd_engine *e, size_t bytes, size_t *off) {
+  if (!e->pin) {
+    void *p = nullptr;
+    HIPCHK(hipHostMalloc(&p, kPinCap, hipHostMallocDefault));
+    e->pin = static_cast<char *>(p);
+    e->pin_cap = kPinCap;
+  }
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (e->pin_used + need > e->pin_cap) CHK(xfer_sync(e));   // full: finish what is queued, start over
+  *off = e->pin_used;
+  e->pin_used += need;
+  return SGTD_OK;
+}
+
+int d2h(sgtd_engine *e, void *dst, const void *src_dev, size_t bytes) {
+  if (bytes == 0) return SGTD_OK;
+  if (bytes > kPinMax) {
+    HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
+    return SGTD_OK;
+  }
+  size_t off;
+  CHK(pin_room(e, bytes, &off));
+  HIPCHK(hipMemcpyAsync(e->pin + off, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
+  e->pin_pending.push_back({dst, off, bytes});
+  return SGTD_OK;
+}
+
+int h2d(sgtd_engine *e, void *dst_dev, const void *src, size_t bytes) {
+  if (bytes == 0) return SGTD_OK;
+  if (bytes > kPinMax) {
+    HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, e->stream));
+    return SGTD_OK;
+  }
+  size_t off;
+  CHK(pin_room(e, bytes, &off));
+  std::memcpy(e->pin + off, src, bytes);
+  HIPCHK(hipMemcpyAsync(dst_dev, e->pin + off, bytes, hipMemcpyHostToDevice, e->stream));
+  return SGTD_OK;
 }
 
 int grid_for(long long n, int threads) { return (int)((n + threads - 1) / threads); }
@@ -300,7 +367,7 @@ int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64
   HIPCHK(hipMemcpyAsync(kp_buf.p, off.data(), (size_t)(n_frames + 1) * sizeof(long long),
                         hipMemcpyHostToDevice, e->stream));
   // the staging vector dies at return: make the copy complete first
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(xfer_sync(e));
   const long long total = off[n_frames] - off[0];
   if (device_ptrs) {
     *d_xyz = xyz;
@@ -309,8 +376,8 @@ int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64
     CHK(ensure(e, xyz_buf, (size_t)std::max<long long>(total + off[0], 1) * 3 * sizeof(float)));
     CHK(ensure(e, label_buf, (size_t)std::max<long long>(total + off[0], 1) * sizeof(u32)));
     if (total > 0) {
-      HIPCHK(hipMemcpyAsync(xyz_buf.as<float>() + off[0] * 3, xyz + off[0] * 3,
-                            (size_t)total * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+      CHK(h2d(e, xyz_buf.as<float>() + off[0] * 3, xyz + off[0] * 3,
+                            (size_t)total * 3 * sizeof(float)));
       HIPCHK(hipMemcpyAsync(label_buf.as<u32>() + off[0], label + off[0], (size_t)total * sizeof(u32),
                             hipMemcpyHostToDevice, e->stream));
     }
@@ -325,12 +392,12 @@ int copy_out(sgtd_engine *e, const DescStore &s, size_t first, size_t n, sgtd_de
   if (n == 0) return SGTD_OK;
 #define CP(field, T, w)                                                                       \
   if (out->field)                                                                             \
-    HIPCHK(hipMemcpyAsync(out->field + dst0 * (w), s.field.as<T>() + first * (w),             \
-                          n * (w) * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+    CHK(d2h(e, out->field + dst0 * (w), s.field.as<T>() + first * (w),             \
+                          n * (w) * sizeof(T)));
   CP(side, double, 3) CP(angle, double, 3) CP(center, double, 3) CP(vertex, float, 9)
   CP(label, int, 3) CP(frame, u32, 1) CP(node_id, int, 3)
 #undef CP
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(xfer_sync(e));
   return SGTD_OK;
 }
 
@@ -338,14 +405,13 @@ int copy_in(sgtd_engine *e, DescStore &s, size_t first, size_t n, const sgtd_des
   if (n == 0) return SGTD_OK;
 #define CP(field, T, w)                                                                        \
   if (in->field)                                                                               \
-    HIPCHK(hipMemcpyAsync(s.field.as<T>() + first * (w), in->field, n * (w) * sizeof(T),       \
-                          hipMemcpyHostToDevice, e->stream));                                  \
+    CHK(h2d(e, s.field.as<T>() + first * (w), in->field, n * (w) * sizeof(T)));               \
   else                                                                                         \
     HIPCHK(hipMemsetAsync(s.field.as<T>() + first * (w), 0, n * (w) * sizeof(T), e->stream));
   CP(side, double, 3) CP(angle, double, 3) CP(center, double, 3) CP(vertex, float, 9)
   CP(label, int, 3) CP(frame, u32, 1) CP(node_id, int, 3)
 #undef CP
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(xfer_sync(e));
   return SGTD_OK;
 }
 
@@ -766,9 +832,10 @@ int launch_select(sgtd_engine *e) {
       group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->group_first.as<u32>(),
                                                                   e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>());
       HIPCHK(hipGetLastError());
-      const int pgrid = grid_for((long long)max_pass_slots, 256);
+      // resident workgroups (LDS: 880 B per staged group and wave) x 4 rounds, grid-stride over the slots
+      const int pgrid = (int)std::min<long long>(grid_for((long long)max_pass_slots, SGTD_PLAN_THREADS), (long long)e->n_cus * 20);
 #define SGTD_LAUNCH_PLAN(PR)                                                                                   \
-  plan_passes_kernel<PR><<<pgrid, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->gid.as<u32>(), e->pos_of_slot.as<u32>(), nv, \
+  plan_passes_kernel<PR><<<pgrid, SGTD_PLAN_THREADS, 0, e->stream>>>(vs.T, vs.Q, vin, e->gid.as<u32>(), e->pos_of_slot.as<u32>(), nv, \
                                                        e->n_groups.as<u32>(), rows, PP, vs.B.n_visit, vs.B.list,          \
                                                        vs.B.overflow())
       if (pair) SGTD_LAUNCH_PLAN(true); else SGTD_LAUNCH_PLAN(false);
@@ -926,9 +993,9 @@ int sync_batch(sgtd_engine *e) {
     swept = 0;
     u32 total = 0, pool_used = 0;
     u32 ctr[12];     // ProbeBuffers::ctr, one copy
-    HIPCHK(hipMemcpyAsync(ctr, e->cursors.p, sizeof(ctr), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    CHK(d2h(e, ctr, e->cursors.p, sizeof(ctr)));
+    CHK(d2h(e, &total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32)));
+    CHK(xfer_sync(e));
     std::memcpy(&cursor, ctr, 8); std::memcpy(&need, ctr + 4, 8); std::memcpy(&swept, ctr + 6, 8);
     pool_used = ctr[8]; ovf[0] = (int)ctr[10]; ovf[1] = (int)ctr[11];
     if (!ovf[0] && !ovf[1]) {
@@ -965,15 +1032,15 @@ int sync_batch(sgtd_engine *e) {
   e->h_count.resize(nq); e->h_pair_base.resize(nq + 1); e->h_q_M.resize(nq); e->h_q_P.resize(nq);
   e->h_n_cand.resize(nq); e->h_cand_frame.resize((size_t)nq * cn); e->h_cand_votes.resize((size_t)nq * cn);
   e->h_pair_off.resize((size_t)nq * (cn + 1));
-  HIPCHK(hipMemcpyAsync(e->h_count.data(), e->q_count.p, nq * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_pair_base.data(), e->q_pair_base.p, (nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_q_M.data(), e->q_M.p, nq * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_q_P.data(), e->q_P.p, nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_n_cand.data(), e->n_cand.p, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_cand_frame.data(), e->cand_frame.p, (size_t)nq * cn * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_cand_votes.data(), e->cand_votes.p, (size_t)nq * cn * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_pair_off.data(), e->pair_off.p, (size_t)nq * (cn + 1) * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(d2h(e, e->h_count.data(), e->q_count.p, nq * sizeof(u32)));
+  CHK(d2h(e, e->h_pair_base.data(), e->q_pair_base.p, (nq + 1) * sizeof(u32)));
+  CHK(d2h(e, e->h_q_M.data(), e->q_M.p, nq * sizeof(u32)));
+  CHK(d2h(e, e->h_q_P.data(), e->q_P.p, nq * sizeof(unsigned long long)));
+  CHK(d2h(e, e->h_n_cand.data(), e->n_cand.p, nq * sizeof(int)));
+  CHK(d2h(e, e->h_cand_frame.data(), e->cand_frame.p, (size_t)nq * cn * sizeof(int)));
+  CHK(d2h(e, e->h_cand_votes.data(), e->cand_votes.p, (size_t)nq * cn * sizeof(int)));
+  CHK(d2h(e, e->h_pair_off.data(), e->pair_off.p, (size_t)nq * (cn + 1) * sizeof(long long)));
+  CHK(xfer_sync(e));
   sgtd_stats &s = e->stats;
   s.last_queries = nq;
   s.last_D = 0; s.last_P = 0; s.last_M = 0; s.last_cand_pairs = 0;
@@ -1193,13 +1260,14 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->seg[1].hot, &e->seg[1].perm, &e->seg[1].hash, &e->seg[1].bucket_start, &e->seg[1].bucket_key, &e->seg[1].dir, &e->slice_of, &e->sq_sum,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->b_kp_off_dev, &e->b_xyz_dev, &e->b_label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->n_valid, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->pos_of_slot, &e->rec_off, &e->pass_pool, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->cursors, &e->list, &e->n_visit,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->pos_of_slot, &e->rec_off, &e->pass_pool, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->inl_pairs, &e->inl_off, &e->cursors, &e->list, &e->n_visit,
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
                     &e->cand_votes, &e->pair_off, &e->pairs};
   for (DevBuf *b : bufs) free_buf(*b);
   for (auto &b : e->scan_lvl) free_buf(b);
+  if (e->pin) (void)hipHostFree(e->pin);
   for (int i = 0; i < EV_COUNT; i++)
     if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   delete e;
@@ -1250,8 +1318,8 @@ int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sg
   CHK(launch_build(e, dx, dl, e->b_kp_off_dev.as<long long>(), 1, max_n, e->current_frame_id, 0,
                    e->tmp.view(), stride, e->tmp_count.as<u32>()));
   u32 cnt = 0;
-  HIPCHK(hipMemcpyAsync(&cnt, e->tmp_count.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(d2h(e, &cnt, e->tmp_count.p, sizeof(u32)));
+  CHK(xfer_sync(e));
   *n_out = cnt;
   if ((int64_t)cnt > capacity) return SGTD_ERR_CAPACITY;
   return copy_out(e, e->tmp, 0, cnt, out, 0);
@@ -1380,8 +1448,8 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
     HIPCHK(hipGetLastError());
   }
   u32 cnt = (u32)nq;
-  HIPCHK(hipMemcpyAsync(e->q_count.p, &cnt, sizeof(u32), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(h2d(e, e->q_count.p, &cnt, sizeof(u32)));
+  CHK(xfer_sync(e));
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));
   return launch_select(e);
 }
@@ -1464,8 +1532,8 @@ int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, i
   if (n > capacity) return SGTD_ERR_CAPACITY;
   if (n == 0) return SGTD_OK;
   std::vector<u64> pr(n);
-  HIPCHK(hipMemcpyAsync(pr.data(), e->pairs.as<u64>() + e->h_pair_base[q], n * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(d2h(e, pr.data(), e->pairs.as<u64>() + e->h_pair_base[q], n * sizeof(u64)));
+  CHK(xfer_sync(e));
   for (int64_t i = 0; i < n; i++) {
     if (q_idx) q_idx[i] = (int32_t)(pr[i] >> 32);
     if (db_entry) db_entry[i] = (int64_t)(pr[i] & 0xFFFFFFFFull);
@@ -1586,9 +1654,9 @@ int sgtd_result_verify(sgtd_handle e, int q, double *score, double *pose) {
   HIPCHK(hipSetDevice(e->cfg.device_id));
   if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
   const int cn = e->dc.cand_num;
-  if (score) HIPCHK(hipMemcpyAsync(score, e->v_score.as<double>() + (size_t)q * cn, cn * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  if (pose) HIPCHK(hipMemcpyAsync(pose, e->v_pose.as<double>() + (size_t)q * cn * 12, (size_t)cn * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (score) CHK(d2h(e, score, e->v_score.as<double>() + (size_t)q * cn, cn * sizeof(double)));
+  if (pose) CHK(d2h(e, pose, e->v_pose.as<double>() + (size_t)q * cn * 12, (size_t)cn * 12 * sizeof(double)));
+  CHK(xfer_sync(e));
   return SGTD_OK;
 }
 
@@ -1614,8 +1682,8 @@ int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t ca
   const int64_t lo = e->h_pair_off[(size_t)q * (cn + 1) + cand], hi = e->h_pair_off[(size_t)q * (cn + 1) + cand + 1];
   std::vector<unsigned char> fl((size_t)(hi - lo));
   if (hi > lo) {
-    HIPCHK(hipMemcpyAsync(fl.data(), e->v_inlier.as<unsigned char>() + e->h_pair_base[q] + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    CHK(d2h(e, fl.data(), e->v_inlier.as<unsigned char>() + e->h_pair_base[q] + lo, (size_t)(hi - lo)));
+    CHK(xfer_sync(e));
   }
   int64_t cnt = 0;
   for (int64_t j = 0; j < hi - lo; j++)
@@ -1625,6 +1693,38 @@ int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t ca
     }
   *n = cnt;
   return (idx && cnt > capacity) ? SGTD_ERR_CAPACITY : SGTD_OK;
+}
+
+int sgtd_result_inlier_pairs(sgtd_handle e, int q, int64_t *cand_off, int32_t *q_idx, int64_t *db_entry, int64_t capacity,
+                             int64_t *n_pairs) {
+  if (e && e->grp) return multi::result_inlier_pairs(e, q, cand_off, q_idx, db_entry, capacity, n_pairs);
+  if (!e || !n_pairs || !cand_off) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num;
+  const int64_t total = e->h_pair_off[(size_t)q * (cn + 1) + cn];
+  CHK(ensure(e, e->inl_pairs, (size_t)std::max<int64_t>(total, 1) * sizeof(u64)));
+  CHK(ensure(e, e->inl_off, (size_t)(cn + 1) * sizeof(long long)));
+  inlier_pairs_kernel<<<1, SGTD_INLIER_THREADS, 0, e->stream>>>(e->pairs.as<u64>() + e->h_pair_base[q], e->v_inlier.as<unsigned char>() + e->h_pair_base[q],
+                                                                e->pair_off.as<long long>() + (size_t)q * (cn + 1), cn, e->inl_pairs.as<u64>(),
+                                                                e->inl_off.as<long long>());
+  HIPCHK(hipGetLastError());
+  std::vector<long long> off((size_t)cn + 1);
+  CHK(d2h(e, off.data(), e->inl_off.p, off.size() * sizeof(long long)));
+  CHK(xfer_sync(e));
+  for (int k = 0; k <= cn; k++) cand_off[k] = off[(size_t)k];
+  const int64_t n = off[(size_t)cn];
+  *n_pairs = n;
+  if (n > capacity) return SGTD_ERR_CAPACITY;
+  if (n == 0) return SGTD_OK;
+  std::vector<u64> pr((size_t)n);
+  CHK(d2h(e, pr.data(), e->inl_pairs.p, (size_t)n * sizeof(u64)));
+  CHK(xfer_sync(e));
+  for (int64_t i = 0; i < n; i++) {
+    if (q_idx) q_idx[i] = (int32_t)(pr[(size_t)i] >> 32);
+    if (db_entry) db_entry[i] = (int64_t)(pr[(size_t)i] & 0xFFFFFFFFull);
+  }
+  return SGTD_OK;
 }
 
 int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, int32_t *best_frame, double *best_score) {
@@ -1640,10 +1740,10 @@ int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, in
   search_loop_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->v_score.as<double>(), e->cand_frame.as<int>(), e->n_cand.as<int>(), cn, nq,
                                                                icp_threshold, d_cand, d_frame, d_score);
   HIPCHK(hipGetLastError());
-  if (best_cand) HIPCHK(hipMemcpyAsync(best_cand, d_cand, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  if (best_frame) HIPCHK(hipMemcpyAsync(best_frame, d_frame, nq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  if (best_score) HIPCHK(hipMemcpyAsync(best_score, d_score, nq * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (best_cand) CHK(d2h(e, best_cand, d_cand, nq * sizeof(int)));
+  if (best_frame) CHK(d2h(e, best_frame, d_frame, nq * sizeof(int)));
+  if (best_score) CHK(d2h(e, best_score, d_score, nq * sizeof(double)));
+  CHK(xfer_sync(e));
   return SGTD_OK;
 }
 
@@ -1782,7 +1882,7 @@ int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_d
   // scattered ids (a match list): gathered on the device, then one copy per field
   CHK(ensure(e, e->fetch_idx, (size_t)n * sizeof(long long)));
   CHK(ensure_store(e, e->fetch, (size_t)n));
-  HIPCHK(hipMemcpyAsync(e->fetch_idx.p, db_entry, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, e->stream));
+  CHK(h2d(e, e->fetch_idx.p, db_entry, (size_t)n * sizeof(long long)));
   gather_entries_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->fetch_idx.as<long long>(), n, e->tab.view(), e->fetch.view());
   HIPCHK(hipGetLastError());
   return copy_out(e, e->fetch, 0, (size_t)n, out, 0);

@@ -342,3 +342,32 @@ __global__ void search_loop_kernel(const double *score, const int *cand_frame, c
     best_cand[q] = -1; best_frame[q] = -1; best_score[q] = 0;   // loop_result = (-1, 0) (:144)
   }
 }
+
+
+// The inlier pairs (sucess_match_vec, STDesc.cpp:516-539) of every candidate of ONE query, compacted in
+// match-list order: out[j] = the j-th pair whose inlier flag is set, cand_off[k] = inlier pairs before
+// candidate k's list (cand_off[cand_num] = all of them).  One workgroup walks the query's pairs.
+#define SGTD_INLIER_THREADS 1024
+__global__ __launch_bounds__(SGTD_INLIER_THREADS) void inlier_pairs_kernel(const u64 *pairs, const unsigned char *inlier,
+                                                                           const long long *pair_off /* of the query, [cand_num + 1] */,
+                                                                           int cand_num, u64 *out, long long *cand_off) {
+  __shared__ u32 lds[SGTD_INLIER_THREADS / SGTD_WAVE + 1];
+  __shared__ u32 s_ex[SGTD_INLIER_THREADS];
+  const long long total = pair_off[cand_num];
+  const int tid = threadIdx.x;
+  const long long bound = tid <= cand_num ? pair_off[tid] : -1;      // thread k watches candidate k's first pair
+  u32 carry = 0;
+  for (long long i0 = 0; i0 < total; i0 += SGTD_INLIER_THREADS) {
+    const long long i = i0 + tid;
+    const u32 f = (i < total && inlier[i]) ? 1u : 0u;
+    u32 tot;
+    const u32 ex = block_excl_scan(f, lds, tot);
+    if (f) out[carry + ex] = pairs[i];
+    s_ex[tid] = ex;
+    __syncthreads();
+    if (bound >= i0 && bound < i0 + SGTD_INLIER_THREADS && bound < total) cand_off[tid] = (long long)(carry + s_ex[bound - i0]);
+    __syncthreads();
+    carry += tot;
+  }
+  if (bound >= 0 && bound >= total) cand_off[tid] = (long long)carry;    // lists that start at the end (empty ones, the closing offset)
+}

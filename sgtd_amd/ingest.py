@@ -110,3 +110,21 @@ def write_graph_json(path, xyz, label, pose12, extra=True):
         doc["densitys"] = []
     with open(path, "w") as f:
         json.dump(doc, f)
+
+
+CACHE_MAGIC = b"SGTDGB01"
+
+
+def write_cache(cache_path, xyz, label, pose12):
+    """the binary graph-batch cache of sgtd_graphs_save_cache (graph_ingest.hip.h) straight from
+    arrays: xyz (F, N, 3) f32, label (F, N), pose12 (F, 12) f32 — what sgtd_graphs_load_cache and
+    examples/localize read without parsing a JSON file per frame"""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    f, n = xyz.shape[0], xyz.shape[1]
+    with open(cache_path, "wb") as fh:
+        fh.write(CACHE_MAGIC)
+        fh.write(np.array([f, f * n], np.int64).tobytes())
+        fh.write((np.arange(f + 1, dtype=np.int64) * n).tobytes())
+        fh.write(np.ascontiguousarray(pose12, np.float32).reshape(f, 12).tobytes())
+        fh.write(np.ascontiguousarray(label).astype(np.uint32).reshape(f * n).tobytes())
+        fh.write(xyz.reshape(f * n * 3).tobytes())

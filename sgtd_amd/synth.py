@@ -17,6 +17,7 @@ nearest to a perturbed copy of a random map pose (uniform yaw, N(0,0.5 m)
 shift) with N(0, sigma_query) noise, ground truth = that map frame.
 All randomness: numpy PCG64 seeded with (20251121, stream).
 """
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -103,9 +104,31 @@ def _observe(landmarks, labels, tree, pose, n_kp, sigma, rng, tie_k=10):
     return out, labels[idx].astype(np.uint32)
 
 
+def _cache_path(kind, key):
+    """generated sets are deterministic functions of their parameters: large ones are kept under
+    SGTD_SYNTH_CACHE (default /tmp/sgtd_synth_cache; empty = off) so that the test session and the
+    bench that follows it on the same box do not regenerate the same 10 000-frame map several times"""
+    import hashlib
+    root = os.environ.get("SGTD_SYNTH_CACHE", "/tmp/sgtd_synth_cache")
+    if not root:
+        return None
+    h = hashlib.sha256(repr((kind, BASE_SEED, key, np.__version__)).encode()).hexdigest()[:24]
+    return os.path.join(root, "%s_%s.npz" % (kind, h))
+
+
 def make_map(n_frames, n_kp=200, stream=1, spacing=2.0, swath=100.0, radius=50.0,
              sigma=0.02, label_lo=3, label_hi=11, z_sigma=1.5):
     from scipy.spatial import cKDTree
+
+    cache = _cache_path("map", (n_frames, n_kp, stream, spacing, swath, radius, sigma, label_lo, label_hi, z_sigma)) if n_frames >= 2000 else None
+    if cache and os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            m = SynthMap(xyz=z["xyz"], label=z["label"], pose=z["pose"], landmarks=z["landmarks"], landmark_label=z["landmark_label"])
+            m._tree = cKDTree(m.landmarks[:, :2])
+            return m
+        except Exception:
+            pass      # a damaged file: regenerate
 
     rng = _rng(stream, 0)
     pose, amp = _trajectory(n_frames, spacing, swath)
@@ -121,6 +144,14 @@ def make_map(n_frames, n_kp=200, stream=1, spacing=2.0, swath=100.0, radius=50.0
     xyz, label = _observe(landmarks, lab, tree, pose, n_kp, sigma, rng)
     m = SynthMap(xyz=xyz, label=label, pose=pose, landmarks=landmarks, landmark_label=lab)
     m._tree = tree
+    if cache:
+        try:
+            os.makedirs(os.path.dirname(cache), exist_ok=True)
+            tmp = cache + ".%d.tmp.npz" % os.getpid()
+            np.savez(tmp, xyz=xyz, label=label, pose=pose, landmarks=landmarks, landmark_label=lab)
+            os.replace(tmp, cache)
+        except Exception:
+            pass
     return m
 
 
@@ -141,11 +172,27 @@ def make_queries(smap, n_queries, stream=1, sigma=0.05, shift_sigma=0.5, frames=
     return SynthQueries(xyz=xyz, label=label, gt_frame=gt.astype(np.int64), pose=pose)
 
 
+def effective_cpus():
+    """host threads this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a container that shows 256 hardware threads may be allowed 16 CPUs' worth of time: teams sized
+    by the former only get in each other's way)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def frames_with_knn_ties(xyz, k, chunk=512):
     """indices of the frames of xyz (F, N, 3) f32 that have duplicate points or an exact f32
     distance tie among the k+1 nearest of any point (the same test as has_knn_ties, batched;
     torch CPU kernels: individually rounded IEEE f32 operations, all host threads)"""
     import torch
+    if torch.get_num_threads() > effective_cpus():
+        torch.set_num_threads(effective_cpus())
     x = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32))
     kk = min(k + 1, x.shape[1])
     bad = []

@@ -20,7 +20,7 @@ def _build():
            "-L" + os.path.join(ROOT, "sgtd_amd"), "-lsgtd_accel",
            "-L" + os.path.join(ROOT, "oracle"), "-lsgtd_oracle",
            "-Wl,-rpath," + os.path.join(ROOT, "sgtd_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
-           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
     subprocess.check_call(cmd)
 
 
@@ -33,7 +33,7 @@ def _build_shim():
     src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", SHIM_EXE,
            "-L" + os.path.join(ROOT, "sgtd_amd"), "-lsgtd_accel", "-Wl,-rpath," + os.path.join(ROOT, "sgtd_amd"),
-           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
     subprocess.check_call(cmd)
 
 

@@ -17,7 +17,7 @@ def _build():
     _lib.build_library()
     cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "localize.cpp"),
            "-o", EXE, "-L" + os.path.join(ROOT, "sgtd_amd"), "-lsgtd_accel",
-           "-Wl,-rpath," + os.path.join(ROOT, "sgtd_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+           "-Wl,-rpath," + os.path.join(ROOT, "sgtd_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
     subprocess.check_call(cmd)
 
 

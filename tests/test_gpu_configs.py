@@ -1,5 +1,6 @@
 """GPU tests at the sizes BASELINE.json's configs name.
 
+cfg2  F = 1 000, N = 200, 1 000 queries: sampled oracle comparison at exactly configs[1]'s size;
 cfg3  F = 4 541 (the KITTI-00 length), self-localization: every map frame re-observed
       (semantic_graph_localization.cpp:567) — properties on all 4 541 queries, the full
       oracle comparison (candidates, votes, ordered match lists) on a sample;
@@ -9,7 +10,7 @@ north-star point  F = 10 000, 1 GPU: sampled oracle comparison + identical top-1
 cfg5  two sessions of one world (independent noise draws), 13 "wild" label classes
       (get_json_wild.cpp:10-12), 2 x 2 500 frames: sampled oracle comparison + both
       sessions retrieved.
-The oracle map builds (14-35 s each on the GPU box's host) dominate the run time.
+(The oracle maps are inserted with orc_add_frames: builds on all host threads, a few seconds each.)
 """
 import numpy as np
 import pytest
@@ -26,13 +27,12 @@ def mods():
 
 
 def _oracle_map(oracle, smaps, threads=0):
-    import os
+    from sgtd_amd.synth import effective_cpus
     n = sum(m.xyz.shape[0] for m in smaps)
-    o = oracle.OracleManager(num_threads=threads or max(1, (os.cpu_count() or 8) - 4), max_frame_n=max(20000, n + 1))
+    # (the reference's thread rule, nproc - 4, on the CPUs this container may really use)
+    o = oracle.OracleManager(num_threads=threads or max(1, effective_cpus() - 4), max_frame_n=max(20000, n + 1))
     for m in smaps:
-        for f in range(m.xyz.shape[0]):
-            o.build(m.xyz[f], m.label[f], export=False)
-            o.add_last()
+        o.add_frames(m.xyz, m.label)     # = build + add_last per frame (tests/test_oracle_kat.py), builds on all host threads
     return o
 
 
@@ -57,6 +57,36 @@ def _list_properties(g, res, q):
     assert np.all((np.diff(v) < 0) | ((np.diff(v) == 0) & (np.diff(f) > 0)))
     assert np.array_equal(np.diff(res.pair_off[q, :nc + 1]), v)        # a candidate's list holds its votes
     return nc
+
+
+def test_cfg2_1k_frame_map_200_keypoints_sampled_parity(mods):
+    """BASELINE configs[1] at exactly its size: synthetic 200 keypoints/frame, 1 000-frame map,
+    descriptor build + match of 1 000 query frames on one GPU; the oracle compared on a sample
+    (candidates, votes, ordered match lists, list offsets, P/M counters), properties on the rest"""
+    oracle, manager, synth = mods
+    F, N, Q = 1000, 200, 1000
+    m = synth.make_map(F, N, stream=2)
+    qs = synth.make_queries(m, Q, stream=2)
+    g = manager.STDescManager()
+    g.add_frames(m.xyz, m.label)
+    res = g.query_frames(qs.xyz, qs.label)
+    assert np.all(res.n_cand > 0)
+    d = np.linalg.norm(m.pose[np.clip(res.top1(), 0, F - 1), :2] - qs.pose[:, :2], axis=1)
+    assert np.mean(d < 5.0) >= 0.99
+    for q in range(0, Q, 41):
+        _list_properties(g, res, q)
+    o = _oracle_map(oracle, [m])
+    P = M = 0
+    checked = (0, 333, 500, 999)
+    for q in checked:
+        r = _same_as_oracle(g, o, res, q, qs.xyz[q], qs.label[q])
+        assert res.cand_frame[q, 0] == r["cand_frame"][0]
+        c = o.counters()
+        P += c["P"]; M += c["M"]
+    sub = g.query_frames(qs.xyz[list(checked)], qs.label[list(checked)])
+    st = g.stats()
+    assert st["last_P"] == P and st["last_M"] == M and np.array_equal(sub.cand_frame, res.cand_frame[list(checked)])
+    g.close()
 
 
 def test_cfg3_kitti_length_map_every_frame_reobserved(mods):

@@ -136,7 +136,7 @@ def test_bench_refuses_a_gpu_count_that_disagrees_with_the_launcher():
 
 def test_bench_finds_the_committed_traffic_row_of_its_default_workload():
     """bench.py's roofline object takes the HBM bytes per sweep launch and the VALU issue fraction
-    from profiles/r02_traffic.json (PMC passes cannot run inside the bench): the row of the
+    from the newest profiles/r<NN>_traffic.json (PMC passes cannot run inside the bench): the row of the
     default workload must be there, with the fields the bench reads, and be self-consistent"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
@@ -149,7 +149,7 @@ def test_bench_finds_the_committed_traffic_row_of_its_default_workload():
     finally:
         sys.argv = argv
     row = bench.load_traffic(args.frames, args.keypoints, args.queries, 1)
-    assert row is not None, "no row for the default workload in profiles/r02_traffic.json"
+    assert row is not None, "no row for the default workload in profiles/r*_traffic.json"
     assert row["bytes_per_launch"] == int(2 * row["FETCH_SIZE_KB"] * 1024 + row["WRITE_SIZE_KB"] * 1024)
     assert 0.0 < row["valu_issue_frac"] <= 1.0
     assert abs(row["valu_issue_frac"] - row["SQ_INSTS_VALU"] * 4.0 / (row["kernel_cycles"] * 1024.0)) < 1e-9

@@ -199,3 +199,26 @@ def test_few_points_yield_nothing():
     xyz = np.zeros((5, 3), np.float32)
     xyz[:, 0] = np.arange(5)
     assert OracleManager().build(xyz, np.ones(5, np.uint32)).n == 0
+
+
+def test_batch_insert_equals_frame_by_frame():
+    """orc_add_frames (builds on all host threads, inserts in order) leaves the table and the frame
+    counter exactly as the reference's loop of BuildSingleScanSTD + AddSTDescs does"""
+    from sgtd_amd import synth
+    m = synth.make_map(40, 60, stream=23)
+    a, b = OracleManager(), OracleManager()
+    for f in range(40):
+        a.build(m.xyz[f], m.label[f], export=False)
+        a.add_last()
+    b.add_frames(m.xyz[:25], m.label[:25])
+    b.add_frames(m.xyz[25:], m.label[25:])
+    assert a.current_frame_id == b.current_frame_id == 40
+    ka, oa, ea = a.table_dump()
+    kb, ob, eb = b.table_dump()
+    assert np.array_equal(ka, kb) and np.array_equal(oa, ob) and np.array_equal(ea, eb)
+    q = synth.make_queries(m, 2, stream=23)
+    for i in range(2):
+        ra = (a.build(q.xyz[i], q.label[i], export=False), a.select())[1]
+        rb = (b.build(q.xyz[i], q.label[i], export=False), b.select())[1]
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), k

@@ -1,5 +1,5 @@
 """Randomised differential stress of the GPU path against the oracle (not part of the pytest
-suite: run on the GPU box, `python tools/stress_parity.py [seconds] [seed]`).  Every round draws
+suite: run on the GPU box, `python tools/stress_parity.py [seconds] [seed] [log.jsonl]`).  Every round draws
 a configuration (K, resolution, thresholds, labels), a small map, an insertion pattern
 (frames in one batch / frame by frame / appended after queries = tail segment / caller-stamped
 frame ids out of order), optionally a multi-device handle, and compares candidates, votes,
@@ -113,6 +113,18 @@ def main():
         if rnd % 10 == 0 or verbose:
             print(d, flush=True)
     print("stress ok: %d rounds in %.0f s (seed %d)" % (rnd, time.time() - t0, seed))
+    if len(sys.argv) > 3:     # one line per session, appended to a JSON-lines log (profiles/r03_stress.jsonl)
+        import json
+        import subprocess
+        root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+        try:
+            head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            head = ""
+        with open(sys.argv[3], "a") as fh:
+            fh.write(json.dumps({"rounds_without_a_difference": rnd, "seconds": round(time.time() - t0, 1), "seed": seed, "git_head": head,
+                                 "compared": "candidates, votes, ordered match lists, P/M counters, ordered rough list (q, cell, entry, frame, dis) against oracle/sgtd_oracle.cpp",
+                                 "last_round": d}) + "\n")
 
 
 if __name__ == "__main__":
