@@ -55,7 +55,7 @@
 #endif
 
 #ifndef SGTD_SHIM_FILL_THREADS
-#define SGTD_SHIM_FILL_THREADS 6u   // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call
+#define SGTD_SHIM_FILL_THREADS 4u   // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call
 #endif
 
 namespace sgtd_shim {

@@ -225,10 +225,15 @@ __global__ void group_first_kernel(const u32 *gid, const u32 *n_valid_p, u32 *gr
 // 32 lanes per group, grid-stride.
 __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryView Q, const u32 *order,
                                                             const u32 *group_first, const u32 *n_groups_p,
-                                                            const u32 *n_valid_p, unsigned char *rows) {
+                                                            const u32 *n_valid_p, unsigned char *rows, u32 rows_cap,
+                                                            int *overflow) {
   const int c = (int)(threadIdx.x & 31);
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 5;
   const long long n_groups = (*n_valid_p) ? (long long)*n_groups_p : 0;
+  if (n_groups > (long long)rows_cap) {     // more home cells than GroupRows were reserved: the host reserves more and re-runs the batch
+    if (blockIdx.x == 0 && threadIdx.x == 0) overflow[0] = 1;
+    return;
+  }
   for (long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; g < n_groups; g += stride) {
     if (c >= SGTD_NCELL) continue;      // (the ballots below only look at lanes c < 27 of either half)
     const long long d = (long long)order[group_first[g]];
@@ -368,16 +373,17 @@ __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int 
 template <bool PAIR>
 __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableView T, QueryView Q, const u32 *order, const u32 *gid,
                                                           const u32 *pos_of_slot, const u32 *n_valid_p,
-                                                          const u32 *n_groups_p, const unsigned char *rows, PassPool P,
+                                                          const u32 *n_groups_p, const unsigned char *rows, u32 rows_cap, PassPool P,
                                                           u32 *n_visit, uint2 *list, int *overflow) {
   __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][SGTD_PLAN_GROUPS * SGTD_ROW_QUADS];
   const int lane = lane_id();
   uint4 *my_rows = s_rows[threadIdx.x >> 6];
   const u32 nv = *n_valid_p;
   const u32 n_pass = pass_slot_count(nv, *n_groups_p, PAIR);
+  const bool no_rows = *n_groups_p > rows_cap;      // group_resolve_kernel raised the overflow flag: no pass gets a record
   // every wave takes 64 consecutive slots at a time, grid-stride (the grid is sized by resident waves)
   for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; (s & ~63u) < n_pass; s += gridDim.x * blockDim.x) {
-  const u32 p = s < n_pass ? pos_of_slot[s] : SGTD_NO_PASS;
+  const u32 p = (s < n_pass && !no_rows) ? pos_of_slot[s] : SGTD_NO_PASS;
   const bool act = p != SGTD_NO_PASS;
   int K = 0;
   u32 g = 0, d[2] = {0, 0};
@@ -1377,8 +1383,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
                                                           const unsigned char *slot_of_all, u32 frame_span, u32 frame_lo) {
   constexpr int NW = 256 / SGTD_WAVE;
   extern __shared__ unsigned char s_slot8[];   // [frame_span rounded up to 16] when SLOT_TABLE
-  __shared__ u32 s_pre[NW][32];
-  __shared__ u32 s_ptr[NW][32];
+  __shared__ u64 s_bits[NW][64];        // per wave: range starts of the current 4096 stream positions
   __shared__ u32 s_hist[NW][64];
   __shared__ u64 s_cand[SGTD_CAND_HASH];
   if (B.overflow()[0]) return;
@@ -1415,19 +1420,53 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   u32 visits = 0, total = 0, running = 0;
   // segment by segment: a candidate frame lives in one segment, so its matches still arrive in
   // (i, cell, j) order
+  u64 *bits = s_bits[wid];
   for (int sg = 0; sg < B.n_seg; sg++)
   for (u32 d0 = d_first; d0 < d_last; d0 += SGTD_SUB_DESCS) {
-    const u32 R = sub_open(Q, B, sg, q, d0, cnt, s_pre[wid], s_ptr[wid], visits);
+    // The records of the sub-block's 32 descriptors as ONE stream: the non-empty lists are its ranges
+    // (range j in lane j: offset in the stream, address delta, descriptor), a record's range comes from
+    // the marks of the range starts in an LDS bit window — the sweep's locate: one LDS read, two
+    // v_mbcnt and two ds_bpermute per 64 records instead of a five-step binary search per record.
+    u32 n = 0, p = 0, v = 0;
+    if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
+      const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
+      const uint2 lp = B.list[d];
+      n = lp.y; p = lp.x; v = B.n_visit[d];
+    }
+    const u32 inc = wave_incl_scan(n);
+    const u32 R = (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
+    visits += wave_sum(v);
     total += R;
+    const u64 hm = __builtin_amdgcn_ballot_w64(n != 0u);
+    const u32 nr = (u32)__builtin_popcountll(hm);
+    const u32 jdst = (n != 0u ? __builtin_amdgcn_mbcnt_hi((u32)(hm >> 32), __builtin_amdgcn_mbcnt_lo((u32)hm, 0u)) : 63u) << 2;   // (lane 63 is nobody's range)
+    const u32 pre = inc - n;
+    const u32 offj = (u32)__builtin_amdgcn_ds_permute((int)jdst, (int)pre);
+    const u32 delc = (u32)__builtin_amdgcn_ds_permute((int)jdst, (int)(p - pre));     // record address = stream position + delta
+    const u32 ddc = (u32)__builtin_amdgcn_ds_permute((int)jdst, lane);
+    const u32 offc = (u32)lane < nr ? offj : ((u32)lane == nr ? R : 0xFFFFFFFFu);
+    const bool marks = (u32)lane <= nr && offc != 0u;
+    auto window = [&](u32 w_first) {     // the marks of stream positions [64 w_first, 64 w_first + 4096)
+      bits[lane] = 0;
+      const u32 wr = ((offc - 1u) >> 6) - w_first;
+      if (marks && wr < 64u) atomicOr(reinterpret_cast<unsigned long long *>(bits + wr), 1ull << ((offc - 1u) & 63u));
+      __builtin_amdgcn_wave_barrier();
+    };
     // the records of the next four words are loaded while the current four are looked up
     u32 nid[4], ndd[4];
     auto load4 = [&](u32 r0) {
+      const u32 w0 = r0 >> 6;
+      if ((w0 & 63u) == 0u) window(w0);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const u32 r = r0 + u * SGTD_WAVE + lane;
-        u32 ad;
-        sub_locate(s_pre[wid], s_ptr[wid], r < R ? r : 0u, ndd[u], ad);
-        nid[u] = B.rec[ad];
+        const u32 w_lo = (w0 + u) << 6;
+        const u64 bm = bits[(w0 + u) & 63u];
+        const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(offc <= w_lo)) - 1u;
+        const u32 j4 = __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, before)) << 2;
+        const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)delc);
+        ndd[u] = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)ddc);
+        const u32 r = w_lo + lane;
+        nid[u] = B.rec[r < R ? r + dsel : 0u];
       }
     };
     if (R) load4(0);
@@ -1456,6 +1495,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
         running += (u32)__builtin_popcountll(m);
       }
     }
+    __builtin_amdgcn_wave_barrier();     // (the next sub-block rebuilds the window)
   }
   __builtin_amdgcn_wave_barrier();
   out[lane] = s_hist[wid][lane];
@@ -1608,6 +1648,13 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
       const u32 c_own = (u32)__builtin_popcountll(s_mask[wid][lane]);   // pairs this word adds to slot == lane
       __builtin_amdgcn_wave_barrier();
       const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(gm >> 32), __builtin_amdgcn_mbcnt_lo((u32)gm, 0u)), count = (u32)__builtin_popcountll(gm);
+#ifdef SGTD_EXP_WRITE_DIRECT
+      // experiment: no staging lines — every pair goes straight to its list (runs of one slot are contiguous)
+      const u32 base = __shfl(running, s);
+      if (valid) pairs[base + rank] = pr[u];
+      running += c_own;
+      (void)count;
+#else
       u32 have = __shfl(fill, s);
       if (__builtin_amdgcn_ballot_w64(valid && have + count > (u32)CAP)) {   // some slot would overflow its line: drain all
         flush();
@@ -1620,6 +1667,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
         else s_stage[wid][s][have + rank] = pr[u];
       }
       if (c_own > (u32)CAP) running += c_own; else fill += c_own;
+#endif
       __builtin_amdgcn_wave_barrier();
     }
   }

@@ -132,6 +132,8 @@ struct sgtd_engine {
   DevBuf n_valid, cell_rows, gid, q_prefix, group_first, n_groups;
   DevBuf pos_of_slot, rec_off, pass_pool;   // pass slots and records (probe_kernels.hip.h)
   size_t pool_units = 0;                    // pass pool capacity in 16-B units (0: sized by the first batch; grown on overflow)
+  size_t group_cap = 0;                     // GroupRows reserved (0: sized by the first batch; grown on overflow)
+  size_t group_cap_hook = 0;                // SGTD_GROUP_CAP (test hook): the first reservation
   int sorted_chunk = 0;                // > 0: fixed descriptors per ticket (SGTD_SORTED_CHUNK), else adaptive
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
   // host copies after sync
@@ -217,7 +219,7 @@ void free_store(DescStore &s) {
 // caller's data into pinned memory at once, queue pinned -> device; the pinned bytes are reused
 // only after the next xfer_sync.  Transfers beyond kPinMax take the direct path (bandwidth-bound).
 // ---------------------------------------------------------------------------
-constexpr size_t kPinMax = (size_t)4 << 20, kPinCap = (size_t)16 << 20;
+constexpr size_t kPinMax = (size_t)256 << 10, kPinCap = (size_t)8 << 20;   // (beyond 256 KB a transfer is bandwidth-bound: the extra host copy would cost more than it saves)
 
 int xfer_sync(sgtd_engine *e) {
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -759,9 +761,16 @@ int launch_select(sgtd_engine *e) {
   const bool lds_votes = hist_bytes <= 150 * 1024;
   const int groups = (blocks + 3) / 4;
   const int agrid = ((nq + 7) / 8) * groups * 8;   // workgroup b serves query (b/8/groups)*8 + b%8
-  // one GroupRow per distinct home cell of the batch (at most one per descriptor slot)
-  CHK(ensure(e, e->cell_rows, (size_t)std::max<long long>(n_slots, 1) * SGTD_GROUP_ROW_BYTES));
+  // one GroupRow (1 KB) per distinct home cell of the batch: at most one per descriptor slot, in practice a
+  // twelfth of that (0.7 M cells for 9.1 M descriptors at the default batch).  Reserved: every slot for
+  // small batches, an eighth of the slots for large ones — a 15-GB reservation cost the first batch
+  // 0.4 s of hipMalloc — and what a batch really needed, plus a quarter, once one has overflowed it
+  // (group_resolve_kernel raises the overflow flag, sync_batch re-runs).
+  if (e->group_cap_hook) { if (e->group_cap == 0) e->group_cap = e->group_cap_hook; }
+  else e->group_cap = std::max<size_t>(e->group_cap, (size_t)std::max<long long>(std::min<long long>(n_slots, 65536), n_slots / 8));
+  CHK(ensure(e, e->cell_rows, std::max<size_t>(e->group_cap, 1) * SGTD_GROUP_ROW_BYTES));
   const unsigned char *rows = e->cell_rows.as<unsigned char>();
+  const u32 rows_cap = (u32)std::min<size_t>(e->group_cap, 0xFFFFFFFFu);
   {
     // ---- order of the batch's descriptors by home key (label code + truncated cell):
     // stable 8-bit radix passes over 12 + 3*cbits key bits, then one GroupRow of bucket
@@ -830,13 +839,13 @@ int launch_select(sgtd_engine *e) {
         HIPCHK(hipMemsetAsync(vs.B.amb_count(), 0, sizeof(u32), e->stream));   // the undecided-record queue
       }
       group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->group_first.as<u32>(),
-                                                                  e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>());
+                                                                  e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>(), rows_cap, vs.B.overflow());
       HIPCHK(hipGetLastError());
       // resident workgroups (LDS: 880 B per staged group and wave) x 4 rounds, grid-stride over the slots
       const int pgrid = (int)std::min<long long>(grid_for((long long)max_pass_slots, SGTD_PLAN_THREADS), (long long)e->n_cus * 20);
 #define SGTD_LAUNCH_PLAN(PR)                                                                                   \
   plan_passes_kernel<PR><<<pgrid, SGTD_PLAN_THREADS, 0, e->stream>>>(vs.T, vs.Q, vin, e->gid.as<u32>(), e->pos_of_slot.as<u32>(), nv, \
-                                                       e->n_groups.as<u32>(), rows, PP, vs.B.n_visit, vs.B.list,          \
+                                                       e->n_groups.as<u32>(), rows, rows_cap, PP, vs.B.n_visit, vs.B.list,          \
                                                        vs.B.overflow())
       if (pair) SGTD_LAUNCH_PLAN(true); else SGTD_LAUNCH_PLAN(false);
 #undef SGTD_LAUNCH_PLAN
@@ -993,7 +1002,9 @@ int sync_batch(sgtd_engine *e) {
     swept = 0;
     u32 total = 0, pool_used = 0;
     u32 ctr[12];     // ProbeBuffers::ctr, one copy
+    u32 n_groups = 0;
     CHK(d2h(e, ctr, e->cursors.p, sizeof(ctr)));
+    if (e->n_groups.p) CHK(d2h(e, &n_groups, e->n_groups.p, sizeof(u32)));
     CHK(d2h(e, &total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32)));
     CHK(xfer_sync(e));
     std::memcpy(&cursor, ctr, 8); std::memcpy(&need, ctr + 4, 8); std::memcpy(&swept, ctr + 6, 8);
@@ -1009,7 +1020,10 @@ int sync_batch(sgtd_engine *e) {
     if (attempt == 7) return SGTD_ERR_CAPACITY;
     // grow towards the u32 index limit; a batch that does not fit even there must be split
     const size_t lim = 0xFFFFFFF0ull;
-    if (ovf[0] && (size_t)pool_used > e->pool_units) {
+    if (ovf[0] && (size_t)n_groups > e->group_cap) {
+      // more distinct home cells than GroupRows were reserved
+      e->group_cap = (size_t)n_groups + (size_t)n_groups / 4 + 1024;
+    } else if (ovf[0] && (size_t)pool_used > e->pool_units) {
       // the pass records did not fit (the cursor kept counting: pool_used is what the batch needs)
       if (e->pool_units >= 0xFFFFFF00ull) return SGTD_ERR_CAPACITY;
       e->pool_units = std::min<size_t>(0xFFFFFF00ull, (size_t)pool_used + (size_t)pool_used / 4 + 65536);
@@ -1226,6 +1240,9 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (const char *o = getenv("SGTD_COARSE_AT")) e->coarse_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }
+  // test hooks: start with a tiny pass pool / GroupRow reservation so that their overflow / re-run paths run
+  if (const char *o = getenv("SGTD_POOL_UNITS")) e->pool_units = (size_t)std::max(64ll, atoll(o));
+  if (const char *o = getenv("SGTD_GROUP_CAP")) e->group_cap_hook = (size_t)std::max(1ll, atoll(o));
   if (const char *o = getenv("SGTD_PAIR_CAP")) { e->pair_cap = (size_t)std::max(64ll, atoll(o)); e->rec_cap_fixed = true; }
   for (int i = 0; i < EV_COUNT; i++)
     if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }

@@ -637,6 +637,36 @@ def test_sharded_search_loop_equals_single_table(mods):
         m.close()
 
 
+@pytest.mark.gpu
+def test_pass_pool_and_group_rows_grow_on_overflow(mods, monkeypatch):
+    """the planner's work buffers (pass records, GroupRows) start small and are regrown by a re-run of the
+    batch, like the match-record buffer: the repaired batch equals the oracle's lists"""
+    oracle, manager, synth = mods
+    m = synth.make_map(50, 160, stream=77)
+    qs = synth.make_queries(m, 6, stream=77)
+    o = oracle.OracleManager()
+    o.add_frames(m.xyz, m.label)
+    for env in ({"SGTD_POOL_UNITS": "64"}, {"SGTD_GROUP_CAP": "3"}, {"SGTD_POOL_UNITS": "64", "SGTD_GROUP_CAP": "1", "SGTD_REC_CAP": "2048"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = manager.STDescManager()
+        for k in env:
+            monkeypatch.delenv(k)
+        g.add_frames(m.xyz, m.label)
+        res = g.query_frames(qs.xyz, qs.label)
+        assert g.stats()["overflowed"] == 1, env
+        for q in range(6):
+            o.build(qs.xyz[q], qs.label[q], export=False)
+            r = o.select()
+            nc = int(res.n_cand[q])
+            assert np.array_equal(res.cand_frame[q, :nc], r["cand_frame"]) and np.array_equal(res.cand_votes[q, :nc], r["cand_votes"]), env
+            qi, de = g.result_pairs(q, res)
+            assert np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"]), env
+        res2 = g.query_frames(qs.xyz, qs.label)        # the grown buffers serve the next batch without a re-run
+        assert g.stats()["overflowed"] == 0 and np.array_equal(res2.cand_frame, res.cand_frame)
+        g.close()
+
+
 def test_overflowed_batch_is_resolved_before_the_sharded_export(mods, monkeypatch):
     """a batch that outgrows the match-record buffer has empty candidate tables
     until it is re-run; ShardedMap.query / search_loop must export the repaired tables"""
