@@ -124,6 +124,7 @@ struct sgtd_engine {
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
   DevBuf inl_pairs, inl_off;                  // sgtd_result_inlier_pairs staging
+  DevBuf v_hyp64, v_hyp32, v_bound;           // hypotheses between the two passes of sgtd_verify
   bool verified = false;
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
@@ -1277,7 +1278,7 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->seg[1].hot, &e->seg[1].perm, &e->seg[1].hash, &e->seg[1].bucket_start, &e->seg[1].bucket_key, &e->seg[1].dir, &e->slice_of, &e->sq_sum,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->b_kp_off_dev, &e->b_xyz_dev, &e->b_label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->n_valid, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->pos_of_slot, &e->rec_off, &e->pass_pool, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->inl_pairs, &e->inl_off, &e->cursors, &e->list, &e->n_visit,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->pos_of_slot, &e->rec_off, &e->pass_pool, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->inl_pairs, &e->inl_off, &e->v_hyp64, &e->v_hyp32, &e->v_bound, &e->cursors, &e->list, &e->n_visit,
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
@@ -1659,6 +1660,12 @@ int sgtd_verify(sgtd_handle e) {
   P.passed = e->c_pair.as<u64>();
   P.thr2 = 9.0;   // sqrt_rn(y) < 3.0 <=> y < 9.0 (sqrt(9) = 3, sqrt(pred(9)) rounds to pred(3)); dis_threshold :469
   { const char *o = getenv("SGTD_VERIFY_EXACT"); P.exact_only = (o && atoi(o)) ? 1 : 0; }
+  CHK(ensure(e, e->v_hyp64, (size_t)nq * cn * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F64 * sizeof(double)));
+  CHK(ensure(e, e->v_hyp32, (size_t)nq * cn * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F32 * sizeof(float)));
+  CHK(ensure(e, e->v_bound, (size_t)nq * cn * 2 * sizeof(u32)));
+  P.hyp64 = e->v_hyp64.as<double>(); P.hyp32 = e->v_hyp32.as<float>(); P.bound = e->v_bound.as<u32>();
+  verify_solve_kernel<<<nq * cn, SGTD_WAVE, 0, e->stream>>>(P);
+  HIPCHK(hipGetLastError());
   verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
   e->verified = true;

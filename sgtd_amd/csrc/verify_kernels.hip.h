@@ -1,10 +1,10 @@
 // verify_kernels.hip.h — candidate_verify + triangle_solver
 // (src/sgtd/src/STDesc.cpp:462-547 and :549-571), SURVEY §8f row 1.
 //
-// One workgroup per (query, candidate).  match_list_ of the candidate = the candidate's
+// Two kernels, one workgroup per (query, candidate) each.  match_list_ of the candidate = the candidate's
 // pair range written by block_write_kernel, in the reference's order.
 //   hypotheses  (:467-468,481-487) every skip_len-th pair, use_size <= 50 of them: one thread
-//               each solves the 3x3 Kabsch problem of its triangle pair (triangle_solver)
+//               each solves the 3x3 Kabsch problem of its triangle pair (triangle_solver) — verify_solve_kernel
 //   votes       (:488-505) every thread owns two pairs of the current 512-pair tile and
 //               tests them against all hypotheses (R, t broadcast from LDS); the per-hypothesis
 //               counts are wave ballots accumulated in lane h.  A vertex is pre-tested in
@@ -46,6 +46,9 @@ struct VerifyParams {
   double *pose;                // [nq][cand_num][12]  rot row-major (9) then t (3)
   unsigned char *inlier;       // [total pairs] flag per pair of every list
   u64 *passed;                 // [total pairs] scratch: bit h = the pair votes for hypothesis h of its candidate
+  double *hyp64;               // [nq * cand_num][SGTD_VERIFY_MAX_HYP][12] hypotheses (R row-major, t), pass 1 -> pass 2
+  float *hyp32;                // [nq * cand_num][SGTD_VERIFY_MAX_HYP][24] the same in f32, every value twice
+  u32 *bound;                  // [nq * cand_num][2] largest |rot entry| and |t|_1 of the candidate's hypotheses (float bits)
   double thr2;                 // smallest y with sqrt_rn(y) >= 3.0 (dis_threshold, :469)
   int exact_only;              // test hook (SGTD_VERIFY_EXACT=1): no f32 pre-test, every vertex A test in f64
 };
@@ -161,12 +164,62 @@ __device__ __forceinline__ bool vertex_close(const double *Rt, const double v[3]
   return ((dx * dx + dy * dy) + dz * dz) < thr2;
 }
 
-// (four waves per SIMD: the solver's f64 temporaries must not set the register budget of the vote loop)
-__global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void verify_kernel(VerifyParams P) {
-  __shared__ double s_Rt[SGTD_VERIFY_MAX_HYP][12];
-  __shared__ __attribute__((aligned(16))) float s_Rtf[SGTD_VERIFY_MAX_HYP][12];   // the same rounded to f32 (pre-test)
+// ---- pass 1: the hypotheses (:467-468,481-487).  One 64-thread workgroup per (query, candidate): thread h
+// solves the 3x3 Kabsch problem of pair h * skip_len.  Out: per hypothesis (R, t) in f64 (12 doubles) and
+// the same rounded to f32 with every value TWICE (24 floats: the operands of the vote pass's packed f32
+// chain as it reads them through the scalar data path), per (query, candidate) the bounds of the f32
+// pre-test's error (largest |rot entry|, largest |t|_1, as float bit patterns; NaN: every pre-test undecided).
+#define SGTD_HYP_F64 12
+#define SGTD_HYP_F32 24
+__global__ __launch_bounds__(SGTD_WAVE) void verify_solve_kernel(VerifyParams P) {
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x / P.cand_num, c = blockIdx.x % P.cand_num;
+  if (c >= P.n_cand[q]) return;
+  const long long *po = P.pair_off + (size_t)q * (P.cand_num + 1);
+  const u32 base = P.q_pair_base[q] + (u32)po[c];
+  const long long n = po[c + 1] - po[c];
+  const int skip_len = (int)(n / 50) + 1;          // :467
+  const int use_size = (int)(n / skip_len);        // :468
+  const size_t qslot0 = (size_t)q * (size_t)P.q_stride;
+  u32 rm_bits = P.exact_only ? 0x7FC00000u : 0u, tm_bits = 0u;
+  if (tid < use_size) {
+    double qv[9], ev[9], qc[3], ec[3], out[12];
+    const u64 pr = P.pairs[base + (long long)tid * skip_len];
+    const size_t qd = qslot0 + (size_t)(pr >> 32), g = (size_t)(pr & 0xFFFFFFFFull);
+    for (int k = 0; k < 9; k++) { qv[k] = (double)P.q_vertex[qd * 9 + k]; ev[k] = (double)P.t_vertex[g * 9 + k]; }
+    for (int k = 0; k < 3; k++) { qc[k] = P.q_center[qd * 3 + k]; ec[k] = P.t_center[g * 3 + k]; }
+    solve_triangle_dev(qv, qc, ev, ec, out);
+    double *h64 = P.hyp64 + ((size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP + tid) * SGTD_HYP_F64;
+    float *h32 = P.hyp32 + ((size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP + tid) * SGTD_HYP_F32;
+    for (int k = 0; k < 12; k++) { h64[k] = out[k]; const float f = (float)out[k]; h32[2 * k] = f; h32[2 * k + 1] = f; }
+    // largest |rot entry| and |t|_1, rounded up, as float bit patterns (non-negative floats order like
+    // their bits; a NaN beats everything)
+    double rm = 0, tm = fabs(out[9]) + fabs(out[10]) + fabs(out[11]);
+    for (int k = 0; k < 9; k++) rm = fmax(rm, fabs(out[k]));
+    if (!(rm == rm)) rm = __builtin_nan("");
+    rm_bits = max(rm_bits, __float_as_uint((float)(rm * 1.000001)));
+    tm_bits = __float_as_uint((float)(tm * 1.000001));
+  }
+#pragma unroll
+  for (int d = SGTD_WAVE / 2; d > 0; d >>= 1) {
+    rm_bits = max(rm_bits, (u32)__shfl_xor((int)rm_bits, d));
+    tm_bits = max(tm_bits, (u32)__shfl_xor((int)tm_bits, d));
+  }
+  if (tid == 0) { P.bound[2 * (size_t)blockIdx.x] = rm_bits; P.bound[2 * (size_t)blockIdx.x + 1] = tm_bits; }
+}
+
+// ---- pass 2: votes, best hypothesis, inliers.  The hypotheses are wave-uniform: they come through the
+// scalar data path (written by the kernel before: the constant address space's promise holds) straight into
+// the scalar operands of the packed f32 chain — no LDS broadcast reads (12 of them per step made the loop
+// LDS-bound), no splat moves.
+#ifndef SGTD_VERIFY_WAVES
+#define SGTD_VERIFY_WAVES __attribute__((amdgpu_waves_per_eu(5, 8)))
+#endif
+typedef const __attribute__((address_space(4))) f32x2 *sgtd_const_f32x2;
+typedef const __attribute__((address_space(4))) double *sgtd_const_f64;
+__global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_kernel(VerifyParams P) {
   __shared__ u32 s_votes[SGTD_VERIFY_MAX_HYP];
-  __shared__ u32 s_best, s_count, s_rmax, s_tmax;
+  __shared__ u32 s_best, s_count;
   const int tid = threadIdx.x, lane = lane_id();
   const int q = blockIdx.x / P.cand_num, c = blockIdx.x % P.cand_num;
   double *score = P.score + (size_t)q * P.cand_num + c;
@@ -177,33 +230,11 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
   const int skip_len = (int)(n / 50) + 1;          // :467
   const int use_size = (int)(n / skip_len);        // :468
   const size_t qslot0 = (size_t)q * (size_t)P.q_stride;
-
-  auto load_pair = [&](long long j, double qv[9], double ev[9], size_t &qd, size_t &g) {
-    const u64 pr = P.pairs[base + j];
-    qd = qslot0 + (size_t)(pr >> 32);
-    g = (size_t)(pr & 0xFFFFFFFFull);
-    for (int k = 0; k < 9; k++) { qv[k] = (double)P.q_vertex[qd * 9 + k]; ev[k] = (double)P.t_vertex[g * 9 + k]; }
-  };
+  const sgtd_const_f32x2 hyp32 = (sgtd_const_f32x2)(unsigned long long)(P.hyp32 + (size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F32);
+  const sgtd_const_f64 hyp64 = (sgtd_const_f64)(unsigned long long)(P.hyp64 + (size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F64);
 
   if (tid < SGTD_VERIFY_MAX_HYP) s_votes[tid] = 0;
-  if (tid == 0) { s_count = 0; s_rmax = P.exact_only ? 0x7FC00000u : 0u; s_tmax = 0; }   // NaN bound: every pre-test undecided
-  __syncthreads();
-  if (tid < use_size) {
-    double qv[9], ev[9], qc[3], ec[3], out[12];
-    size_t qd, g;
-    load_pair((long long)tid * skip_len, qv, ev, qd, g);
-    for (int k = 0; k < 3; k++) { qc[k] = P.q_center[qd * 3 + k]; ec[k] = P.t_center[g * 3 + k]; }
-    solve_triangle_dev(qv, qc, ev, ec, out);
-    for (int k = 0; k < 12; k++) { s_Rt[tid][k] = out[k]; s_Rtf[tid][k] = (float)out[k]; }
-    // largest |rot entry| and |t|_1 over the hypotheses, rounded up, as float bit patterns
-    // (non-negative floats order like their bits; a NaN beats everything and makes every
-    // f32 pre-test undecided)
-    double rm = 0, tm = fabs(out[9]) + fabs(out[10]) + fabs(out[11]);
-    for (int k = 0; k < 9; k++) rm = fmax(rm, fabs(out[k]));
-    if (!(rm == rm)) rm = __builtin_nan("");
-    atomicMax(&s_rmax, __float_as_uint((float)(rm * 1.000001)));
-    atomicMax(&s_tmax, __float_as_uint((float)(tm * 1.000001)));
-  }
+  if (tid == 0) s_count = 0;
   __syncthreads();
 
   // ---- votes of every hypothesis (:488-505).  f32 pre-test of a vertex, both pairs of a thread
@@ -218,7 +249,7 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
   constexpr int PPT = SGTD_VERIFY_PPT;
   static_assert(PPT == 2, "two pairs per thread: the halves of v_pk_*_f32");
   const float uf = 5.9604644775390625e-08f;
-  const float rmaxf = __uint_as_float(s_rmax), tmaxf = __uint_as_float(s_tmax);
+  const float rmaxf = __uint_as_float(P.bound[2 * (size_t)blockIdx.x]), tmaxf = __uint_as_float(P.bound[2 * (size_t)blockIdx.x + 1]);
   const float thrf = (float)(sqrt(P.thr2) * 1.000001);
   for (long long j0 = 0; j0 < n; j0 += (long long)PPT * SGTD_VERIFY_THREADS) {
     bool valid[PPT];
@@ -247,41 +278,56 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
       const float h2 = hi * hi * (1.0f + 8.0f * uf);                     // ... and hi2 = NaN (never certainly out)
       if (u == 0) { lo2.x = l2; hi2.x = h2; } else { lo2.y = l2; hi2.y = h2; }
     }
+    // Which of the wave's 2 x 64 pairs still vote for hypothesis h is kept as two 64-bit LANE MASKS in
+    // scalar registers (not as per-lane booleans: those cost a v_cndmask / v_cmp pair at every use and
+    // made this loop 140 VALU instructions per step; SQ counters, profiles/r03o_sq_verify.json).
+    const u64 valid0 = __builtin_amdgcn_ballot_w64(valid[0]), valid1 = __builtin_amdgcn_ballot_w64(valid[1]);
     for (int h = 0; h < use_size; h++) {
-      const float4 r0 = reinterpret_cast<const float4 *>(s_Rtf[h])[0];   // R00 R01 R02 R10
-      const float4 r1 = reinterpret_cast<const float4 *>(s_Rtf[h])[1];   // R11 R12 R20 R21
-      const float4 r2 = reinterpret_cast<const float4 *>(s_Rtf[h])[2];   // R22 t0 t1 t2
-      auto bc = [](float x) { f32x2 r = {x, x}; return r; };
+      f32x2 R[12];      // R00 R01 R02 R10 R11 R12 R20 R21 R22 t0 t1 t2, each in both halves (scalar registers)
+#pragma unroll
+      for (int k = 0; k < 12; k++) R[k] = hyp32[h * 12 + k];
       // vertex m of both pairs: certainly close (stays in), certainly far (leaves), or undecided in
       // f32 — then decided exactly, as the reference computes it
-      auto vertex = [&](int m, bool (&in)[PPT]) {
-        const f32x2 px = __builtin_elementwise_fma(bc(r0.x), v[m][0], __builtin_elementwise_fma(bc(r0.y), v[m][1], __builtin_elementwise_fma(bc(r0.z), v[m][2], bc(r2.y))));
-        const f32x2 py = __builtin_elementwise_fma(bc(r0.w), v[m][0], __builtin_elementwise_fma(bc(r1.x), v[m][1], __builtin_elementwise_fma(bc(r1.y), v[m][2], bc(r2.z))));
-        const f32x2 pz = __builtin_elementwise_fma(bc(r1.z), v[m][0], __builtin_elementwise_fma(bc(r1.w), v[m][1], __builtin_elementwise_fma(bc(r2.x), v[m][2], bc(r2.w))));
+      auto vertex = [&](int m, u64 &in0, u64 &in1) {
+        const f32x2 px = __builtin_elementwise_fma(R[0], v[m][0], __builtin_elementwise_fma(R[1], v[m][1], __builtin_elementwise_fma(R[2], v[m][2], R[9])));
+        const f32x2 py = __builtin_elementwise_fma(R[3], v[m][0], __builtin_elementwise_fma(R[4], v[m][1], __builtin_elementwise_fma(R[5], v[m][2], R[10])));
+        const f32x2 pz = __builtin_elementwise_fma(R[6], v[m][0], __builtin_elementwise_fma(R[7], v[m][1], __builtin_elementwise_fma(R[8], v[m][2], R[11])));
         const f32x2 dx = px - w[m][0], dy = py - w[m][1], dz = pz - w[m][2];
         const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        bool amb[PPT];
-        amb[0] = in[0] && !(d2.x < lo2.x) && !(d2.x > hi2.x); in[0] = in[0] && d2.x < lo2.x;
-        amb[1] = in[1] && !(d2.y < lo2.y) && !(d2.y > hi2.y); in[1] = in[1] && d2.y < lo2.y;
-        if (__ballot(amb[0] || amb[1])) {     // rare
+        const u64 sure0 = __builtin_amdgcn_ballot_w64(d2.x < lo2.x), sure1 = __builtin_amdgcn_ballot_w64(d2.y < lo2.y);
+        const u64 far0 = __builtin_amdgcn_ballot_w64(d2.x > hi2.x), far1 = __builtin_amdgcn_ballot_w64(d2.y > hi2.y);
+        u64 amb0 = in0 & ~sure0 & ~far0, amb1 = in1 & ~sure1 & ~far1;     // (a NaN is neither sure nor far)
+        in0 &= sure0; in1 &= sure1;
+        if (amb0 | amb1) {     // rare
+          double Rt[12];
 #pragma unroll
-          for (int u = 0; u < PPT; u++)
-            if (amb[u]) {
-              const double qa[3] = {(double)(u ? v[m][0].y : v[m][0].x), (double)(u ? v[m][1].y : v[m][1].x), (double)(u ? v[m][2].y : v[m][2].x)};
-              const double ea[3] = {(double)(u ? w[m][0].y : w[m][0].x), (double)(u ? w[m][1].y : w[m][1].x), (double)(u ? w[m][2].y : w[m][2].x)};
-              in[u] = vertex_close(s_Rt[h], qa, ea, P.thr2);
-            }
+          for (int k = 0; k < 12; k++) Rt[k] = hyp64[h * 12 + k];
+          bool ex0 = false, ex1 = false;
+          if ((amb0 >> lane) & 1ull) {
+            const double qa[3] = {(double)v[m][0].x, (double)v[m][1].x, (double)v[m][2].x};
+            const double ea[3] = {(double)w[m][0].x, (double)w[m][1].x, (double)w[m][2].x};
+            ex0 = vertex_close(Rt, qa, ea, P.thr2);
+          }
+          if ((amb1 >> lane) & 1ull) {
+            const double qa[3] = {(double)v[m][0].y, (double)v[m][1].y, (double)v[m][2].y};
+            const double ea[3] = {(double)w[m][0].y, (double)w[m][1].y, (double)w[m][2].y};
+            ex1 = vertex_close(Rt, qa, ea, P.thr2);
+          }
+          in0 |= __builtin_amdgcn_ballot_w64(ex0);
+          in1 |= __builtin_amdgcn_ballot_w64(ex1);
         }
       };
-      bool in[PPT] = {valid[0], valid[1]};
-      vertex(0, in);
-      if (__ballot(in[0] || in[1])) {       // wrong hypotheses fail at vertex A for the whole wave
-        vertex(1, in);
-        if (__ballot(in[0] || in[1])) vertex(2, in);
-        if (in[0]) passed[0] |= 1ull << h;
-        if (in[1]) passed[1] |= 1ull << h;
-        const u32 cnt = (u32)__popcll(__ballot(in[0])) + (u32)__popcll(__ballot(in[1]));
-        if (lane == h) acc += cnt;
+      u64 in0 = valid0, in1 = valid1;
+      vertex(0, in0, in1);
+      if (in0 | in1) {       // wrong hypotheses fail at vertex A for the whole wave
+        vertex(1, in0, in1);
+        if (in0 | in1) vertex(2, in0, in1);
+        if (in0 | in1) {
+          if ((in0 >> lane) & 1ull) passed[0] |= 1ull << h;
+          if ((in1 >> lane) & 1ull) passed[1] |= 1ull << h;
+          const u32 cnt = (u32)__builtin_popcountll(in0) + (u32)__builtin_popcountll(in1);
+          if (lane == h) acc += cnt;
+        }
       }
     }
     // what the inlier pass needs of this pair: no second walk over the vertices
@@ -310,7 +356,6 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
     return;
   }
   // ---- inliers of the best hypothesis (:516-539): the pairs that voted for it
-  const double *Rt = s_Rt[best];
   u32 mine = 0;
   for (long long j = tid; j < n; j += SGTD_VERIFY_THREADS) {
     const bool in = (P.passed[base + j] >> best) & 1ull;
@@ -321,7 +366,7 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) __attribute__((amdgpu_waves_pe
   if (lane == 0 && mine) atomicAdd(&s_count, mine);
   __syncthreads();
   if (tid == 0) *score = (double)s_count;           // :539
-  if (tid < 12) P.pose[((size_t)q * P.cand_num + c) * 12 + tid] = Rt[tid];
+  if (tid < 12) P.pose[((size_t)q * P.cand_num + c) * 12 + tid] = P.hyp64[((size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP + best) * SGTD_HYP_F64 + tid];
 }
 
 // SearchLoop's choice among the verified candidates (:105-146): the first candidate with
