@@ -375,7 +375,11 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
                                                           const u32 *pos_of_slot, const u32 *n_valid_p,
                                                           const u32 *n_groups_p, const unsigned char *rows, u32 rows_cap, PassPool P,
                                                           u32 *n_visit, uint2 *list, int *overflow) {
+#ifdef SGTD_PLAN_DIRECT
+  __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][1];
+#else
   __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][SGTD_PLAN_GROUPS * SGTD_ROW_QUADS];
+#endif
   const int lane = lane_id();
   uint4 *my_rows = s_rows[threadIdx.x >> 6];
   const u32 nv = *n_valid_p;
@@ -384,16 +388,23 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
   // every wave takes 64 consecutive slots at a time, grid-stride (the grid is sized by resident waves)
   for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; (s & ~63u) < n_pass; s += gridDim.x * blockDim.x) {
   const u32 p = (s < n_pass && !no_rows) ? pos_of_slot[s] : SGTD_NO_PASS;
-  const bool act = p != SGTD_NO_PASS;
   int K = 0;
   u32 g = 0, d[2] = {0, 0};
+  bool act = p != SGTD_NO_PASS;
   if (act) {
     g = gid[p];
     K = (PAIR && p + 1 < nv && gid[p + 1] == g) ? 2 : 1;
     d[0] = order[p];
     d[1] = K == 2 ? order[p + 1] : d[0];
+    // a home cell none of whose 27 buckets exists in this table segment (the rule for the small tail
+    // segment of an appended map): nothing to plan or sweep — before anything of the descriptors is read
+    if (reinterpret_cast<const u32 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES)[8 * SGTD_NCELL] == 0u) {
+      for (int k = 0; k < K; k++) { n_visit[d[k]] = 0; list[d[k]] = make_uint2(0u, 0u); }
+      act = false;
+    }
   }
   u32 hq[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};   // q0, q1, q2 (f32), lo2, hi2 as words
+  if (!act) K = 0;
   u32 qfr[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gate[2] = {0, 0};
   // per descriptor and offset -1, 0, +1: the halves (second side) and thirds (third side) its
   // threshold box reaches as bit masks: halves in bits 2 o .. 2 o + 1, thirds in bits 8 + 3 o .. 8 + 3 o + 2
@@ -431,6 +442,14 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
   const u32 g_lo = (u32)__builtin_amdgcn_readlane((int)g, __builtin_ctzll(act_mask));
   const u32 g_hi = (u32)__builtin_amdgcn_readlane((int)g, 63 - __builtin_clzll(act_mask));
   u32 my_off = SGTD_NO_PASS;
+#ifdef SGTD_PLAN_DIRECT
+  // experiment: no LDS staging — every lane reads its group's rows from global memory (lanes of one
+  // group share addresses); one round, occupancy set by the registers
+  for (u32 gc = g_lo; gc <= g_lo; gc++) {
+    const bool mine = act;
+    const u32 *row = reinterpret_cast<const u32 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES);
+    (void)g_hi; (void)my_rows;
+#else
   for (u32 gc = g_lo; gc <= g_hi; gc += SGTD_PLAN_GROUPS) {
     const u32 ng = min((u32)SGTD_PLAN_GROUPS, g_hi - gc + 1u);
     __builtin_amdgcn_wave_barrier();
@@ -454,6 +473,7 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
     __builtin_amdgcn_wave_barrier();
     const bool mine = act && g - gc < (u32)SGTD_PLAN_GROUPS;      // (g >= gc for every lane not yet served)
     const u32 *row = reinterpret_cast<const u32 *>(my_rows + (mine ? g - gc : 0u) * SGTD_ROW_QUADS);
+#endif
     // room for the record: an upper bound of the ranges
     const u32 m_exist = row[8 * SGTD_NCELL], m_ovf = row[8 * SGTD_NCELL + 1];
     u32 ub = mine ? 2u * (u32)__builtin_popcount(gate_any & m_exist) + (u32)__builtin_popcount(gate_any & m_ovf) : 0u;

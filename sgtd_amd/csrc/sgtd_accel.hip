@@ -768,7 +768,12 @@ int launch_select(sgtd_engine *e) {
   // 0.4 s of hipMalloc — and what a batch really needed, plus a quarter, once one has overflowed it
   // (group_resolve_kernel raises the overflow flag, sync_batch re-runs).
   if (e->group_cap_hook) { if (e->group_cap == 0) e->group_cap = e->group_cap_hook; }
-  else e->group_cap = std::max<size_t>(e->group_cap, (size_t)std::max<long long>(std::min<long long>(n_slots, 65536), n_slots / 8));
+  else {
+    // distinct home cells of a batch: every slot's for small batches (a single frame: ~40 % of its slots), about
+    // 1.5 M at most on the shipped resolution (0.39 M for 256 frames, 0.7 M for 2048), never more than half the slots
+    const long long want = n_slots <= 65536 ? n_slots : std::min<long long>(n_slots / 2, std::max<long long>(n_slots / 8, 1500000));
+    e->group_cap = std::max<size_t>(e->group_cap, (size_t)want);
+  }
   CHK(ensure(e, e->cell_rows, std::max<size_t>(e->group_cap, 1) * SGTD_GROUP_ROW_BYTES));
   const unsigned char *rows = e->cell_rows.as<unsigned char>();
   const u32 rows_cap = (u32)std::min<size_t>(e->group_cap, 0xFFFFFFFFu);
@@ -796,7 +801,9 @@ int launch_select(sgtd_engine *e) {
     const size_t max_pass_slots = (size_t)pass_slot_count((u32)n_slots, (u32)n_slots, pair) + 64;
     CHK(ensure(e, e->pos_of_slot, max_pass_slots * sizeof(u32)));
     CHK(ensure(e, e->rec_off, max_pass_slots * sizeof(u32)));
-    if (e->pool_units == 0) e->pool_units = std::max<size_t>(65536, (size_t)n_slots * 10);   // 160 B per descriptor slot, grown on overflow
+    // 160 B per descriptor slot (110 used at the 10 000-frame default), 256 B for tables beyond 1e8 entries (more of
+    // the 27 cells of a home cell have a bucket: 190 B used at 100 000 frames); grown on overflow
+    if (e->pool_units == 0) e->pool_units = std::max<size_t>(65536, (size_t)n_slots * (e->n_entries > 100000000 ? 16 : 10));
     CHK(ensure(e, e->pass_pool, (e->pool_units + SGTD_PASS_SLACK_UNITS) * sizeof(uint4)));
     const u32 *nv = e->n_valid.as<u32>();
     query_prefix_kernel<<<1, 256, 0, e->stream>>>(e->q_count.as<u32>(), e->q_prefix.as<u32>(), nq, e->n_valid.as<u32>());
@@ -1018,6 +1025,9 @@ int sync_batch(sgtd_engine *e) {
       break;
     }
     e->stats.overflowed = 1;
+    if (getenv("SGTD_DEBUG"))
+      fprintf(stderr, "sgtd: batch re-run (attempt %d): flags %d %d, records %llu of %zu (+%llu wanted), pass pool %u of %zu units, home cells %u of %zu rows, pairs %u of %zu\n",
+              attempt, ovf[0], ovf[1], cursor, e->rec_cap, need, pool_used, e->pool_units, n_groups, e->group_cap, total, e->pair_cap);
     if (attempt == 7) return SGTD_ERR_CAPACITY;
     // grow towards the u32 index limit; a batch that does not fit even there must be split
     const size_t lim = 0xFFFFFFF0ull;
