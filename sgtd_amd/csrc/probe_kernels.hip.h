@@ -51,7 +51,17 @@ struct TableView {
   u32 frame_lo;                // votes are indexed by frame - frame_lo
   u32 frame_span;              // number of vote bins per query
   u32 coarse_at;               // a visit list of more ranges than this is planned without slice pruning (62; SGTD_COARSE_AT: test hook)
+  u32 whole_at;                // ... and one of more ranges than this even then, with one range per bucket (62; SGTD_WHOLE_AT: test hook)
+  // the tail segment (entries appended after the table was finalized), if any: a second directory and
+  // hash; its probe layout starts at ent + tail_off (behind the main segment's sentinels), 0: no tail
+  u32 tail_off;
+  const BucketDir *dir1;
+  const HashSlot *hash1;
+  u32 hash_mask1;
+  u32 n_entries1;
 };
+// bytes of a home cell's GroupRow slot: the main segment's rows (+ masks) in the first KB, the tail's in the second
+__host__ __device__ __forceinline__ u32 group_row_bytes(const TableView &T) { return T.tail_off ? 2u * SGTD_GROUP_ROW_BYTES : SGTD_GROUP_ROW_BYTES; }
 
 struct QueryView {
   const double *side;   // [n_slots*3]
@@ -84,12 +94,9 @@ struct ProbeBuffers {
   __host__ __device__ __forceinline__ u32 *pool_cursor() const { return ctr + 8; }
   __host__ __device__ __forceinline__ int *overflow() const { return reinterpret_cast<int *>(ctr + 10); }
   __host__ __device__ __forceinline__ u32 *xcd_heads() const { return ctr + 1024; }
-  // per table segment sg and descriptor slot d, at [sg * seg_stride + d] (the sweep of segment sg
-  // gets the pointers advanced to its part):
-  uint2 *list;          // {first record of the descriptor's list from that segment, matches of the descriptor there}
-  u32 *n_visit;         // entries the reference's loop visits for the descriptor there (STDesc.cpp:372)
-  long long seg_stride; // descriptor slots of the batch
-  int n_seg;            // table segments swept (main, tail)
+  // per descriptor slot d:
+  uint2 *list;          // {first record of the descriptor's list, its matches}
+  u32 *n_visit;         // entries the reference's loop visits for the descriptor (STDesc.cpp:372)
   u32 *votes;           // [n_queries * frame_span]
   u32 id_bits;          // a record's local frame (frame - table frame_lo) is rec >> id_bits
   // records whose f32 test fell between the two thresholds: stored provisionally as matches,
@@ -237,7 +244,6 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
   for (long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; g < n_groups; g += stride) {
     if (c >= SGTD_NCELL) continue;      // (the ballots below only look at lanes c < 27 of either half)
     const long long d = (long long)order[group_first[g]];
-    uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
     const double q0 = Q.side[d * 3 + 0], q1 = Q.side[d * 3 + 1], q2 = Q.side[d * 3 + 2];
     const u32 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
     const int ix = c / 9 - 1, iy = (c / 3) % 3 - 1, iz = c % 3 - 1;  // voxel_round order (:327-333)
@@ -256,28 +262,35 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
     // empty cell -1, the clamp above would sweep cell 0 a second time — that slot stays empty
     const bool minus_one = nonneg && ((ix < 0 && (int)(q0 + (double)ix) < 0) || (iy < 0 && (int)(q1 + (double)iy) < 0) ||
                                       (iz < 0 && (int)(q2 + (double)iz) < 0));
-    if (!minus_one && x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536) {
-      const u64 key = pack_key(code, (u32)x, (u32)y, (u32)z);
-      u32 h = hash_key(key) & T.hash_mask;
-      while (true) {
-        const HashSlot s = T.hash[h];
-        if (s.key == key) {
-          const uint4 *row = reinterpret_cast<const uint4 *>(T.dir + s.bucket);
-          lo = row[0]; hi = row[1];
-          break;
+    const bool probe = !minus_one && x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536;
+    const u64 key = probe ? pack_key(code, (u32)x, (u32)y, (u32)z) : 0ull;
+    for (int sg = 0; sg < (T.tail_off ? 2 : 1); sg++) {     // main segment, tail segment
+      const HashSlot *hash = sg ? T.hash1 : T.hash;
+      const BucketDir *dir = sg ? T.dir1 : T.dir;
+      const u32 mask = sg ? T.hash_mask1 : T.hash_mask;
+      uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+      if (probe) {
+        u32 h = hash_key(key) & mask;
+        while (true) {
+          const HashSlot s = hash[h];
+          if (s.key == key) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(dir + s.bucket);
+            lo = row[0]; hi = row[1];
+            break;
+          }
+          if (s.key == SGTD_EMPTY_KEY) break;
+          h = (h + 1) & mask;
         }
-        if (s.key == SGTD_EMPTY_KEY) break;
-        h = (h + 1) & T.hash_mask;
       }
+      uint4 *out = reinterpret_cast<uint4 *>(rows + (size_t)g * group_row_bytes(T) + (size_t)sg * SGTD_GROUP_ROW_BYTES) + 2 * c;
+      out[0] = lo;     // start, cum[0..2]
+      out[1] = hi;     // cum[3..6]
+      // behind the 27 rows: which cells have a bucket at all, and which of those an overflow slice
+      // (plan_passes_kernel bounds a pass's number of ranges with them before it walks the rows)
+      const u64 ex = __builtin_amdgcn_ballot_w64(hi.w != 0u), ov = __builtin_amdgcn_ballot_w64(hi.w != hi.z);
+      const int sh = (int)(threadIdx.x & 32);
+      if (c == 0) out[2 * SGTD_NCELL] = make_uint4((u32)(ex >> sh) & 0x7FFFFFFu, (u32)(ov >> sh) & 0x7FFFFFFu, 0u, 0u);
     }
-    uint4 *out = reinterpret_cast<uint4 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES) + 2 * c;
-    out[0] = lo;     // start, cum[0..2]
-    out[1] = hi;     // cum[3..6]
-    // behind the 27 rows: which cells have a bucket at all, and which of those an overflow slice
-    // (plan_passes_kernel bounds a pass's number of ranges with them before it walks the rows)
-    const u64 ex = __builtin_amdgcn_ballot_w64(hi.w != 0u), ov = __builtin_amdgcn_ballot_w64(hi.w != hi.z);
-    const int sh = (int)(threadIdx.x & 32);
-    if (c == 0) out[2 * SGTD_NCELL] = make_uint4((u32)(ex >> sh) & 0x7FFFFFFu, (u32)(ov >> sh) & 0x7FFFFFFu, 0u, 0u);
   }
 }
 
@@ -362,24 +375,26 @@ __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int 
 // walk their group's 27 directory rows there ONCE, writing the ranges as they go: a record's room
 // is taken from the pool beforehand (one atomic per wave) for an upper bound of its ranges — two
 // per gated cell that has a bucket, one more where the bucket has an overflow slice (the masks
-// group_resolve_kernel left behind the rows).  n_visit / list point at this table segment's
-// part; a pass without a single entry to visit gets no record and its (empty) results are
-// written here.
+// group_resolve_kernel left behind the rows).  A pass without a single entry to visit gets no
+// record and its (empty) results are written here.
 #ifndef SGTD_PLAN_GROUPS
 #define SGTD_PLAN_GROUPS 16   // (4 / 6 / 8 / 12 groups per round measured +1.07 / +0.50 / +0.24 / +0 ms: a round costs a whole walk)
 #endif
 #define SGTD_PLAN_THREADS 128
 #define SGTD_ROW_QUADS (2 * SGTD_NCELL + 1)     // 16-B quarters of one GroupRow: 27 rows + the masks
-template <bool PAIR>
+// TAIL: the table has a tail segment — a GroupRow slot holds two sets of rows, half as many groups are
+// staged per round, and a cell's ranges are the main segment's followed by the tail's (the reference's
+// bucket holds the appended entries behind the older ones).
+template <bool PAIR, bool TAIL>
 __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableView T, QueryView Q, const u32 *order, const u32 *gid,
                                                           const u32 *pos_of_slot, const u32 *n_valid_p,
                                                           const u32 *n_groups_p, const unsigned char *rows, u32 rows_cap, PassPool P,
                                                           u32 *n_visit, uint2 *list, int *overflow) {
-#ifdef SGTD_PLAN_DIRECT
-  __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][1];
-#else
-  __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][SGTD_PLAN_GROUPS * SGTD_ROW_QUADS];
-#endif
+  constexpr u32 SEGS = TAIL ? 2u : 1u;
+  constexpr u32 GQ = SEGS * SGTD_ROW_QUADS;                   // staged quarters per group
+  constexpr u32 NG = SGTD_PLAN_GROUPS / SEGS;                 // groups staged per round
+  constexpr size_t ROWB = (size_t)SEGS * SGTD_GROUP_ROW_BYTES;
+  __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][NG * GQ];
   const int lane = lane_id();
   uint4 *my_rows = s_rows[threadIdx.x >> 6];
   const u32 nv = *n_valid_p;
@@ -396,9 +411,12 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
     K = (PAIR && p + 1 < nv && gid[p + 1] == g) ? 2 : 1;
     d[0] = order[p];
     d[1] = K == 2 ? order[p + 1] : d[0];
-    // a home cell none of whose 27 buckets exists in this table segment (the rule for the small tail
-    // segment of an appended map): nothing to plan or sweep — before anything of the descriptors is read
-    if (reinterpret_cast<const u32 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES)[8 * SGTD_NCELL] == 0u) {
+    // a home cell none of whose 27 buckets exists in the table: nothing to plan or sweep — before
+    // anything of the descriptors is read
+    const u32 *gr = reinterpret_cast<const u32 *>(rows + (size_t)g * ROWB);
+    u32 any = gr[8 * SGTD_NCELL];
+    if (TAIL) any |= gr[SGTD_GROUP_ROW_BYTES / 4 + 8 * SGTD_NCELL];
+    if (any == 0u) {
       for (int k = 0; k < K; k++) { n_visit[d[k]] = 0; list[d[k]] = make_uint2(0u, 0u); }
       act = false;
     }
@@ -442,26 +460,20 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
   const u32 g_lo = (u32)__builtin_amdgcn_readlane((int)g, __builtin_ctzll(act_mask));
   const u32 g_hi = (u32)__builtin_amdgcn_readlane((int)g, 63 - __builtin_clzll(act_mask));
   u32 my_off = SGTD_NO_PASS;
-#ifdef SGTD_PLAN_DIRECT
-  // experiment: no LDS staging — every lane reads its group's rows from global memory (lanes of one
-  // group share addresses); one round, occupancy set by the registers
-  for (u32 gc = g_lo; gc <= g_lo; gc++) {
-    const bool mine = act;
-    const u32 *row = reinterpret_cast<const u32 *>(rows + (size_t)g * SGTD_GROUP_ROW_BYTES);
-    (void)g_hi; (void)my_rows;
-#else
-  for (u32 gc = g_lo; gc <= g_hi; gc += SGTD_PLAN_GROUPS) {
-    const u32 ng = min((u32)SGTD_PLAN_GROUPS, g_hi - gc + 1u);
+  for (u32 gc = g_lo; gc <= g_hi; gc += NG) {
+    const u32 ng = min(NG, g_hi - gc + 1u);
     __builtin_amdgcn_wave_barrier();
-    {   // flat copy of ng x 55 quarters, four loads in flight per lane
-      const u32 n_quads = ng * SGTD_ROW_QUADS;
+    {   // flat copy of ng x 55 (110) quarters, four loads in flight per lane
+      const u32 n_quads = ng * GQ;
       for (u32 i0 = 0; i0 < n_quads; i0 += 4 * SGTD_WAVE) {
         uint4 t[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const u32 i = min(i0 + u * SGTD_WAVE + lane, n_quads - 1u);
-          const u32 gg = i / SGTD_ROW_QUADS, q = i - gg * SGTD_ROW_QUADS;
-          t[u] = reinterpret_cast<const uint4 *>(rows + (size_t)(gc + gg) * SGTD_GROUP_ROW_BYTES)[q];
+          const u32 gg = i / GQ, q = i - gg * GQ;
+          // (the tail's rows start at the slot's second KB, quarter 64)
+          const u32 src = TAIL && q >= SGTD_ROW_QUADS ? q - SGTD_ROW_QUADS + SGTD_GROUP_ROW_BYTES / 16 : q;
+          t[u] = reinterpret_cast<const uint4 *>(rows + (size_t)(gc + gg) * ROWB)[src];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -471,16 +483,25 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
       }
     }
     __builtin_amdgcn_wave_barrier();
-    const bool mine = act && g - gc < (u32)SGTD_PLAN_GROUPS;      // (g >= gc for every lane not yet served)
-    const u32 *row = reinterpret_cast<const u32 *>(my_rows + (mine ? g - gc : 0u) * SGTD_ROW_QUADS);
-#endif
+    const bool mine = act && g - gc < NG;      // (g >= gc for every lane not yet served)
+    const u32 *row = reinterpret_cast<const u32 *>(my_rows + (mine ? g - gc : 0u) * GQ);
     // room for the record: an upper bound of the ranges
-    const u32 m_exist = row[8 * SGTD_NCELL], m_ovf = row[8 * SGTD_NCELL + 1];
-    u32 ub = mine ? 2u * (u32)__builtin_popcount(gate_any & m_exist) + (u32)__builtin_popcount(gate_any & m_ovf) : 0u;
+    u32 n_ex = 0, n_ov = 0;
+#pragma unroll
+    for (u32 sg = 0; sg < SEGS; sg++) {
+      const u32 *m = row + sg * 4 * SGTD_ROW_QUADS + 8 * SGTD_NCELL;
+      n_ex += (u32)__builtin_popcount(gate_any & m[0]);
+      n_ov += (u32)__builtin_popcount(gate_any & m[1]);
+    }
+    u32 ub = mine ? 2u * n_ex + n_ov : 0u;
     // more ranges than the sweep has lanes (only with many overflow slices): the halves of a cell as
-    // ONE unpruned range, all six sub-cells — a superset of what the descriptors reach
+    // ONE unpruned range, all six sub-cells — a superset of what the descriptors reach; with a tail
+    // segment even that can be too many: then every bucket is one range, overflow slice included (it
+    // follows the halves)
     const bool coarse = ub > T.coarse_at;
-    if (coarse) ub = (u32)__builtin_popcount(gate_any & m_exist) + (u32)__builtin_popcount(gate_any & m_ovf);
+    if (coarse) ub = n_ex + n_ov;
+    const bool whole = TAIL && coarse && ub > T.whole_at;
+    if (whole) ub = n_ex;
     const u32 units = ub ? SGTD_PASS_HDR_UNITS + ((ub + 1u) * 12u + 15u) / 16u : 0u;
     const u32 inc = wave_incl_scan(units);
     const u32 wave_units = (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
@@ -504,10 +525,11 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
         }
       };
 #pragma unroll 1
-      for (int c = 0; c < SGTD_NCELL; c++) {     // (unrolled, the compiler keeps 54 gate predicates in scalar registers)
+      for (int cs = 0; cs < (int)(SGTD_NCELL * SEGS); cs++) {     // (unrolled, the compiler keeps 54 gate predicates in scalar registers)
+        const int c = TAIL ? cs >> 1 : cs;
         const int oy = (c / 3) % 3, oz = c % 3;
-        const u32 *rc = row + 8 * c;             // {start, cum0 .. cum6}
-        const u32 cum6 = rc[7], cum5 = rc[6], start = rc[0];
+        const u32 *rc = row + 8 * c + (TAIL && (cs & 1) ? 4 * SGTD_ROW_QUADS : 0);             // {start, cum0 .. cum6}
+        const u32 cum6 = rc[7], cum5 = rc[6], start = rc[0] + (TAIL && (cs & 1) ? T.tail_off : 0u);
         // sub-cells reached by any gated descriptor: bits 0..2 the thirds of the lower half, 3..5 of the upper
         u32 sub = 0, meta = (u32)c;
 #pragma unroll
@@ -521,6 +543,10 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
         }
         const bool live = (gate_any >> c) & 1u;
         sub |= (sub & (sub >> 2) & 0x9u) << 1;   // per half the thirds from the first to the last reached one
+        if (whole) {
+          put(start, live ? cum6 : 0u, meta);                   // the whole bucket
+          continue;
+        }
         if (!coarse) {
           // half h: entries before its first reached third (cum[i - 1], 0 for i = 0) and up to its last
           const u32 m0 = sub & 7u, m1 = sub & 0x38u;
@@ -538,7 +564,7 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
       const bool rec = emit && n != 0u;
       if (rec) {
         my_off = off;
-        *wp = RangeWords{total, T.n_entries - total, 0x300u};   // the sentinel range
+        *wp = RangeWords{total, T.n_entries - total, 0x300u};   // the sentinel range (the main segment's sentinels)
         uint4 *h = P.pool + off;
         h[0] = make_uint4(n | ((u32)K << 8), total, d[0], d[1]);
         h[1] = make_uint4(qfr[0], qfr[1], hq[0][0], hq[1][0]);
@@ -1146,12 +1172,12 @@ __device__ __forceinline__ BlockId assemble_block(int n_queries, int blocks_per_
 
 // the 32-descriptor sub-block [d0, d0+32) of query q: prefix of n_match and list
 // pointers into LDS; returns the number of records
-__device__ __forceinline__ u32 sub_open(const QueryView &Q, const ProbeBuffers &B, int sg, int q, u32 d0, u32 cnt,
+__device__ __forceinline__ u32 sub_open(const QueryView &Q, const ProbeBuffers &B, int q, u32 d0, u32 cnt,
                                         u32 *s_pre /*[32]*/, u32 *s_ptr /*[32]*/, u32 &visits) {
   const int lane = lane_id();
   u32 n = 0, p = 0, v = 0;
   if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
-    const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
+    const long long d = (long long)q * Q.stride + d0 + lane;
     const uint2 lp = B.list[d];
     n = lp.y; p = lp.x; v = B.n_visit[d];
   }
@@ -1181,13 +1207,13 @@ __device__ __forceinline__ void sub_locate(const u32 *s_pre, const u32 *s_ptr, u
 // of a list possibly short: one list search serves four records (the record buffer has room
 // for the reads past a list's end).  s_pre: exclusive quad offsets, s_ptr: list starts, s_cnt:
 // list lengths; returns the number of quads, `records` the number of records.
-__device__ __forceinline__ u32 sub_open_quads(const QueryView &Q, const ProbeBuffers &B, int sg, int q, u32 d0, u32 cnt,
+__device__ __forceinline__ u32 sub_open_quads(const QueryView &Q, const ProbeBuffers &B, int q, u32 d0, u32 cnt,
                                               u32 *s_pre /*[32]*/, u32 *s_ptr /*[32]*/, u32 *s_cnt /*[32]*/,
                                               u32 &visits, u32 &records) {
   const int lane = lane_id();
   u32 n = 0, p = 0, v = 0;
   if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
-    const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
+    const long long d = (long long)q * Q.stride + d0 + lane;
     const uint2 lp = B.list[d];
     n = lp.y; p = lp.x; v = B.n_visit[d];
   }
@@ -1254,10 +1280,9 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
                                                u32 frame_lo, u32 limit, u32 *s_hist, u32 *votes, u32 *s_pre, u32 *s_ptr,
                                                u32 *s_cnt, u32 &visits, u32 &total) {
   const int lane = lane_id();
-  for (int sg = 0; sg < B.n_seg; sg++)
   for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
     u32 records;
-    const u32 RQ = sub_open_quads(Q, B, sg, q, d0, cnt, s_pre, s_ptr, s_cnt, visits, records);
+    const u32 RQ = sub_open_quads(Q, B, q, d0, cnt, s_pre, s_ptr, s_cnt, visits, records);
     total += records;
     // the quads of the next two words are loaded while the current two are counted
     uint4 nrec[SGTD_VOTE_WORDS];
@@ -1428,8 +1453,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   const u32 d_last = min(d_first + SGTD_PROBE_CHUNK, cnt);
   // room for the block's compact list: at most every record of the block
   u32 nm = 0;
-  for (int sg = 0; sg < B.n_seg; sg++)
-    for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.list[(long long)sg * B.seg_stride + (long long)q * Q.stride + dd].y;
+    for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.list[(long long)q * Q.stride + dd].y;
   const u32 r_blk = wave_sum(nm);
   u32 start = 0;
   if (lane == 0) start = atomicAdd(L.cursor, r_blk);
@@ -1441,7 +1465,6 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   // segment by segment: a candidate frame lives in one segment, so its matches still arrive in
   // (i, cell, j) order
   u64 *bits = s_bits[wid];
-  for (int sg = 0; sg < B.n_seg; sg++)
   for (u32 d0 = d_first; d0 < d_last; d0 += SGTD_SUB_DESCS) {
     // The records of the sub-block's 32 descriptors as ONE stream: the non-empty lists are its ranges
     // (range j in lane j: offset in the stream, address delta, descriptor), a record's range comes from
@@ -1449,7 +1472,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
     // v_mbcnt and two ds_bpermute per 64 records instead of a five-step binary search per record.
     u32 n = 0, p = 0, v = 0;
     if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
-      const long long d = (long long)sg * B.seg_stride + (long long)q * Q.stride + d0 + lane;
+      const long long d = (long long)q * Q.stride + d0 + lane;
       const uint2 lp = B.list[d];
       n = lp.y; p = lp.x; v = B.n_visit[d];
     }
@@ -1709,8 +1732,7 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
     const u32 i = i0 + threadIdx.x;
     const long long d = (long long)q * Q.stride + i;
     u32 n = 0;
-    if (i < cnt)
-      for (int sg = 0; sg < B.n_seg; sg++) n += B.list[(long long)sg * B.seg_stride + d].y;
+    if (i < cnt) n = B.list[d].y;
     u32 tot;
     const u32 ex = block_excl_scan(n, lds, tot);
     if (i < cnt) {
@@ -1718,8 +1740,8 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
       for (u32 k = 0; k < n; k++) {
         long long best = 0x7FFFFFFFFFFFFFFFll;
         u32 at = 0;
-        for (int sg = 0; sg < B.n_seg; sg++) {
-          const uint2 lp = B.list[(long long)sg * B.seg_stride + d];
+        {
+          const uint2 lp = B.list[d];
           const u32 p0 = lp.x, m = lp.y;
           for (u32 j = 0; j < m; j++) {
             const long long key = ((long long)B.rec_cell[p0 + j] << 32) | (long long)id_entry(map, B.rec[p0 + j]);

@@ -85,7 +85,7 @@ struct sgtd_engine {
   u32 append_min_frame = 0xFFFFFFFFu;    // smallest frame id appended since the main segment was built
   int64_t tail_max = 0;                  // SGTD_TAIL_MAX: entries the tail may hold before a merge (0 = an eighth of the main segment)
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
-  u32 coarse_at = 62;                    // SGTD_COARSE_AT: see TableView
+  u32 coarse_at = 62, whole_at = 62;     // SGTD_COARSE_AT, SGTD_WHOLE_AT: see TableView
   int tail_batches = 0;                  // query batches swept with the current tail (it is merged after a few: see settle_tail)
   DevBuf slice_of, sq_sum;
   // entry ids of the probe layout (common.hip.h IdMap), rebuilt over the whole table by every finalize
@@ -553,9 +553,23 @@ int build_segment(sgtd_engine *e, sgtd_engine::Segment &S, long long g0, long lo
                                                                e->slice_of.as<unsigned char>(), S.perm.as<u32>(),
                                                                S.dir.as<BucketDir>());
   HIPCHK(hipGetLastError());
-  CHK(ensure(e, S.hot, (size_t)(E + SGTD_SENTINELS) * sizeof(HotEntry)));
+  // the probe layout of the tail segment lies BEHIND the main segment's (and its sentinels) in the main
+  // segment's buffer: one base address for both, so that a pass's visit list can run through both segments
+  HotEntry *hot = nullptr;
+  if (&S == &e->seg[1]) {
+    sgtd_engine::Segment &M = e->seg[0];
+    const size_t m_ent = (size_t)(M.g1 - M.g0) + SGTD_SENTINELS;
+    CHK(ensure(e, M.hot, (m_ent + (size_t)E + SGTD_SENTINELS) * sizeof(HotEntry), /*keep=*/true));
+    hot = M.hot.as<HotEntry>() + m_ent;
+  } else {
+    // (with room for the largest tail do_finalize accepts, so that an append does not move the layout;
+    // none under the SGTD_TAIL_MAX test hook: the tail's build then grows the buffer and moves it)
+    const size_t tail_room = e->tail_max > 0 ? 0 : (size_t)std::max<long long>(262144, E / 8) + SGTD_SENTINELS;
+    CHK(ensure(e, S.hot, ((size_t)(E + SGTD_SENTINELS) + tail_room) * sizeof(HotEntry)));
+    hot = S.hot.as<HotEntry>();
+  }
   gather_hot_kernel<<<grid_for(E + SGTD_SENTINELS, 256), 256, 0, e->stream>>>(
-      S.perm.as<u32>(), side, frame, e->id_by_frame ? e->id_of_g.as<u32>() : nullptr, id_map(e, e->id_bits), S.hot.as<HotEntry>(), E, (u32)g0);
+      S.perm.as<u32>(), side, frame, e->id_by_frame ? e->id_of_g.as<u32>() : nullptr, id_map(e, e->id_bits), hot, E, (u32)g0);
   HIPCHK(hipGetLastError());
   u32 cap = 1024;
   while (cap < 2ull * U) cap <<= 1;
@@ -698,16 +712,21 @@ struct Views {
   int blocks_per_query;
 };
 
-Views make_views(sgtd_engine *e, int sgi = 0) {
+Views make_views(sgtd_engine *e) {
   Views v;
   v.span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   TableView &T = v.T;
-  const sgtd_engine::Segment &S = e->seg[sgi];
+  const sgtd_engine::Segment &S = e->seg[0], &S1 = e->seg[1];
   T.ent = S.hot.as<HotEntry>(); T.map = id_map(e, e->id_bits ? e->id_bits : 13); T.cold_side = e->tab.side.as<double>();
   T.dir = S.dir.as<BucketDir>();
   T.hash = S.hash.as<HashSlot>(); T.hash_mask = S.hash_mask;
-  T.coarse_at = e->coarse_at;
+  T.coarse_at = e->coarse_at; T.whole_at = e->whole_at;
   T.n_entries = (u32)(S.g1 - S.g0); T.frame_lo = e->have_frames ? e->frame_lo : 0; T.frame_span = v.span;
+  // the tail segment (appends after the table was finalized): its own directory and hash, its probe
+  // layout behind the main segment's in the same buffer
+  T.tail_off = e->n_seg > 1 ? T.n_entries + SGTD_SENTINELS : 0u;
+  T.dir1 = S1.dir.as<BucketDir>(); T.hash1 = S1.hash.as<HashSlot>(); T.hash_mask1 = S1.hash_mask;
+  T.n_entries1 = e->n_seg > 1 ? (u32)(S1.g1 - S1.g0) : 0u;
   QueryView &Q = v.Q;
   Q.side = e->qd.side.as<double>(); Q.qrec = e->qd.qrec.as<QueryRec>();
   Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
@@ -720,7 +739,6 @@ Views make_views(sgtd_engine *e, int sgi = 0) {
   B.amb_queue = e->amb_queue.as<uint2>();
   B.amb_cap = (u32)std::min<size_t>(e->amb_queue.bytes / sizeof(uint2), 0xFFFFFFF0u);
   B.list = e->list.as<uint2>(); B.n_visit = e->n_visit.as<u32>();
-  B.seg_stride = (long long)e->nq * e->q_stride; B.n_seg = e->n_seg;
   B.votes = e->votes.as<u32>();
   v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   return v;
@@ -733,8 +751,8 @@ int launch_select(sgtd_engine *e) {
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   CHK(ensure(e, e->cursors, kCtrWords * sizeof(u32)));
-  CHK(ensure(e, e->list, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(uint2)));
-  CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * e->n_seg * sizeof(u32)));
+  CHK(ensure(e, e->list, (size_t)std::max<long long>(n_slots, 1) * sizeof(uint2)));
+  CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->votes, (size_t)nq * span * sizeof(u32)));
   CHK(ensure(e, e->slot_of, (size_t)nq * span));
   CHK(ensure(e, e->q_M, (size_t)nq * sizeof(u32)));
@@ -774,7 +792,8 @@ int launch_select(sgtd_engine *e) {
     const long long want = n_slots <= 65536 ? n_slots : std::min<long long>(n_slots / 2, std::max<long long>(n_slots / 8, 1500000));
     e->group_cap = std::max<size_t>(e->group_cap, (size_t)want);
   }
-  CHK(ensure(e, e->cell_rows, std::max<size_t>(e->group_cap, 1) * SGTD_GROUP_ROW_BYTES));
+  const int row_slots = e->n_seg > 1 ? 2 : 1;       // with a tail segment: its 27 rows in the second KB of the slot
+  CHK(ensure(e, e->cell_rows, std::max<size_t>(e->group_cap, 1) * SGTD_GROUP_ROW_BYTES * row_slots));
   const unsigned char *rows = e->cell_rows.as<unsigned char>();
   const u32 rows_cap = (u32)std::min<size_t>(e->group_cap, 0xFFFFFFFFu);
   {
@@ -836,32 +855,27 @@ int launch_select(sgtd_engine *e) {
     PassPool PP;
     PP.pool = e->pass_pool.as<uint4>(); PP.rec_off = e->rec_off.as<u32>();
     PP.cursor = v.B.pool_cursor(); PP.cap = (u32)std::min<size_t>(e->pool_units, 0xFFFFFF00u);
-    for (int sg = 0; sg < e->n_seg; sg++) {
-      // one GroupRow per home cell against this segment's directory, the passes' visit lists
-      // from it, then the sweep; the descriptors' lists from segment sg are recorded in part sg
-      // of list / n_visit (the pass pool takes the records of all segments, one after the other)
-      Views vs = make_views(e, sg);
-      vs.B.list += (size_t)sg * n_slots; vs.B.n_visit += (size_t)sg * n_slots;
-      if (sg > 0) {
-        HIPCHK(hipMemsetAsync(vs.B.xcd_heads(), 0, 8 * 1024 * sizeof(u32), e->stream));
-        HIPCHK(hipMemsetAsync(vs.B.amb_count(), 0, sizeof(u32), e->stream));   // the undecided-record queue
-      }
+    {
+      // one GroupRow per home cell (both segments' directory rows), the passes' visit lists from it, then
+      // ONE sweep: a pass's list runs through the main segment's ranges and then the tail's, cell by cell
+      Views &vs = v;
       group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->group_first.as<u32>(),
                                                                   e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>(), rows_cap, vs.B.overflow());
       HIPCHK(hipGetLastError());
       // resident workgroups (LDS: 880 B per staged group and wave) x 4 rounds, grid-stride over the slots
       const int pgrid = (int)std::min<long long>(grid_for((long long)max_pass_slots, SGTD_PLAN_THREADS), (long long)e->n_cus * 20);
-#define SGTD_LAUNCH_PLAN(PR)                                                                                   \
-  plan_passes_kernel<PR><<<pgrid, SGTD_PLAN_THREADS, 0, e->stream>>>(vs.T, vs.Q, vin, e->gid.as<u32>(), e->pos_of_slot.as<u32>(), nv, \
+#define SGTD_LAUNCH_PLAN(PR, TL)                                                                               \
+  plan_passes_kernel<PR, TL><<<pgrid, SGTD_PLAN_THREADS, 0, e->stream>>>(vs.T, vs.Q, vin, e->gid.as<u32>(), e->pos_of_slot.as<u32>(), nv, \
                                                        e->n_groups.as<u32>(), rows, rows_cap, PP, vs.B.n_visit, vs.B.list,          \
                                                        vs.B.overflow())
-      if (pair) SGTD_LAUNCH_PLAN(true); else SGTD_LAUNCH_PLAN(false);
+      if (vs.T.tail_off) { if (pair) SGTD_LAUNCH_PLAN(true, true); else SGTD_LAUNCH_PLAN(false, true); }
+      else { if (pair) SGTD_LAUNCH_PLAN(true, false); else SGTD_LAUNCH_PLAN(false, false); }
 #undef SGTD_LAUNCH_PLAN
       HIPCHK(hipGetLastError());
-      if (sg == 0 && e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));   // ms_probe = the sweep(s) from here
+      if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SORT], e->stream));   // ms_probe = the sweep from here
       // 32-bit byte offsets into the probe layout while it stays below 4 GB (record addresses
       // are a wave-uniform base + a 32-bit lane offset either way)
-      const bool narrow = ((unsigned long long)vs.T.n_entries + SGTD_SENTINELS) * sizeof(HotEntry) < (1ull << 32);
+      const bool narrow = ((unsigned long long)vs.T.n_entries + SGTD_SENTINELS + (vs.T.tail_off ? vs.T.n_entries1 + SGTD_SENTINELS : 0u)) * sizeof(HotEntry) < (1ull << 32);
       // can a descriptor of the batch carry a frame id the table holds?  Frames built by
       // sgtd_query_frames are stamped with the current frame id (one beyond the newest map frame
       // in the reference's use); descriptors handed in by the caller carry whatever they carry
@@ -1249,6 +1263,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
   if (const char *o = getenv("SGTD_TAIL_MAX")) e->tail_max = atoll(o);
   if (const char *o = getenv("SGTD_COARSE_AT")) e->coarse_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
+  if (const char *o = getenv("SGTD_WHOLE_AT")) e->whole_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }
   // test hooks: start with a tiny pass pool / GroupRow reservation so that their overflow / re-run paths run

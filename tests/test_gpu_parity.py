@@ -968,7 +968,15 @@ def test_multi_device_handle_on_two_gpus(mods):
 # ---------------------------------------------------------------------------
 # incremental insert: appends after a query go to a tail segment
 # ---------------------------------------------------------------------------
-def test_appends_go_to_a_tail_segment_and_keep_parity(mods, monkeypatch):
+@pytest.mark.parametrize("plan", [None, ("0", "62"), ("0", "0"), ("6", "12")])
+def test_appends_go_to_a_tail_segment_and_keep_parity(mods, monkeypatch, plan):
+    # plan: (SGTD_COARSE_AT, SGTD_WHOLE_AT) — the planner's fallbacks for visit lists of more ranges than
+    # the sweep has lanes: a cell's halves as one range, then (only with a tail: two segments' ranges per
+    # cell) a whole bucket as one range; 62 / 62 in production
+    if plan is not None:
+        monkeypatch.setenv("SGTD_COARSE_AT", plan[0])
+        monkeypatch.setenv("SGTD_WHOLE_AT", plan[1])
+        monkeypatch.setenv("SGTD_TAIL_MAX", "1000000")   # (and no room reserved behind the main segment: the tail's build moves the layout)
     _, manager, synth = mods
     g, o = _pair(mods)
     m = synth.make_map(60, 150, stream=33)
