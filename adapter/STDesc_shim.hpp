@@ -229,6 +229,11 @@ int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::ve
   return SGTD_OK;
 }
 
+// milliseconds SearchLoop spent, by part, summed over this thread's calls: the device work and its
+// transfers (select .. fetch) and the host-side construction of the reference's result containers (fill)
+struct SearchTiming { double select = 0, verify = 0, inliers = 0, fetch = 0, fill = 0; long calls = 0; };
+inline SearchTiming &search_timing() { static thread_local SearchTiming t; return t; }
+
 // ---- STDesc.cpp:84-147 with candidate_verify (:462-547) on the device ---------------------
 // Vec3 / Mat3 = Eigen::Vector3d / Eigen::Matrix3d (operator[] and operator()(row, col)).
 // The match lists stay on the device: only the inlier pairs of every candidate
@@ -244,30 +249,32 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   loop_result = std::pair<int, double>(-1, 0);
   if (stds_vec.empty()) return SGTD_OK;            // "No STDescs!" (:89-93)
   const auto t1 = std::chrono::high_resolution_clock::now();
-#ifdef SGTD_SHIM_TIMING
-  auto lap = [&](const char *what) {
-    static thread_local std::chrono::high_resolution_clock::time_point last = t1;
+  // where the call's time went (search_timing(), summed over the calls of this thread)
+  auto last = t1;
+  auto lap = [&](double SearchTiming::*part, const char *what) {
     const auto now = std::chrono::high_resolution_clock::now();
-    std::fprintf(stderr, "  [shim] %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+    search_timing().*part += ms;
     last = now;
-  };
-  { static thread_local bool first = true; (void)first; }
-#define SGTD_LAP(x) lap(x)
+#ifdef SGTD_SHIM_TIMING
+    std::fprintf(stderr, "  [shim] %-10s %.3f ms\n", what, ms);
 #else
-#define SGTD_LAP(x) do { } while (0)
+    (void)what;
 #endif
+  };
+#define SGTD_LAP(part) lap(&SearchTiming::part, #part)
   Selection s;
   int st = select(h, stds_vec, candidate_num, s, /*with_pairs=*/false);  // :98
   if (st != SGTD_OK) return st;
   CS1 = (int)(std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count() * 1000);
-  SGTD_LAP("select");
+  SGTD_LAP(select);
   st = sgtd_verify(h);                             // :105-118 for every candidate
   if (st != SGTD_OK) return st;
   const int cn = candidate_num;
   std::vector<double> score(cn), pose((size_t)cn * 12);   // rot row-major (9), then t (3)
   st = sgtd_result_verify(h, 0, score.data(), pose.data());
   if (st != SGTD_OK) return st;
-  SGTD_LAP("verify");
+  SGTD_LAP(verify);
   // the inlier pairs of every candidate (sucess_match_vec, :516-539) in one call, then ONE fetch of
   // the table entries they name
   std::vector<int64_t> ioff((size_t)cn + 1, 0);
@@ -280,11 +287,14 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
     st = sgtd_result_inlier_pairs(h, 0, ioff.data(), iq.data(), want.data(), n_inl, &n_inl);
     if (st != SGTD_OK) return st;
   }
-  SGTD_LAP("inliers");
+  SGTD_LAP(inliers);
+#ifdef SGTD_SHIM_TIMING
+  std::fprintf(stderr, "  [shim] %lld inlier pairs over %d candidates\n", (long long)n_inl, s.n_cand);
+#endif
   SoaBuf ent(want.size());
   st = sgtd_fetch_entries(h, want.data(), (int64_t)want.size(), &ent.v);
   if (st != SGTD_OK) return st;
-  SGTD_LAP("fetch");
+  SGTD_LAP(fetch);
   double best_score = 0;
   int best = -1;
   const size_t first = match_result_list.size();
@@ -307,7 +317,9 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   // The ~10^5 descriptors (416 bytes and a heap-allocated node_id each) are written by a few
   // short-lived threads, every candidate's list by one of them: threads that exit, not an OpenMP team —
   // an idle team spins after its region and slowed the HIP calls that follow (8 threads: 38.7 ms per
-  // frame against 27.9 single-threaded, 256 threads: 180 ms).
+  // frame against 27.9 single-threaded, 256 threads: 180 ms).  Filling the query side of the pairs
+  // while the table side is still being fetched was measured too: the fetch then takes 18-22 ms instead
+  // of 3-4 (the copy's own host threads lose their cores) — the fill starts after it.
   auto fill = [&](int k0, int k1) {
     for (int k = k0; k < k1; k++) {
       if (!(score[k] >= 0)) continue;
@@ -342,7 +354,9 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
     }
     for (auto &th : team) th.join();
   }
-  SGTD_LAP("pairs");
+  SGTD_LAP(fill);
+#undef SGTD_LAP
+  search_timing().calls++;
   if (best >= 0 && best_score > icp_threshold) {   // :138-146
     const LoopResult &b = match_result_list[first + (size_t)best];
     loop_result = std::pair<int, double>(b.match_id, best_score);
