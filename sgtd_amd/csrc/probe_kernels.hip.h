@@ -180,9 +180,15 @@ __global__ __launch_bounds__(256) void query_prefix_kernel(const u32 *count, u32
   if (threadIdx.x == 0) *n_valid = carry;
 }
 
+// Below the cell, the home key carries `sub_bits` bits (0..6) of where in the cell's second and third
+// interval the descriptor lies (2^(sub_bits / 2) x 2^(sub_bits - sub_bits / 2) classes), so that the
+// two descriptors of a pass (consecutive positions of one home cell) reach about the same slices of
+// the buckets — their shared visit list is the union of what either reaches (4 bits: 14 % fewer
+// entries loaded).  The host takes the bits the key leaves free below a multiple of the sort's 8-bit
+// digits, or 4 bits and one more sort pass.
 // keys/vals are compact: the descriptor (q, i) goes to index q_prefix[q] + i
 __global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, u64 *keys, u32 *vals, long long n_slots,
-                                 int cbits) {
+                                 int cbits, int sub_bits) {
   const long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n_slots) return;
   const int q = (int)(d / Q.stride);
@@ -195,7 +201,10 @@ __global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, u64 *keys, u3
   const u64 x = min((u64)(u32)(int)Q.side[d * 3 + 0], cmask), y = min((u64)(u32)(int)Q.side[d * 3 + 1], cmask),
             z = min((u64)(u32)(int)Q.side[d * 3 + 2], cmask);
   const u32 idx = q_prefix[q] + i;
-  keys[idx] = (((code << cbits | x) << cbits | y) << cbits) | z;
+  const int ny = 1 << (sub_bits >> 1), nz = 1 << (sub_bits - (sub_bits >> 1));
+  const double f1 = Q.side[d * 3 + 1] - (double)(int)Q.side[d * 3 + 1], f2 = Q.side[d * 3 + 2] - (double)(int)Q.side[d * 3 + 2];
+  const u64 sub = (u64)min(max((int)(f1 * ny), 0), ny - 1) * nz + (u64)min(max((int)(f2 * nz), 0), nz - 1);
+  keys[idx] = ((((code << cbits | x) << cbits | y) << cbits) | z) << sub_bits | sub;
   vals[idx] = (u32)d;
 }
 
@@ -203,12 +212,12 @@ __global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, u64 *keys, u3
 // changes or where the next key carries an overflow marker (such a descriptor is a group of
 // its own: its key does not name its cell).  flags[p] says whether position p+1 starts a new
 // group, so the EXCLUSIVE scan of the flags is the group id of p (position 0 is group 0).
-__global__ void group_heads_kernel(const u64 *keys, const u32 *n_valid_p, u32 *flags, long long n, int cbits) {
+__global__ void group_heads_kernel(const u64 *keys, const u32 *n_valid_p, u32 *flags, long long n, int cbits, int sub_bits) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   u32 head = 0;
   if (p + 1 < (long long)*n_valid_p) {
-    const u64 a = keys[p + 1], b = keys[p];
+    const u64 a = keys[p + 1] >> sub_bits, b = keys[p] >> sub_bits;
     const u64 cmask = (1ull << cbits) - 1ull;
     head = (a != b) || ((a & cmask) == cmask) || (((a >> cbits) & cmask) == cmask) ||
            (((a >> (2 * cbits)) & cmask) == cmask);

@@ -811,7 +811,12 @@ int launch_select(sgtd_engine *e) {
     // bits per cell coordinate of the sort key: the largest cell a built descriptor can have
     int cbits = 1;
     while ((1ll << cbits) < (long long)(e->dc.max_len * e->dc.scale) + 3 && cbits < 16) cbits++;
-    const int key_bits = 12 + 3 * cbits;
+    // (+ the position inside the cell, home_keys_kernel: the bits that are free below the next multiple of a sort
+    // digit, or four bits and one more pass)
+    const int spare = (8 - (12 + 3 * cbits) % 8) % 8;
+    int sub_bits = spare >= 2 ? std::min(spare, 6) : 4;
+    if (const char *o = getenv("SGTD_HOME_SUB_BITS")) sub_bits = std::min(6, std::max(0, atoi(o)));   // experiment knob
+    const int key_bits = 12 + 3 * cbits + sub_bits;
     CHK(ensure(e, e->q_prefix, (size_t)nq * sizeof(u32)));
     CHK(ensure(e, e->group_first, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->n_groups, sizeof(u32)));
@@ -827,10 +832,10 @@ int launch_select(sgtd_engine *e) {
     const u32 *nv = e->n_valid.as<u32>();
     query_prefix_kernel<<<1, 256, 0, e->stream>>>(e->q_count.as<u32>(), e->q_prefix.as<u32>(), nq, e->n_valid.as<u32>());
     HIPCHK(hipGetLastError());
-    home_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), kin, vin, n_slots, cbits);
+    home_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), kin, vin, n_slots, cbits, sub_bits);
     HIPCHK(hipGetLastError());
     CHK(radix_sort_pairs(e, kin, kout, vin, vout, n_slots, key_bits, false, nv));   // only the n_valid compact elements are live
-    group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits);
+    group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits, sub_bits);
     HIPCHK(hipGetLastError());
     CHK(device_scan(e, e->gid.as<u32>(), e->gid.as<u32>(), n_slots));
     group_first_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), nv, e->group_first.as<u32>(),
