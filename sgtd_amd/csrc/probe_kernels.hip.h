@@ -129,15 +129,18 @@ struct PendingLoads {
 };
 
 #ifndef SGTD_PAIR
-// descriptors of one home cell swept together by a wave (shared visit list, locate and loads): 1 or 2.
-#define SGTD_PAIR 2
+// descriptors of one home cell swept together by a wave (shared visit list, locate and loads): 1, 2 or 4.
+#define SGTD_PAIR 4
 #endif
-static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2, "the pair sweep computes both distances with packed f32 math");
+static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2 || SGTD_PAIR == 4, "the sweep computes the distances two at a time with packed f32 math");
+#define SGTD_PASS_KMAX (SGTD_PAIR < 2 ? 2 : SGTD_PAIR)      // descriptor columns of a pass record's header
 
 struct WaveSlab {
-  u32 start[SGTD_PAIR];                  // first record of the stream's slab
-  u32 next[SGTD_PAIR], end[SGTD_PAIR];   // this wave's private ranges of match records: one bump stream per
-                                         // descriptor of a pair, so that every descriptor's list stays contiguous
+  // this wave's private ranges of match records: one bump stream per descriptor column of a pass, so
+  // that every descriptor's list stays contiguous.  The streams' state is parked in the lanes of ONE
+  // vector register between passes (lane k: next free record of stream k, lane 4 + k: end of its slab)
+  // — scalar registers are what the sweep runs out of.
+  u32 state;
   u64 swept;                             // entries this wave loaded
 #ifdef SGTD_EXP_PHASE
   u64 ph[8], t;                          // experiment build: cycles per phase of the wave's life
@@ -310,17 +313,19 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
 // entries serve both).  plan_passes_kernel turns every pass into a RECORD in HBM, one lane per
 // pass, so that the sweep starts from a ready visit list instead of deriving it per wave:
 //
-//   header, 64 B (one 4-B load per lane i < 16, in flight during the pass before; v_readlane at the pass's start):
-//     w0 = n | K << 8     n = non-empty ranges of the visit list (<= 62), K = descriptors (1, 2)
+//   header, 2 + 7 KM words for KM = SGTD_PASS_KMAX descriptor columns (64 B for 2, 128 B for 4: one 4-B load
+//   per lane, in flight during the pass before; v_readlane at the pass's start):
+//     w0 = n | K << 8 | R << 12   n = non-empty ranges of the visit list (<= 62), K = descriptor columns
+//                         the sweep tests (1, 2, 4), R = descriptors of the pass (a pass of three is swept
+//                         with a fourth column whose gate fails everywhere)
 //     w1 = total          entries in the visit list
-//     w2, w3              descriptor slots d
-//     w4, w5              the descriptors' frames as the entry ids name them (frame - frame_lo,
-//                         0xFFFFFFFF for a frame the table does not hold)
-//     w6..w15             q0, q1, q2 (f32), lo2, hi2 (f32_bounds), each for descriptor 0 and 1
+//     then KM words each (pass_hdr_word): descriptor slots d; the descriptors' frames as the entry ids name
+//     them (frame - frame_lo, 0xFFFFFFFF for a frame the table does not hold); q0, q1, q2 (f32); lo2, hi2
+//     (f32_bounds)
 //   ranges, 12 B each, n + 1 of them (lane j of the sweep loads range j):
 //     offc   exclusive offset of range j in the visit list
 //     dlc    start - offc (entry index of list position p in range j = p + dlc)
-//     meta   cell (0..26) | bit 8: the cell fails descriptor 0's gate | bit 9: descriptor 1's
+//     meta   cell (0..26) | bit 8 + k: the cell fails descriptor k's gate
 //   Range n is the sentinel: it starts at `total` and maps onto the 64 entries with sides +inf
 //   behind the table's last entry, so the lanes of the last 64-entry word beyond the list need
 //   no special case.
@@ -335,12 +340,17 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
 // starts each sum from the descriptor's own gate penalty (a slice too many is harmless, a cell
 // too many is not).
 //
-// Pass slots: leader position p of group g (first position f) owns slot g + ((p + (f & 1)) >> 1)
-// — injective and increasing in p, at most n_groups + (n_valid + 1) / 2 + 1 slots, the unused
-// ones (at most one per group) hold SGTD_NO_PASS; the sweep's tickets are ranges of slots.
+// Pass slots: leader position p = f + KM i of group g (first position f) owns slot
+// g + ceil(f / KM) + i — injective and increasing in p (ceil(a) + ceil(b) <= ceil(a + b) + 1), at most
+// n_groups + ceil(n_valid / KM) + 1 slots, the unused ones (at most one per group) hold
+// SGTD_NO_PASS; the sweep's tickets are ranges of slots.
 // ---------------------------------------------------------------------------
 #define SGTD_NO_PASS 0xFFFFFFFFu
-#define SGTD_PASS_HDR_UNITS 4          // 64-B header in 16-B units
+#define SGTD_PASS_HDR_WORDS (SGTD_PASS_KMAX == 4 ? 32 : 16)
+#define SGTD_PASS_HDR_UNITS (SGTD_PASS_HDR_WORDS / 4)          // the header in 16-B units
+#define SGTD_META_SENTINEL (((1u << SGTD_PASS_KMAX) - 1u) << 8)   // every gate fails
+enum { PH_SLOT = 0, PH_FRAME, PH_Q0, PH_Q1, PH_Q2, PH_LO2, PH_HI2 };
+__host__ __device__ constexpr int pass_hdr_word(int field, int k) { return 2 + field * SGTD_PASS_KMAX + k; }
 #define SGTD_PASS_SLACK_UNITS 64       // behind the pool: the sweep's 64 lanes load 12 B each whatever n is
 
 struct __attribute__((packed, aligned(4))) RangeWords { u32 offc, dlc, meta; };
@@ -354,7 +364,7 @@ struct PassPool {
 
 __host__ __device__ __forceinline__ u32 pass_slot_count(u32 n_valid, u32 n_groups, bool pair) {
   if (!n_valid) return 0u;
-  return pair ? n_groups + ((n_valid + 1u) >> 1) + 1u : n_valid;
+  return pair ? n_groups + (n_valid + SGTD_PAIR - 1u) / SGTD_PAIR + 1u : n_valid;
 }
 
 // pos_of_slot[s] = sorted position of the leader of pass slot s (the array is pre-set to SGTD_NO_PASS)
@@ -364,7 +374,7 @@ __global__ void pass_slots_kernel(const u32 *gid, const u32 *group_first, const 
   if (p >= n || p >= (long long)*n_valid_p) return;
   if (!pair) { pos_of_slot[p] = (u32)p; return; }
   const u32 g = gid[p], f = group_first[g];
-  if ((((u32)p - f) & 1u) == 0u) pos_of_slot[g + (((u32)p + (f & 1u)) >> 1)] = (u32)p;
+  if ((((u32)p - f) % SGTD_PAIR) == 0u) pos_of_slot[g + (f + SGTD_PAIR - 1u) / SGTD_PAIR + ((u32)p - f) / SGTD_PAIR] = (u32)p;
 }
 
 __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int &lo, int &hi) {
@@ -412,32 +422,44 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
   // every wave takes 64 consecutive slots at a time, grid-stride (the grid is sized by resident waves)
   for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; (s & ~63u) < n_pass; s += gridDim.x * blockDim.x) {
   const u32 p = (s < n_pass && !no_rows) ? pos_of_slot[s] : SGTD_NO_PASS;
+  constexpr int KM = SGTD_PASS_KMAX;
   int K = 0;
-  u32 g = 0, d[2] = {0, 0};
+  u32 g = 0, d[KM];
+#pragma unroll
+  for (int k = 0; k < KM; k++) d[k] = 0;
   bool act = p != SGTD_NO_PASS;
   if (act) {
     g = gid[p];
-    K = (PAIR && p + 1 < nv && gid[p + 1] == g) ? 2 : 1;
-    d[0] = order[p];
-    d[1] = K == 2 ? order[p + 1] : d[0];
+    K = 1;
+    if (PAIR) {
+#pragma unroll
+      for (int k = 1; k < SGTD_PAIR; k++) K += (K == k && p + k < nv && gid[p + k] == g) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < KM; k++) d[k] = order[p + (k < K ? k : 0)];
     // a home cell none of whose 27 buckets exists in the table: nothing to plan or sweep — before
     // anything of the descriptors is read
     const u32 *gr = reinterpret_cast<const u32 *>(rows + (size_t)g * ROWB);
     u32 any = gr[8 * SGTD_NCELL];
     if (TAIL) any |= gr[SGTD_GROUP_ROW_BYTES / 4 + 8 * SGTD_NCELL];
     if (any == 0u) {
-      for (int k = 0; k < K; k++) { n_visit[d[k]] = 0; list[d[k]] = make_uint2(0u, 0u); }
+#pragma unroll
+      for (int k = 0; k < KM; k++)
+        if (k < K) { n_visit[d[k]] = 0; list[d[k]] = make_uint2(0u, 0u); }
       act = false;
     }
   }
-  u32 hq[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};   // q0, q1, q2 (f32), lo2, hi2 as words
+  u32 hq[KM][5];   // q0, q1, q2 (f32), lo2, hi2 as words
   if (!act) K = 0;
-  u32 qfr[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, gate[2] = {0, 0};
+  u32 qfr[KM], gate[KM];
   // per descriptor and offset -1, 0, +1: the halves (second side) and thirds (third side) its
   // threshold box reaches as bit masks: halves in bits 2 o .. 2 o + 1, thirds in bits 8 + 3 o .. 8 + 3 o + 2
-  u32 reach[2] = {0, 0};
+  u32 reach[KM];
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < KM; k++) {
+    qfr[k] = 0xFFFFFFFFu; gate[k] = 0; reach[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) hq[k][i] = 0;
     if (k < K) {
       const uint4 *r = reinterpret_cast<const uint4 *>(Q.qrec + d[k]);
       const uint4 a = r[0], b = r[1], c = r[2], e = r[3];
@@ -459,7 +481,9 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
       }
     }
   }
-  const u32 gate_any = gate[0] | gate[1];
+  u32 gate_any = 0;
+#pragma unroll
+  for (int k = 0; k < KM; k++) gate_any |= gate[k];
   // the wave's groups are consecutive ids (slots grow with the sorted position): first and last active lane
   const u64 act_mask = __builtin_amdgcn_ballot_w64(act);
   if (!act_mask) {
@@ -522,7 +546,9 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
     const bool room = (u64)base + wave_units <= (u64)P.cap;
     if (!room && lane == 0) overflow[0] = 1;                 // the host grows the pool and re-runs the batch
     const u32 off = base + inc - units;
-    u32 n = 0, total = 0, visits[2] = {0, 0};
+    u32 n = 0, total = 0, visits[KM];
+#pragma unroll
+    for (int k = 0; k < KM; k++) visits[k] = 0;
     if (mine) {
       RangeWords *wp = reinterpret_cast<RangeWords *>(P.pool + off + SGTD_PASS_HDR_UNITS);   // next range of the record
       const bool emit = ub != 0u && room;
@@ -542,7 +568,7 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
         // sub-cells reached by any gated descriptor: bits 0..2 the thirds of the lower half, 3..5 of the upper
         u32 sub = 0, meta = (u32)c;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < KM; k++) {
           const bool lv = (gate[k] >> c) & 1u;     // (gate[k] = 0 for k >= K)
           const u32 zk = (reach[k] >> (8 + 3 * oz)) & 7u, yk = (reach[k] >> (2 * oy)) & 3u;
           const u32 sk = ((yk & 1u) ? zk : 0u) | ((yk & 2u) ? zk << 3 : 0u);
@@ -573,15 +599,24 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
       const bool rec = emit && n != 0u;
       if (rec) {
         my_off = off;
-        *wp = RangeWords{total, T.n_entries - total, 0x300u};   // the sentinel range (the main segment's sentinels)
+        *wp = RangeWords{total, T.n_entries - total, SGTD_META_SENTINEL};   // the sentinel range (the main segment's sentinels)
+        u32 hw[SGTD_PASS_HDR_WORDS];
+#pragma unroll
+        for (int i = 0; i < SGTD_PASS_HDR_WORDS; i++) hw[i] = 0;
+        hw[0] = n | ((u32)(K == 3 ? 4 : K) << 8) | ((u32)K << 12);     // (three descriptors: swept with a fourth column that fails every gate)
+        hw[1] = total;
+#pragma unroll
+        for (int k = 0; k < KM; k++) {
+          hw[pass_hdr_word(PH_SLOT, k)] = d[k]; hw[pass_hdr_word(PH_FRAME, k)] = qfr[k];
+          hw[pass_hdr_word(PH_Q0, k)] = hq[k][0]; hw[pass_hdr_word(PH_Q1, k)] = hq[k][1]; hw[pass_hdr_word(PH_Q2, k)] = hq[k][2];
+          hw[pass_hdr_word(PH_LO2, k)] = hq[k][3]; hw[pass_hdr_word(PH_HI2, k)] = hq[k][4];
+        }
         uint4 *h = P.pool + off;
-        h[0] = make_uint4(n | ((u32)K << 8), total, d[0], d[1]);
-        h[1] = make_uint4(qfr[0], qfr[1], hq[0][0], hq[1][0]);
-        h[2] = make_uint4(hq[0][1], hq[1][1], hq[0][2], hq[1][2]);
-        h[3] = make_uint4(hq[0][3], hq[1][3], hq[0][4], hq[1][4]);
+#pragma unroll
+        for (int i = 0; i < SGTD_PASS_HDR_UNITS; i++) h[i] = make_uint4(hw[4 * i], hw[4 * i + 1], hw[4 * i + 2], hw[4 * i + 3]);
       }
 #pragma unroll
-      for (int k = 0; k < 2; k++)
+      for (int k = 0; k < KM; k++)
         if (k < K) {
           n_visit[d[k]] = visits[k];
           if (!rec) list[d[k]] = make_uint2(0u, 0u);
@@ -593,17 +628,39 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
 }
 
 // What the sweep holds about the pass it is working on
-template <int K>
 struct PassView {
-  // wave-uniform, from the header
-  float q0f[K], q1f[K], q2f[K], lo2[K], hi2[K];
-  u32 qframe[K], slot[K];
-  u32 n, total;
+  u32 hv;            // lane i: header word i (pass_hdr_word)
+  u32 n, total;      // wave-uniform
+  u32 k_real;        // descriptors of the pass (columns beyond have no list)
   // lane j: range j (lanes beyond the sentinel: offc = 0xFFFFFFFF)
   u32 offc, dlc, meta;
+  __device__ __forceinline__ u32 word(int field, int k) const { return (u32)__builtin_amdgcn_readlane((int)hv, pass_hdr_word(field, k)); }
 };
 
-// STDesc.cpp:372-399 for the K query descriptors of one pass by one wavefront: streams the
+// vec with lane k replaced by the wave-uniform val
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int LANE>
+__device__ __forceinline__ u32 write_lane(u32 vec, u32 val) {
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(val), "n"(LANE));     // (the lane as an inline constant: one scalar operand)
+  return vec;
+}
+
+// a wave-uniform value held in a vector register (operand of v_cmp / v_pk_* without taking scalar registers)
+__device__ __forceinline__ u32 in_vgpr(u32 x) {
+  u32 v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+  return v;
+}
+
+// STDesc.cpp:372-399 for the K descriptor columns of one pass by one wavefront: streams the
 // (union) visit list once, tests every entry against each descriptor, compacts each
 // descriptor's matches in visit order into its own list.
 // WIDE = false: the probe layout is below 4 GB, so entry addresses are a uniform base + a
@@ -613,17 +670,21 @@ struct PassView {
 // FRAMES = false: no descriptor of the batch carries a frame id the table holds (the reference
 // stamps every query descriptor with current_frame_id_, one beyond the map's last frame, quirk 1
 // of SURVEY §8a), so the frame test of :373 is true for every entry and is not evaluated.
+// Registers: the loop's scalar state is, per column, the list's base address and its match count;
+// the thresholds and frames are wave-uniform values in VECTOR registers, the query sides scalar
+// pairs (packed operands), the streams' cursors are parked in WaveSlab::state.
 template <bool DIAG, bool WIDE, bool FRAMES, int K>
 __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffers &B, const QueryView &Q, double rough,
-                                           const PassView<K> &pv, u64 *bits, WaveSlab &slab, PendingLoads pending) {
+                                           const PassView &pv, u64 *bits, WaveSlab &slab, PendingLoads pending) {
   static_assert(!DIAG || K == 1, "the diagnostic sweep takes one descriptor at a time");
+  constexpr int KP = (K + 1) / 2;      // packed pairs of descriptor columns
   const int lane = lane_id();
   const u32 id_bits = T.map.bits;
   const u32 total = pv.total;
   // the diagnostic sweep evaluates the reference's form verbatim on the exact f64 sides, :356-357
   double dq0 = 0.0, dq1 = 0.0, dq2 = 0.0, thr = 0.0;
   if constexpr (DIAG) {
-    const QueryRec &r = Q.qrec[pv.slot[0]];
+    const QueryRec &r = Q.qrec[pv.word(PH_SLOT, 0)];
     dq0 = r.q0; dq1 = r.q1; dq2 = r.q2;
     thr = norm3(dq0, dq1, dq2) * rough;
   }
@@ -638,9 +699,14 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   // records of one descriptor are contiguous: make sure its stream's slab can take the worst
   // case (every visited entry matches)
   bool fits = true;
+  u32 next0[K];         // first record of the column's list
 #pragma unroll
-  for (int k = 0; k < K; k++) {
-    if (total && (u64)slab.next[k] + total > (u64)slab.end[k]) {
+  for (int k = 0; k < K; k++) next0[k] = 0;
+  static_for<K>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if ((u32)k >= pv.k_real) return;      // (the fourth column of a pass of three has no list)
+    u32 nxt = (u32)__builtin_amdgcn_readlane((int)slab.state, k), end = (u32)__builtin_amdgcn_readlane((int)slab.state, 4 + k);
+    if (total && (u64)nxt + total > (u64)end) {
       // a slab must have room for the worst case of a descriptor (every visit matches) when
       // the descriptor starts, but only the matches stay: slabs of 8 worst cases keep the space
       // abandoned at a slab's end to about an eighth however long the visit lists are
@@ -648,23 +714,41 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
       u64 got = 0;
       if (lane == 0) got = atomicAdd(B.rec_cursor(), (unsigned long long)take);
       got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
-      if (got + take <= (u64)B.rec_cap) { slab.start[k] = (u32)got; slab.next[k] = (u32)got; slab.end[k] = (u32)got + take; }
-      else { slab.start[k] = 0; slab.next[k] = 0; slab.end[k] = 0; }   // the buffer is exhausted: nothing of this stream fits any more
+      if (got + take <= (u64)B.rec_cap) { nxt = (u32)got; end = (u32)got + take; }
+      else { nxt = 0; end = 0; }   // the buffer is exhausted: nothing of this stream fits any more
+      slab.state = write_lane<k>(slab.state, nxt);
+      slab.state = write_lane<4 + k>(slab.state, end);
     }
-    fits = fits && ((u64)slab.next[k] + total <= (u64)slab.end[k]);
-  }
+    fits = fits && ((u64)nxt + total <= (u64)end);
+    next0[k] = nxt;
+  });
   if (!fits && lane == 0) B.overflow()[0] = 1;
   __builtin_amdgcn_wave_barrier();
 
   u32 matches[K];
-  char *slab_base[K];   // wave-uniform: the slab's first record; record r of the slab is at byte 4 r
-  u32 rel[K];           // the descriptor's list starts at record rel of its slab
+  char *list_base[K];   // wave-uniform: the list's first record; record r of the list is at byte 4 r
 #pragma unroll
   for (int k = 0; k < K; k++) {
     matches[k] = 0;
-    slab_base[k] = reinterpret_cast<char *>(B.rec + slab.start[k]);
-    rel[k] = slab.next[k] - slab.start[k];
+    list_base[k] = reinterpret_cast<char *>(B.rec + next0[k]);
   }
+  // wave-uniform constants of the columns in vector registers
+  u32 lo2v[K], hi2v[K], qfv[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    lo2v[k] = in_vgpr(pv.word(PH_LO2, k)); hi2v[k] = in_vgpr(pv.word(PH_HI2, k));
+    qfv[k] = (FRAMES || DIAG) ? in_vgpr(pv.word(PH_FRAME, k)) : 0u;
+  }
+  f32x2 qx[KP], qy[KP], qz[KP];
+  if constexpr (K >= 2) {
+#pragma unroll
+    for (int kp = 0; kp < KP; kp++) {
+      qx[kp] = f32x2{__uint_as_float(pv.word(PH_Q0, 2 * kp)), __uint_as_float(pv.word(PH_Q0, 2 * kp + 1))};
+      qy[kp] = f32x2{__uint_as_float(pv.word(PH_Q1, 2 * kp)), __uint_as_float(pv.word(PH_Q1, 2 * kp + 1))};
+      qz[kp] = f32x2{__uint_as_float(pv.word(PH_Q2, 2 * kp)), __uint_as_float(pv.word(PH_Q2, 2 * kp + 1))};
+    }
+  }
+  const float q0s = __uint_as_float(pv.word(PH_Q0, 0)), q1s = __uint_as_float(pv.word(PH_Q1, 0)), q2s = __uint_as_float(pv.word(PH_Q2, 0));
   const u32 n_words = (total + 63u) >> 6;
   slab.swept += total;
   // position -> range.  The starts of the non-empty ranges are marked in a bit array over the
@@ -672,8 +756,8 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   // positions; the mark of a range that starts at position p > 0 is bit p - 1): the range of
   // position 64 w + l is the number of ranges that start at or before 64 w (one compare against
   // the per-lane offsets + popcount, scalar) plus the marks of positions 64 w + 1 .. 64 w + l
-  // (v_mbcnt over the window word) — one LDS read and one ds_bpermute per 64 entries (three for
-  // a pair: the two gate penalties), whatever the number of ranges.
+  // (v_mbcnt over the window word) — one LDS read and one ds_bpermute per 64 entries (1 + K for
+  // two or four columns: their gate penalties), whatever the number of ranges.
   const bool marks = (u32)lane <= pv.n && pv.offc != 0u;
   auto window = [&](u32 w_first) {     // w_first: a multiple of 64 words
     bits[lane] = 0;
@@ -684,7 +768,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   // one load group = NW consecutive words: located and their loads issued back to back (issue),
   // tested later (tests).  NW is a compile-time count: straight-line code.
   //   v      s0, s1, s2 (f32), id of the lane's entry per word
-  //   pen    pair: 0 / +inf per descriptor (the entry's cell passes its gate or not)
+  //   pen    0 / +inf per column (the entry's cell passes the descriptor's gate or not), packed pairs
   //   cellv  cell (0..26) of the lane's entry (diagnostic sweep)
   auto issue = [&](auto &v, auto &pen, auto &cellv, u32 w0) {
     constexpr int NW = (int)(sizeof(v) / sizeof(v[0]));
@@ -699,9 +783,12 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
       const u32 j4 = __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, before)) << 2;
       const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)dlc_sel);
       if (DIAG) cellv[u] = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)cellc);
-      if constexpr (K == 2) {
-        pen[u].x = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(penc[0])));
-        pen[u].y = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(penc[1])));
+      if constexpr (K >= 2) {
+#pragma unroll
+        for (int kp = 0; kp < KP; kp++) {
+          pen[u][kp].x = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(penc[2 * kp])));
+          pen[u][kp].y = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)__float_as_uint(penc[2 * kp + 1])));
+        }
       }
       // entry = position + the range's delta; beyond the list: the sentinel entries
       const float4 *pa = WIDE ? reinterpret_cast<const float4 *>(T.ent + (w_lo + lane + dsel))
@@ -715,35 +802,35 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   };
   auto tests = [&](auto &v, auto &pen, auto &cellv, u32 w0) {
     constexpr int NW = (int)(sizeof(v) / sizeof(v[0]));
-    u32 m_start[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) m_start[k] = matches[k];
     u64 amb_any = 0;     // wave mask: some entry of the group fell between the two f32 thresholds
-    // squared f32 distances of word u's entries to the K descriptors; the pair's two sums run
+    // squared f32 distances of word u's entries to the K descriptors; the sums of two columns run
     // in the halves of packed f32 operations and start from the gate penalties
     auto dist2 = [&](int u, float (&d2)[K]) {
-      if constexpr (K == 2) {
-        const f32x2 qx = {pv.q0f[0], pv.q0f[1]}, qy = {pv.q1f[0], pv.q1f[1]}, qz = {pv.q2f[0], pv.q2f[1]};
+      if constexpr (K >= 2) {
         const f32x2 sx = {v[u].x, v[u].x}, sy = {v[u].y, v[u].y}, sz = {v[u].z, v[u].z};
-        const f32x2 dx = qx - sx, dy = qy - sy, dz = qz - sz;
-        f32x2 acc = __builtin_elementwise_fma(dx, dx, pen[u]);      // pen 0: fl(dx * dx) as in f32_bounds
-        acc = __builtin_elementwise_fma(dy, dy, acc);
-        acc = __builtin_elementwise_fma(dz, dz, acc);
-        d2[0] = acc.x; d2[1] = acc.y;
+#pragma unroll
+        for (int kp = 0; kp < KP; kp++) {
+          const f32x2 dx = qx[kp] - sx, dy = qy[kp] - sy, dz = qz[kp] - sz;
+          f32x2 acc = __builtin_elementwise_fma(dx, dx, pen[u][kp]);      // pen 0: fl(dx * dx) as in f32_bounds
+          acc = __builtin_elementwise_fma(dy, dy, acc);
+          acc = __builtin_elementwise_fma(dz, dz, acc);
+          d2[2 * kp] = acc.x; d2[2 * kp + 1] = acc.y;
+        }
       } else {
-        const float dx = pv.q0f[0] - v[u].x, dy = pv.q1f[0] - v[u].y, dz = pv.q2f[0] - v[u].z;
+        const float dx = q0s - v[u].x, dy = q1s - v[u].y, dz = q2s - v[u].z;
         d2[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
       }
     };
-    // one (word, descriptor) test; PUSH = false: store the matches, true: replay of the group
-    // that only queues the provisional records (rare)
+    // one (word, column) test; PUSH = false: store the matches — `count` runs up; true: replay of
+    // the group that only queues the provisional records (rare), words in reverse — `count` runs
+    // back down to the record index of the word's first match
     auto test = [&](auto push_tag, int u, int k, float d2, u32 &count) mutable {
       constexpr bool PUSH = decltype(push_tag)::value;
       u32 id = __float_as_uint(v[u].w);
       // (the replay shares nothing with the first evaluation: no mask of the hot loop stays alive for it)
       if constexpr (PUSH) asm volatile("" : "+v"(id), "+v"(d2));
       // unsigned (src.frame_id_ - db.frame_id_) > 0  <=>  frame ids differ (:373)
-      const bool other = !(FRAMES || DIAG) || pv.qframe[k] != (id >> id_bits);
+      const bool other = !(FRAMES || DIAG) || qfv[k] != (id >> id_bits);
       bool hit, amb = false;
       u64 m;
       double dis = 0.0;
@@ -758,36 +845,37 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         m = __builtin_amdgcn_ballot_w64(hit);
       } else {
         // (sentinel entries and gated-out cells: d2 = +inf, above every hi2 — f32_bounds keeps it finite)
-        const bool near = !(d2 > pv.hi2[k]);     // not certainly outside (NaN stays in)
+        const bool near = !(d2 > __uint_as_float(hi2v[k]));     // not certainly outside (NaN stays in)
         hit = near && other;
-        amb = hit && !(d2 < pv.lo2[k]);          // not certainly inside either: provisional
+        amb = hit && !(d2 < __uint_as_float(lo2v[k]));          // not certainly inside either: provisional
         m = FRAMES ? __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other)   // two plain compares: no mask round trip
                    : __builtin_amdgcn_ballot_w64(near);
       }
-      // record index inside the slab
-      const u32 at = rel[k] + count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+      if constexpr (PUSH) count -= (u32)__builtin_popcountll(m);
+      // record index inside the list
+      const u32 at = count + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
       if constexpr (!PUSH) {
-        // wave-uniform base (the slab) + a 32-bit lane offset: no 64-bit VALU address math
+        // wave-uniform base (the list) + a 32-bit lane offset: no 64-bit VALU address math
 #ifdef SGTD_EXP_NOSTORE
         if (at == 0xFFFFFFF0u)
 #endif
-        if (hit && fits) *reinterpret_cast<u32 *>(slab_base[k] + (at << 2)) = id;
+        if (hit && fits) *reinterpret_cast<u32 *>(list_base[k] + (at << 2)) = id;
         if constexpr (DIAG) {
-          if (hit && fits) { B.rec_cell[(size_t)slab.start[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)slab.start[k] + at] = dis; }
+          if (hit && fits) { B.rec_cell[(size_t)next0[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)next0[k] + at] = dis; }
         }
         // amb_any |= m & ballot(!(d2 < lo2)) — as one unit, so that no hit mask outlives its test
         // (left to the scheduler, the masks of a whole group wait in scalar registers for this)
         if (!DIAG)
           asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n\ts_and_b64 vcc, vcc, %3\n\ts_or_b64 %0, %0, vcc"
-                       : "+s"(amb_any) : "s"(__float_as_uint(pv.lo2[k])), "v"(d2), "s"(m) : "vcc");
+                       : "+s"(amb_any) : "v"(lo2v[k]), "v"(d2), "s"(m) : "vcc");
+        count += (u32)__builtin_popcountll(m);
       } else {
         if (amb && fits) {
           const u32 qa = atomicAdd(B.amb_count(), 1u);
-          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(slab.start[k] + at, pv.slot[k]);
+          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(next0[k] + at, pv.word(PH_SLOT, k));
           else B.overflow()[0] = 1;    // re-run with a larger queue (grows with the record buffer)
         }
       }
-      count += (u32)__builtin_popcountll(m);
     };
     PH_ADD(2);
 #pragma unroll
@@ -798,12 +886,15 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
       for (int k = 0; k < K; k++) test(std::false_type{}, u, k, DIAG ? 0.0f : d2[k], matches[k]);
     }
     if (!DIAG && amb_any) {   // rare: about one in 10^4 matches
+      u32 back[K];
 #pragma unroll
-      for (int u = 0; u < NW; u++) {
+      for (int k = 0; k < K; k++) back[k] = matches[k];
+#pragma unroll
+      for (int u = NW - 1; u >= 0; u--) {
         float d2[K];
         dist2(u, d2);
 #pragma unroll
-        for (int k = 0; k < K; k++) test(std::true_type{}, u, k, d2[k], m_start[k]);
+        for (int k = 0; k < K; k++) test(std::true_type{}, u, k, d2[k], back[k]);
       }
     }
     PH_ADD(3);
@@ -823,7 +914,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     auto group = [&](auto nw_tag, u32 w0) {
       constexpr int NW = decltype(nw_tag)::value;
       float4 v[NW];
-      f32x2 pen[NW];
+      f32x2 pen[NW][KP];
       u32 cellv[NW];
       issue(v, pen, cellv, w0);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -844,17 +935,20 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   }
   // the pass's results: lane k stores for descriptor k
   {
-    u32 r_slot = pv.slot[0], r_ptr = slab.next[0], r_match = matches[0];
-    if constexpr (K == 2) {
-      if (lane == 1) { r_slot = pv.slot[1]; r_ptr = slab.next[1]; r_match = matches[1]; }
-    }
-    if (lane < K) B.list[r_slot] = make_uint2(r_ptr, fits ? r_match : 0u);
-  }
+    u32 r_slot = pv.hv, r_ptr = next0[0], r_match = matches[0];
+    // (lane k's own header word is not the slot: fetch the K slot words by lane)
+    r_slot = (u32)__builtin_amdgcn_ds_bpermute((pass_hdr_word(PH_SLOT, 0) + min(lane, K - 1)) << 2, (int)pv.hv);
 #pragma unroll
-  for (int k = 0; k < K; k++) {
-    if (!fits && lane == 0) atomicAdd(B.rec_need(), (unsigned long long)matches[k]);
-    if (fits) slab.next[k] += matches[k];
+    for (int k = 1; k < K; k++)
+      if (lane == k) { r_ptr = next0[k]; r_match = matches[k]; }
+    if ((u32)lane < pv.k_real) B.list[r_slot] = make_uint2(r_ptr, fits ? r_match : 0u);
   }
+  static_for<K>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if ((u32)k >= pv.k_real) return;
+    if (!fits && lane == 0) atomicAdd(B.rec_need(), (unsigned long long)matches[k]);
+    if (fits) slab.state = write_lane<k>(slab.state, next0[k] + matches[k]);
+  });
   __builtin_amdgcn_wave_barrier();
   PH_ADD(4);
 }
@@ -952,10 +1046,10 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_WAVES void probe_sor
     return (u32)__builtin_amdgcn_readlane((int)ov, i);
   };
   // header (lane i < 16: word i) and ranges (lane j: range j) of the current and the next pass
-  u32 hv = 0, r_off = 0xFFFFFFFFu, r_dl = 0, r_meta = 0x300u, hv_n = 0, rn_off = 0xFFFFFFFFu, rn_dl = 0, rn_meta = 0x300u;
+  u32 hv = 0, r_off = 0xFFFFFFFFu, r_dl = 0, r_meta = SGTD_META_SENTINEL, hv_n = 0, rn_off = 0xFFFFFFFFu, rn_dl = 0, rn_meta = SGTD_META_SENTINEL;
   auto fetch = [&](u32 off, u32 &h, u32 &a, u32 &b, u32 &c) {
     if (off == SGTD_NO_PASS) return;
-    h = reinterpret_cast<const u32 *>(P.pool + off)[lane & 15];
+    h = reinterpret_cast<const u32 *>(P.pool + off)[lane & (SGTD_PASS_HDR_WORDS - 1)];
     // every lane loads 12 B whatever n is (no wait for the header): the lanes beyond the
     // sentinel read into the following records or the pool's slack and are masked below
     const RangeWords rw = reinterpret_cast<const RangeWords *>(P.pool + off + SGTD_PASS_HDR_UNITS)[lane];
@@ -970,27 +1064,20 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_WAVES void probe_sor
     pend.h = &hv_n; pend.a = &rn_off; pend.b = &rn_dl; pend.c = &rn_meta;
     PH_ADD(5);      // between passes: tickets, the next record's fetch
     const u32 w0 = (u32)__builtin_amdgcn_readlane((int)hv, 0);
-    const u32 n = w0 & 0xFFu, kk = w0 >> 8;
-    auto pass = [&](auto k_tag) {
-      constexpr int KK = decltype(k_tag)::value;
-      PassView<KK> pv;
-      pv.n = n; pv.total = (u32)__builtin_amdgcn_readlane((int)hv, 1);
-#pragma unroll
-      for (int k = 0; k < KK; k++) {
-        pv.slot[k] = (u32)__builtin_amdgcn_readlane((int)hv, 2 + k);
-        pv.qframe[k] = (u32)__builtin_amdgcn_readlane((int)hv, 4 + k);
-        pv.q0f[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 6 + k));
-        pv.q1f[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 8 + k));
-        pv.q2f[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 10 + k));
-        pv.lo2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 12 + k));
-        pv.hi2[k] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)hv, 14 + k));
-      }
+    const u32 n = w0 & 0xFFu, kk = (w0 >> 8) & 0xFu;
+    PassView pv;
+    pv.hv = hv; pv.n = n; pv.total = (u32)__builtin_amdgcn_readlane((int)hv, 1); pv.k_real = w0 >> 12;
+    {
       const bool mine = (u32)lane <= n;
       pv.offc = mine ? r_off : 0xFFFFFFFFu;
       pv.dlc = r_dl;
-      pv.meta = mine ? r_meta : 0x300u;
+      pv.meta = mine ? r_meta : SGTD_META_SENTINEL;
+    }
+    auto pass = [&](auto k_tag) {
+      constexpr int KK = decltype(k_tag)::value;
       sweep_pass<DIAG, WIDE, FRAMES, KK>(T, B, Q, rough, pv, s_bits[threadIdx.x >> 6], slab, pend);
     };
+    if constexpr (!DIAG && SGTD_PAIR >= 4) { if (kk == 4) pass(std::integral_constant<int, 4>{}); }
     if constexpr (!DIAG && SGTD_PAIR >= 2) { if (kk == 2) pass(std::integral_constant<int, 2>{}); }
     if (kk == 1) pass(std::integral_constant<int, 1>{});
     off_c = off_n;

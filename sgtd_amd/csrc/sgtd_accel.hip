@@ -849,8 +849,8 @@ int launch_select(sgtd_engine *e) {
     // previous batch measured (2 until there is one); SGTD_SORTED_CHUNK overrides
     u32 chunk = 2;
     if (e->stats.last_D > 0 && e->stats.last_P_swept > 0) {
-      // last_P_swept counts a pair's shared list once: visits per pass ~ P_swept / (D / 1.9)
-      const double per_pass = (double)e->stats.last_P_swept / ((double)e->stats.last_D / (pair ? 1.9 : 1.0));
+      // last_P_swept counts a pass's shared list once: visits per pass ~ P_swept / (D / descriptors per pass)
+      const double per_pass = (double)e->stats.last_P_swept / ((double)e->stats.last_D / (pair ? (SGTD_PAIR >= 4 ? 3.2 : 1.9) : 1.0));
       chunk = (u32)std::min(8.0, std::max(1.0, std::floor(3072.0 / per_pass + 0.5)));
     }
     if (e->sorted_chunk > 0) chunk = (u32)std::min(SGTD_TICKET_MAX, e->sorted_chunk);
