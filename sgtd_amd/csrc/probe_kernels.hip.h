@@ -1507,8 +1507,12 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
 // compact list of one query's candidate matches, block after block in list order: the pairs
 // (q_idx << 32 | g) of the records whose frame made the candidate list, and their slots.
 // Written by block_count_kernel, consumed by block_write_kernel (no second record walk).
+// NARROW (entry ids with at most 19 rank bits — frames of up to 524 288 entries): 32-bit words
+// slot << 26 | descriptor index inside the block << 19 | rank of the entry among its frame's — the
+// slot names the frame.
+#define SGTD_NARROW_RANK_BITS 19
 struct CompactLists {
-  u64 *pair;             // [cap] slot << 58 | q_idx << 32 | entry id
+  u64 *pair;             // [cap] slot << 58 | q_idx << 32 | entry id (NARROW: u32 words, see above)
   u32 *blk_start;        // [nq * blocks_per_query] first entry of the block's list
   u32 *blk_n;            // [nq * blocks_per_query] entries of the block's list
   u32 *cursor;           // global allocation cursor
@@ -1518,7 +1522,7 @@ struct CompactLists {
 // SLOT_TABLE: the frame -> candidate slot map of the query is the byte array topk_kernel wrote
 // (slot_of, 0xFF = not a candidate), staged in LDS and indexed directly — one ds_read_u8 per
 // record; for maps whose frame span does not fit LDS the 256-entry hash of the candidates
-template <bool SLOT_TABLE>
+template <bool SLOT_TABLE, bool NARROW>
 __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
                                                           const int *cand_frame, int cand_num,
                                                           int blocks_per_query, u32 *blk_count, CompactLists L,
@@ -1630,7 +1634,10 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
           if (fits) {
             const u32 pos = start + running + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
             // slot rides in the top 6 bits of the q_idx half (q_idx < 36 * 65535 < 2^26)
-            L.pair[pos] = ((u64)((sl << 26) | (d0 + dd[u])) << 32) | (u64)rid[u];
+            if constexpr (NARROW)
+              reinterpret_cast<u32 *>(L.pair)[pos] = (sl << 26) | ((d0 - d_first + dd[u]) << SGTD_NARROW_RANK_BITS) | (rid[u] & ((1u << B.id_bits) - 1u));
+            else
+              L.pair[pos] = ((u64)((sl << 26) | (d0 + dd[u])) << 32) | (u64)rid[u];
           }
         }
         running += (u32)__builtin_popcountll(m);
@@ -1709,11 +1716,12 @@ __global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32
 #endif
 // pass 2: every candidate's match_list_ in (i, cell, j) order (:437-449);
 // pair = query descriptor index << 32 | insertion index of the table entry
+template <bool NARROW>
 __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuffers B, CompactLists L,
                                                           int blocks_per_query,
                                                           const u32 *blk_excl, int cand_num,
                                                           const long long *pair_off, const u32 *q_pair_base,
-                                                          u64 *pairs, IdMap map) {
+                                                          u64 *pairs, IdMap map, const int *n_cand, const int *cand_frame) {
   constexpr int NW = 256 / SGTD_WAVE;
   constexpr int CAP = SGTD_WRITE_CAP;   // staged pairs per slot = one 128-B (16) or 64-B (8) line
   __shared__ u64 s_mask[NW][64];         // per wave and slot: lanes of the current word that carry the slot
@@ -1727,12 +1735,16 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   const size_t bslot = (size_t)q * blocks_per_query + id.blk;
   const u32 nv = L.blk_n[bslot];
   if (nv == 0) return;
-  const u64 *cp = L.pair + L.blk_start[bslot];
+  using Word = std::conditional_t<NARROW, u32, u64>;
+  const Word *cp = reinterpret_cast<const Word *>(L.pair) + L.blk_start[bslot];
+  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
   // lane s carries, for candidate slot s, the output position of its first staged
-  // pair (`running`) and the number of staged pairs (`fill`)
-  u32 running = 0, fill = 0;
+  // pair (`running`) and the number of staged pairs (`fill`) — and, NARROW, the position of its
+  // frame's first entry in the id map (a compact word names the frame by its slot)
+  u32 running = 0, fill = 0, first_of_slot = 0;
   if (lane < cand_num)
     running = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + lane] + blk_excl[bslot * 64 + lane];
+  if (NARROW && lane < cand_num && lane < n_cand[q]) first_of_slot = map.frame_first[(u32)cand_frame[(size_t)q * cand_num + lane] - map.frame_lo];
   // all staged pairs go out as CAP-lane groups, 64 / CAP slots per store instruction
   auto flush = [&]() {
     constexpr int SPI = SGTD_WAVE / CAP;
@@ -1748,7 +1760,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   };
   // the next two words of the compact list are loaded while the current two are split (the
   // raw words are only unpacked at the top of the next step: touching them earlier would wait)
-  u64 nraw[SGTD_WRITE_WORDS];
+  Word nraw[SGTD_WRITE_WORDS];
   auto load2 = [&](u32 r0) {
 #pragma unroll
     for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
@@ -1764,14 +1776,22 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
 #pragma unroll
     for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
       const bool ok = r0 + u * SGTD_WAVE + lane < nv;
-      pr[u] = nraw[u] & 0x03FFFFFFFFFFFFFFull;
-      sl[u] = ok ? (u32)(nraw[u] >> 58) : 0xFFu;
-      first[u] = map.frame_first[(u32)nraw[u] >> map.bits];
+      if constexpr (NARROW) {
+        const u32 w = (u32)nraw[u];
+        sl[u] = ok ? w >> 26 : 0xFFu;
+        // q_idx << 32 | rank; the frame's first entry comes from the slot's lane
+        pr[u] = ((u64)(d_first + ((w >> SGTD_NARROW_RANK_BITS) & 127u)) << 32) | (u64)(w & ((1u << SGTD_NARROW_RANK_BITS) - 1u));
+        first[u] = (u32)__builtin_amdgcn_ds_bpermute((int)((sl[u] & 63u) << 2), (int)first_of_slot);
+      } else {
+        pr[u] = nraw[u] & 0x03FFFFFFFFFFFFFFull;
+        sl[u] = ok ? (u32)(nraw[u] >> 58) : 0xFFu;
+        first[u] = map.frame_first[(u32)nraw[u] >> map.bits];
+      }
     }
     if (r0 + SGTD_WRITE_WORDS * SGTD_WAVE < nv) load2(r0 + SGTD_WRITE_WORDS * SGTD_WAVE);
 #pragma unroll
     for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
-      u32 g = first[u] + ((u32)pr[u] & ((1u << map.bits) - 1u));
+      u32 g = first[u] + ((u32)pr[u] & ((1u << (NARROW ? SGTD_NARROW_RANK_BITS : map.bits)) - 1u));
       if (map.by_frame) g = map.by_frame[g];
       pr[u] = (pr[u] & 0xFFFFFFFF00000000ull) | (u64)g;
     }

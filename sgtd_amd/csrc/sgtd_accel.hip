@@ -86,6 +86,7 @@ struct sgtd_engine {
   int64_t tail_max = 0;                  // SGTD_TAIL_MAX: entries the tail may hold before a merge (0 = an eighth of the main segment)
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
   u32 coarse_at = 62, whole_at = 62;     // SGTD_COARSE_AT, SGTD_WHOLE_AT: see TableView
+  bool wide_pairs = false;               // SGTD_WIDE_PAIRS (test hook): 8-byte compact words whatever the ids' rank bits
   int tail_batches = 0;                  // query batches swept with the current tail (it is merged after a few: see settle_tail)
   DevBuf slice_of, sq_sum;
   // entry ids of the probe layout (common.hip.h IdMap), rebuilt over the whole table by every finalize
@@ -744,6 +745,21 @@ Views make_views(sgtd_engine *e) {
   return v;
 }
 
+// pass 2 of the match-list assembly (both word widths of the compact lists)
+int launch_block_write(sgtd_engine *e, const Views &v, const CompactLists &CL, int agrid, int blocks) {
+  const int cn = e->dc.cand_num;
+  if (v.T.map.bits <= SGTD_NARROW_RANK_BITS && !e->wide_pairs)
+    block_write_kernel<true><<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL, blocks, e->blk_count.as<u32>(), cn, e->pair_off.as<long long>(),
+                                                            e->q_pair_base.as<u32>(), e->pairs.as<u64>(), v.T.map, e->n_cand.as<int>(),
+                                                            e->cand_frame.as<int>());
+  else
+    block_write_kernel<false><<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL, blocks, e->blk_count.as<u32>(), cn, e->pair_off.as<long long>(),
+                                                             e->q_pair_base.as<u32>(), e->pairs.as<u64>(), v.T.map, e->n_cand.as<int>(),
+                                                             e->cand_frame.as<int>());
+  HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
 int launch_select(sgtd_engine *e) {
   const int nq = e->nq;
   const long long n_slots = (long long)nq * e->q_stride;
@@ -945,17 +961,29 @@ int launch_select(sgtd_engine *e) {
   CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
   CL.cursor = v.B.compact_cursor(); CL.cap = (u32)std::min<size_t>(e->c_pair.bytes / sizeof(u64), 0xFFFFFFF0u);
+  // the compact lists' words: 4 bytes where an entry's rank among its frame's fits 19 bits, else 8
+  const bool narrow_pairs = v.T.map.bits <= SGTD_NARROW_RANK_BITS && !e->wide_pairs;
   if (span <= 48 * 1024) {
     const int sl_bytes = (int)((span + 15) & ~15u);
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_count_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, sl_bytes));
-    block_count_kernel<true><<<agrid, 256, sl_bytes, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
-                                                                  blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr,
-                                                                  e->slot_of.as<unsigned char>(), span, v.T.frame_lo);
+#define SGTD_LAUNCH_COUNT(NP)                                                                                          \
+  do {                                                                                                                 \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_count_kernel<true, NP>),                          \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, sl_bytes));                                 \
+    block_count_kernel<true, NP><<<agrid, 256, sl_bytes, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn, \
+                                                                      blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr,      \
+                                                                      e->slot_of.as<unsigned char>(), span, v.T.frame_lo);        \
+  } while (0)
+    if (narrow_pairs) SGTD_LAUNCH_COUNT(true); else SGTD_LAUNCH_COUNT(false);
+#undef SGTD_LAUNCH_COUNT
   } else {
-    block_count_kernel<false><<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
-                                                             blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr,
-                                                             e->slot_of.as<unsigned char>(), span, v.T.frame_lo);
+    if (narrow_pairs)
+      block_count_kernel<false, true><<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
+                                                                    blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr,
+                                                                    e->slot_of.as<unsigned char>(), span, v.T.frame_lo);
+    else
+      block_count_kernel<false, false><<<agrid, 256, 0, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
+                                                                     blocks, e->blk_count.as<u32>(), CL, nullptr, nullptr,
+                                                                     e->slot_of.as<unsigned char>(), span, v.T.frame_lo);
   }
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
@@ -967,10 +995,7 @@ int launch_select(sgtd_engine *e) {
                                                (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
-  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL,
-                                                    blocks, e->blk_count.as<u32>(), cn,
-                                                    e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
-                                                    e->pairs.as<u64>(), v.T.map);
+  CHK(launch_block_write(e, v, CL, agrid, blocks));
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
   e->batch_valid = true;
@@ -1012,9 +1037,7 @@ int rerun_write(sgtd_engine *e) {
   query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
                                                (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
   HIPCHK(hipGetLastError());
-  block_write_kernel<<<agrid, 256, 0, e->stream>>>(v.Q, v.B, CL, blocks, e->blk_count.as<u32>(), cn,
-                                                    e->pair_off.as<long long>(), e->q_pair_base.as<u32>(), e->pairs.as<u64>(), v.T.map);
-  HIPCHK(hipGetLastError());
+  CHK(launch_block_write(e, v, CL, agrid, blocks));
   return SGTD_OK;
 }
 
@@ -1268,6 +1291,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
   if (const char *o = getenv("SGTD_TAIL_MAX")) e->tail_max = atoll(o);
   if (const char *o = getenv("SGTD_COARSE_AT")) e->coarse_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
+  if (const char *o = getenv("SGTD_WIDE_PAIRS")) e->wide_pairs = atoi(o) != 0;
   if (const char *o = getenv("SGTD_WHOLE_AT")) e->whole_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }

@@ -968,6 +968,24 @@ def test_multi_device_handle_on_two_gpus(mods):
 # ---------------------------------------------------------------------------
 # incremental insert: appends after a query go to a tail segment
 # ---------------------------------------------------------------------------
+def test_eight_byte_compact_words_keep_parity(mods, monkeypatch):
+    # the compact candidate lists between the two assembly passes use 4-byte words (slot, descriptor in
+    # block, rank in frame) whenever an entry's rank among its frame's entries fits 19 bits, 8-byte words
+    # (slot, q_idx, id) otherwise — frames of more than 524 288 descriptors; SGTD_WIDE_PAIRS forces those
+    monkeypatch.setenv("SGTD_WIDE_PAIRS", "1")
+    _, manager, synth = mods
+    g, o = _pair(mods)
+    m = synth.make_map(40, 150, stream=35)
+    qs = synth.make_queries(m, 3, stream=35)
+    g.add_frames(m.xyz, m.label)
+    for f in range(40):
+        o.build(m.xyz[f], m.label[f], export=False)
+        o.add_last()
+    res = g.query_frames(qs.xyz, qs.label)
+    for q in range(3):
+        _check_query(g, o, res, q, o.build(qs.xyz[q], qs.label[q]))
+
+
 @pytest.mark.parametrize("plan", [None, ("0", "62"), ("0", "0"), ("6", "12")])
 def test_appends_go_to_a_tail_segment_and_keep_parity(mods, monkeypatch, plan):
     # plan: (SGTD_COARSE_AT, SGTD_WHOLE_AT) — the planner's fallbacks for visit lists of more ranges than
