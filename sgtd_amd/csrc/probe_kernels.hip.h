@@ -78,6 +78,8 @@ struct ProbeBuffers {
   unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
+  u32 rec_rate;         // room a descriptor's list is given when its pass starts: rec_rate / 256 of the visit list (+ 256 records),
+                        // at most the whole list; a list that outgrows what its slab has left moves to a new one
   // the batch's counters live in ONE buffer (a single base address in the kernels' scalar
   // registers): words 0-1 the global slab cursor of the match records (64-bit: requests can
   // add up beyond 2^32), 2 the undecided-record queue's fill, 3 the compact lists' cursor,
@@ -101,7 +103,7 @@ struct ProbeBuffers {
   u32 id_bits;          // a record's local frame (frame - table frame_lo) is rec >> id_bits
   // records whose f32 test fell between the two thresholds: stored provisionally as matches,
   // queued here and decided on the exact sides by resolve_undecided_kernel right after the sweep
-  uint2 *amb_queue;     // [amb_cap] (record index, descriptor slot)
+  uint2 *amb_queue;     // [amb_cap] (index of the record in the descriptor's list, descriptor slot)
   u32 amb_cap;
 };
 
@@ -138,7 +140,8 @@ static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2 || SGTD_PAIR == 4, "the sweep com
 struct WaveSlab {
   // this wave's private ranges of match records: one bump stream per descriptor column of a pass, so
   // that every descriptor's list stays contiguous.  The streams' state is parked in the lanes of ONE
-  // vector register between passes (lane k: next free record of stream k, lane 4 + k: end of its slab)
+  // vector register between passes (lane k: next free record of stream k, lane 4 + k: end of its slab;
+  // during a pass lane 8 + k: the room the pass's list has in the slab)
   // — scalar registers are what the sweep runs out of.
   u32 state;
   u64 swept;                             // entries this wave loaded
@@ -698,28 +701,38 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   const u32 lane16 = (u32)lane << 4;
   // records of one descriptor are contiguous: make sure its stream's slab can take the worst
   // case (every visited entry matches)
+  // A list is given the room its matches are EXPECTED to need (rec_rate / 256 of the visit list, measured
+  // on the batch before, three times over) — not the worst case, every visit a match: with visit lists of
+  // 10^4 entries and 8192 waves, worst-case reservations alone exceed the 32-bit record index.  A list that
+  // does outgrow what its slab has left is moved to a fresh slab (relocate below, rare).
   bool fits = true;
+  bool tight = false;   // some column's room is below the worst case: the groups check it
   u32 next0[K];         // first record of the column's list
 #pragma unroll
   for (int k = 0; k < K; k++) next0[k] = 0;
+  const u32 want = DIAG ? total : min(total, (total >> 8) * B.rec_rate + (((total & 255u) * B.rec_rate) >> 8) + 256u);
+  // a slab of `take` records from the global cursor (0, 0: the buffer is exhausted)
+  auto new_slab = [&](u32 take, u32 &nxt, u32 &end) {
+    u64 got = 0;
+    if (lane == 0) got = atomicAdd(B.rec_cursor(), (unsigned long long)take);
+    got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
+    if (got + take <= (u64)B.rec_cap) { nxt = (u32)got; end = (u32)got + take; }
+    else { nxt = 0; end = 0; }
+  };
   static_for<K>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if ((u32)k >= pv.k_real) return;      // (the fourth column of a pass of three has no list)
     u32 nxt = (u32)__builtin_amdgcn_readlane((int)slab.state, k), end = (u32)__builtin_amdgcn_readlane((int)slab.state, 4 + k);
-    if (total && (u64)nxt + total > (u64)end) {
-      // a slab must have room for the worst case of a descriptor (every visit matches) when
-      // the descriptor starts, but only the matches stay: slabs of 8 worst cases keep the space
-      // abandoned at a slab's end to about an eighth however long the visit lists are
-      const u32 take = total > (1u << 28) ? total : max(SGTD_REC_SLAB, 8u * total);
-      u64 got = 0;
-      if (lane == 0) got = atomicAdd(B.rec_cursor(), (unsigned long long)take);
-      got = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)got);
-      if (got + take <= (u64)B.rec_cap) { nxt = (u32)got; end = (u32)got + take; }
-      else { nxt = 0; end = 0; }   // the buffer is exhausted: nothing of this stream fits any more
+    if (total && (u64)nxt + want > (u64)end) {
+      // only the matches stay in a slab: slabs of 8 expected lists keep the space abandoned at a
+      // slab's end to about an eighth however long the visit lists are
+      new_slab(want > (1u << 28) ? want : max(SGTD_REC_SLAB, 8u * want), nxt, end);
       slab.state = write_lane<k>(slab.state, nxt);
       slab.state = write_lane<4 + k>(slab.state, end);
     }
-    fits = fits && ((u64)nxt + total <= (u64)end);
+    fits = fits && ((u64)nxt + want <= (u64)end);
+    tight = tight || (end - nxt < total);
+    slab.state = write_lane<8 + k>(slab.state, end - nxt);
     next0[k] = nxt;
   });
   if (!fits && lane == 0) B.overflow()[0] = 1;
@@ -872,7 +885,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
       } else {
         if (amb && fits) {
           const u32 qa = atomicAdd(B.amb_count(), 1u);
-          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(next0[k] + at, pv.word(PH_SLOT, k));
+          if (qa < B.amb_cap) B.amb_queue[qa] = make_uint2(at, pv.word(PH_SLOT, k));
           else B.overflow()[0] = 1;    // re-run with a larger queue (grows with the record buffer)
         }
       }
@@ -911,6 +924,38 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     // dump word, which it can count: 6.9 ms, three times the store instructions.  Eight-word groups
     // ahead of the four-word ones — fewer round trips per pass, 24 more vector registers: 5.76 ms
     // against 5.64.)
+    // Room: a group adds at most 64 NW records to a list.  `safe` counts the four-word groups every list
+    // still has room for (recomputed from the lists' real lengths when it runs out); a list without room
+    // for the next group moves: a slab for what it holds + what the rest of the visit list is expected to
+    // add, its records copied, the old ones abandoned.
+    u32 safe = 0;
+    auto make_room = [&](u32 w0) {
+      safe = 0xFFFFFFFFu;
+      static_for<K>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if ((u32)k >= pv.k_real || !fits) return;
+        u32 room = (u32)__builtin_amdgcn_readlane((int)slab.state, 8 + k);
+        if (room - matches[k] < 256u) {
+          const u32 rest = total - min(total, w0 << 6);          // visits still to come
+          const u32 more = min(rest, (rest >> 8) * B.rec_rate + (((rest & 255u) * B.rec_rate) >> 8) + 512u);
+          const u32 need = matches[k] + more;
+          u32 nxt, end;
+          new_slab(max(SGTD_REC_SLAB, need > (1u << 28) ? need : 4u * need), nxt, end);
+          if (end - nxt < need) { fits = false; if (lane == 0) B.overflow()[0] = 1; return; }
+          u32 *from = B.rec + next0[k], *to = B.rec + nxt;
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // the list's records so far are in L2 ...
+          for (u32 i = (u32)lane; i < matches[k]; i += SGTD_WAVE)
+            to[i] = __hip_atomic_load(from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and are read from there
+          next0[k] = nxt;
+          list_base[k] = reinterpret_cast<char *>(to);
+          room = end - nxt;
+          slab.state = write_lane<4 + k>(slab.state, end);
+          slab.state = write_lane<8 + k>(slab.state, room);
+        }
+        safe = min(safe, (room - matches[k]) >> 8);
+      });
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // (the copies have left before the list's next records are stored)
+    };
     auto group = [&](auto nw_tag, u32 w0) {
       constexpr int NW = decltype(nw_tag)::value;
       float4 v[NW];
@@ -922,11 +967,19 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     };
     u32 w0 = 0;
     bool touched = false;
+    auto check_room = [&]() {   // (before every four-word group and once before the tail: at most 256 records per list either)
+      if (tight) {
+        if (safe == 0) make_room(w0);
+        safe--;
+      }
+    };
     for (; w0 + 4u <= n_words; w0 += 4u) {
+      check_room();
       group(std::integral_constant<int, 4>{}, w0);
       if (!touched) { pending.touch(); touched = true; }
     }
     const u32 left = n_words - w0;   // wave-uniform
+    if (left) check_room();
     if (left & 2u) { group(std::integral_constant<int, 2>{}, w0); w0 += 2; }
     if (left & 1u) { group(std::integral_constant<int, 1>{}, w0); w0 += 1; }
     if (!touched) pending.touch();   // every path through the sweep leaves them complete
@@ -1101,11 +1154,12 @@ __global__ void resolve_undecided_kernel(TableView T, QueryView Q, ProbeBuffers 
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint2 it = B.amb_queue[i];
     const QueryRec &r = Q.qrec[it.y];
-    const double *sp = T.cold_side + (size_t)id_entry(T.map, B.rec[it.x]) * 3;
+    u32 *rec = B.rec + (size_t)B.list[it.y].x + it.x;      // (index in the list: a list may have moved during its pass)
+    const double *sp = T.cold_side + (size_t)id_entry(T.map, *rec) * 3;
     const double dx = r.q0 - sp[0], dy = r.q1 - sp[1], dz = r.q2 - sp[2];
     const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
     if (!(d2 < r.thr2)) {
-      B.rec[it.x] = SGTD_DEAD_ID;
+      *rec = SGTD_DEAD_ID;
       atomicSub(&q_M[(u32)((long long)it.y / Q.stride)], 1u);
     }
   }

@@ -86,6 +86,7 @@ struct sgtd_engine {
   int64_t tail_max = 0;                  // SGTD_TAIL_MAX: entries the tail may hold before a merge (0 = an eighth of the main segment)
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
   u32 coarse_at = 62, whole_at = 62;     // SGTD_COARSE_AT, SGTD_WHOLE_AT: see TableView
+  u32 rec_rate_hook = 0;                 // SGTD_REC_RATE (test hook): ProbeBuffers::rec_rate, 1..256
   bool wide_pairs = false;               // SGTD_WIDE_PAIRS (test hook): 8-byte compact words whatever the ids' rank bits
   int tail_batches = 0;                  // query batches swept with the current tail (it is merged after a few: see settle_tail)
   DevBuf slice_of, sq_sum;
@@ -737,6 +738,16 @@ Views make_views(sgtd_engine *e) {
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
   B.rec = e->rec.as<u32>(); B.id_bits = e->id_bits ? e->id_bits : 13;
   B.ctr = e->cursors.as<u32>();
+  // room a list gets when its pass starts (ProbeBuffers::rec_rate): three times the matches per visited entry
+  // and descriptor of the batch before; a quarter of the visit list for the first batch
+  {
+    const double per_pass = SGTD_PAIR >= 4 ? 3.2 : (SGTD_PAIR >= 2 ? 1.9 : 1.0);
+    B.rec_rate = 64;
+    if (e->stats.last_P_swept > 0 && e->stats.last_M > 0)
+      B.rec_rate = (u32)std::min(256.0, std::max(16.0, std::ceil(3.0 * 256.0 * (double)e->stats.last_M / ((double)e->stats.last_P_swept * per_pass))));
+    if (e->diag) B.rec_rate = 256;
+    if (e->rec_rate_hook) B.rec_rate = e->rec_rate_hook;
+  }
   B.amb_queue = e->amb_queue.as<uint2>();
   B.amb_cap = (u32)std::min<size_t>(e->amb_queue.bytes / sizeof(uint2), 0xFFFFFFF0u);
   B.list = e->list.as<uint2>(); B.n_visit = e->n_visit.as<u32>();
@@ -1291,6 +1302,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (const char *o = getenv("SGTD_SORTED_CHUNK")) e->sorted_chunk = atoi(o);
   if (const char *o = getenv("SGTD_TAIL_MAX")) e->tail_max = atoll(o);
   if (const char *o = getenv("SGTD_COARSE_AT")) e->coarse_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
+  if (const char *o = getenv("SGTD_REC_RATE")) e->rec_rate_hook = (u32)std::min(256, std::max(1, atoi(o)));
   if (const char *o = getenv("SGTD_WIDE_PAIRS")) e->wide_pairs = atoi(o) != 0;
   if (const char *o = getenv("SGTD_WHOLE_AT")) e->whole_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
@@ -1722,6 +1734,17 @@ int sgtd_verify(sgtd_handle e) {
   HIPCHK(hipGetLastError());
   verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
+#ifdef SGTD_EXP_VSTAT
+  {
+    unsigned long long st[8];
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_vstat), sizeof(st)));
+    fprintf(stderr, "[vstat] steps %llu anyA %llu | combos %llu passA %llu passAB %llu passABC %llu | pairs %llu pairs-anyA %llu\n",
+            st[0], st[1], st[7], st[2], st[3], st[4], st[5], st[6]);
+    unsigned long long z[8] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vstat), z, sizeof(z)));
+  }
+#endif
   e->verified = true;
   return SGTD_OK;
 }

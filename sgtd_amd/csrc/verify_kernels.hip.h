@@ -215,6 +215,15 @@ __global__ __launch_bounds__(SGTD_WAVE) void verify_solve_kernel(VerifyParams P)
 #ifndef SGTD_VERIFY_WAVES
 #define SGTD_VERIFY_WAVES __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
+#ifdef SGTD_EXP_VSTAT
+// experiment build: how the (pair, hypothesis) tests fall out.  0 steps (128 pairs x hypothesis), 1 steps where some
+// pair passes A, 2 / 3 / 4 (pair, hypothesis) combinations that pass A / A,B / A,B,C, 5 pairs, 6 pairs that pass A
+// for some hypothesis, 7 valid (pair, hypothesis) combinations
+__device__ unsigned long long g_vstat[8];
+#define VSTAT(i, x) do { if (lane == 0) atomicAdd(&g_vstat[i], (unsigned long long)(x)); } while (0)
+#else
+#define VSTAT(i, x) do { } while (0)
+#endif
 typedef const __attribute__((address_space(4))) f32x2 *sgtd_const_f32x2;
 typedef const __attribute__((address_space(4))) double *sgtd_const_f64;
 __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_kernel(VerifyParams P) {
@@ -282,6 +291,9 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
     // scalar registers (not as per-lane booleans: those cost a v_cndmask / v_cmp pair at every use and
     // made this loop 140 VALU instructions per step; SQ counters, profiles/r03o_sq_verify.json).
     const u64 valid0 = __builtin_amdgcn_ballot_w64(valid[0]), valid1 = __builtin_amdgcn_ballot_w64(valid[1]);
+#ifdef SGTD_EXP_VSTAT
+    u64 any0 = 0, any1 = 0;
+#endif
     for (int h = 0; h < use_size; h++) {
       f32x2 R[12];      // R00 R01 R02 R10 R11 R12 R20 R21 R22 t0 t1 t2, each in both halves (scalar registers)
 #pragma unroll
@@ -318,10 +330,18 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
         }
       };
       u64 in0 = valid0, in1 = valid1;
+      VSTAT(0, 1); VSTAT(7, __builtin_popcountll(in0) + __builtin_popcountll(in1));
       vertex(0, in0, in1);
+      VSTAT(2, __builtin_popcountll(in0) + __builtin_popcountll(in1));
+#ifdef SGTD_EXP_VSTAT
+      any0 |= in0; any1 |= in1;
+#endif
       if (in0 | in1) {       // wrong hypotheses fail at vertex A for the whole wave
+        VSTAT(1, 1);
         vertex(1, in0, in1);
+        VSTAT(3, __builtin_popcountll(in0) + __builtin_popcountll(in1));
         if (in0 | in1) vertex(2, in0, in1);
+        VSTAT(4, __builtin_popcountll(in0) + __builtin_popcountll(in1));
         if (in0 | in1) {
           if ((in0 >> lane) & 1ull) passed[0] |= 1ull << h;
           if ((in1 >> lane) & 1ull) passed[1] |= 1ull << h;
@@ -330,6 +350,10 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
         }
       }
     }
+#ifdef SGTD_EXP_VSTAT
+    VSTAT(5, __builtin_popcountll(valid0) + __builtin_popcountll(valid1));
+    VSTAT(6, __builtin_popcountll(any0) + __builtin_popcountll(any1));
+#endif
     // what the inlier pass needs of this pair: no second walk over the vertices
 #pragma unroll
     for (int u = 0; u < PPT; u++) {

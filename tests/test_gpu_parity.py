@@ -968,6 +968,27 @@ def test_multi_device_handle_on_two_gpus(mods):
 # ---------------------------------------------------------------------------
 # incremental insert: appends after a query go to a tail segment
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("rate", ["1", "256"])
+def test_match_lists_that_outgrow_their_room_move(mods, monkeypatch, rate):
+    # a descriptor's match list is given room for the matches it is EXPECTED to have (SGTD_REC_RATE / 256 of
+    # its visit list + 256 records; measured on the batch before in production) and moves to a fresh slab
+    # when it outgrows what its slab has left.  1: nearly every slab ends with a move; 256: the worst case is
+    # reserved, nothing ever moves.  Undecided records are queued by their index in the list, so they survive it.
+    monkeypatch.setenv("SGTD_REC_RATE", rate)
+    _, manager, synth = mods
+    g, o = _pair(mods, rough_dis_threshold=0.04)      # (longer lists than the default threshold gives)
+    m = synth.make_map(60, 150, stream=36)
+    qs = synth.make_queries(m, 4, stream=36)
+    g.add_frames(m.xyz, m.label)
+    for f in range(60):
+        o.build(m.xyz[f], m.label[f], export=False)
+        o.add_last()
+    for _ in range(2):
+        res = g.query_frames(qs.xyz, qs.label)
+        for q in range(4):
+            _check_query(g, o, res, q, o.build(qs.xyz[q], qs.label[q]))
+
+
 def test_eight_byte_compact_words_keep_parity(mods, monkeypatch):
     # the compact candidate lists between the two assembly passes use 4-byte words (slot, descriptor in
     # block, rank in frame) whenever an entry's rank among its frame's entries fits 19 bits, 8-byte words
