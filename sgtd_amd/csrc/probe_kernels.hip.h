@@ -837,9 +837,6 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     // one (word, column) test; PUSH = false: store the matches — `count` runs up; true: replay of
     // the group that only queues the provisional records (rare), words in reverse — `count` runs
     // back down to the record index of the word's first match
-#ifdef SGTD_ASM_STORE
-    const u64 fits_mask = fits ? ~0ull : 0ull;
-#endif
     auto test = [&](auto push_tag, int u, int k, float d2, u32 &count) mutable {
       constexpr bool PUSH = decltype(push_tag)::value;
       u32 id = __float_as_uint(v[u].w);
@@ -874,16 +871,6 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         // wave-uniform base (the list) + a 32-bit lane offset: no 64-bit VALU address math
 #ifdef SGTD_EXP_NOSTORE
         if (at == 0xFFFFFFF0u)
-#endif
-#ifdef SGTD_ASM_STORE
-        if constexpr (!DIAG) {
-          // the store under the hit mask as one unit: exec is all ones here (the sweep's control flow is
-          // wave-uniform from the kernel's first instruction), so it is set from the mask and set back —
-          // no saved copy, no skip branch around a store that nearly every word takes
-          const u32 boff = at << 2;
-          asm volatile("s_and_b64 exec, %0, %1\n\tglobal_store_dword %2, %3, %4\n\ts_mov_b64 exec, -1"
-                       : : "s"(m), "s"(fits_mask), "v"(boff), "v"(id), "s"(list_base[k]) : "memory");
-        } else
 #endif
         if (hit && fits) *reinterpret_cast<u32 *>(list_base[k] + (at << 2)) = id;
         if constexpr (DIAG) {
@@ -936,7 +923,9 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     // number the compiler cannot know either: 6.3 ms against 5.85; with unconditional stores into a
     // dump word, which it can count: 6.9 ms, three times the store instructions.  Eight-word groups
     // ahead of the four-word ones — fewer round trips per pass, 24 more vector registers: 5.76 ms
-    // against 5.64.)
+    // against 5.64.  The store as an asm unit that sets exec from the hit mask and back, without the
+    // saved copy and the skip branch — four scalar instructions less per test: no difference, 5.07 ms
+    // against 5.01.)
     // Room: a group adds at most 64 NW records to a list.  `safe` counts the four-word groups every list
     // still has room for (recomputed from the lists' real lengths when it runs out); a list without room
     // for the next group moves: a slab for what it holds + what the rest of the visit list is expected to
