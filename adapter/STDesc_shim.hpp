@@ -55,7 +55,7 @@
 #endif
 
 #ifndef SGTD_SHIM_FILL_THREADS
-#define SGTD_SHIM_FILL_THREADS 4u   // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call
+#define SGTD_SHIM_FILL_THREADS 8u   // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call (2 / 4 / 8 / 12 measured: 6.4 / 5.4 / 4.1 / 3.1 ms for the fill)
 #endif
 
 namespace sgtd_shim {
@@ -79,6 +79,56 @@ struct SoaBuf {
   }
   size_t capacity() const { return frame.size(); }
 };
+
+// The same arrays in page-locked memory (sgtd_host_alloc), kept by the calling thread from call to call
+// and grown when a call needs more: the entries SearchLoop fetches (20 MB per frame) arrive by one DMA
+// transfer per field instead of through the runtime's pageable staging.  Falls back to ordinary memory
+// if the allocation fails.
+struct PinnedSoa {
+  sgtd_desc_soa v{};
+  size_t cap = 0;
+  bool pinned = false;
+  std::vector<void *> owned;
+  SoaBuf *plain = nullptr;
+  bool reserve(size_t n) {
+    if (n <= cap) return true;
+    release();
+    const size_t want = n + n / 4 + 1024;
+    void *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[7] = {want * 3 * sizeof(double), want * 3 * sizeof(double), want * 3 * sizeof(double), want * 9 * sizeof(float),
+                             want * 3 * sizeof(int32_t), want * sizeof(uint32_t), want * 3 * sizeof(int32_t)};
+    bool ok = true;
+    for (int i = 0; i < 7 && ok; i++) ok = sgtd_host_alloc(bytes[i], &p[i]) == SGTD_OK && p[i];
+    if (ok) {
+      owned.assign(p, p + 7);
+      v.side = (double *)p[0]; v.angle = (double *)p[1]; v.center = (double *)p[2]; v.vertex = (float *)p[3];
+      v.label = (int32_t *)p[4]; v.frame = (uint32_t *)p[5]; v.node_id = (int32_t *)p[6];
+      pinned = true;
+    } else {
+      for (void *q : p) if (q) sgtd_host_free(q);
+      plain = new SoaBuf(want);
+      v = plain->v;
+      pinned = false;
+    }
+    cap = want;
+    return true;
+  }
+  void release() {
+    for (void *q : owned) sgtd_host_free(q);
+    owned.clear();
+    delete plain; plain = nullptr;
+    cap = 0; v = sgtd_desc_soa{};
+  }
+  PinnedSoa() = default;
+  PinnedSoa(const PinnedSoa &) = delete;
+  PinnedSoa &operator=(const PinnedSoa &) = delete;
+  // (a thread that ends — the process's main thread at exit — does not call into the HIP runtime any
+  // more: page-locked buffers are given back by release_thread_buffers(), otherwise with the process)
+  ~PinnedSoa() { delete plain; }
+};
+inline PinnedSoa &fetched_entries() { static thread_local PinnedSoa p; return p; }
+// gives the calling thread's page-locked buffers back (before the thread ends or the handle is destroyed)
+inline void release_thread_buffers() { fetched_entries().release(); }
 
 template <class Desc>
 void to_soa(const std::vector<Desc> &in, SoaBuf &b) {
@@ -230,16 +280,16 @@ int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::ve
 }
 
 // milliseconds SearchLoop spent, by part, summed over this thread's calls: the device work and its
-// transfers (select .. fetch) and the host-side construction of the reference's result containers (fill)
-struct SearchTiming { double select = 0, verify = 0, inliers = 0, fetch = 0, fill = 0; long calls = 0; };
+// transfers (select .. inliers) and the host-side construction of the reference's result containers (fill)
+struct SearchTiming { double select = 0, verify = 0, inliers = 0, fill = 0; long calls = 0; };   // inliers: the inlier pairs and their table entries
 inline SearchTiming &search_timing() { static thread_local SearchTiming t; return t; }
 
 // ---- STDesc.cpp:84-147 with candidate_verify (:462-547) on the device ---------------------
 // Vec3 / Mat3 = Eigen::Vector3d / Eigen::Matrix3d (operator[] and operator()(row, col)).
 // The match lists stay on the device: only the inlier pairs of every candidate
-// (sucess_match_vec, what LOOP_RESULT::loop_std_pair holds) are fetched — one device compaction
-// (sgtd_result_inlier_pairs), one gather of the table entries they name — instead of the ~10^5
-// pairs of the full lists.
+// (sucess_match_vec, what LOOP_RESULT::loop_std_pair holds) are fetched — one device compaction and
+// one gather of the table entries they name, back to back (sgtd_result_inlier_entries) — instead of
+// the ~10^5 pairs of the full lists.
 template <class Desc, class Vec3, class Mat3, class LoopResult>
 int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, double> &loop_result,
                std::pair<Vec3, Mat3> &loop_transform, std::vector<std::pair<Desc, Desc>> &loop_std_pair,
@@ -275,26 +325,20 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   st = sgtd_result_verify(h, 0, score.data(), pose.data());
   if (st != SGTD_OK) return st;
   SGTD_LAP(verify);
-  // the inlier pairs of every candidate (sucess_match_vec, :516-539) in one call, then ONE fetch of
-  // the table entries they name
+  // the inlier pairs of every candidate (sucess_match_vec, :516-539) and the table entries they name, in one call
   std::vector<int64_t> ioff((size_t)cn + 1, 0);
   int64_t n_inl = 0;
-  st = sgtd_result_inlier_pairs(h, 0, ioff.data(), nullptr, nullptr, 0, &n_inl);
-  if (st != SGTD_OK && st != SGTD_ERR_CAPACITY) return st;
-  std::vector<int32_t> iq((size_t)n_inl);
-  std::vector<int64_t> want((size_t)n_inl);
-  if (n_inl) {
-    st = sgtd_result_inlier_pairs(h, 0, ioff.data(), iq.data(), want.data(), n_inl, &n_inl);
-    if (st != SGTD_OK) return st;
-  }
+  PinnedSoa &pe = fetched_entries();      // page-locked, reused from frame to frame
+  const int64_t most = s.off[s.n_cand];   // every pair of every candidate's list
+  pe.reserve((size_t)most);
+  std::vector<int32_t> iq((size_t)most);
+  st = sgtd_result_inlier_entries(h, 0, ioff.data(), iq.data(), &pe.v, most, &n_inl);
+  if (st != SGTD_OK) return st;
+  const sgtd_desc_soa &ent = pe.v;
   SGTD_LAP(inliers);
 #ifdef SGTD_SHIM_TIMING
   std::fprintf(stderr, "  [shim] %lld inlier pairs over %d candidates\n", (long long)n_inl, s.n_cand);
 #endif
-  SoaBuf ent(want.size());
-  st = sgtd_fetch_entries(h, want.data(), (int64_t)want.size(), &ent.v);
-  if (st != SGTD_OK) return st;
-  SGTD_LAP(fetch);
   double best_score = 0;
   int best = -1;
   const size_t first = match_result_list.size();
@@ -307,8 +351,8 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
       for (int b = 0; b < 3; b++) r.loop_transform.second(a, b) = pose[(size_t)k * 12 + a * 3 + b];
       r.loop_transform.first[a] = pose[(size_t)k * 12 + 9 + a];
     }
-    // a candidate that failed verification (score -1) has no sucess_match_vec
-    r.loop_std_pair.resize(score[k] >= 0 ? (size_t)(ioff[(size_t)k + 1] - ioff[(size_t)k]) : 0);
+    // (a candidate that failed verification — score -1 — has no sucess_match_vec; the others' are built by
+    // the fill threads below)
     if (score[k] > best_score) { best_score = score[k]; best = k; }   // :125-131
   }
   // LOOP_RESULT::loop_std_pair of EVERY candidate is filled: the caller copies the list of whichever
@@ -320,14 +364,16 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   // frame against 27.9 single-threaded, 256 threads: 180 ms).  Filling the query side of the pairs
   // while the table side is still being fetched was measured too: the fetch then takes 18-22 ms instead
   // of 3-4 (the copy's own host threads lose their cores) — the fill starts after it.
+  // Every pair is CONSTRUCTED in place (reserve + emplace_back: the query descriptor copied, the table
+  // descriptor filled in a local and moved), not value-initialised by a resize and then assigned: a resize
+  // zeroes the 832 bytes of every pair first — 129 MB per frame, on the calling thread.
   auto fill = [&](int k0, int k1) {
     for (int k = k0; k < k1; k++) {
       if (!(score[k] >= 0)) continue;
       std::vector<std::pair<Desc, Desc>> &lp = match_result_list[first + (size_t)k].loop_std_pair;
+      lp.reserve((size_t)(ioff[(size_t)k + 1] - ioff[(size_t)k]));
       for (int64_t j = ioff[(size_t)k]; j < ioff[(size_t)k + 1]; j++) {
-        std::pair<Desc, Desc> &pr = lp[(size_t)(j - ioff[(size_t)k])];
-        pr.first = stds_vec[(size_t)iq[(size_t)j]];
-        Desc &d = pr.second;
+        Desc d;
         const size_t i = (size_t)j;
         for (int c = 0; c < 3; c++) {
           d.side_length_[c] = ent.side[3 * i + c]; d.angle_[c] = ent.angle[3 * i + c]; d.center_[c] = ent.center[3 * i + c];
@@ -336,6 +382,7 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
         }
         d.frame_id_ = ent.frame[i];
         d.node_id = {ent.node_id[3 * i], ent.node_id[3 * i + 1], ent.node_id[3 * i + 2]};
+        lp.emplace_back(stds_vec[(size_t)iq[(size_t)j]], std::move(d));
       }
     }
   };

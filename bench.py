@@ -192,13 +192,13 @@ def cpp_adapter_leg(smap, queries, n_frames):
                   r"(\d+)/(\d+) agree with the batched run, ([0-9.]+) inlier pairs per loop", out.stdout)
     if not m:
         raise RuntimeError("unexpected output: " + out.stdout[-500:])
-    parts = re.search(r"SearchLoop by part \(ms per frame\): select ([0-9.]+), verify ([0-9.]+), inlier pairs ([0-9.]+), entry fetch ([0-9.]+), "
+    parts = re.search(r"SearchLoop by part \(ms per frame\): select ([0-9.]+), verify ([0-9.]+), inlier pairs and their entries ([0-9.]+), "
                       r"host fill of loop_std_pair ([0-9.]+)", out.stdout)
     by_part = None
     if parts:
-        v = [float(parts.group(i)) for i in range(1, 6)]
-        by_part = {"select": v[0], "verify": v[1], "inlier_pairs": v[2], "entry_fetch": v[3], "host_fill_of_loop_std_pair": v[4],
-                   "device_and_transfers": round(sum(v[:4]), 3)}
+        v = [float(parts.group(i)) for i in range(1, 5)]
+        by_part = {"select": v[0], "verify": v[1], "inlier_pairs_and_entries": v[2], "host_fill_of_loop_std_pair": v[3],
+                   "device_and_transfers": round(sum(v[:3]), 3)}
     return {"cpp_adapter_ms_per_frame": float(m.group(2)), "cpp_adapter_search_loop_by_part_ms": by_part, "cpp_adapter_ms_build": float(m.group(3)),
             "cpp_adapter_ms_search_loop": float(m.group(4)), "cpp_adapter_frames": int(m.group(1)),
             "cpp_adapter_agree_with_batched": "%s/%s" % (m.group(5), m.group(6)), "cpp_adapter_inlier_pairs_per_loop": float(m.group(7)),

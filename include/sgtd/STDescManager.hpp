@@ -96,7 +96,7 @@ class STDescManager {
     if (status_ != SGTD_OK)   // the reference's constructor cannot fail; a missing device is fatal here
       throw std::runtime_error(std::string("sgtd_create: ") + sgtd_strerror(status_));
   }
-  ~STDescManager() { sgtd_destroy(h_); }
+  ~STDescManager() { sgtd_shim::release_thread_buffers(); sgtd_destroy(h_); }   // (the page-locked fetch buffers of the calling thread go first)
   STDescManager(const STDescManager &) = delete;
   STDescManager &operator=(const STDescManager &) = delete;
 

@@ -21,6 +21,7 @@
 #ifndef SGTD_ACCEL_H
 #define SGTD_ACCEL_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -250,6 +251,13 @@ int sgtd_result_inliers(sgtd_handle h, int q, int cand, int32_t *idx, int64_t ca
  * LOOP_RESULT::loop_std_pair (STDesc.cpp:119-124) without fetching the full match lists. */
 int sgtd_result_inlier_pairs(sgtd_handle h, int q, int64_t *cand_off, int32_t *q_idx, int64_t *db_entry,
                              int64_t capacity, int64_t *n_pairs);
+/* The same pairs with the table side already fetched: q_idx[i] and entry i of `entries` (the fields whose
+ * pointers are set) are the i-th inlier pair — the compaction, the gather of the table entries and the copies
+ * run back to back on the device, no list of indices travels to the host and back.  capacity in pairs
+ * (the sum of the candidates' list lengths, sgtd_result_candidates' last offset, always suffices);
+ * *n_pairs = needed.  SGTD_ERR_CAPACITY leaves cand_off and *n_pairs valid. */
+int sgtd_result_inlier_entries(sgtd_handle h, int q, int64_t *cand_off, int32_t *q_idx, sgtd_desc_soa *entries,
+                               int64_t capacity, int64_t *n_pairs);
 /* STDescManager::SearchLoop's choice (STDesc.cpp:105-146) for every query of the batch:
  * the first candidate with the strictly largest verify_score, accepted if it exceeds
  * icp_threshold; best_frame = -1 and best_score = 0 otherwise (loop_result (-1, 0)).
@@ -289,6 +297,13 @@ int sgtd_graphs_view(const sgtd_graph_batch *b, int *n_frames, int64_t *n_keypoi
                      const uint32_t **label, const int64_t **kp_off, const float **poses);
 const char *sgtd_graphs_error(const sgtd_graph_batch *b);
 void sgtd_graphs_free(sgtd_graph_batch *b);
+
+/* Page-locked host memory for the destination buffers of the fetch calls (sgtd_fetch_entries,
+ * sgtd_result_pairs, ...): a copy into it is one direct DMA transfer — pageable memory goes through the
+ * runtime's staging at about a third of the rate.  Allocation is slow (milliseconds): keep the buffers
+ * across calls, as adapter/STDesc_shim.hpp does.  bytes == 0 yields *out = NULL. */
+int sgtd_host_alloc(size_t bytes, void **out);
+int sgtd_host_free(void *p);
 
 /* table entries by insertion index (to rebuild pair<STDesc,STDesc>) */
 int sgtd_fetch_entries(sgtd_handle h, const int64_t *db_entry, int64_t n,

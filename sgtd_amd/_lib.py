@@ -22,9 +22,9 @@ SYMBOLS = [
     "sgtd_set_stream", "sgtd_set_timing", "sgtd_current_frame_id", "sgtd_max_descs", "sgtd_build",
     "sgtd_add", "sgtd_add_frames", "sgtd_finalize", "sgtd_query_frames", "sgtd_query_descs", "sgtd_max_batch",
     "sgtd_result_candidates", "sgtd_export_candidates_dev", "sgtd_result_query_desc_count", "sgtd_result_pairs",
-    "sgtd_result_query_descs", "sgtd_result_votes", "sgtd_result_rough", "sgtd_fetch_entries",
+    "sgtd_result_query_descs", "sgtd_result_votes", "sgtd_result_rough", "sgtd_fetch_entries", "sgtd_host_alloc", "sgtd_host_free",
     "sgtd_table_dump", "sgtd_sync", "sgtd_get_stats",
-    "sgtd_verify", "sgtd_export_verify_dev", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_result_inlier_pairs", "sgtd_search_loop",
+    "sgtd_verify", "sgtd_export_verify_dev", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_result_inlier_pairs", "sgtd_result_inlier_entries", "sgtd_search_loop",
     "sgtd_graphs_load", "sgtd_graphs_save_cache", "sgtd_graphs_load_cache", "sgtd_graphs_view",
     "sgtd_graphs_error", "sgtd_graphs_free", "sgtd_save_table", "sgtd_load_table",
 ]

@@ -1828,6 +1828,51 @@ int sgtd_result_inlier_pairs(sgtd_handle e, int q, int64_t *cand_off, int32_t *q
   return SGTD_OK;
 }
 
+int sgtd_result_inlier_entries(sgtd_handle e, int q, int64_t *cand_off, int32_t *q_idx, sgtd_desc_soa *entries, int64_t capacity,
+                               int64_t *n_pairs) {
+  if (!e || !n_pairs || !cand_off) return SGTD_ERR_INVALID;
+  if (e->grp) {
+    // several devices: the pairs from the devices that own the candidates, then their entries (db_entry ids name the owner)
+    std::vector<int64_t> ent((size_t)std::max<int64_t>(capacity, 0));
+    const int st = sgtd_result_inlier_pairs(e, q, cand_off, q_idx, ent.data(), capacity, n_pairs);
+    if (st != SGTD_OK) return st;
+    return entries ? sgtd_fetch_entries(e, ent.data(), *n_pairs, entries) : SGTD_OK;
+  }
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num;
+  const int64_t total = e->h_pair_off[(size_t)q * (cn + 1) + cn];
+  CHK(ensure(e, e->inl_pairs, (size_t)std::max<int64_t>(total, 1) * sizeof(u64)));
+  CHK(ensure(e, e->inl_off, (size_t)(cn + 1) * sizeof(long long)));
+  // index list, q_idx list and the gathered entries for the most there can be, so that everything is enqueued
+  // before the one wait for the offsets
+  CHK(ensure(e, e->fetch_idx, (size_t)std::max<int64_t>(total, 1) * (sizeof(long long) + sizeof(int))));
+  CHK(ensure_store(e, e->fetch, (size_t)std::max<int64_t>(total, 1)));
+  long long *d_idx = e->fetch_idx.as<long long>();
+  int *d_qi = reinterpret_cast<int *>(d_idx + std::max<int64_t>(total, 1));
+  inlier_pairs_kernel<<<1, SGTD_INLIER_THREADS, 0, e->stream>>>(e->pairs.as<u64>() + e->h_pair_base[q], e->v_inlier.as<unsigned char>() + e->h_pair_base[q],
+                                                                e->pair_off.as<long long>() + (size_t)q * (cn + 1), cn, e->inl_pairs.as<u64>(),
+                                                                e->inl_off.as<long long>());
+  HIPCHK(hipGetLastError());
+  if (total > 0) {
+    split_pairs_kernel<<<grid_for(total, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, d_idx, d_qi);
+    HIPCHK(hipGetLastError());
+    gather_entries_counted_kernel<<<grid_for(total, 256), 256, 0, e->stream>>>(d_idx, e->inl_off.as<long long>() + cn, e->tab.view(), e->fetch.view());
+    HIPCHK(hipGetLastError());
+  }
+  std::vector<long long> off((size_t)cn + 1);
+  CHK(d2h(e, off.data(), e->inl_off.p, off.size() * sizeof(long long)));
+  CHK(xfer_sync(e));
+  for (int k = 0; k <= cn; k++) cand_off[k] = off[(size_t)k];
+  const int64_t n = off[(size_t)cn];
+  *n_pairs = n;
+  if (n > capacity) return SGTD_ERR_CAPACITY;
+  if (n == 0) return SGTD_OK;
+  if (q_idx) CHK(d2h(e, q_idx, d_qi, (size_t)n * sizeof(int)));
+  if (entries) return copy_out(e, e->fetch, 0, (size_t)n, entries, 0);
+  return xfer_sync(e);
+}
+
 int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, int32_t *best_frame, double *best_score) {
   if (e && e->grp) return multi::search_loop(e, icp_threshold, best_cand, best_frame, best_score);
   if (!e) return SGTD_ERR_INVALID;
@@ -1968,6 +2013,18 @@ int sgtd_graphs_view(const sgtd_graph_batch *b, int *n_frames, int64_t *n_keypoi
 const char *sgtd_graphs_error(const sgtd_graph_batch *b) { return b ? b->error.c_str() : ""; }
 
 void sgtd_graphs_free(sgtd_graph_batch *b) { delete b; }
+
+int sgtd_host_alloc(size_t bytes, void **out) {
+  if (!out) return SGTD_ERR_INVALID;
+  *out = nullptr;
+  if (bytes == 0) return SGTD_OK;
+  return hipHostMalloc(out, bytes, hipHostMallocPortable) == hipSuccess ? SGTD_OK : SGTD_ERR_HIP;
+}
+
+int sgtd_host_free(void *p) {
+  if (!p) return SGTD_OK;
+  return hipHostFree(p) == hipSuccess ? SGTD_OK : SGTD_ERR_INVALID;
+}
 
 int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_desc_soa *out) {
   if (e && e->grp) return multi::fetch_entries(e, db_entry, n, out);

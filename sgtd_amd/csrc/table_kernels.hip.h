@@ -429,9 +429,27 @@ __global__ void bucket_sq_kernel(const u32 *bucket_start, u32 n_buckets, u32 n_e
 
 // sgtd_fetch_entries: table entries idx[0..n) gathered into contiguous staging arrays (one
 // device-to-host copy per field afterwards instead of one per entry)
+__device__ __forceinline__ void gather_entry(const long long *idx, long long i, const DescArrays &tab, const DescArrays &out);
 __global__ void gather_entries_kernel(const long long *idx, long long n, DescArrays tab, DescArrays out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  gather_entry(idx, i, tab, out);
+}
+// the same with the count still on the device (the launch covers an upper bound)
+__global__ void gather_entries_counted_kernel(const long long *idx, const long long *n_p, DescArrays tab, DescArrays out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_p) return;
+  gather_entry(idx, i, tab, out);
+}
+// pairs (q_idx << 32 | g) -> the two index lists
+__global__ void split_pairs_kernel(const u64 *pairs, const long long *n_p, long long *idx, int *q_idx) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_p) return;
+  const u64 pr = pairs[i];
+  idx[i] = (long long)(pr & 0xFFFFFFFFull);
+  q_idx[i] = (int)(pr >> 32);
+}
+__device__ __forceinline__ void gather_entry(const long long *idx, long long i, const DescArrays &tab, const DescArrays &out) {
   const size_t g = (size_t)idx[i];
 #pragma unroll
   for (int k = 0; k < 3; k++) {

@@ -139,6 +139,25 @@ int main(int argc, char **argv) {
       CHECK(match_result_list[k].match_id == cf[k]);
       if (sc >= 0) {
         CHECK((int)match_result_list[k].loop_std_pair.size() == ns);
+        // sucess_match_vec: the pairs the restatement names (positions in candidate k's match list), both sides
+        std::vector<double> side(3), vertex(9);
+        std::vector<int32_t> label(3), node(3); uint32_t fr = 0;
+        orc_desc_soa out{side.data(), nullptr, nullptr, vertex.data(), label.data(), &fr, node.data()};
+        for (int r = 0; r < ns; r += 3) {
+          const std::pair<sgtd::STDesc, sgtd::STDesc> &pr = match_result_list[k].loop_std_pair[r];
+          const int64_t at = co[k] + sidx[r], e = en[at];
+          orc_fetch_entries(oracle, &e, 1, &out);
+          CHECK(pr.second.frame_id_ == fr && (int)fr == cf[k]);
+          const sgtd::STDesc &qd = query_stds_vec[qi[at]];
+          for (int c = 0; c < 3; c++) {
+            CHECK(pr.second.side_length_[c] == side[c]);
+            CHECK(pr.second.vertex_A_[c] == vertex[c] && pr.second.vertex_B_[c] == vertex[3 + c] && pr.second.vertex_C_[c] == vertex[6 + c]);
+            CHECK((int)pr.second.vertex_attached_[c] == label[c]);
+            CHECK(pr.second.node_id.size() == 3 && pr.second.node_id[c] == node[c]);
+            CHECK(pr.first.side_length_[c] == qd.side_length_[c] && pr.first.vertex_A_[c] == qd.vertex_A_[c]);
+            CHECK(pr.first.node_id.size() == 3 && pr.first.node_id[c] == qd.node_id[c]);
+          }
+        }
         for (int a = 0; a < 3; a++) {
           CHECK(match_result_list[k].loop_transform.first[a] == t[a]);
           for (int b = 0; b < 3; b++) CHECK(match_result_list[k].loop_transform.second.m[a][b] == rot[a * 3 + b]);
