@@ -78,6 +78,8 @@ struct ProbeBuffers {
   unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
   double *rec_dis;      // [rec_cap] distance (diagnostic build only)
   u32 rec_cap;
+  u32 rec_slab;         // smallest slab a wave takes from the global cursor (SGTD_REC_SLAB; less for small record buffers:
+                        // every stream of every wave holds one, and together they must stay a fraction of the buffer)
   u32 rec_rate;         // room a descriptor's list is given when its pass starts: rec_rate / 256 of the visit list (+ 256 records),
                         // at most the whole list; a list that outgrows what its slab has left moves to a new one
   // the batch's counters live in ONE buffer (a single base address in the kernels' scalar
@@ -726,7 +728,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     if (total && (u64)nxt + want > (u64)end) {
       // only the matches stay in a slab: slabs of 8 expected lists keep the space abandoned at a
       // slab's end to about an eighth however long the visit lists are
-      new_slab(want > (1u << 28) ? want : max(SGTD_REC_SLAB, 8u * want), nxt, end);
+      new_slab(want > (1u << 28) ? want : max(B.rec_slab, 8u * want), nxt, end);
       slab.state = write_lane<k>(slab.state, nxt);
       slab.state = write_lane<4 + k>(slab.state, end);
     }
@@ -942,7 +944,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
           const u32 more = min(rest, (rest >> 8) * B.rec_rate + (((rest & 255u) * B.rec_rate) >> 8) + 512u);
           const u32 need = matches[k] + more;
           u32 nxt, end;
-          new_slab(max(SGTD_REC_SLAB, need > (1u << 28) ? need : 4u * need), nxt, end);
+          new_slab(max(B.rec_slab, need > (1u << 28) ? need : 4u * need), nxt, end);
           if (end - nxt < need) { fits = false; if (lane == 0) B.overflow()[0] = 1; return; }
           u32 *from = B.rec + next0[k], *to = B.rec + nxt;
           __builtin_amdgcn_s_waitcnt(0x0F70);   // the list's records so far are in L2 ...

@@ -738,6 +738,14 @@ Views make_views(sgtd_engine *e) {
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
   B.rec = e->rec.as<u32>(); B.id_bits = e->id_bits ? e->id_bits : 13;
   B.ctr = e->cursors.as<u32>();
+  // the smallest slab: the streams of all resident waves hold one each (8192 waves x SGTD_PAIR streams) — together
+  // at most a quarter of the record buffer (a 33 M-record buffer of a small batch: 512-record slabs)
+  {
+    const size_t streams = (size_t)e->n_cus * 32 * SGTD_PAIR;
+    u32 slab = SGTD_REC_SLAB;
+    while (slab > 512u && (size_t)slab * streams * 4 > e->rec_cap) slab >>= 1;
+    B.rec_slab = slab;
+  }
   // room a list gets when its pass starts (ProbeBuffers::rec_rate): three times the matches per visited entry
   // and descriptor of the batch before; a quarter of the visit list for the first batch
   {
@@ -1095,7 +1103,7 @@ int sync_batch(sgtd_engine *e) {
       if (e->rec_cap >= lim) return SGTD_ERR_CAPACITY;
       // what was stored fits rec_cap, `need` matches did not; slabs leave about an eighth unused,
       // every wave strands part of its last slab
-      const size_t want = (size_t)((double)(e->rec_cap + need) * 1.4) + (size_t)e->n_cus * 32 * SGTD_REC_SLAB;
+      const size_t want = (size_t)((double)(e->rec_cap + need) * 1.4) + (size_t)e->n_cus * 32 * SGTD_PAIR * 512;
       (void)cursor;
       e->rec_cap = std::min<size_t>(lim, std::max<size_t>(e->rec_cap * 2, want));
     } else if (ovf[1]) {
