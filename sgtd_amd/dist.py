@@ -17,6 +17,7 @@ candidate list bit for bit: the global top-k of disjoint frame sets is the
 top-k of the union of the local top-k lists.  The match lists of the winners
 stay on their owner rank (`owner_of`).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -223,3 +224,83 @@ class ReplicatedMap:
                           torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev))
         self.mgr.export_candidates(*self._bufs)
         return gather_query_slices(self._bufs[0], self._bufs[1], n_queries_total)
+
+
+# ---------------------------------------------------------------------------
+# ablation: the table sharded by bucket KEY instead of by frame range
+# ---------------------------------------------------------------------------
+def key_owner(code, x, y, z, world):
+    """rank that owns the bucket (label code, cell): a multiplicative hash of the table key"""
+    k = (np.asarray(code, np.uint64) << np.uint64(48)) | (np.asarray(x, np.uint64) << np.uint64(32)) | \
+        (np.asarray(y, np.uint64) << np.uint64(16)) | np.asarray(z, np.uint64)
+    return ((k * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(world)
+
+
+def topk_from_votes(votes, cand_num, min_votes=5):
+    """the reference's candidate rule (STDesc.cpp:423-433) on a full vote histogram [nq, F]:
+    arg-max rounds = votes descending, ties to the lowest frame id, a frame needs >= 5 votes.
+    Returns frames, votes int32 [nq, cand_num] (-1 / 0 in unused slots) and n_cand [nq]."""
+    nq, F = votes.shape
+    v = votes.to(torch.int64)
+    frame = torch.arange(F, device=votes.device, dtype=torch.int64)[None, :].expand(nq, F)
+    key = v * (F + 1) + (F - frame)                       # votes first, then the LOWER frame id
+    k = min(cand_num, F)
+    top = torch.topk(key, k, dim=1).indices
+    tv = torch.gather(v, 1, top)
+    ok = tv >= min_votes
+    frames = torch.full((nq, cand_num), -1, dtype=torch.int32, device=votes.device)
+    out_v = torch.zeros((nq, cand_num), dtype=torch.int32, device=votes.device)
+    frames[:, :k] = torch.where(ok, top, torch.full_like(top, -1)).to(torch.int32)
+    out_v[:, :k] = torch.where(ok, tv, torch.zeros_like(tv)).to(torch.int32)
+    return frames, out_v, ok.sum(dim=1).to(torch.int32)
+
+
+class KeyShardedMap:
+    """ABLATION, not the product path: every rank holds the buckets whose key hashes to it — a slice of
+    EVERY frame's descriptors — so a frame's votes are the sum of the ranks' votes and the exchange is an
+    all-reduce of the whole Q x F histogram (4 B x Q x F per rank: 82 MB for 2048 queries on a 10 000-frame
+    map) instead of the all-gather of the top-candidate_num tables of the frame-range form (400 B per
+    query and rank).  Candidates and votes only: a candidate's match list is spread over all ranks.
+    Host-side and slow by construction (descriptors are built once per frame and filtered on the host);
+    it exists to show that both shardings select the same candidates and what the second one moves."""
+
+    def __init__(self, rank, world, device_id=0, **cfg):
+        from .manager import STDescManager
+        from . import _lib
+        self.rank, self.world = rank, world
+        self.mgr = STDescManager(device_id=device_id, **cfg)
+        self.cand_num = self.mgr.config_setting_["candidate_num"]
+        self._L = _lib.lib()
+        self.n_frames = 0
+        self.kept = 0
+
+    def add_frames(self, xyz, label):
+        """ALL frames of the map, in order, on every rank; each keeps the descriptors of its buckets"""
+        for f in range(len(xyz)):
+            d = self.mgr.BuildSingleScanSTD(xyz[f], label[f])
+            code = np.array([self._L.sgtd_label_code(int(a), int(b), int(c)) for a, b, c in d.label], np.uint64)
+            cell = (d.side + 0.5).astype(np.int64)                       # position of STDesc.cpp:153-160
+            mine = np.nonzero(key_owner(code, cell[:, 0], cell[:, 1], cell[:, 2], self.world) == self.rank)[0]
+            self.mgr.AddSTDescs(d.take(mine))                            # (an empty slice still advances the frame counter)
+            self.kept += len(mine)
+            self.n_frames += 1
+        self.mgr.finalize()
+
+    def local_votes(self, xyz, label):
+        """this rank's share of the vote histogram of a query batch, int32 [nq, n_frames + 1]"""
+        res = self.mgr.query_frames(xyz, label)
+        nq = len(res.n_cand)
+        votes = torch.zeros((nq, self.n_frames + 1), dtype=torch.int32)
+        for q in range(nq):
+            lo, v = self.mgr.result_votes(q)
+            votes[q, lo:lo + len(v)] = torch.from_numpy(v.astype(np.int32))
+        return votes
+
+    def query(self, xyz, label, group=None):
+        """all ranks pass the same query batch; returns (frames, votes, n_cand) identical on every rank
+        and the bytes this rank put into the all-reduce"""
+        votes = self.local_votes(xyz, label)
+        if self.world > 1:
+            dist.all_reduce(votes, op=dist.ReduceOp.SUM, group=group)
+        f, v, n = topk_from_votes(votes, self.cand_num)
+        return f, v, n, votes.numel() * 4

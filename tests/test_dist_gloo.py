@@ -135,3 +135,32 @@ def test_single_process_merge_matches_oracle_without_process_group():
     for q in range(N_Q):
         k = int(n[q])
         assert mf[q, :k].tolist() == truth[q][0].tolist() and mv[q, :k].tolist() == truth[q][1].tolist()
+
+
+def test_topk_from_votes_is_the_reference_rule():
+    """the key-sharded ablation picks its candidates from the all-reduced histogram: arg-max rounds of
+    STDesc.cpp:423-433 (most votes, ties to the lowest frame id, at least 5 votes)"""
+    import numpy as np
+    import torch
+    from sgtd_amd.dist import topk_from_votes, key_owner
+    rng = np.random.default_rng(5)
+    votes = rng.integers(0, 9, size=(7, 300)).astype(np.int32)       # many ties
+    votes[3, :] = 0                                                    # a query without a candidate
+    votes[4, :20] = 4                                                  # fewer than candidate_num frames reach 5 votes
+    votes[4, 20:] = 0
+    votes[4, 7] = 11
+    f, v, n = topk_from_votes(torch.from_numpy(votes), 50)
+    for q in range(7):
+        work = votes[q].astype(np.int64).copy()
+        want_f, want_v = [], []
+        for _ in range(50):                                            # the reference's rounds
+            best = int(np.argmax(work))                                # first maximum = lowest frame id
+            if work[best] < 5:
+                break
+            want_f.append(best); want_v.append(int(work[best]))
+            work[best] = 0
+        assert int(n[q]) == len(want_f)
+        assert f[q, :len(want_f)].tolist() == want_f and v[q, :len(want_v)].tolist() == want_v
+        assert (f[q, len(want_f):] == -1).all() and (v[q, len(want_f):] == 0).all()
+    own = key_owner(rng.integers(0, 4096, 1000), rng.integers(0, 200, 1000), rng.integers(0, 200, 1000), rng.integers(0, 200, 1000), 8)
+    assert own.min() >= 0 and own.max() < 8 and len(np.unique(own)) == 8

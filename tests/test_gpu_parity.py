@@ -989,6 +989,33 @@ def test_match_lists_that_outgrow_their_room_move(mods, monkeypatch, rate):
             _check_query(g, o, res, q, o.build(qs.xyz[q], qs.label[q]))
 
 
+def test_key_sharded_ablation_selects_the_same_candidates(mods):
+    # SURVEY §8e's ablation (sgtd_amd/dist.py KeyShardedMap): buckets dealt to the ranks by key; the sum of the
+    # ranks' vote histograms (what the all-reduce delivers) gives the single table's candidates and votes
+    import torch
+    from sgtd_amd.dist import KeyShardedMap, topk_from_votes
+    _, manager, synth = mods
+    m = synth.make_map(40, 120, stream=37)
+    qs = synth.make_queries(m, 5, stream=37)
+    single = manager.STDescManager()
+    single.add_frames(m.xyz, m.label)
+    want = single.query_frames(qs.xyz, qs.label)
+    shards = [KeyShardedMap(r, 3) for r in range(3)]
+    for sh in shards:
+        sh.add_frames(m.xyz, m.label)
+    assert sum(sh.kept for sh in shards) == single.stats()["n_entries"] and min(sh.kept for sh in shards) > 0
+    votes = sum(sh.local_votes(qs.xyz, qs.label) for sh in shards)
+    f, v, n = topk_from_votes(votes, shards[0].cand_num)
+    for q in range(5):
+        nc = int(want.n_cand[q])
+        assert int(n[q]) == nc and nc > 0
+        np.testing.assert_array_equal(f[q, :nc].numpy(), want.cand_frame[q, :nc])
+        np.testing.assert_array_equal(v[q, :nc].numpy(), want.cand_votes[q, :nc])
+    single.close()
+    for sh in shards:
+        sh.mgr.close()
+
+
 def test_eight_byte_compact_words_keep_parity(mods, monkeypatch):
     # the compact candidate lists between the two assembly passes use 4-byte words (slot, descriptor in
     # block, rank in frame) whenever an entry's rank among its frame's entries fits 19 bits, 8-byte words
