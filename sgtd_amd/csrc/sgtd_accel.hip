@@ -1178,7 +1178,7 @@ int settle_pending(sgtd_engine *e) {
   return SGTD_OK;
 }
 
-// A tail segment makes every batch sweep the descriptors twice (+20 % step time).  While appends
+// A tail segment makes every visit list run through two sets of buckets (+11 % step time).  While appends
 // keep arriving that is the cheap side of the trade (each append sorts only the tail); once
 // SGTD_TAIL_BATCHES batches in a row have used the same tail the next one merges it into the main segment
 // (one full build, ~0.25 ms per million entries).
@@ -1513,7 +1513,12 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
     // of growing it through overflow re-runs (each costs a whole sweep)
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const double want = 1.3 * est_matches_per_query(e, max_n) * (double)n_queries;
+    // ... plus what the slabs of all resident streams leave unused: each holds about half a slab of eight expected lists
+    const double per_query = est_matches_per_query(e, max_n);
+    const double per_desc = per_query / std::max(1.0, 0.62 * (double)max_n * e->dc.tpi);
+    const double slab_slack = (double)e->n_cus * 32.0 * SGTD_PAIR * 0.5 * 8.0 * (3.0 * per_desc + 256.0);
+    const double margin = e->n_entries > 100000000 ? 1.75 : 1.3;    // (long buckets: the estimate runs low at 100 000 frames)
+    const double want = margin * per_query * (double)n_queries + std::min(slab_slack, margin * per_query * (double)n_queries);
     const double cap_mem = (double)free_b / 4.0 / 16.0;    // records + compact list + pairs, a quarter of what is free
     const size_t cap = (size_t)std::min(std::min(want, cap_mem), (double)0xFFFFFFF0ull);
     if (cap > e->rec_cap) e->rec_cap = cap;
