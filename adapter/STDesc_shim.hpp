@@ -229,6 +229,41 @@ int AddSTDescs(sgtd_handle h, const std::vector<Desc> &stds_vec, unsigned int &c
 // ---- STDesc.cpp:318-460 --------------------------------------------------------------------
 // the device part of candidate_selector: candidates, votes, list offsets and the (query
 // descriptor, table entry) index pairs of every list, in the reference's order
+// one STDesc from entry i of a fetched structure of arrays
+template <class Desc>
+inline Desc desc_from(const sgtd_desc_soa &e, size_t i) {
+  Desc d;
+  for (int c = 0; c < 3; c++) {
+    d.side_length_[c] = e.side[3 * i + c]; d.angle_[c] = e.angle[3 * i + c]; d.center_[c] = e.center[3 * i + c];
+    d.vertex_A_[c] = e.vertex[9 * i + c]; d.vertex_B_[c] = e.vertex[9 * i + 3 + c]; d.vertex_C_[c] = e.vertex[9 * i + 6 + c];
+    d.vertex_attached_[c] = (double)e.label[3 * i + c];
+  }
+  d.frame_id_ = e.frame[i];
+  d.node_id = {e.node_id[3 * i], e.node_id[3 * i + 1], e.node_id[3 * i + 2]};
+  return d;
+}
+
+// fill(k0, k1) builds the lists k0 .. k1 - 1; the n lists (off: n + 1 offsets into the pairs) are dealt to up to
+// SGTD_SHIM_FILL_THREADS short-lived threads in runs of about equal numbers of pairs, the last run on the caller.
+// Threads that exit, not an OpenMP team: an idle team spins after its region and slowed the HIP calls that
+// follow (8 threads: 38.7 ms per frame against 27.9 single-threaded, 256 threads: 180 ms at the time).
+template <class F>
+void deal_lists(int n, const int64_t *off, F &&fill) {
+  const int64_t total = off[n] - off[0];
+  const int n_thr = total > 8192 ? (int)std::min<unsigned>(SGTD_SHIM_FILL_THREADS, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  std::vector<std::thread> team;
+  int k0 = 0;
+  for (int t = 0; t < n_thr; t++) {
+    int k1 = k0;
+    const int64_t until = off[0] + total * (t + 1) / n_thr;
+    while (k1 < n && (t == n_thr - 1 || off[k1 + 1] <= until)) k1++;
+    if (t == n_thr - 1) fill(k0, n);
+    else if (k1 > k0) team.emplace_back(fill, k0, k1);
+    k0 = k1;
+  }
+  for (auto &th : team) th.join();
+}
+
 struct Selection {
   int32_t n_cand = 0;
   std::vector<int32_t> frame, votes, q_idx;
@@ -261,19 +296,24 @@ int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::ve
   int st = select(h, stds_vec, candidate_num, s);
   if (st != SGTD_OK) return st;
   const int64_t total = s.off[s.n_cand];
-  SoaBuf ent((size_t)total);                       // the table side of every pair<STDesc, STDesc>
-  st = sgtd_fetch_entries(h, s.entry.data(), total, &ent.v);
+  PinnedSoa &pe = fetched_entries();               // the table side of every pair<STDesc, STDesc>: page-locked, reused
+  pe.reserve((size_t)total);
+  st = sgtd_fetch_entries(h, s.entry.data(), total, &pe.v);
   if (st != SGTD_OK) return st;
-  std::vector<Desc> db;
-  from_soa(ent, (size_t)total, db);
-  for (int k = 0; k < s.n_cand; k++) {
-    MatchList ml;
-    ml.match_id_.first = (int)current_frame_id;    // :436
-    ml.match_id_.second = s.frame[k];              // :437
-    ml.match_list_.reserve((size_t)(s.off[k + 1] - s.off[k]));
-    for (int64_t r = s.off[k]; r < s.off[k + 1]; r++) ml.match_list_.emplace_back(stds_vec[s.q_idx[(size_t)r]], std::move(db[(size_t)r]));
-    candidate_matcher_vec.push_back(std::move(ml));
-  }
+  const sgtd_desc_soa &ent = pe.v;
+  const size_t first = candidate_matcher_vec.size();
+  candidate_matcher_vec.resize(first + (size_t)s.n_cand);
+  // every pair constructed in place (no resize: it would zero 832 bytes per pair first), the lists dealt to threads
+  deal_lists(s.n_cand, s.off.data(), [&](int k0, int k1) {
+    for (int k = k0; k < k1; k++) {
+      MatchList &ml = candidate_matcher_vec[first + (size_t)k];
+      ml.match_id_.first = (int)current_frame_id;    // :436
+      ml.match_id_.second = s.frame[k];              // :437
+      ml.match_list_.reserve((size_t)(s.off[k + 1] - s.off[k]));
+      for (int64_t r = s.off[k]; r < s.off[k + 1]; r++)
+        ml.match_list_.emplace_back(stds_vec[(size_t)s.q_idx[(size_t)r]], desc_from<Desc>(ent, (size_t)r));
+    }
+  });
   const auto t2 = std::chrono::high_resolution_clock::now();
   CS1 = (int)(std::chrono::duration<double>(t2 - t1).count() * 1000);   // int CS1 truncates a double ms value, :455
   return SGTD_OK;
@@ -359,48 +399,21 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   // candidate its registration step prefers (semantic_graph_localization.cpp:622,672-718), and the
   // member is a plain std::vector — nothing can be deferred.
   // The ~10^5 descriptors (416 bytes and a heap-allocated node_id each) are written by a few
-  // short-lived threads, every candidate's list by one of them: threads that exit, not an OpenMP team —
-  // an idle team spins after its region and slowed the HIP calls that follow (8 threads: 38.7 ms per
-  // frame against 27.9 single-threaded, 256 threads: 180 ms).  Filling the query side of the pairs
-  // while the table side is still being fetched was measured too: the fetch then takes 18-22 ms instead
-  // of 3-4 (the copy's own host threads lose their cores) — the fill starts after it.
+  // short-lived threads, every candidate's list by one of them (deal_lists).  Filling the query side of
+  // the pairs while the table side is still being fetched was measured too: the fetch then takes 18-22 ms
+  // instead of 3-4 (the copy's own host threads lose their cores) — the fill starts after it.
   // Every pair is CONSTRUCTED in place (reserve + emplace_back: the query descriptor copied, the table
-  // descriptor filled in a local and moved), not value-initialised by a resize and then assigned: a resize
+  // descriptor built and moved), not value-initialised by a resize and then assigned: a resize
   // zeroes the 832 bytes of every pair first — 129 MB per frame, on the calling thread.
-  auto fill = [&](int k0, int k1) {
+  deal_lists(s.n_cand, ioff.data(), [&](int k0, int k1) {
     for (int k = k0; k < k1; k++) {
       if (!(score[k] >= 0)) continue;
       std::vector<std::pair<Desc, Desc>> &lp = match_result_list[first + (size_t)k].loop_std_pair;
       lp.reserve((size_t)(ioff[(size_t)k + 1] - ioff[(size_t)k]));
-      for (int64_t j = ioff[(size_t)k]; j < ioff[(size_t)k + 1]; j++) {
-        Desc d;
-        const size_t i = (size_t)j;
-        for (int c = 0; c < 3; c++) {
-          d.side_length_[c] = ent.side[3 * i + c]; d.angle_[c] = ent.angle[3 * i + c]; d.center_[c] = ent.center[3 * i + c];
-          d.vertex_A_[c] = ent.vertex[9 * i + c]; d.vertex_B_[c] = ent.vertex[9 * i + 3 + c]; d.vertex_C_[c] = ent.vertex[9 * i + 6 + c];
-          d.vertex_attached_[c] = (double)ent.label[3 * i + c];
-        }
-        d.frame_id_ = ent.frame[i];
-        d.node_id = {ent.node_id[3 * i], ent.node_id[3 * i + 1], ent.node_id[3 * i + 2]};
-        lp.emplace_back(stds_vec[(size_t)iq[(size_t)j]], std::move(d));
-      }
+      for (int64_t j = ioff[(size_t)k]; j < ioff[(size_t)k + 1]; j++)
+        lp.emplace_back(stds_vec[(size_t)iq[(size_t)j]], desc_from<Desc>(ent, (size_t)j));
     }
-  };
-  {
-    // candidates dealt to the threads in runs of about equal numbers of pairs
-    const int n_thr = n_inl > 8192 ? (int)std::min<unsigned>(SGTD_SHIM_FILL_THREADS, std::max(1u, std::thread::hardware_concurrency())) : 1;
-    std::vector<std::thread> team;
-    int k0 = 0;
-    for (int t = 0; t < n_thr; t++) {
-      int k1 = k0;
-      const int64_t until = n_inl * (t + 1) / n_thr;
-      while (k1 < s.n_cand && (t == n_thr - 1 || ioff[(size_t)k1 + 1] <= until)) k1++;
-      if (t == n_thr - 1) fill(k0, s.n_cand);
-      else if (k1 > k0) team.emplace_back(fill, k0, k1);
-      k0 = k1;
-    }
-    for (auto &th : team) th.join();
-  }
+  });
   SGTD_LAP(fill);
 #undef SGTD_LAP
   search_timing().calls++;

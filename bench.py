@@ -199,7 +199,10 @@ def cpp_adapter_leg(smap, queries, n_frames):
         v = [float(parts.group(i)) for i in range(1, 5)]
         by_part = {"select": v[0], "verify": v[1], "inlier_pairs_and_entries": v[2], "host_fill_of_loop_std_pair": v[3],
                    "device_and_transfers": round(sum(v[:3]), 3)}
-    return {"cpp_adapter_ms_per_frame": float(m.group(2)), "cpp_adapter_search_loop_by_part_ms": by_part, "cpp_adapter_ms_build": float(m.group(3)),
+    sel = re.search(r"candidate_selector alone: ([0-9.]+) ms per frame for ([0-9.]+) pairs", out.stdout)
+    return {"cpp_adapter_ms_per_frame": float(m.group(2)), "cpp_adapter_search_loop_by_part_ms": by_part,
+            "cpp_adapter_ms_candidate_selector_alone": float(sel.group(1)) if sel else None,
+            "cpp_adapter_pairs_in_match_lists": float(sel.group(2)) if sel else None, "cpp_adapter_ms_build": float(m.group(3)),
             "cpp_adapter_ms_search_loop": float(m.group(4)), "cpp_adapter_frames": int(m.group(1)),
             "cpp_adapter_agree_with_batched": "%s/%s" % (m.group(5), m.group(6)), "cpp_adapter_inlier_pairs_per_loop": float(m.group(7)),
             "cpp_adapter_note": "examples/localize LOCALIZE_PER_FRAME: BuildSingleScanSTD + SearchLoop (device verification, every "

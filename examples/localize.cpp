@@ -218,8 +218,8 @@ int main(int argc, char **argv) {
     OK(sgtd_add_frames(mgr.handle(), map.xyz, map.label, map.off, map.n, 0));   // the map, batched (the per-frame form is tests/cpp/test_manager.cpp)
     OK(sgtd_current_frame_id(mgr.handle(), &mgr.current_frame_id_));
     OK(sgtd_finalize(mgr.handle()));
-    double ms_build = 0, ms_search = 0;
-    long same = 0, pairs = 0;
+    double ms_build = 0, ms_search = 0, ms_selector = 0;
+    long same = 0, pairs = 0, list_pairs = 0;
     std::vector<int32_t> bf(1);
     for (int i = 0; i < n_pf; i++) {
       std::vector<sgtd::PointXYZL> cloud;
@@ -244,10 +244,20 @@ int main(int argc, char **argv) {
       OK(sgtd_search_loop(h, icp_threshold, nullptr, bf.data(), nullptr));
       same += bf[0] == search_result.first;
       pairs += (long)loop_std_pair.size();
+      // the other drop-in: candidate_selector alone (:318-460), every match list as pair<STDesc, STDesc> — what a
+      // node that keeps its own candidate_verify calls
+      auto d0 = std::chrono::steady_clock::now();
+      std::vector<sgtd::STDMatchList> candidate_matcher_vec;
+      mgr.candidate_selector(stds, candidate_matcher_vec);
+      auto d1 = std::chrono::steady_clock::now();
+      OK(mgr.last_status());
+      ms_selector += std::chrono::duration<double, std::milli>(d1 - d0).count();
+      for (const auto &ml : candidate_matcher_vec) list_pairs += (long)ml.match_list_.size();
     }
     std::printf("per-frame calls through STDescManager (%d frames): %.3f ms per frame = BuildSingleScanSTD %.3f + SearchLoop %.3f; "
                 "%ld/%d agree with the batched run, %.1f inlier pairs per loop\n",
                 n_pf, (ms_build + ms_search) / n_pf, ms_build / n_pf, ms_search / n_pf, same, n_pf, (double)pairs / n_pf);
+    std::printf("candidate_selector alone: %.3f ms per frame for %.0f pairs in the match lists\n", ms_selector / n_pf, (double)list_pairs / n_pf);
     const sgtd_shim::SearchTiming &tm = sgtd_shim::search_timing();
     if (tm.calls)
       std::printf("SearchLoop by part (ms per frame): select %.3f, verify %.3f, inlier pairs and their entries %.3f, host fill of loop_std_pair %.3f\n",
