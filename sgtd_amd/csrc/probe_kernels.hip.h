@@ -117,7 +117,8 @@ struct ProbeBuffers {
 #define SGTD_VOTE_WORDS 2        // 64-quad words of records in flight per wave in the vote pass
 #endif
 #ifndef SGTD_WRITE_WORDS
-#define SGTD_WRITE_WORDS 2       // 64-pair words of the compact list in flight per wave in block_write
+#define SGTD_WRITE_WORDS 4       // 64-pair words of the compact list per step of a wave in block_write (their slot masks take ONE
+                                 // LDS round trip together; 2 words: 1.56 ms, 4: 1.51)
 #endif
 
 // Loads that were issued before a pass's sweep and are first used after it (the next pass's
@@ -1782,7 +1783,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
                                                           u64 *pairs, IdMap map, const int *n_cand, const int *cand_frame) {
   constexpr int NW = 256 / SGTD_WAVE;
   constexpr int CAP = SGTD_WRITE_CAP;   // staged pairs per slot = one 128-B (16) or 64-B (8) line
-  __shared__ u64 s_mask[NW][64];         // per wave and slot: lanes of the current word that carry the slot
+  __shared__ u64 s_mask[NW][SGTD_WRITE_WORDS][64];   // per wave, word in flight and slot: lanes of the word that carry the slot
   __shared__ u64 s_stage[NW][64][CAP + 1];   // per wave and slot: pairs waiting for a full-line store (rows padded by one
                                              // word: a 128-byte row stride put every slot's k-th pair on the same banks)
   if (B.overflow()[0] || B.overflow()[1]) return;
@@ -1853,19 +1854,30 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
       if (map.by_frame) g = map.by_frame[g];
       pr[u] = (pr[u] & 0xFFFFFFFF00000000ull) | (u64)g;
     }
+    // lanes with equal slot, by commutative LDS ORs (the result does not depend on the order the hardware
+    // applies them in) — for all words of the step at once: one LDS round trip, not one per word
+    u64 gms[SGTD_WRITE_WORDS];
+    u32 c_owns[SGTD_WRITE_WORDS];
+#pragma unroll
+    for (int u = 0; u < SGTD_WRITE_WORDS; u++) s_mask[wid][u][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < SGTD_WRITE_WORDS; u++)
+      if (sl[u] != 0xFFu) atomicOr(&s_mask[wid][u][sl[u] & 63u], 1ull << lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
+      gms[u] = sl[u] != 0xFFu ? s_mask[wid][u][sl[u] & 63u] : 0ull;
+      c_owns[u] = (u32)__builtin_popcountll(s_mask[wid][u][lane]);     // pairs the word adds to slot == lane
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < SGTD_WRITE_WORDS; u++) {
       const bool valid = sl[u] != 0xFFu;
       const int s = (int)(sl[u] & 63u);
-      // lanes with equal slot, by commutative LDS ORs (the result does not depend on the
-      // order the hardware applies them in): rank = lanes below me in my group
-      s_mask[wid][lane] = 0;
-      __builtin_amdgcn_wave_barrier();
-      if (valid) atomicOr(&s_mask[wid][s], 1ull << lane);
-      __builtin_amdgcn_wave_barrier();
-      const u64 gm = valid ? s_mask[wid][s] : 0ull;
-      const u32 c_own = (u32)__builtin_popcountll(s_mask[wid][lane]);   // pairs this word adds to slot == lane
-      __builtin_amdgcn_wave_barrier();
+      const u64 gm = gms[u];
+      const u32 c_own = c_owns[u];
+      // rank = lanes below me in my group
       const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(gm >> 32), __builtin_amdgcn_mbcnt_lo((u32)gm, 0u)), count = (u32)__builtin_popcountll(gm);
 #ifdef SGTD_EXP_WRITE_DIRECT
       // experiment: no staging lines — every pair goes straight to its list (runs of one slot are contiguous)
