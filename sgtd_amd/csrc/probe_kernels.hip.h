@@ -1520,7 +1520,9 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
 // no global atomics, no pre-zeroed vote buffer.  A frame span beyond LDS is cut into tiles of
 // tile_span bins, one workgroup per (query, tile) = blockIdx.(x, y): every tile's workgroup walks
 // all of the query's records and counts the ones of its frames.
+#ifndef SGTD_VOTES_Q_THREADS
 #define SGTD_VOTES_Q_THREADS 1024
+#endif
 __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(QueryView Q, ProbeBuffers B, u32 frame_span,
                                                                             u32 frame_lo, u32 tile_span, int blocks_per_query,
                                                                             u32 *q_M, unsigned long long *q_P) {
