@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void query_prefix_kernel(const u32 *count, u32
 // entries loaded).  The host takes the bits the key leaves free below a multiple of the sort's 8-bit
 // digits, or 4 bits and one more sort pass.
 // keys/vals are compact: the descriptor (q, i) goes to index q_prefix[q] + i
-__global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, u64 *keys, u32 *vals, long long n_slots,
+template <class KeyT>      // u32 where 12 + 3 cbits + sub_bits <= 32 (the shipped resolution), else u64
+__global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, KeyT *keys, u32 *vals, long long n_slots,
                                  int cbits, int sub_bits) {
   const long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n_slots) return;
@@ -213,7 +214,7 @@ __global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, u64 *keys, u3
   const int ny = 1 << (sub_bits >> 1), nz = 1 << (sub_bits - (sub_bits >> 1));
   const double f1 = Q.side[d * 3 + 1] - (double)(int)Q.side[d * 3 + 1], f2 = Q.side[d * 3 + 2] - (double)(int)Q.side[d * 3 + 2];
   const u64 sub = (u64)min(max((int)(f1 * ny), 0), ny - 1) * nz + (u64)min(max((int)(f2 * nz), 0), nz - 1);
-  keys[idx] = ((((code << cbits | x) << cbits | y) << cbits) | z) << sub_bits | sub;
+  keys[idx] = (KeyT)(((((code << cbits | x) << cbits | y) << cbits) | z) << sub_bits | sub);
   vals[idx] = (u32)d;
 }
 
@@ -221,12 +222,13 @@ __global__ void home_keys_kernel(QueryView Q, const u32 *q_prefix, u64 *keys, u3
 // changes or where the next key carries an overflow marker (such a descriptor is a group of
 // its own: its key does not name its cell).  flags[p] says whether position p+1 starts a new
 // group, so the EXCLUSIVE scan of the flags is the group id of p (position 0 is group 0).
-__global__ void group_heads_kernel(const u64 *keys, const u32 *n_valid_p, u32 *flags, long long n, int cbits, int sub_bits) {
+template <class KeyT>
+__global__ void group_heads_kernel(const KeyT *keys, const u32 *n_valid_p, u32 *flags, long long n, int cbits, int sub_bits) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   u32 head = 0;
   if (p + 1 < (long long)*n_valid_p) {
-    const u64 a = keys[p + 1] >> sub_bits, b = keys[p] >> sub_bits;
+    const u64 a = (u64)keys[p + 1] >> sub_bits, b = (u64)keys[p] >> sub_bits;
     const u64 cmask = (1ull << cbits) - 1ull;
     head = (a != b) || ((a & cmask) == cmask) || (((a >> cbits) & cmask) == cmask) ||
            (((a >> (2 * cbits)) & cmask) == cmask);

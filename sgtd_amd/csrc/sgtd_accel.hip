@@ -435,7 +435,8 @@ void note_frames(sgtd_engine *e, u32 lo, u32 hi) {
 // stable LSD radix sort of (key, val) pairs by the low `bits` of the key, 8-bit digits; passes
 // whose digit is the same for every key are skipped (skip_const: costs a host round trip per
 // pass, only used by the once-per-map table build).  The result is in kin / vin.
-int radix_sort_pairs(sgtd_engine *e, u64 *&kin, u64 *&kout, u32 *&vin, u32 *&vout, long long n, int bits,
+template <class KeyT>
+int radix_sort_pairs(sgtd_engine *e, KeyT *&kin, KeyT *&kout, u32 *&vin, u32 *&vout, long long n, int bits,
                      bool skip_const, const u32 *n_dev = nullptr) {
   const int nblocks = (int)((n + SGTD_RS_TILE - 1) / SGTD_RS_TILE);
   CHK(ensure(e, e->hist, (size_t)256 * nblocks * sizeof(u32)));
@@ -443,7 +444,7 @@ int radix_sort_pairs(sgtd_engine *e, u64 *&kin, u64 *&kout, u32 *&vin, u32 *&vou
   std::vector<u32> tot(256);
   for (int shift = 0; shift < bits; shift += 8) {
     u32 *hist = e->hist.as<u32>();
-    radix_hist_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, n, shift, hist, nblocks, n_dev);
+    radix_hist_kernel<KeyT><<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, n, shift, hist, nblocks, n_dev);
     HIPCHK(hipGetLastError());
     if (skip_const) {
       radix_digit_totals_kernel<<<256, SGTD_SCAN_THREADS, 0, e->stream>>>(hist, nblocks, e->digit_tot.as<u32>());
@@ -456,7 +457,7 @@ int radix_sort_pairs(sgtd_engine *e, u64 *&kin, u64 *&kout, u32 *&vin, u32 *&vou
       if (constant) continue;  // every key has the same digit here: the pass is the identity
     }
     CHK(device_scan(e, hist, hist, (long long)256 * nblocks));
-    radix_scatter_kernel<<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, n, shift,
+    radix_scatter_kernel<KeyT><<<nblocks, SGTD_RS_THREADS, 0, e->stream>>>(kin, vin, kout, vout, n, shift,
                                                                        e->hist.as<u32>(), nblocks, n_dev);
     HIPCHK(hipGetLastError());
     std::swap(kin, kout);
@@ -867,10 +868,18 @@ int launch_select(sgtd_engine *e) {
     const u32 *nv = e->n_valid.as<u32>();
     query_prefix_kernel<<<1, 256, 0, e->stream>>>(e->q_count.as<u32>(), e->q_prefix.as<u32>(), nq, e->n_valid.as<u32>());
     HIPCHK(hipGetLastError());
-    home_keys_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), kin, vin, n_slots, cbits, sub_bits);
-    HIPCHK(hipGetLastError());
-    CHK(radix_sort_pairs(e, kin, kout, vin, vout, n_slots, key_bits, false, nv));   // only the n_valid compact elements are live
-    group_heads_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits, sub_bits);
+    if (key_bits <= 32) {      // 32-bit keys: a third less traffic in every sort pass
+      u32 *k32 = reinterpret_cast<u32 *>(kin), *k32o = reinterpret_cast<u32 *>(kout);
+      home_keys_kernel<u32><<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), k32, vin, n_slots, cbits, sub_bits);
+      HIPCHK(hipGetLastError());
+      CHK(radix_sort_pairs(e, k32, k32o, vin, vout, n_slots, key_bits, false, nv));   // only the n_valid compact elements are live
+      group_heads_kernel<u32><<<grid_for(n_slots, 256), 256, 0, e->stream>>>(k32, nv, e->gid.as<u32>(), n_slots, cbits, sub_bits);
+    } else {
+      home_keys_kernel<u64><<<grid_for(n_slots, 256), 256, 0, e->stream>>>(v.Q, e->q_prefix.as<u32>(), kin, vin, n_slots, cbits, sub_bits);
+      HIPCHK(hipGetLastError());
+      CHK(radix_sort_pairs(e, kin, kout, vin, vout, n_slots, key_bits, false, nv));
+      group_heads_kernel<u64><<<grid_for(n_slots, 256), 256, 0, e->stream>>>(kin, nv, e->gid.as<u32>(), n_slots, cbits, sub_bits);
+    }
     HIPCHK(hipGetLastError());
     CHK(device_scan(e, e->gid.as<u32>(), e->gid.as<u32>(), n_slots));
     group_first_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), nv, e->group_first.as<u32>(),

@@ -124,8 +124,9 @@ __global__ void frame_range_check_kernel(const u32 *frame, long long n, u32 lo, 
 #define SGTD_RS_ROUNDS 16
 #define SGTD_RS_TILE (SGTD_RS_THREADS * SGTD_RS_ROUNDS)
 
-// hist[digit * nblocks + block]
-__global__ __launch_bounds__(SGTD_RS_THREADS) void radix_hist_kernel(const u64 *keys, long long n, int shift,
+// hist[digit * nblocks + block]   (KeyT: u64, or u32 for keys of at most 32 bits — a third less traffic per pass)
+template <class KeyT>
+__global__ __launch_bounds__(SGTD_RS_THREADS) void radix_hist_kernel(const KeyT *keys, long long n, int shift,
                                                                       u32 *hist, int nblocks,
                                                                       const u32 *n_dev = nullptr) {
   __shared__ u32 h[256];
@@ -154,8 +155,9 @@ __global__ void radix_digit_totals_kernel(const u32 *hist, int nblocks, u32 *tot
 }
 
 // stable scatter: hist now holds the exclusive scan (global base per digit,block)
+template <class KeyT>
 __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
-    const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out, long long n,
+    const KeyT *keys_in, const u32 *vals_in, KeyT *keys_out, u32 *vals_out, long long n,
     int shift, const u32 *hist_scanned, int nblocks, const u32 *n_dev = nullptr) {
   constexpr int NW = SGTD_RS_THREADS / SGTD_WAVE;
   __shared__ u32 run[256];          // next free position per digit for this block
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(SGTD_RS_THREADS) void radix_scatter_kernel(
     __syncthreads();
     long long i = base + (long long)r * SGTD_RS_THREADS + tid;
     const bool valid = i < n;
-    u64 k = valid ? keys_in[i] : 0;
+    KeyT k = valid ? keys_in[i] : 0;
     u32 v = valid ? vals_in[i] : 0;
     u32 digit = (u32)(k >> shift) & 255u;
     u32 rank, count;
