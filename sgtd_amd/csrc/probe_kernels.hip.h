@@ -1,12 +1,14 @@
 // probe_kernels.hip.h — candidate_selector (src/sgtd/src/STDesc.cpp:318-460)
 //
-//   probe     (:351-400) one wavefront per PASS — one query descriptor, or two
+//   probe     (:351-400) one wavefront per PASS — up to four query descriptors
 //             of one home cell: the 27 cells (truncating (int)(side+inc), gate
 //             ||side-centre|| < 1.5, hash lookup key -> bucket) become one
 //             concatenated visit list of non-empty ranges — per cell and half of
 //             the second side's interval the thirds of the third side's that a
 //             descriptor's threshold box reaches, and the bucket's overflow slice
-//             (common.hip.h, table_kernels.hip.h).  plan_passes_kernel derives the
+//             (common.hip.h, table_kernels.hip.h); with a tail segment (entries
+//             appended after the table was finalized) a cell's main bucket, then
+//             its tail bucket, in the same list.  plan_passes_kernel derives the
 //             list of every pass, one LANE per pass, and leaves it as a record in
 //             HBM; the sweep (probe_sorted_kernel) prefetches the next pass's record
 //             while it streams the current list with all 64 lanes from the
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void query_prefix_kernel(const u32 *count, u32
 
 // Below the cell, the home key carries `sub_bits` bits (0..6) of where in the cell's second and third
 // interval the descriptor lies (2^(sub_bits / 2) x 2^(sub_bits - sub_bits / 2) classes), so that the
-// two descriptors of a pass (consecutive positions of one home cell) reach about the same slices of
+// descriptors of a pass (up to four consecutive positions of one home cell) reach about the same slices of
 // the buckets — their shared visit list is the union of what either reaches (4 bits: 14 % fewer
 // entries loaded).  The host takes the bits the key leaves free below a multiple of the sort's 8-bit
 // digits, or 4 bits and one more sort pass.
@@ -315,10 +317,10 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
 }
 
 // ---------------------------------------------------------------------------
-// Passes.  A PASS is what one wavefront sweeps at a time: one query descriptor, or two
-// consecutive descriptors of one home cell (sorted positions first + 2 i, first + 2 i + 1 of
-// the group — they share the GroupRow, so one visit list, one locate and one 16-B load per 64
-// entries serve both).  plan_passes_kernel turns every pass into a RECORD in HBM, one lane per
+// Passes.  A PASS is what one wavefront sweeps at a time: up to SGTD_PAIR (four) consecutive
+// descriptors of one home cell (sorted positions first + 4 i .. first + 4 i + 3 of the group —
+// they share the GroupRow, so one visit list, one locate and one 16-B load per 64 entries serve
+// all of them).  plan_passes_kernel turns every pass into a RECORD in HBM, one lane per
 // pass, so that the sweep starts from a ready visit list instead of deriving it per wave:
 //
 //   header, 2 + 7 KM words for KM = SGTD_PASS_KMAX descriptor columns (64 B for 2, 128 B for 4: one 4-B load
@@ -343,8 +345,8 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
 // and half of the second side's interval the thirds of the third side's that hold entries with
 // |side1 - q1| <= thr' and |side2 - q2| <= thr' (an entry outside cannot match: its squared
 // distance, as the reference computes it, is at least fl(d * d) >= thr2 for that axis), and the
-// bucket's overflow slice (all of it; most buckets have none).  For a pair the list is the
-// union of the two descriptors' lists; the sweep tests every loaded entry against both and
+// bucket's overflow slice (all of it; most buckets have none).  For a pass of several descriptors
+// the list is the union of their lists; the sweep tests every loaded entry against each of them and
 // starts each sum from the descriptor's own gate penalty (a slice too many is harmless, a cell
 // too many is not).
 //
