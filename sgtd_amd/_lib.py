@@ -149,6 +149,10 @@ def lib():
     L.sgtd_result_verify.argtypes = [vp, C.c_int, vp, vp]
     L.sgtd_export_verify_dev.argtypes = [vp, vp, vp]
     L.sgtd_result_inliers.argtypes = [vp, C.c_int, C.c_int, vp, i64, C.POINTER(i64)]
+    L.sgtd_result_inlier_pairs.argtypes = [vp, C.c_int, vp, vp, vp, i64, C.POINTER(i64)]
+    L.sgtd_result_inlier_entries.argtypes = [vp, C.c_int, vp, vp, C.POINTER(DescSoa), i64, C.POINTER(i64)]
+    L.sgtd_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.sgtd_host_free.argtypes = [vp]
     L.sgtd_search_loop.argtypes = [vp, C.c_double, vp, vp, vp]
     L.sgtd_graphs_load.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(vp)]
     L.sgtd_graphs_save_cache.argtypes = [vp, C.c_char_p]

@@ -314,6 +314,19 @@ class STDescManager:
         self._check(self._L.sgtd_result_inliers(self._h, q, cand, _p(idx), len(idx), C.byref(n)))
         return idx[:n.value].copy()
 
+    def result_inlier_entries(self, q, capacity):
+        """sucess_match_vec of EVERY candidate of query q with the table side already fetched: ->
+        (cand_off[candidate_num + 1], q_idx[n], Descs of the n table entries); capacity = the sum of the
+        candidates' list lengths (result pair_off's last entry) always suffices"""
+        cn = self.config_setting_["candidate_num"]
+        off = np.zeros(cn + 1, np.int64)
+        qi = np.zeros(max(int(capacity), 1), np.int32)
+        d = Descs(max(int(capacity), 1))
+        s = d.soa()
+        n = C.c_int64(0)
+        self._check(self._L.sgtd_result_inlier_entries(self._h, q, _p(off), _p(qi), C.byref(s), int(capacity), C.byref(n)))
+        return off, qi[:n.value].copy(), d.head(n.value)
+
     def search_loop(self, icp_threshold=None):
         """SearchLoop's result for every query of the last batch (after verify()):
         (best_cand, best_frame, best_score) arrays; frame -1 / score 0 = no loop (:144)"""

@@ -376,6 +376,21 @@ def test_verify_parity(mods, n_kp, n_frames):
             if o_score > best_s:
                 best_s, best_k = o_score, k
         assert np.all(score[n_c:] == -1)
+        # the fused call: every candidate's inlier pairs with their table entries, one device pass
+        qi_all, de_all = mgr.result_pairs(q, res)
+        off, iq, ent = mgr.result_inlier_entries(q, int(res.pair_off[q, n_c]))
+        for k in range(n_c):
+            n_pairs = int(res.pair_off[q, k + 1] - res.pair_off[q, k])
+            o_score, _, _, o_idx = orc.verify(k, n_pairs)
+            a, b = int(off[k]), int(off[k + 1])
+            if o_score < 0:
+                continue
+            assert b - a == len(o_idx)
+            at = int(res.pair_off[q, k]) + np.asarray(o_idx, np.int64)
+            assert np.array_equal(iq[a:b], qi_all[at])
+            want = mgr.fetch_entries(de_all[at])
+            assert np.array_equal(ent.side[a:b], want.side) and np.array_equal(ent.frame[a:b], want.frame)
+            assert np.array_equal(ent.vertex[a:b], want.vertex) and np.array_equal(ent.node_id[a:b], want.node_id)
         if best_s > mgr.icp_threshold_:
             assert bc[q] == best_k and bf[q] == res.cand_frame[q, best_k] and bs[q] == best_s
         else:
