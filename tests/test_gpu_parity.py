@@ -396,6 +396,17 @@ def test_verify_parity(mods, n_kp, n_frames):
         else:
             assert bc[q] == -1 and bf[q] == -1 and bs[q] == 0
     assert checked > 0
+    # a buffer that is too small: SGTD_ERR_CAPACITY with the offsets and the needed count still delivered
+    import ctypes as C
+    off = np.zeros(mgr.config_setting_["candidate_num"] + 1, np.int64)
+    qi = np.zeros(1, np.int32)
+    need = C.c_int64(0)
+    st = mgr._L.sgtd_result_inlier_entries(mgr._h, 0, off.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p), None, 1, C.byref(need))
+    assert st == -4 and need.value > 1 and off[int(res.n_cand[0])] == need.value
+    assert mgr._L.sgtd_result_inlier_entries(mgr._h, 0, None, None, None, 0, C.byref(need)) == -1      # no offsets array
+    p = C.c_void_p(0)
+    assert mgr._L.sgtd_host_alloc(1 << 20, C.byref(p)) == 0 and p.value
+    assert mgr._L.sgtd_host_free(p) == 0 and mgr._L.sgtd_host_free(None) == 0
     mgr.close()
 
 
