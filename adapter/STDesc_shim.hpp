@@ -144,23 +144,26 @@ void to_soa(const std::vector<Desc> &in, SoaBuf &b) {
   }
 }
 
-// (Filled by the calling thread.  The reference links OpenMP (CMakeLists.txt:22-44), but a parallel
-// fill does not pay here: with a team of 8 the call got SLOWER — 38.7 ms per frame against 27.9 — and
-// with a team of all 256 hardware threads 180 ms: the idle team spins after every region and takes
-// the cores the HIP runtime's own threads need for the copies and launches that follow.)
+// one STDesc from entry i of a structure of arrays
+template <class Desc>
+inline Desc desc_from(const sgtd_desc_soa &e, size_t i) {
+  Desc d;
+  for (int c = 0; c < 3; c++) {
+    d.side_length_[c] = e.side[3 * i + c]; d.angle_[c] = e.angle[3 * i + c]; d.center_[c] = e.center[3 * i + c];
+    d.vertex_A_[c] = e.vertex[9 * i + c]; d.vertex_B_[c] = e.vertex[9 * i + 3 + c]; d.vertex_C_[c] = e.vertex[9 * i + 6 + c];
+    d.vertex_attached_[c] = (double)e.label[3 * i + c];
+  }
+  d.frame_id_ = e.frame[i];
+  d.node_id = {e.node_id[3 * i], e.node_id[3 * i + 1], e.node_id[3 * i + 2]};
+  return d;
+}
+
+// (a frame's few thousand descriptors, constructed in place by the calling thread)
 template <class Desc>
 void from_soa(const SoaBuf &b, size_t n, std::vector<Desc> &out) {
-  out.resize(n);
-  for (size_t i = 0; i < n; i++) {
-    Desc &d = out[i];
-    for (int k = 0; k < 3; k++) {
-      d.side_length_[k] = b.side[3 * i + k]; d.angle_[k] = b.angle[3 * i + k]; d.center_[k] = b.center[3 * i + k];
-      d.vertex_A_[k] = b.vertex[9 * i + k]; d.vertex_B_[k] = b.vertex[9 * i + 3 + k]; d.vertex_C_[k] = b.vertex[9 * i + 6 + k];
-      d.vertex_attached_[k] = (double)b.label[3 * i + k];
-    }
-    d.frame_id_ = b.frame[i];
-    d.node_id = {b.node_id[3 * i], b.node_id[3 * i + 1], b.node_id[3 * i + 2]};
-  }
+  out.clear();
+  out.reserve(n);
+  for (size_t i = 0; i < n; i++) out.push_back(desc_from<Desc>(b.v, i));
 }
 
 // ---- constructor body (STDesc.h:359-365): ConfigSetting -> sgtd_config -------------------
@@ -229,20 +232,6 @@ int AddSTDescs(sgtd_handle h, const std::vector<Desc> &stds_vec, unsigned int &c
 // ---- STDesc.cpp:318-460 --------------------------------------------------------------------
 // the device part of candidate_selector: candidates, votes, list offsets and the (query
 // descriptor, table entry) index pairs of every list, in the reference's order
-// one STDesc from entry i of a fetched structure of arrays
-template <class Desc>
-inline Desc desc_from(const sgtd_desc_soa &e, size_t i) {
-  Desc d;
-  for (int c = 0; c < 3; c++) {
-    d.side_length_[c] = e.side[3 * i + c]; d.angle_[c] = e.angle[3 * i + c]; d.center_[c] = e.center[3 * i + c];
-    d.vertex_A_[c] = e.vertex[9 * i + c]; d.vertex_B_[c] = e.vertex[9 * i + 3 + c]; d.vertex_C_[c] = e.vertex[9 * i + 6 + c];
-    d.vertex_attached_[c] = (double)e.label[3 * i + c];
-  }
-  d.frame_id_ = e.frame[i];
-  d.node_id = {e.node_id[3 * i], e.node_id[3 * i + 1], e.node_id[3 * i + 2]};
-  return d;
-}
-
 // fill(k0, k1) builds the lists k0 .. k1 - 1; the n lists (off: n + 1 offsets into the pairs) are dealt to up to
 // SGTD_SHIM_FILL_THREADS short-lived threads in runs of about equal numbers of pairs, the last run on the caller.
 // Threads that exit, not an OpenMP team: an idle team spins after its region and slowed the HIP calls that
