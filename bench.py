@@ -282,8 +282,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    def make_map_once(n_frames, n_kp, stream_id):
+        """the synthetic world of a run with several ranks: rank 0 generates it (and leaves it in synth's cache,
+        SGTD_SYNTH_CACHE), the others load it after a barrier — not N copies of the same minute of numpy work
+        on one host; without a cache (small maps, cache switched off) every rank generates it itself"""
+        if world > 1 and n_frames >= 2000 and os.environ.get("SGTD_SYNTH_CACHE", "x"):
+            if rank == 0:
+                m = synth.make_map(n_frames, n_kp, stream=stream_id)
+            dist.barrier()
+            if rank != 0:
+                m = synth.make_map(n_frames, n_kp, stream=stream_id)
+            return m
+        return synth.make_map(n_frames, n_kp, stream=stream_id)
+
     F, N, Q = args.frames, args.keypoints, args.queries
-    smap = synth.make_map(F, N, stream=1)
+    smap = make_map_once(F, N, 1)
     # cold + probe layout of the whole table: ~155 B per descriptor, <= 36*N per frame
     table_bytes = 155.0 * 36 * N * F
     mode = "single"
@@ -572,7 +585,7 @@ def main():
         try:
             F4, Q4 = 100000, 256
             lo4, hi4 = shard_range(F4, world, rank)
-            m4 = synth.make_map(F4, N, stream=4)          # every rank generates the world, keeps its frames
+            m4 = make_map_once(F4, N, 4)                  # every rank holds the world, keeps its frames
             q4 = synth.make_queries(m4, Q4, stream=4)
             s4 = ShardedMap(F4, rank, world, device_id=local_rank)
             s4.mgr.set_stream(stream.cuda_stream)
