@@ -86,7 +86,11 @@ typedef struct sgtd_stats {
    * with sgtd_set_timing; measured with hipEvents on the handle's stream)     */
   float ms_build, ms_sort, ms_probe, ms_votes, ms_topk, ms_count, ms_scan, ms_write, ms_total;
   int32_t overflowed;      /* last batch outgrew a work buffer and was re-run  */
-  int32_t reserved;
+  int32_t select_form;     /* how the last batch's match records were turned into votes and lists
+                              (STDesc.cpp:404-453): 0 = one wave per 128-descriptor block (votes, topk,
+                              block_count / _scan / _write), 1 = the lists by one workgroup per query
+                              (pairs_query_kernel), 2 = votes + top-k by one workgroup per query as
+                              well (votes_topk_kernel)                                        */
   int64_t last_P_swept;    /* table entries the sweep really loaded: last_P minus the
                               sub-cells of the visited buckets that no match can lie in */
   double bucket_len_sq_over_E; /* sum over buckets of len^2 / E: the bucket length a table entry
@@ -96,6 +100,14 @@ typedef struct sgtd_stats {
   float ms_finalize;       /* wall time of the last probe-layout build: proportional to the
                               appended entries while they fit the tail segment              */
   float reserved2;
+  /* since the handle was created (what a caller sees over a stream of DIFFERENT batches): */
+  int64_t batches_total;     /* query batches completed                                       */
+  int64_t reruns_total;      /* launches of a whole batch beyond the first (a work buffer
+                                overflowed: match records, pass pool, GroupRows, undecided queue) */
+  int64_t rewrites_total;    /* re-runs of the list pass alone (candidate-pair buffer too small) */
+  int64_t list_moves_total;  /* match lists that outgrew the room they were given and moved to a
+                                fresh slab during the sweep (probe_kernels.hip.h make_room)      */
+  int64_t last_list_moves;   /* ... of the last batch                                         */
 } sgtd_stats;
 
 typedef struct sgtd_engine *sgtd_handle;

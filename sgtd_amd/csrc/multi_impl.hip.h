@@ -409,6 +409,10 @@ int get_stats(sgtd_engine *e, sgtd_stats *out) {
     t.last_P += x.last_P; t.last_M += x.last_M; t.last_P_swept += x.last_P_swept;
     t.hbm_bytes_table += x.hbm_bytes_table;
     t.overflowed |= x.overflowed;
+    t.select_form = x.select_form;
+    t.batches_total = x.batches_total;
+    t.reruns_total += x.reruns_total; t.rewrites_total += x.rewrites_total;
+    t.list_moves_total += x.list_moves_total; t.last_list_moves += x.last_list_moves;
     t.ms_total = std::max(t.ms_total, x.ms_total);
   }
   if (g->merged) {

@@ -88,8 +88,8 @@ struct ProbeBuffers {
   // registers): words 0-1 the global slab cursor of the match records (64-bit: requests can
   // add up beyond 2^32), 2 the undecided-record queue's fill, 3 the compact lists' cursor,
   // 4-5 matches that found no room (sizes the regrown buffer), 6-7 table entries the sweep
-  // really loaded (after slice pruning), 8 the pass pool's cursor, 10-11 the overflow flags
-  // (0: match records / pass pool / undecided queue, 1: candidate pairs), from word 1024 the
+  // really loaded (after slice pruning), 8 the pass pool's cursor, 9 match lists that moved to a fresh
+  // slab, 10-11 the overflow flags (0: match records / pass pool / undecided queue, 1: candidate pairs), from word 1024 the
   // sweep's eight ticket-queue heads, 1024 words (4 KB: own L2 channel) apart
   u32 *ctr;
   __host__ __device__ __forceinline__ unsigned long long *rec_cursor() const { return reinterpret_cast<unsigned long long *>(ctr); }
@@ -98,6 +98,7 @@ struct ProbeBuffers {
   __host__ __device__ __forceinline__ unsigned long long *rec_need() const { return reinterpret_cast<unsigned long long *>(ctr + 4); }
   __host__ __device__ __forceinline__ unsigned long long *swept() const { return reinterpret_cast<unsigned long long *>(ctr + 6); }
   __host__ __device__ __forceinline__ u32 *pool_cursor() const { return ctr + 8; }
+  __host__ __device__ __forceinline__ u32 *list_moves() const { return ctr + 9; }
   __host__ __device__ __forceinline__ int *overflow() const { return reinterpret_cast<int *>(ctr + 10); }
   __host__ __device__ __forceinline__ u32 *xcd_heads() const { return ctr + 1024; }
   // per descriptor slot d:
@@ -957,6 +958,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
             to[i] = __hip_atomic_load(from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and are read from there
           next0[k] = nxt;
           list_base[k] = reinterpret_cast<char *>(to);
+          if (lane == 0) atomicAdd(B.list_moves(), 1u);
           room = end - nxt;
           slab.state = write_lane<4 + k>(slab.state, end);
           slab.state = write_lane<8 + k>(slab.state, room);

@@ -1,0 +1,424 @@
+// select_kernels.hip.h — the passes over the match records behind the sweep
+// (src/sgtd/src/STDesc.cpp:404-453) for batches with enough query frames to give every CU
+// a query of its own: TWO launches, one workgroup per query each, instead of
+// votes / topk / block_count / block_scan / block_write:
+//
+//   votes_topk_kernel   (:404-433) streams the query's match lists into an LDS vote histogram
+//                       (the query's final match_array) and runs the reference's arg-max
+//                       rounds right there.  A candidate's vote count IS the length of its
+//                       match_list_ (every record votes once, :410-417, and belongs to the list
+//                       of its frame, :437-449), so the offsets of the query's lists are the
+//                       prefix sums of the candidates' votes — no counting pass.
+//   pairs_query_kernel  (:434-449) streams the same lists once more, in list order, tile by
+//                       tile of up to 8192 records: the tile's candidate records are
+//                       compacted per wave in stream order, counted per (wave, slot), and
+//                       scattered into ONE slot-sorted LDS image of the tile (a stable counting
+//                       sort: equal-slot records keep the stream's order = the reference's
+//                       (i, cell, j) order).  The image goes out with coalesced stores: the
+//                       run of slot s continues that candidate's list where the tile before
+//                       left it.  No compact intermediate list in HBM, no per-block offsets,
+//                       and all partial output lines of a query are written by one CU within
+//                       a few microseconds of each other (they merge in that XCD's L2).
+//
+// probe_kernels.hip.h keeps the five-kernel form for what these do not cover: small batches
+// (one wave per 128-descriptor block fills the chip where one workgroup per query does not),
+// frame spans beyond LDS, entry ids with more than 17 rank bits.
+#pragma once
+#include "probe_kernels.hip.h"
+
+// ---------------------------------------------------------------------------
+// votes + top-k of one query by ONE workgroup
+// ---------------------------------------------------------------------------
+#define SGTD_VT_THREADS 1024
+#define SGTD_VT_BINS 4096      // vote-value histogram of the threshold search (values beyond: last bin)
+// dynamic LDS: u32 hist[frame_span] | u32 vbins[SGTD_VT_BINS] | u64 pool[SGTD_TOPK_POOL]
+__host__ __device__ __forceinline__ size_t votes_topk_lds_bytes(u32 frame_span) {
+  return (((size_t)frame_span + 3) & ~(size_t)3) * 4 + SGTD_VT_BINS * 4 + SGTD_TOPK_POOL * 8;
+}
+
+__global__ __launch_bounds__(SGTD_VT_THREADS) void votes_topk_kernel(QueryView Q, ProbeBuffers B, u32 frame_span, u32 frame_lo,
+                                                                      int blocks_per_query, int cand_num, u32 *q_M,
+                                                                      unsigned long long *q_P, int *n_cand, int *cand_frame,
+                                                                      int *cand_votes, long long *pair_off, u32 *q_pairs) {
+  constexpr int NW = SGTD_VT_THREADS / SGTD_WAVE;
+  extern __shared__ u32 s_dyn[];
+  u32 *s_hist = s_dyn;
+  u32 *s_vb = s_dyn + ((frame_span + 3u) & ~3u);
+  u64 *s_pool = reinterpret_cast<u64 *>(s_vb + SGTD_VT_BINS);
+  __shared__ u32 s_pre[NW][32];
+  __shared__ u32 s_ptr[NW][32];
+  __shared__ u32 s_cnt[NW][32];
+  __shared__ u32 s_M, s_thr, s_n_ge, s_npool;
+  __shared__ unsigned long long s_P;
+  __shared__ u64 s_red[NW];
+  __shared__ int s_picked;
+  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const int q = blockIdx.x;
+  const bool dead = B.overflow()[0] != 0;     // the batch is re-run: leave zeros
+  for (u32 f = tid; f < frame_span; f += SGTD_VT_THREADS) s_hist[f] = 0;
+  for (u32 b = tid; b < SGTD_VT_BINS; b += SGTD_VT_THREADS) s_vb[b] = 0;
+  if (tid == 0) { s_M = 0; s_P = 0; s_npool = 0; s_picked = 0; }
+  __syncthreads();
+  const u32 cnt = Q.count[q];
+  if (!dead) {
+    u32 visits = 0, total = 0;
+    for (int blk = wid; blk < blocks_per_query; blk += NW) {
+      const u32 d_first = (u32)blk * SGTD_PROBE_CHUNK;
+      if (d_first >= cnt) break;
+      votes_of_block<true>(Q, B, q, d_first, cnt, 0u, frame_span, s_hist, nullptr, s_pre[wid], s_ptr[wid], s_cnt[wid], visits, total);
+    }
+    if (lane == 0) {
+      atomicAdd(&s_M, total);
+      atomicAdd(&s_P, (unsigned long long)visits);
+    }
+  }
+  __syncthreads();
+  // match_array of the query (sgtd_result_votes) and the vote-value histogram of the frames that can be candidates
+  u32 *votes = B.votes + (size_t)q * frame_span;
+  for (u32 f = tid; f < frame_span; f += SGTD_VT_THREADS) {
+    const u32 v = s_hist[f];
+    votes[f] = v;
+    if (v >= 5) atomicAdd(&s_vb[min(v, (u32)SGTD_VT_BINS - 1u)], 1u);
+  }
+  if (tid == 0) {      // resolve_undecided_kernel has already subtracted the records it killed
+    atomicAdd(&q_M[q], s_M);
+    atomicAdd(&q_P[q], s_P);
+  }
+  __syncthreads();
+  // ---- :423-433, as topk_kernel: largest t with count(votes >= t) >= cand_num (5 if fewer frames qualify at all)
+  if (tid < SGTD_WAVE) {
+    constexpr int PER = SGTD_VT_BINS / SGTD_WAVE;
+    u32 mine = 0;
+    for (int b = 0; b < PER; b++) mine += s_vb[lane * PER + b];
+    u32 suffix = mine;   // inclusive suffix sum over lanes >= lane
+#pragma unroll
+    for (int d = 1; d < SGTD_WAVE; d <<= 1) {
+      const u32 o = __shfl_down(suffix, d);
+      if (lane + d < SGTD_WAVE) suffix += o;
+    }
+    const u64 okmask = __ballot(suffix >= (u32)cand_num);
+    const u32 n_ge = __shfl(suffix, 0);
+    if (okmask) {
+      const int L = 63 - __builtin_clzll(okmask);
+      if (lane == L) {
+        u32 acc = suffix - mine;
+        int b = L * PER + PER - 1;
+        for (; b >= L * PER; b--) { acc += s_vb[b]; if (acc >= (u32)cand_num) break; }
+        s_thr = (u32)max(b, 5); s_n_ge = acc;
+      }
+    } else if (lane == 0) { s_thr = 5; s_n_ge = n_ge; }
+  }
+  __syncthreads();
+  const u32 thr = s_thr;
+  int *cf = cand_frame + (size_t)q * cand_num, *cv = cand_votes + (size_t)q * cand_num;
+  long long *po = pair_off + (size_t)q * (cand_num + 1);
+  if (s_n_ge <= (u32)SGTD_TOPK_POOL) {
+    for (u32 f = tid; f < frame_span; f += SGTD_VT_THREADS) {
+      const u32 v = s_hist[f];
+      if (v >= thr) s_pool[atomicAdd(&s_npool, 1u)] = ((u64)v << 32) | (u64)(0xFFFFFFFFu - f);
+    }
+    __syncthreads();
+    if (tid < SGTD_WAVE) {
+      constexpr int PER = SGTD_TOPK_POOL / SGTD_WAVE;
+      const u32 np = s_npool;
+      u64 a[PER];
+#pragma unroll
+      for (int k = 0; k < PER; k++) a[k] = ((u32)(k * SGTD_WAVE + lane) < np) ? s_pool[k * SGTD_WAVE + lane] : 0ull;
+      int picked = 0;
+      u32 acc = 0;
+      for (int round = 0; round < cand_num; round++) {
+        u64 best = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) best = a[k] > best ? a[k] : best;
+#pragma unroll
+        for (int dlt = SGTD_WAVE / 2; dlt > 0; dlt >>= 1) {
+          const u64 o = __shfl_xor(best, dlt);
+          best = o > best ? o : best;
+        }
+        if ((u32)(best >> 32) < 5u) break;   // max_vote > 1 && max_vote >= 5 (:427,433)
+#pragma unroll
+        for (int k = 0; k < PER; k++) a[k] = (a[k] == best) ? 0ull : a[k];   // match_array[...] = 0 (:435)
+        if (lane == 0) {
+          const u32 f = 0xFFFFFFFFu - (u32)(best & 0xFFFFFFFFu);
+          cf[picked] = (int)(f + frame_lo);
+          cv[picked] = (int)(u32)(best >> 32);
+          po[picked] = (long long)acc;
+        }
+        acc += (u32)(best >> 32);
+        picked++;
+      }
+      if (lane == 0) {
+        n_cand[q] = picked;
+        q_pairs[q] = acc;
+        for (int k = picked; k < cand_num; k++) { cf[k] = -1; cv[k] = 0; }
+        for (int k = picked; k <= cand_num; k++) po[k] = (long long)acc;
+      }
+    }
+    return;
+  }
+  // ---- general path: more ties at the threshold than the pool holds — the rounds run over the whole
+  // histogram (a picked frame's count is zeroed like match_array's, :435)
+  u32 acc = 0;
+  for (int round = 0; round < cand_num; round++) {
+    u64 best = 0;
+    for (u32 f = tid; f < frame_span; f += SGTD_VT_THREADS) {
+      const u64 key = ((u64)s_hist[f] << 32) | (u64)(0xFFFFFFFFu - f);
+      best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int dlt = SGTD_WAVE / 2; dlt > 0; dlt >>= 1) {
+      const u64 o = __shfl_xor(best, dlt);
+      best = o > best ? o : best;
+    }
+    if (lane == 0) s_red[wid] = best;
+    __syncthreads();
+    if (tid == 0) {
+      u64 b = s_red[0];
+      for (int w = 1; w < NW; w++) b = s_red[w] > b ? s_red[w] : b;
+      const u32 v = (u32)(b >> 32);
+      if (v >= 5) {
+        const u32 f = 0xFFFFFFFFu - (u32)(b & 0xFFFFFFFFu);
+        s_hist[f] = 0;
+        cf[s_picked] = (int)(f + frame_lo);
+        cv[s_picked] = (int)v;
+        po[s_picked] = (long long)acc;
+        acc += v;
+        s_picked++;
+      } else {
+        s_picked |= 0x40000000;  // stop marker
+      }
+    }
+    __syncthreads();
+    if (s_picked & 0x40000000) break;
+  }
+  if (tid == 0) {
+    const int picked = s_picked & 0x3FFFFFFF;
+    n_cand[q] = picked;
+    q_pairs[q] = acc;
+    for (int k = picked; k < cand_num; k++) { cf[k] = -1; cv[k] = 0; }
+    for (int k = picked; k <= cand_num; k++) po[k] = (long long)acc;
+  }
+}
+
+// the lists' offsets from the candidates' votes where topk_kernel picked them (frame spans beyond LDS)
+__global__ __launch_bounds__(256) void cand_prefix_kernel(const int *n_cand, const int *cand_votes, int cand_num, int n_queries,
+                                                          long long *pair_off, u32 *q_pairs) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_queries) return;
+  const int nc = n_cand[q];
+  u32 acc = 0;
+  for (int k = 0; k <= cand_num; k++) {
+    pair_off[(size_t)q * (cand_num + 1) + k] = (long long)acc;
+    if (k < nc) acc += (u32)cand_votes[(size_t)q * cand_num + k];
+  }
+  q_pairs[q] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// match lists of one query by ONE workgroup (:434-449)
+// ---------------------------------------------------------------------------
+#define SGTD_PQ_THREADS 512
+#define SGTD_PQ_WAVES (SGTD_PQ_THREADS / SGTD_WAVE)
+#define SGTD_PQ_WORDS 4                                   // quad-words (64 lanes x 4 consecutive records of one list) per wave and tile
+#define SGTD_PQ_TILE_QUADS (SGTD_PQ_WAVES * SGTD_PQ_WORDS * SGTD_WAVE)
+#define SGTD_PQ_WAVE_RECS (SGTD_PQ_WORDS * SGTD_WAVE * 4)  // records of a wave's share of a tile: its region of the dense image
+#define SGTD_PQ_TILE_RECS (SGTD_PQ_WAVES * SGTD_PQ_WAVE_RECS)
+#define SGTD_PQ_DESCS SGTD_PQ_THREADS                     // descriptors per super-block: one list per thread
+#define SGTD_PQ_RANK_BITS 17                              // image words: slot << 26 | descriptor in super-block << 17 | rank in frame
+static_assert(SGTD_PQ_DESCS <= 512 && SGTD_MAX_CAND <= 64, "an image word holds 6 slot bits and 9 descriptor bits");
+
+// One list of the super-block as the tiles see it: its first quad in the super-block's stream of quads,
+// its first record, its records.
+struct __attribute__((aligned(16))) PqList { u32 pre, first, n, pad; };
+
+// dynamic LDS: u32 image[SGTD_PQ_TILE_RECS] | slot table u8[span rounded to 16] (SLOT_TABLE) or the candidates' hash
+template <bool SLOT_TABLE>
+__global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
+                                                                       const int *cand_frame, int cand_num,
+                                                                       const long long *pair_off, const u32 *q_pair_base,
+                                                                       u64 *pairs, IdMap map, u32 frame_span, u32 frame_lo) {
+  constexpr int NW = SGTD_PQ_WAVES, QW = SGTD_PQ_WORDS;
+  extern __shared__ u32 s_img[];                    // [SGTD_PQ_TILE_RECS]: per wave its dense candidates, then the tile's slot-sorted image
+  unsigned char *s_slot8 = reinterpret_cast<unsigned char *>(s_img + SGTD_PQ_TILE_RECS);
+  __shared__ PqList s_list[SGTD_PQ_DESCS];
+  __shared__ u32 s_pre[SGTD_PQ_DESCS + 8];          // the lists' first quads again, 4 bytes apart (+ a run of end markers: the locate step reads eight at a time)
+  __shared__ u32 s_cnt[NW][64];                     // candidates of the tile per (wave, slot)
+  __shared__ u32 s_run[NW][64];                     // next position in the image per (wave, slot)
+  __shared__ u32 s_scan[NW + 1];
+  __shared__ u64 s_cand[SGTD_CAND_HASH];
+  if (B.overflow()[0] || B.overflow()[1]) return;
+  const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+  const int q = blockIdx.x;
+  const u32 cnt = Q.count[q];
+  const int nc = n_cand[q];
+  if (nc == 0 || cnt == 0) return;     // (workgroup-uniform)
+  // frame -> candidate slot
+  if (SLOT_TABLE) {
+    for (u32 f = tid; f < ((frame_span + 15u) & ~15u) / 4u; f += SGTD_PQ_THREADS) reinterpret_cast<u32 *>(s_slot8)[f] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (tid < nc) s_slot8[(u32)cand_frame[(size_t)q * cand_num + tid] - frame_lo] = (unsigned char)tid;
+  } else {
+    s_cand[tid & (SGTD_CAND_HASH - 1)] = SGTD_CAND_EMPTY;
+    __syncthreads();
+    if (tid < nc) {
+      const u32 f = (u32)cand_frame[(size_t)q * cand_num + tid];
+      u32 h = (f * 0x9E3779B1u) >> 24;
+      while (atomicCAS(&s_cand[h], SGTD_CAND_EMPTY, ((u64)f << 8) | (u64)tid) != SGTD_CAND_EMPTY) h = (h + 1) & (SGTD_CAND_HASH - 1);
+    }
+  }
+  // lane s of every wave: where candidate s's list continues (every wave keeps its own copy in step), the
+  // insertion index of its frame's first entry (an image word names the frame by its slot)
+  u32 out_next = 0, first_of_slot = 0;
+  if (lane < nc) {
+    out_next = q_pair_base[q] + (u32)pair_off[(size_t)q * (cand_num + 1) + lane];
+    first_of_slot = map.frame_first[(u32)cand_frame[(size_t)q * cand_num + lane] - map.frame_lo];
+  }
+  const u32 id_bits = B.id_bits, rank_mask = (1u << id_bits) - 1u;
+  u32 *my_img = s_img + wid * SGTD_PQ_WAVE_RECS;
+  for (u32 sb0 = 0; sb0 < cnt; sb0 += SGTD_PQ_DESCS) {
+    __syncthreads();      // (the tiles of the super-block before are done with s_list; the slot table is complete)
+    // ---- the super-block's lists as one stream of quads
+    u32 n = 0, p = 0;
+    if (sb0 + tid < cnt) {
+      const uint2 lp = B.list[(long long)q * Q.stride + sb0 + tid];
+      p = lp.x; n = lp.y;
+    }
+    const u32 nq = (n + 3u) >> 2;
+    u32 RQ;
+    const u32 pre = block_excl_scan(nq, s_scan, RQ);
+    s_list[tid] = PqList{pre, p, n, 0u};
+    s_pre[tid] = pre;
+    if (tid < 8) s_pre[SGTD_PQ_DESCS + tid] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (RQ == 0) continue;
+    const u32 n_tiles = (RQ + SGTD_PQ_TILE_QUADS - 1) / SGTD_PQ_TILE_QUADS;
+    // a wave's quads of tile t: [t * TILE_QUADS + wid * QW * 64, + QW * 64), word u = 64 consecutive quads.
+    // Locate: j0 = last list that starts at or before the wave's first quad (64 lanes x 8 list starts compared
+    // at once), then per lane the lists that start inside the wave's 256 quads, eight wave-uniform starts at a time.
+    uint4 nrec[QW];
+    u32 nk[QW], ndd[QW];
+    auto fetch = [&](u32 t) {
+      const u32 r0 = t * SGTD_PQ_TILE_QUADS + (u32)wid * (QW * SGTD_WAVE);
+      u32 below = 0;
+#pragma unroll
+      for (int i = 0; i < SGTD_PQ_DESCS / SGTD_WAVE; i++) below += s_pre[i * SGTD_WAVE + lane] <= r0 ? 1u : 0u;     // (the starts ascend: their number is the index)
+      u32 j = wave_sum(below) - 1u;      // list 0 starts at quad 0: at least one
+      u32 r[QW], add[QW];
+#pragma unroll
+      for (int u = 0; u < QW; u++) { r[u] = r0 + u * SGTD_WAVE + lane; add[u] = 0; }
+      const u32 r_last = r0 + QW * SGTD_WAVE - 1u;
+      for (u32 jb = j + 1u; jb < SGTD_PQ_DESCS; jb += 8u) {
+        u32 st[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[i] = (u32)__builtin_amdgcn_readfirstlane((int)s_pre[jb + i]);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+          for (int u = 0; u < QW; u++) add[u] += st[i] <= r[u] ? 1u : 0u;
+        if (st[7] > r_last) break;
+      }
+#pragma unroll
+      for (int u = 0; u < QW; u++) {
+        const u32 jj = min(j + add[u], (u32)SGTD_PQ_DESCS - 1u);
+        const PqList L = s_list[jj];
+        const bool ok = r[u] < RQ;
+        const u32 firstrec = (r[u] - L.pre) << 2;       // record index of the quad inside its list
+        nk[u] = ok ? min(4u, L.n - firstrec) : 0u;
+        ndd[u] = jj;
+        const u32 *src = B.rec + (ok ? L.first + firstrec : 0u);      // 4-byte aligned; the buffer has room for the reads past a list's end
+        nrec[u] = make_uint4(src[0], src[1], src[2], src[3]);
+      }
+    };
+    fetch(0);
+    for (u32 t = 0; t < n_tiles; t++) {
+      uint4 rc[QW];
+      u32 kk[QW], dd[QW];
+#pragma unroll
+      for (int u = 0; u < QW; u++) { rc[u] = nrec[u]; kk[u] = nk[u]; dd[u] = ndd[u]; }
+      if (t + 1 < n_tiles) fetch(t + 1);     // in flight while this tile is sorted
+      // ---- the wave's candidate records, in stream order (word, lane, record of the quad), as image words
+      // in its own region of the image
+      s_cnt[wid][lane] = 0;
+      u32 nd = 0;      // wave-uniform: dense words so far
+#pragma unroll
+      for (int u = 0; u < QW; u++) {
+        const u32 w4[4] = {rc[u].x, rc[u].y, rc[u].z, rc[u].w};
+        u32 sl[4], mine = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const u32 lf = w4[i] >> id_bits;                 // local frame (a dead record's is beyond every span)
+          sl[i] = 0xFFu;
+          if ((u32)i < kk[u] && lf < frame_span) sl[i] = SLOT_TABLE ? (u32)s_slot8[lf] : cand_slot(s_cand, lf + frame_lo);
+          mine += sl[i] != 0xFFu ? 1u : 0u;
+        }
+        const u32 inc = wave_incl_scan(mine);
+        u32 at = nd + inc - mine;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (sl[i] != 0xFFu) my_img[at++] = (sl[i] << 26) | (dd[u] << SGTD_PQ_RANK_BITS) | (w4[i] & rank_mask);
+        nd += (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- dense words back into registers (the image is rebuilt in place), counts per (wave, slot)
+      constexpr int MAXD = SGTD_PQ_WAVE_RECS / SGTD_WAVE;
+      u32 dw[MAXD];
+      const u32 ndw = (nd + SGTD_WAVE - 1) / SGTD_WAVE;
+#pragma unroll
+      for (int w = 0; w < MAXD; w++) {
+        dw[w] = 0xFFFFFFFFu;
+        if ((u32)w < ndw) {
+          if ((u32)(w * SGTD_WAVE + lane) < nd) {
+            dw[w] = my_img[w * SGTD_WAVE + lane];
+            atomicAdd(&s_cnt[wid][dw[w] >> 26], 1u);
+          }
+        }
+      }
+      __syncthreads();
+      // ---- where the wave's records of slot s go in the image: behind the slots before s and the waves before it
+      u32 tot = 0, mine_before = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        const u32 c = s_cnt[w][lane];
+        mine_before += w < wid ? c : 0u;
+        tot += c;
+      }
+      const u32 slot_inc = wave_incl_scan(tot);
+      const u32 slot_off = slot_inc - tot;                                   // lane s: first image position of slot s
+      const u32 n_img = (u32)__builtin_amdgcn_readlane((int)slot_inc, SGTD_WAVE - 1);
+      s_run[wid][lane] = slot_off + mine_before;
+      __builtin_amdgcn_wave_barrier();
+      // stable: equal-slot lanes of a dense word in lane order (wave_group_rank), words in order (the running position)
+#pragma unroll
+      for (int w = 0; w < MAXD; w++) {
+        if ((u32)w < ndw) {
+          const bool valid = dw[w] != 0xFFFFFFFFu;
+          const u32 s = dw[w] >> 26;
+          u32 rank, count;
+          wave_group_rank<6>(s, valid, rank, count);
+          u32 base = 0;
+          if (valid) base = s_run[wid][s];
+          __builtin_amdgcn_wave_barrier();
+          if (valid && rank == count - 1u) s_run[wid][s] = base + count;
+          __builtin_amdgcn_wave_barrier();
+          if (valid) s_img[base + rank] = dw[w];
+        }
+      }
+      __syncthreads();
+      // ---- the image goes out: position e of slot s's run continues candidate s's list
+      for (u32 e0 = (u32)wid * SGTD_WAVE; e0 < n_img; e0 += SGTD_PQ_THREADS) {      // (wave-uniform: the permutes read lanes 0..63)
+        const u32 e = e0 + lane;
+        const bool ok = e < n_img;
+        const u32 wv = s_img[ok ? e : 0u];
+        const u32 s4 = (wv >> 26) << 2;
+        const u32 o = (u32)__builtin_amdgcn_ds_bpermute((int)s4, (int)(out_next - slot_off));
+        u32 g = (u32)__builtin_amdgcn_ds_bpermute((int)s4, (int)first_of_slot) + (wv & ((1u << SGTD_PQ_RANK_BITS) - 1u));
+        if (ok) {
+          if (map.by_frame) g = map.by_frame[g];
+          pairs[o + e] = ((u64)(sb0 + ((wv >> SGTD_PQ_RANK_BITS) & (SGTD_PQ_DESCS - 1u))) << 32) | (u64)g;
+        }
+      }
+      out_next += tot;
+      __syncthreads();      // (the next tile's dense words overwrite the image)
+    }
+  }
+}

@@ -16,6 +16,7 @@
 #include "common.hip.h"
 #include "table_kernels.hip.h"
 #include "probe_kernels.hip.h"
+#include "select_kernels.hip.h"
 #include "verify_kernels.hip.h"
 #include "graph_ingest.hip.h"
 
@@ -128,6 +129,7 @@ struct sgtd_engine {
   DevBuf inl_pairs, inl_off;                  // sgtd_result_inlier_pairs staging
   DevBuf v_hyp64, v_hyp32, v_bound;           // hypotheses between the two passes of sgtd_verify
   bool verified = false;
+  bool pairs_per_query = false;               // the batch's match lists were written by pairs_query_kernel (a re-run of the write pass: the same)
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
   bool rec_cap_fixed = false;          // SGTD_REC_CAP given: no pre-sizing from the table statistics
@@ -139,6 +141,8 @@ struct sgtd_engine {
   size_t group_cap_hook = 0;                // SGTD_GROUP_CAP (test hook): the first reservation
   int sorted_chunk = 0;                // > 0: fixed descriptors per ticket (SGTD_SORTED_CHUNK), else adaptive
   bool diag = false;                   // diagnostic probe build: cell index + distance per match
+  int select_mode = 0;                 // SGTD_SELECT_MODE (test hook): 0 auto, 1 the five-kernel passes over the records, 2 the per-query
+                                       // workgroups (select_kernels.hip.h) wherever they are supported, whatever the batch size
   // host copies after sync
   std::vector<u32> h_count, h_pair_base, h_q_M;
   std::vector<unsigned long long> h_q_P;
@@ -780,6 +784,26 @@ int launch_block_write(sgtd_engine *e, const Views &v, const CompactLists &CL, i
   return SGTD_OK;
 }
 
+// the match lists of every query by a workgroup of its own (select_kernels.hip.h); the slot of a record's frame
+// from a byte table in LDS while the frame span fits, else from the hash of the candidates
+int launch_pairs_query(sgtd_engine *e, const Views &v) {
+  const int cn = e->dc.cand_num;
+  const size_t img = (size_t)SGTD_PQ_TILE_RECS * sizeof(u32);
+  const size_t tab = ((size_t)v.span + 15) & ~(size_t)15;
+  if (img + tab <= 100 * 1024) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_query_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img + tab)));
+    pairs_query_kernel<true><<<e->nq, SGTD_PQ_THREADS, img + tab, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
+                                                                                e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
+                                                                                e->pairs.as<u64>(), v.T.map, v.span, v.T.frame_lo);
+  } else {
+    pairs_query_kernel<false><<<e->nq, SGTD_PQ_THREADS, img, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
+                                                                           e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
+                                                                           e->pairs.as<u64>(), v.T.map, v.span, v.T.frame_lo);
+  }
+  HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
 int launch_select(sgtd_engine *e) {
   const int nq = e->nq;
   const long long n_slots = (long long)nq * e->q_stride;
@@ -803,11 +827,23 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->pair_off, (size_t)nq * (cn + 1) * sizeof(long long)));
   CHK(rec_alloc(e));
 
+  // Which passes over the match records (STDesc.cpp:404-453): one workgroup per query (select_kernels.hip.h) when
+  // the batch has a query for every CU — votes + top-k in one launch while the query's vote histogram fits LDS,
+  // the match lists in one launch while an entry's rank among its frame's fits the image word — else the
+  // five-kernel form with one wave per 128-descriptor block.
+  const u32 tile_span = span <= 36 * 1024 ? span : 36 * 1024;
+  const u32 n_tiles = (span + tile_span - 1) / tile_span;
+  const bool per_query = e->select_mode == 2 || (e->select_mode == 0 && nq >= e->n_cus);
+  const bool fused_pairs = per_query && !e->wide_pairs && (e->id_bits ? e->id_bits : 13) <= SGTD_PQ_RANK_BITS;
+  const bool fused_votes = fused_pairs && votes_topk_lds_bytes(span) <= 150 * 1024;     // (block_count_kernel wants topk_kernel's slot table)
+  const bool votes_per_query = n_tiles == 1 ? nq >= e->n_cus : ((long long)nq * n_tiles >= e->n_cus / 4 && n_tiles <= 8);
   HIPCHK(hipMemsetAsync(e->cursors.p, 0, kCtrWords * sizeof(u32), e->stream));
-  HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));
-  HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
-  HIPCHK(hipMemsetAsync(e->cand_frame.p, 0xFF, (size_t)nq * cn * sizeof(int), e->stream));
-  HIPCHK(hipMemsetAsync(e->cand_votes.p, 0, (size_t)nq * cn * sizeof(int), e->stream));
+  if (!fused_votes) {
+    if (!votes_per_query) HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));   // (global vote atomics)
+    HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
+    HIPCHK(hipMemsetAsync(e->cand_frame.p, 0xFF, (size_t)nq * cn * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->cand_votes.p, 0, (size_t)nq * cn * sizeof(int), e->stream));
+  }
   HIPCHK(hipMemsetAsync(e->q_M.p, 0, (size_t)nq * sizeof(u32), e->stream));
   HIPCHK(hipMemsetAsync(e->q_P.p, 0, (size_t)nq * sizeof(unsigned long long), e->stream));
 
@@ -960,9 +996,13 @@ int launch_select(sgtd_engine *e) {
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_PROBE], e->stream));
     // one 16-wave workgroup per (query, frame tile) when that fills the chip: the tile's LDS
     // histogram is final (no flush atomics); spans beyond LDS take several tiles of 36 Ki frames
-    const u32 tile_span = span <= 36 * 1024 ? span : 36 * 1024;
-    const u32 n_tiles = (span + tile_span - 1) / tile_span;
-    if (n_tiles == 1 ? nq >= e->n_cus : ((long long)nq * n_tiles >= e->n_cus / 4 && n_tiles <= 8)) {
+    if (fused_votes) {
+      const size_t lds = votes_topk_lds_bytes(span);
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      votes_topk_kernel<<<nq, SGTD_VT_THREADS, lds, e->stream>>>(v.Q, v.B, span, v.T.frame_lo, blocks, cn, e->q_M.as<u32>(),
+                                                                  e->q_P.as<unsigned long long>(), e->n_cand.as<int>(), e->cand_frame.as<int>(),
+                                                                  e->cand_votes.as<int>(), e->pair_off.as<long long>(), e->q_pairs.as<u32>());
+    } else if (votes_per_query) {
       const size_t tile_bytes = (size_t)tile_span * sizeof(u32);
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_query_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
@@ -980,11 +1020,36 @@ int launch_select(sgtd_engine *e) {
     HIPCHK(hipGetLastError());
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_VOTES], e->stream));
   }
-  topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, v.T.frame_lo, cn, e->n_cand.as<int>(),
-                                          e->cand_frame.as<int>(), e->cand_votes.as<int>(),
-                                          e->slot_of.as<unsigned char>());
-  HIPCHK(hipGetLastError());
+  if (!fused_votes) {
+    topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, v.T.frame_lo, cn, e->n_cand.as<int>(),
+                                            e->cand_frame.as<int>(), e->cand_votes.as<int>(),
+                                            e->slot_of.as<unsigned char>());
+    HIPCHK(hipGetLastError());
+  }
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
+  if (fused_pairs) {
+    // the lists' offsets are the prefix sums of the candidates' votes; the lists themselves by one workgroup per query
+    if (!fused_votes) {
+      cand_prefix_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->n_cand.as<int>(), e->cand_votes.as<int>(), cn, nq,
+                                                                     e->pair_off.as<long long>(), e->q_pairs.as<u32>());
+      HIPCHK(hipGetLastError());
+    }
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
+    query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
+                                                 (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
+    HIPCHK(hipGetLastError());
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
+    CHK(launch_pairs_query(e, v));
+    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
+    e->pairs_per_query = true;
+    e->stats.select_form = fused_votes ? 2 : 1;
+    e->batch_valid = true;
+    e->verified = false;
+    e->batch_synced = false;
+    return SGTD_OK;
+  }
+  e->pairs_per_query = false;
+  e->stats.select_form = 0;
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
@@ -1051,13 +1116,19 @@ int rerun(sgtd_engine *e) {
 // the candidate-pair buffer was too small: everything up to the per-block counts is intact,
 // only the output offsets and the write pass run again
 int rerun_write(sgtd_engine *e) {
-  const int nq = e->nq, cn = e->dc.cand_num;
+  const int nq = e->nq;
   const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   const int groups = (blocks + 3) / 4;
   const int agrid = ((nq + 7) / 8) * groups * 8;
   CHK(ensure(e, e->pairs, e->pair_cap * sizeof(u64)));
   Views v = make_views(e);
   HIPCHK(hipMemsetAsync(v.B.overflow() + 1, 0, sizeof(int), e->stream));
+  if (e->pairs_per_query) {
+    query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
+                                                 (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
+    HIPCHK(hipGetLastError());
+    return launch_pairs_query(e, v);
+  }
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
@@ -1087,7 +1158,10 @@ int sync_batch(sgtd_engine *e) {
     CHK(xfer_sync(e));
     std::memcpy(&cursor, ctr, 8); std::memcpy(&need, ctr + 4, 8); std::memcpy(&swept, ctr + 6, 8);
     pool_used = ctr[8]; ovf[0] = (int)ctr[10]; ovf[1] = (int)ctr[11];
+    e->stats.last_list_moves = ctr[9];
     if (!ovf[0] && !ovf[1]) {
+      e->stats.batches_total++;
+      e->stats.list_moves_total += ctr[9];
       // slab use varies a little from run to run (which wave sweeps what): when a batch comes within
       // a tenth of the capacity, make room for half as much again (reallocated at the next launch)
       const size_t lim0 = 0xFFFFFFF0ull;
@@ -1095,6 +1169,7 @@ int sync_batch(sgtd_engine *e) {
       break;
     }
     e->stats.overflowed = 1;
+    if (ovf[0]) e->stats.reruns_total++; else e->stats.rewrites_total++;
     if (getenv("SGTD_DEBUG"))
       fprintf(stderr, "sgtd: batch re-run (attempt %d): flags %d %d, records %llu of %zu (+%llu wanted), pass pool %u of %zu units, home cells %u of %zu rows, pairs %u of %zu\n",
               attempt, ovf[0], ovf[1], cursor, e->rec_cap, need, pool_used, e->pool_units, n_groups, e->group_cap, total, e->pair_cap);
@@ -1321,6 +1396,7 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (const char *o = getenv("SGTD_COARSE_AT")) e->coarse_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
   if (const char *o = getenv("SGTD_REC_RATE")) e->rec_rate_hook = (u32)std::min(256, std::max(1, atoi(o)));
   if (const char *o = getenv("SGTD_WIDE_PAIRS")) e->wide_pairs = atoi(o) != 0;
+  if (const char *o = getenv("SGTD_SELECT_MODE")) e->select_mode = std::min(2, std::max(0, atoi(o)));
   if (const char *o = getenv("SGTD_WHOLE_AT")) e->whole_at = (u32)std::min(62ll, std::max(0ll, atoll(o)));
   // test hook: start with a small match-record buffer so that the overflow / re-run path runs
   if (const char *o = getenv("SGTD_REC_CAP")) { e->rec_cap = (size_t)std::max(1024ll, atoll(o)); e->rec_cap_fixed = true; }

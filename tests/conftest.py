@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "auto_mode: test_gpu_select_modes.py — leave the choice of the select passes to the library")
 
 
 @pytest.fixture(scope="session")
