@@ -226,24 +226,25 @@ __global__ __launch_bounds__(256) void cand_prefix_kernel(const int *n_cand, con
 #define SGTD_PQ_DESCS SGTD_PQ_THREADS                     // descriptors per super-block: one list per thread
 #define SGTD_PQ_RANK_BITS 17                              // image words: slot << 26 | descriptor in super-block << 17 | rank in frame
 static_assert(SGTD_PQ_DESCS <= 512 && SGTD_MAX_CAND <= 64, "an image word holds 6 slot bits and 9 descriptor bits");
+static_assert(SGTD_PQ_WAVE_RECS * 4 >= 8 * 64 * 8 && SGTD_PQ_WAVES == 8, "a wave's region of the image holds the ranking masks of eight dense words; image positions rotate over eight regions");
 
-// One list of the super-block as the tiles see it: its first quad in the super-block's stream of quads,
-// its first record, its records.
-struct __attribute__((aligned(16))) PqList { u32 pre, first, n, pad; };
+// One non-empty list of the super-block as the tiles see it: its first quad in the super-block's stream of
+// quads, its first record, its records, its descriptor (index inside the super-block).
+struct __attribute__((aligned(16))) PqList { u32 pre, first, n, desc; };
 
-// dynamic LDS: u32 image[SGTD_PQ_TILE_RECS] | slot table u8[span rounded to 16] (SLOT_TABLE) or the candidates' hash
+// dynamic LDS: u32 image[SGTD_PQ_TILE_RECS] | slot table u8[span rounded to 16, + 16] (SLOT_TABLE)
 template <bool SLOT_TABLE>
 __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
                                                                        const int *cand_frame, int cand_num,
                                                                        const long long *pair_off, const u32 *q_pair_base,
                                                                        u64 *pairs, IdMap map, u32 frame_span, u32 frame_lo) {
   constexpr int NW = SGTD_PQ_WAVES, QW = SGTD_PQ_WORDS;
-  extern __shared__ u32 s_img[];                    // [SGTD_PQ_TILE_RECS]: per wave its dense candidates, then the tile's slot-sorted image
+  extern __shared__ __attribute__((aligned(16))) u32 s_img[];   // [SGTD_PQ_TILE_RECS]: per wave its dense candidates, then the tile's slot-sorted image
+                                                                // (16-byte aligned: the ranking masks in it are 64-bit words)
   unsigned char *s_slot8 = reinterpret_cast<unsigned char *>(s_img + SGTD_PQ_TILE_RECS);
-  __shared__ PqList s_list[SGTD_PQ_DESCS];
-  __shared__ u32 s_pre[SGTD_PQ_DESCS + 8];          // the lists' first quads again, 4 bytes apart (+ a run of end markers: the locate step reads eight at a time)
+  __shared__ PqList s_ne[SGTD_PQ_DESCS];            // the super-block's non-empty lists, in order
+  __shared__ u32 s_start[SGTD_PQ_DESCS + SGTD_WAVE + 8];   // their first quads, ascending (+ end markers: a wave reads the 64 starts behind its first list)
   __shared__ u32 s_cnt[NW][64];                     // candidates of the tile per (wave, slot)
-  __shared__ u32 s_run[NW][64];                     // next position in the image per (wave, slot)
   __shared__ u32 s_scan[NW + 1];
   __shared__ u64 s_cand[SGTD_CAND_HASH];
   if (B.overflow()[0] || B.overflow()[1]) return;
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView 
   const u32 cnt = Q.count[q];
   const int nc = n_cand[q];
   if (nc == 0 || cnt == 0) return;     // (workgroup-uniform)
-  // frame -> candidate slot
+  // frame -> candidate slot (the byte behind the span answers for the ids of dead records)
   if (SLOT_TABLE) {
-    for (u32 f = tid; f < ((frame_span + 15u) & ~15u) / 4u; f += SGTD_PQ_THREADS) reinterpret_cast<u32 *>(s_slot8)[f] = 0xFFFFFFFFu;
+    for (u32 f = tid; f < (((frame_span + 15u) & ~15u) + 16u) / 4u; f += SGTD_PQ_THREADS) reinterpret_cast<u32 *>(s_slot8)[f] = 0xFFFFFFFFu;
     __syncthreads();
     if (tid < nc) s_slot8[(u32)cand_frame[(size_t)q * cand_num + tid] - frame_lo] = (unsigned char)tid;
   } else {
@@ -274,57 +275,72 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView 
     first_of_slot = map.frame_first[(u32)cand_frame[(size_t)q * cand_num + lane] - map.frame_lo];
   }
   const u32 id_bits = B.id_bits, rank_mask = (1u << id_bits) - 1u;
+  const u64 lane_bit = 1ull << lane;
   u32 *my_img = s_img + wid * SGTD_PQ_WAVE_RECS;
   for (u32 sb0 = 0; sb0 < cnt; sb0 += SGTD_PQ_DESCS) {
-    __syncthreads();      // (the tiles of the super-block before are done with s_list; the slot table is complete)
-    // ---- the super-block's lists as one stream of quads
+    __syncthreads();      // (the tiles of the super-block before are done with the lists; the slot table is complete)
+    // ---- the super-block's non-empty lists as one stream of quads
     u32 n = 0, p = 0;
     if (sb0 + tid < cnt) {
       const uint2 lp = B.list[(long long)q * Q.stride + sb0 + tid];
       p = lp.x; n = lp.y;
     }
-    const u32 nq = (n + 3u) >> 2;
-    u32 RQ;
-    const u32 pre = block_excl_scan(nq, s_scan, RQ);
-    s_list[tid] = PqList{pre, p, n, 0u};
-    s_pre[tid] = pre;
-    if (tid < 8) s_pre[SGTD_PQ_DESCS + tid] = 0xFFFFFFFFu;
+    u32 RQ, K;
+    const u32 pre = block_excl_scan((n + 3u) >> 2, s_scan, RQ);
+    const u32 kx = block_excl_scan(n ? 1u : 0u, s_scan, K);
+    if (n) { s_ne[kx] = PqList{pre, p, n, (u32)tid}; s_start[kx] = pre; }
+    if ((u32)tid >= K) s_start[tid] = 0xFFFFFFFFu;
+    if (tid < SGTD_WAVE + 8) s_start[SGTD_PQ_DESCS + tid] = 0xFFFFFFFFu;
     __syncthreads();
     if (RQ == 0) continue;
     const u32 n_tiles = (RQ + SGTD_PQ_TILE_QUADS - 1) / SGTD_PQ_TILE_QUADS;
-    // a wave's quads of tile t: [t * TILE_QUADS + wid * QW * 64, + QW * 64), word u = 64 consecutive quads.
-    // Locate: j0 = last list that starts at or before the wave's first quad (64 lanes x 8 list starts compared
-    // at once), then per lane the lists that start inside the wave's 256 quads, eight wave-uniform starts at a time.
+    // A wave's quads of tile t: [t * TILE_QUADS + wid * QW * 64, + QW * 64), word u = 64 consecutive quads.
+    // Locate (the sweep's): k0 = the list that holds the wave's first quad (64 lanes x 8 starts compared at once),
+    // lane l then holds the start of list k0 + 1 + l; the starts inside the wave's 256 quads become marks in one
+    // 64-bit scalar per word (bit b of word u: a list starts at quad 64 u + b + 1), a quad's list is k0 + the
+    // marks before it (scalar popcounts + v_mbcnt).
     uint4 nrec[QW];
     u32 nk[QW], ndd[QW];
     auto fetch = [&](u32 t) {
       const u32 r0 = t * SGTD_PQ_TILE_QUADS + (u32)wid * (QW * SGTD_WAVE);
       u32 below = 0;
 #pragma unroll
-      for (int i = 0; i < SGTD_PQ_DESCS / SGTD_WAVE; i++) below += s_pre[i * SGTD_WAVE + lane] <= r0 ? 1u : 0u;     // (the starts ascend: their number is the index)
-      u32 j = wave_sum(below) - 1u;      // list 0 starts at quad 0: at least one
-      u32 r[QW], add[QW];
+      for (int i = 0; i < SGTD_PQ_DESCS / SGTD_WAVE; i++) below += s_start[i * SGTD_WAVE + lane] <= r0 ? 1u : 0u;     // (the starts ascend: their number is the index)
+      const u32 k0 = wave_sum(below) - 1u;      // the first list starts at quad 0: at least one
+      const u32 st = s_start[k0 + 1u + (u32)lane];
+      u32 kl[QW];
+      u32 c_prev = 0;
+      bool slow = false;
 #pragma unroll
-      for (int u = 0; u < QW; u++) { r[u] = r0 + u * SGTD_WAVE + lane; add[u] = 0; }
-      const u32 r_last = r0 + QW * SGTD_WAVE - 1u;
-      for (u32 jb = j + 1u; jb < SGTD_PQ_DESCS; jb += 8u) {
-        u32 st[8];
+      for (int u = 0; u < QW; u++) {
+        const u32 w_lo = r0 + (u32)u * SGTD_WAVE;
+        const u32 c = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st <= w_lo + SGTD_WAVE));
+        u64 marks = 0;
+        for (u32 i = c_prev; i < c; i++) marks |= 1ull << ((u32)__builtin_amdgcn_readlane((int)st, (int)i) - 1u - w_lo);
+        kl[u] = k0 + c_prev + __builtin_amdgcn_mbcnt_hi((u32)(marks >> 32), __builtin_amdgcn_mbcnt_lo((u32)marks, 0u));
+        c_prev = c;
+        slow = slow || c >= (u32)SGTD_WAVE;
+      }
+      if (slow) {   // more than 64 lists start inside the wave's quads (lists of a few records): a search per quad
 #pragma unroll
-        for (int i = 0; i < 8; i++) st[i] = (u32)__builtin_amdgcn_readfirstlane((int)s_pre[jb + i]);
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-          for (int u = 0; u < QW; u++) add[u] += st[i] <= r[u] ? 1u : 0u;
-        if (st[7] > r_last) break;
+        for (int u = 0; u < QW; u++) {
+          const u32 r = r0 + (u32)u * SGTD_WAVE + (u32)lane;
+          u32 lo = 0, hi = K;
+          while (hi - lo > 1u) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_start[mid] <= r) lo = mid; else hi = mid;
+          }
+          kl[u] = lo;
+        }
       }
 #pragma unroll
       for (int u = 0; u < QW; u++) {
-        const u32 jj = min(j + add[u], (u32)SGTD_PQ_DESCS - 1u);
-        const PqList L = s_list[jj];
-        const bool ok = r[u] < RQ;
-        const u32 firstrec = (r[u] - L.pre) << 2;       // record index of the quad inside its list
+        const u32 r = r0 + (u32)u * SGTD_WAVE + (u32)lane;
+        const PqList L = s_ne[min(kl[u], K - 1u)];
+        const bool ok = r < RQ;
+        const u32 firstrec = (r - L.pre) << 2;       // record index of the quad inside its list
         nk[u] = ok ? min(4u, L.n - firstrec) : 0u;
-        ndd[u] = jj;
+        ndd[u] = L.desc << SGTD_PQ_RANK_BITS;
         const u32 *src = B.rec + (ok ? L.first + firstrec : 0u);      // 4-byte aligned; the buffer has room for the reads past a list's end
         nrec[u] = make_uint4(src[0], src[1], src[2], src[3]);
       }
@@ -336,6 +352,14 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView 
 #pragma unroll
       for (int u = 0; u < QW; u++) { rc[u] = nrec[u]; kk[u] = nk[u]; dd[u] = ndd[u]; }
       if (t + 1 < n_tiles) fetch(t + 1);     // in flight while this tile is sorted
+#if defined(SGTD_EXP_PQ) && SGTD_EXP_PQ == 2
+      {   // experiment build (never shipped): the locate and the loads alone — 1.31 ms of the kernel's 2.68
+        u32 x = 0;
+        for (int u = 0; u < QW; u++) x ^= rc[u].x ^ rc[u].y ^ rc[u].z ^ rc[u].w ^ kk[u] ^ dd[u];
+        if (x == 0x12345678u) pairs[0] = x;
+        continue;
+      }
+#endif
       // ---- the wave's candidate records, in stream order (word, lane, record of the quad), as image words
       // in its own region of the image
       s_cnt[wid][lane] = 0;
@@ -347,32 +371,64 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView 
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const u32 lf = w4[i] >> id_bits;                 // local frame (a dead record's is beyond every span)
-          sl[i] = 0xFFu;
-          if ((u32)i < kk[u] && lf < frame_span) sl[i] = SLOT_TABLE ? (u32)s_slot8[lf] : cand_slot(s_cand, lf + frame_lo);
+          if (SLOT_TABLE) {
+            sl[i] = (u32)s_slot8[min(lf, frame_span)];
+            sl[i] = (u32)i < kk[u] ? sl[i] : 0xFFu;
+          } else {
+            sl[i] = 0xFFu;
+            if ((u32)i < kk[u] && lf < frame_span) sl[i] = cand_slot(s_cand, lf + frame_lo);
+          }
           mine += sl[i] != 0xFFu ? 1u : 0u;
         }
         const u32 inc = wave_incl_scan(mine);
         u32 at = nd + inc - mine;
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          if (sl[i] != 0xFFu) my_img[at++] = (sl[i] << 26) | (dd[u] << SGTD_PQ_RANK_BITS) | (w4[i] & rank_mask);
+          if (sl[i] != 0xFFu) my_img[at++] = (sl[i] << 26) | dd[u] | (w4[i] & rank_mask);
         nd += (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
       }
       __builtin_amdgcn_wave_barrier();
-      // ---- dense words back into registers (the image is rebuilt in place), counts per (wave, slot)
-      constexpr int MAXD = SGTD_PQ_WAVE_RECS / SGTD_WAVE;
-      u32 dw[MAXD];
+      // ---- dense words back into registers; the wave's region of the image then serves as scratch for the
+      // ranking: per batch of eight dense words and slot the lanes of the word that carry the slot (commutative
+      // LDS ORs: the result does not depend on the order the hardware applies them in).  A record's rank among the
+      // wave's records of its slot = the slot's records in the words before (lane s counts slot s) + the lanes
+      // before it in its own word's mask: stable in stream order.
+      constexpr int MAXD = SGTD_PQ_WAVE_RECS / SGTD_WAVE, BATCH = 8;
+      u32 dw[MAXD], rk[MAXD];
       const u32 ndw = (nd + SGTD_WAVE - 1) / SGTD_WAVE;
 #pragma unroll
       for (int w = 0; w < MAXD; w++) {
-        dw[w] = 0xFFFFFFFFu;
-        if ((u32)w < ndw) {
-          if ((u32)(w * SGTD_WAVE + lane) < nd) {
-            dw[w] = my_img[w * SGTD_WAVE + lane];
-            atomicAdd(&s_cnt[wid][dw[w] >> 26], 1u);
+        dw[w] = 0xFFFFFFFFu; rk[w] = 0;
+        if ((u32)w < ndw && (u32)(w * SGTD_WAVE + lane) < nd) dw[w] = my_img[w * SGTD_WAVE + lane];
+      }
+      u32 run_s = 0;        // lane s: the wave's records of slot s so far
+      u64 *m = reinterpret_cast<u64 *>(my_img);      // [BATCH][64]
+#pragma unroll
+      for (int b0 = 0; b0 < MAXD; b0 += BATCH) {
+        if ((u32)b0 < ndw) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int w = 0; w < BATCH; w++)
+            if ((u32)(b0 + w) < ndw) m[w * SGTD_WAVE + lane] = 0;
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int w = 0; w < BATCH; w++)
+            if ((u32)(b0 + w) < ndw && dw[b0 + w] != 0xFFFFFFFFu) atomicOr(&m[w * SGTD_WAVE + (dw[b0 + w] >> 26)], lane_bit);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int w = 0; w < BATCH; w++) {
+            if ((u32)(b0 + w) < ndw) {
+              const u64 own = m[w * SGTD_WAVE + lane];
+              const u32 s = (dw[b0 + w] >> 26) & 63u;
+              const u64 gm = m[w * SGTD_WAVE + s];
+              const u32 before = (u32)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)run_s);
+              rk[b0 + w] = before + __builtin_amdgcn_mbcnt_hi((u32)(gm >> 32), __builtin_amdgcn_mbcnt_lo((u32)gm, 0u));
+              run_s += (u32)__builtin_popcountll(own);
+            }
           }
         }
       }
+      s_cnt[wid][lane] = run_s;
       __syncthreads();
       // ---- where the wave's records of slot s go in the image: behind the slots before s and the waves before it
       u32 tot = 0, mine_before = 0;
@@ -385,40 +441,37 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView 
       const u32 slot_inc = wave_incl_scan(tot);
       const u32 slot_off = slot_inc - tot;                                   // lane s: first image position of slot s
       const u32 n_img = (u32)__builtin_amdgcn_readlane((int)slot_inc, SGTD_WAVE - 1);
-      s_run[wid][lane] = slot_off + mine_before;
-      __builtin_amdgcn_wave_barrier();
-      // stable: equal-slot lanes of a dense word in lane order (wave_group_rank), words in order (the running position)
+      const u32 my_base = slot_off + mine_before;
+      // image position p lives in the region of wave (p / 64) % NW, at word 64 (p / (64 NW)) + p % 64: every wave
+      // flushes the 64-record chunks of its own region — nobody else reads them, so the next tile's dense words
+      // can follow without a barrier
 #pragma unroll
       for (int w = 0; w < MAXD; w++) {
         if ((u32)w < ndw) {
-          const bool valid = dw[w] != 0xFFFFFFFFu;
-          const u32 s = dw[w] >> 26;
-          u32 rank, count;
-          wave_group_rank<6>(s, valid, rank, count);
-          u32 base = 0;
-          if (valid) base = s_run[wid][s];
-          __builtin_amdgcn_wave_barrier();
-          if (valid && rank == count - 1u) s_run[wid][s] = base + count;
-          __builtin_amdgcn_wave_barrier();
-          if (valid) s_img[base + rank] = dw[w];
+          const u32 pos = (u32)__builtin_amdgcn_ds_bpermute((int)((dw[w] >> 26) << 2), (int)my_base) + rk[w];
+          if (dw[w] != 0xFFFFFFFFu)
+            s_img[((pos >> 6) & (NW - 1)) * SGTD_PQ_WAVE_RECS + ((pos >> 9) << 6) + (pos & 63u)] = dw[w];
         }
       }
       __syncthreads();
       // ---- the image goes out: position e of slot s's run continues candidate s's list
-      for (u32 e0 = (u32)wid * SGTD_WAVE; e0 < n_img; e0 += SGTD_PQ_THREADS) {      // (wave-uniform: the permutes read lanes 0..63)
-        const u32 e = e0 + lane;
+      for (u32 c = (u32)wid; c * SGTD_WAVE < n_img; c += NW) {      // (wave-uniform: the permutes read lanes 0..63)
+        const u32 e = c * SGTD_WAVE + lane;
         const bool ok = e < n_img;
-        const u32 wv = s_img[ok ? e : 0u];
-        const u32 s4 = (wv >> 26) << 2;
+        const u32 wv = my_img[((c / NW) << 6) + lane];
+        const u32 s4 = ok ? (wv >> 26) << 2 : 0u;
         const u32 o = (u32)__builtin_amdgcn_ds_bpermute((int)s4, (int)(out_next - slot_off));
         u32 g = (u32)__builtin_amdgcn_ds_bpermute((int)s4, (int)first_of_slot) + (wv & ((1u << SGTD_PQ_RANK_BITS) - 1u));
         if (ok) {
           if (map.by_frame) g = map.by_frame[g];
+#if defined(SGTD_EXP_PQ) && SGTD_EXP_PQ == 1
+          if (g == 0xFFFFFFF3u)      // experiment build (never shipped): no stores — 2.47 ms of 2.68
+#endif
           pairs[o + e] = ((u64)(sb0 + ((wv >> SGTD_PQ_RANK_BITS) & (SGTD_PQ_DESCS - 1u))) << 32) | (u64)g;
         }
       }
       out_next += tot;
-      __syncthreads();      // (the next tile's dense words overwrite the image)
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

@@ -789,7 +789,7 @@ int launch_block_write(sgtd_engine *e, const Views &v, const CompactLists &CL, i
 int launch_pairs_query(sgtd_engine *e, const Views &v) {
   const int cn = e->dc.cand_num;
   const size_t img = (size_t)SGTD_PQ_TILE_RECS * sizeof(u32);
-  const size_t tab = ((size_t)v.span + 15) & ~(size_t)15;
+  const size_t tab = (((size_t)v.span + 15) & ~(size_t)15) + 16;     // (+ the bytes that answer for dead records)
   if (img + tab <= 100 * 1024) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_query_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img + tab)));
     pairs_query_kernel<true><<<e->nq, SGTD_PQ_THREADS, img + tab, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
