@@ -69,8 +69,11 @@ def parse():
                     help="other map sizes measured for map_size_sweep ('' = no other sizes, 'none' = also skip the incremental-insert leg)")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU work budget of the timed sample")
-    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
-                    help="full = BASELINE.md §2: 10 warm-up + 200 queries at each of 3 thread settings (slow)")
+    ap.add_argument("--cpu-protocol", choices=["bounded", "ref_full", "full"], default="ref_full",
+                    help="ref_full = BASELINE.md §2 (10 warm-up + 200 queries) at the reference's thread rule, a bounded sample at the "
+                         "other settings; full = the protocol at every setting (slow); bounded = a bounded sample everywhere")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct query batches the timed region rotates through (all different from the warm-up batch)")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps timed per kernel for the roofline")
     ap.add_argument("--verify", choices=["on", "off"], default="on",
                     help="also time candidate_verify + SearchLoop on the device (reported beside, never inside, value)")
@@ -116,9 +119,10 @@ def cpu_baseline(smap, queries, gpu_results, mgr, budget_s, protocol):
     q_next = 0
     for name, thr in settings:
         o.set_num_threads(thr)
-        warm = 10 if protocol == "full" else 1
-        want = 200 if protocol == "full" else 10 ** 9
-        lim = budget_s * share[name] if protocol == "bounded" else 1e9
+        whole = protocol == "full" or (protocol == "ref_full" and name == "ref_rule_nproc_minus_4")
+        warm = 10 if whole else 1
+        want = 200 if whole else 10 ** 9
+        lim = 1e9 if whole else budget_s * share[name]
         for w in range(warm):
             o.build(queries.xyz[w % nq_all], queries.label[w % nq_all], export=False)
             o.select()
@@ -160,7 +164,8 @@ def cpu_baseline(smap, queries, gpu_results, mgr, budget_s, protocol):
                      % (prim["queries_timed"], out_settings["all_cores"]["queries_timed"],
                         out_settings["one_thread"]["queries_timed"], F, t_map, protocol)
                      + ("; %d more on the %d CPUs of the cgroup quota" % (out_settings["cgroup_quota_cpus"]["queries_timed"], quota) if quota < ncpu else "")
-                     + ("; queries_timed < 200 per setting (BASELINE.md §2 asks 200: --cpu-protocol full)" if protocol != "full" else ""),
+                     + ("; queries_timed < 200 per setting (BASELINE.md §2 asks 200: --cpu-protocol full)" if protocol == "bounded" else
+                        "; BASELINE.md §2 in full at the reference's thread rule, bounded samples at the other settings" if protocol == "ref_full" else ""),
               ms_per_query=prim["ms_per_query"]["median"], host_cpus=ncpu, host_cpu_quota=quota, best_setting_frames_per_s=best,
               thread_settings=out_settings)
     return cb, parity
@@ -222,6 +227,42 @@ def recall(smap, queries, top1):
             "top1_pose_within_5m": float(np.mean(ok & (dist < 5.0)))}
 
 
+# kernels one step launches, by the form of the passes over the match records (sgtd_stats.select_form) — the
+# names the committed PMC row must carry (a row measured on other kernels is refused, loudly)
+STEP_KERNELS = {
+    0: ("probe_sorted_kernel", "votes_query_kernel", "topk_kernel", "block_count_kernel", "block_write_kernel"),
+    1: ("probe_sorted_kernel", "votes_query_kernel", "topk_kernel", "pairs_query_kernel"),
+    2: ("probe_sorted_kernel", "votes_topk_kernel", "pairs_query_kernel"),
+}
+# stage of sgtd_stats' per-kernel times each kernel of a step belongs to
+STAGE_OF = (("build_frames", "ms_build"), ("probe_sorted", "ms_probe"), ("resolve_undecided", "ms_probe"), ("votes_", "ms_votes"),
+            ("topk_kernel", "ms_topk"), ("block_count", "ms_count"), ("cand_prefix", "ms_count"), ("block_scan", "ms_scan"),
+            ("query_base", "ms_scan"), ("block_write", "ms_write"), ("pairs_query", "ms_write"))
+
+
+def stage_of(kernel):
+    for prefix, key in STAGE_OF:
+        if kernel.startswith(prefix):
+            return key
+    return "ms_sort"      # keys, radix passes, scans, group heads, GroupRows, the plan
+
+
+def check_traffic_row(row, select_form):
+    """the committed PMC row describes THIS step only if it was taken on the kernels this run launches"""
+    want = STEP_KERNELS.get(select_form)
+    if row is None or want is None:
+        return
+    if row.get("select_form") is not None and row.get("select_form") != select_form:
+        raise SystemExit("bench.py: profiles/%s_traffic.json (tag %s, commit %s) was measured with select_form %s, this run launches form %s: "
+                         "re-run profiles/collect_r04.sh" % (str(row.get("profile_tag"))[:3], row.get("profile_tag"), row.get("commit"), row.get("select_form"), select_form))
+    have = row.get("kernels")
+    if have is not None:
+        missing = [w for w in want if not any(k.startswith(w) for k in have)]
+        if missing:
+            raise SystemExit("bench.py: the committed PMC row (tag %s, commit %s) has no kernel named %s — it was measured on other kernels: "
+                             "re-run profiles/collect_r04.sh" % (row.get("profile_tag"), row.get("commit"), missing))
+
+
 def load_traffic(F, N, Q, world):
     """HBM bytes per sweep launch from the committed PMC passes (profiles/r<NN>_traffic.json, written by
     profiles/collect_r<NN>.sh for exactly this configuration; the newest round that has the row), else None"""
@@ -261,7 +302,7 @@ def main():
     import torch
     import torch.distributed as dist
     from sgtd_amd import synth
-    from sgtd_amd.dist import ReplicatedMap, ShardedMap, shard_range
+    from sgtd_amd.dist import ReplicatedMap, ShardedMap, gather_and_merge, shard_range
     from sgtd_amd.manager import STDescManager
 
     rank = int(os.environ.get("RANK", "0"))
@@ -282,16 +323,43 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # a process group for waits that must not occupy the GPUs (a rank that waits in an RCCL barrier spins a kernel
+    # on its device) and for agreeing on success before optional collective stages
+    host_group = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
+
+    def host_barrier():
+        if world > 1:
+            dist.barrier(group=host_group) if host_group is not None else dist.barrier()
+
+    def all_ok(ok):
+        """True on every rank iff `ok` is true on every rank (host-side all-reduce): optional legs run their rank-local
+        part under try/except, agree here, and enter the collective part only together"""
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if host_group is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=host_group)
+        else:
+            t = t.to(dev) if backend == "nccl" else t
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
     def make_map_once(n_frames, n_kp, stream_id):
         """the synthetic world of a run with several ranks: rank 0 generates it (and leaves it in synth's cache,
         SGTD_SYNTH_CACHE), the others load it after a barrier — not N copies of the same minute of numpy work
         on one host; without a cache (small maps, cache switched off) every rank generates it itself"""
         if world > 1 and n_frames >= 2000 and os.environ.get("SGTD_SYNTH_CACHE", "x"):
+            m, err = None, None
             if rank == 0:
-                m = synth.make_map(n_frames, n_kp, stream=stream_id)
-            dist.barrier()
+                try:
+                    m = synth.make_map(n_frames, n_kp, stream=stream_id)
+                except Exception as exc:      # (the barrier below is reached whatever happens here)
+                    err = exc
+            host_barrier()
+            if err is not None:
+                raise err
             if rank != 0:
-                m = synth.make_map(n_frames, n_kp, stream=stream_id)
+                m = synth.make_map(n_frames, n_kp, stream=stream_id)      # from rank 0's cache file, or generated again without one
             return m
         return synth.make_map(n_frames, n_kp, stream=stream_id)
 
@@ -307,6 +375,11 @@ def main():
     n_q_total = Q * world if (mode == "query" or (mode == "table" and args.also_replicated == "on" and fits_one_gpu)) else Q
     queries = synth.make_queries(smap, n_q_total, stream=1)
     n_q_value = Q * world if mode == "query" else Q     # query frames one step of the headline mode serves
+    # The timed region rotates through n_rot batches that differ from each other AND from the warm-up batch
+    # (`queries`, which the parity and recall legs use): a node never sees the same frames twice
+    # (semantic_graph_localization.cpp:567-604), and the room a match list is given is predicted from the batch BEFORE.
+    n_rot = max(1, args.rotate)
+    rot_sets = [synth.make_queries(smap, n_q_total, stream=1000 + b) for b in range(n_rot)]
 
     def to_dev(xyz, label):
         return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
@@ -320,18 +393,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, mgr):
-        """warm-up (incl. work-buffer growth), then K steps between barrier + synchronize, max over ranks"""
+    timed_info = {}
+
+    def timed(step, mgr, steps=None, info=None):
+        """warm-up on the warm-up batch (incl. work-buffer growth), then K steps between barrier + synchronize, max
+        over ranks.  step(i): i < 0 the warm-up batch, i >= 0 the i-th timed step (batch i % n_rot of the rotation)"""
+        steps = args.steps if steps is None else steps
         for _ in range(max(args.warmup, 1)):
-            step()
+            step(-1)
         mgr.sync()          # grows work buffers if the first batch overflowed them
-        step()
+        step(-1)
         mgr.sync()
-        assert mgr.stats()["overflowed"] == 0
+        s0 = mgr.stats()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(steps):
+            step(i)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -339,7 +416,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         mgr.sync()
-        assert mgr.stats()["overflowed"] == 0, "a timed step overflowed a work buffer"
+        s1 = mgr.stats()
+        if info is not None:
+            # nothing is asserted about fresh data: re-runs and list moves inside the timed region are counted and reported
+            # (counted on the device: the steps are enqueued one after the other without a host synchronisation)
+            info.update(batch_launches_in_timed_region=int(s1["batches_total"] - s0["batches_total"]),
+                        launches_that_overflowed_a_work_buffer=int(s1["overflow_launches_total"] - s0["overflow_launches_total"]),
+                        reruns_in_timed_region=int(s1["reruns_total"] - s0["reruns_total"]),
+                        list_pass_reruns_in_timed_region=int(s1["rewrites_total"] - s0["rewrites_total"]),
+                        list_moves_in_timed_region=int(s1["list_moves_total"] - s0["list_moves_total"]),
+                        distinct_batches_in_timed_region=min(n_rot, steps))
         return elapsed
 
     cold = {}
@@ -352,10 +438,12 @@ def main():
         torch.cuda.synchronize()
         cold["map_build_s"] = time.perf_counter() - t0
         d_qxyz, d_qlab = to_dev(queries.xyz, queries.label)
+        d_rot = [to_dev(r.xyz, r.label) for r in rot_sets]
         q_lo, q_hi = 0, Q
 
-        def step():
-            mgr.query_frames(d_qxyz, d_qlab, fetch=False)
+        def step(i=-1):
+            x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
+            mgr.query_frames(x, l, fetch=False)
         # cold start: the very first batch of a fresh handle (work buffers sized from the table
         # statistics; re-run if they were too small)
         t0 = time.perf_counter()
@@ -370,10 +458,12 @@ def main():
         lo, hi = shard_range(F, world, rank)
         sm.add_shard_frames(*to_dev(smap.xyz[lo:hi], smap.label[lo:hi]))
         d_qxyz, d_qlab = to_dev(queries.xyz[:Q], queries.label[:Q])
+        d_rot = [to_dev(r.xyz[:Q], r.label[:Q]) for r in rot_sets]
         q_lo, q_hi = 0, Q
 
-        def step():
-            merged["out"] = sm.query(d_qxyz, d_qlab)[:2]
+        def step(i=-1):
+            x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
+            merged["out"] = sm.query(x, l)[:2]
     else:
         rm = ReplicatedMap(F, rank, world, device_id=local_rank)
         mgr = rm.mgr
@@ -381,20 +471,29 @@ def main():
         rm.add_frames(*to_dev(smap.xyz, smap.label))
         q_lo, q_hi = rank * Q, (rank + 1) * Q
         d_qxyz, d_qlab = to_dev(queries.xyz[q_lo:q_hi], queries.label[q_lo:q_hi])
+        d_rot = [to_dev(r.xyz[q_lo:q_hi], r.label[q_lo:q_hi]) for r in rot_sets]
 
-        def step():
-            merged["out"] = rm.query(d_qxyz, d_qlab, n_q_total)
+        def step(i=-1):
+            x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
+            merged["out"] = rm.query(x, l, n_q_total)
 
-    elapsed = timed(step, mgr)
+    elapsed = timed(step, mgr, info=timed_info)
+    # the same measurement the way rounds 1-3 took it — ONE batch over and over (the room prediction is then exact, no
+    # list ever moves) — beside the headline, which rotates fresh batches
+    k_same = max(3, args.steps // 2)
+    same_elapsed = timed(lambda i: step(-1), mgr, steps=k_same)
+    timed_info.update(same_batch_ms_per_step=1000.0 * same_elapsed / k_same, same_batch_steps=k_same,
+                      rotating_over_same_batch=(elapsed / args.steps) / (same_elapsed / k_same))
+    step(-1); mgr.sync()          # leave the handle on the warm-up batch: the parity, recall and profile legs read its results
     backend_ran = dist.get_backend() if world > 1 else None
     collective = {"nccl": "RCCL (torch.distributed backend nccl)", "gloo": "gloo (NOT RCCL: test fallback)"}.get(backend_ran, backend_ran)
     st = mgr.stats()
 
-    # ---- per-kernel timing for the roofline (HIP events on the handle's stream)
+    # ---- per-kernel timing for the roofline (HIP events on the handle's stream), on the rotating batches
     mgr.set_timing(True)
     acc = {}
-    for _ in range(args.profile_steps):
-        step()
+    for j in range(args.profile_steps):
+        step(j)
         mgr.sync()
         s = mgr.stats()
         for k in KERNEL_KEYS:
@@ -403,46 +502,101 @@ def main():
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
     st = mgr.stats()
     P, M, D = st["last_P"], st["last_M"], st["last_D"]
+    select_form = int(st["select_form"])
     t_probe = kern_ms["ms_probe"] * 1e-3
-    # SURVEY §8d's algorithmic bytes of one sweep launch: 28 B per visited entry, 64 B per query
-    # descriptor, 8 B per match record
-    algo_bytes = 28 * P + 64 * D + 8 * M
-    algo_gbs = algo_bytes / t_probe / 1e9 if t_probe > 0 else 0.0
-    # What can bound the sweep: (a) the bytes its waves really load and store through L2 — 16 B per
-    # entry it loads (after slice pruning and pair sharing; sgtd_stats.last_P_swept) + 4 B per match
-    # record — against the aggregate L2 rate; (b) the HBM bytes the PMC counters saw (2 x FETCH_SIZE
-    # + WRITE_SIZE, separate rocprofv3 passes, profiles/r02_traffic.json) against the HBM peak.
-    # `frac` is the larger of the two fractions and can never exceed 1; the algorithmic rate of
-    # SURVEY §8d (28 B per entry the REFERENCE loop visits) is reported beside it: it exceeds the HBM
-    # peak because pruned slices are never loaded and the rest is mostly served from L2.
+    t_step = elapsed / args.steps
     entry_bytes = st["hbm_bytes_table"] // max(st["n_entries"], 1)   # probe-layout bytes per loaded entry
     P_swept = st.get("last_P_swept") or P
-    l2_gbs = (entry_bytes * P_swept + 4 * M) / t_probe / 1e9 if t_probe > 0 else 0.0
+    # (1) The dominant kernel (the sweep) against the HBM roof: bytes per launch from the committed PMC passes of this
+    # very command (profiles/collect_r04.sh: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE; both counters sit on
+    # the L2's fabric side and count Infinity-Cache hits, so they bound the HBM bytes from above) over the kernel's
+    # average launch duration measured live (HIP events on the launch stream).  A row measured on other kernels than
+    # the ones this run launches is refused.
     tr = load_traffic(F, N, Q, world)
+    check_traffic_row(tr, select_form)
     traffic = tr.get("bytes_per_launch") if tr else None
     hbm_gbs = traffic / t_probe / 1e9 if (traffic and t_probe > 0) else None
-    l2_frac = l2_gbs / L2_PEAK_GBS
-    hbm_frac = hbm_gbs / HBM_PEAK_GBS if hbm_gbs is not None else None
-    if hbm_frac is not None and hbm_frac >= l2_frac:
-        bound, achieved, peak, frac = "hbm", hbm_gbs, HBM_PEAK_GBS, hbm_frac
-    else:
-        bound, achieved, peak, frac = "l2", l2_gbs, L2_PEAK_GBS, l2_frac
-    roofline = {"bound": bound, "kernel": "probe_sorted_kernel (sweep)", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                "frac": min(frac, 1.0), "traffic": traffic, "traffic_profile": tr.get("profile_tag") if tr else None,
-                "hbm_frac": hbm_frac, "l2_frac": l2_frac,
-                # what really limits the sweep: wave64 VALU instructions x 4 cycles over the 1024 SIMDs' cycles,
-                # from the SQ counter pass of the same profile (not measurable live)
+    l2_gbs = (entry_bytes * P_swept + 4 * M) / t_probe / 1e9 if t_probe > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "probe_sorted_kernel (sweep)", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs is not None else None, "traffic": traffic,
+                "traffic_profile": tr.get("profile_tag") if tr else None, "traffic_profile_commit": tr.get("commit") if tr else None,
+                "traffic_note": "PMC bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md §HBM), committed under profiles/ by "
+                                "profiles/collect_r04.sh for this command; both counters include Infinity-Cache hits: an upper bound on HBM bytes",
+                "avg_launch_ms": kern_ms["ms_probe"], "select_form": select_form,
+                "l2_frac": l2_gbs / L2_PEAK_GBS, "l2_GBps_moved_by_the_waves": l2_gbs,
                 "valu_issue_frac": tr.get("valu_issue_frac") if tr else None,
-                "avg_launch_ms": kern_ms["ms_probe"], "probe_layout_bytes_per_loaded_entry": entry_bytes,
-                "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_gbs,
-                "algorithmic_over_hbm_peak": algo_gbs / HBM_PEAK_GBS,
-                "reference_visits_per_s": P / t_probe if t_probe > 0 else 0.0,
-                "note": "bound = the level whose fraction is larger: L2->CU bytes the sweep really moves (16 B x entries loaded "
-                        "+ 4 B x records) vs 34.5 TB/s, or PMC HBM bytes vs 8 TB/s; algorithmic bytes (28 B x reference visits) "
-                        "exceed the HBM peak because pruned sub-cells are never loaded and buckets are re-read from L2; the kernel itself is VALU-issue bound (valu_issue_frac, DESIGN.md §3)",
+                "probe_layout_bytes_per_loaded_entry": entry_bytes,
                 "P_visited": P, "P_swept_after_slice_pruning": st.get("last_P_swept"), "M_matches": M,
-                "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"],
-                "kernel_ms": kern_ms}
+                "D_query_descs": D, "candidate_pairs": st["last_cand_pairs"], "kernel_ms": kern_ms}
+    # (2) The whole step, stage by stage: PMC bytes of the committed profile per stage of sgtd_stats' kernel times, the
+    # times measured live in this run
+    if tr and tr.get("kernels"):
+        stages = {}
+        for kname, kv in tr["kernels"].items():
+            if kname.startswith("__amd") or kname.startswith("at::"):
+                continue        # (memsets and torch's copies: not the library's kernels)
+            sg = stages.setdefault(stage_of(kname), {"read_bytes": 0.0, "write_bytes": 0.0, "kernels": []})
+            sg["read_bytes"] += kv.get("read_bytes") or 0.0
+            sg["write_bytes"] += kv.get("write_bytes") or 0.0
+            sg["kernels"].append(kname)
+        for key, sg in stages.items():
+            ms = kern_ms.get(key, 0.0)
+            sg["ms_live"] = ms
+            sg["GBps"] = (sg["read_bytes"] + sg["write_bytes"]) / (ms * 1e-3) / 1e9 if ms > 0 else None
+            sg["frac_of_hbm_peak"] = sg["GBps"] / HBM_PEAK_GBS if sg["GBps"] else None
+        tot = sum(sg["read_bytes"] + sg["write_bytes"] for sg in stages.values())
+        roofline["step"] = {"stages": stages, "bytes": tot, "read_bytes": sum(sg["read_bytes"] for sg in stages.values()),
+                            "write_bytes": sum(sg["write_bytes"] for sg in stages.values()),
+                            "ms_per_step_timed_region": 1000.0 * t_step, "kernel_ms_sum_live": kern_ms["ms_total"],
+                            "GBps": tot / t_step / 1e9, "frac": tot / t_step / 1e9 / HBM_PEAK_GBS}
+    # (3) What the step cannot avoid moving, against the same roof: the probe layout read once, every match record
+    # written once (the reference's M, 4 B each: votes need every one of them), the candidates' match lists out,
+    # the keypoints in.  (Without the records — they never leave the device — the compulsory I/O is the first, third
+    # and fourth term.)
+    comp = {"probe_layout_once": int(st["hbm_bytes_table"]), "match_records_once": int(4 * M), "candidate_pairs_out": int(8 * st["last_cand_pairs"]),
+            "keypoints_in": int(16 * N * st["last_queries"])}
+    comp_bytes = sum(comp.values())
+    roofline["compulsory_bytes"] = comp_bytes
+    roofline["compulsory"] = dict(comp, bytes=comp_bytes, io_only_bytes=comp_bytes - comp["match_records_once"],
+                                  frac=comp_bytes / t_step / 1e9 / HBM_PEAK_GBS, ms_at_hbm_peak=comp_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                  note="frac = compulsory bytes / measured step time / 8 TB/s: how far the whole step is from streaming "
+                                       "only what it must")
+    # (4) SURVEY §8d's model prices 28 B for every entry the REFERENCE's loop visits; this kernel never loads 86 % of them
+    # (pruned sub-cells, four descriptors per visit list), so the figure is not a bound and is kept out of `frac`
+    algo_bytes = 28 * P + 64 * D + 8 * M
+    roofline["survey_8d_model"] = {"bytes_per_launch": algo_bytes, "GBps": algo_bytes / t_probe / 1e9 if t_probe > 0 else None,
+                                   "over_hbm_peak": algo_bytes / t_probe / 1e9 / HBM_PEAK_GBS if t_probe > 0 else None,
+                                   "reference_visits_per_s": P / t_probe if t_probe > 0 else 0.0,
+                                   "note": "28 B x reference visits + 64 B x descriptors + 8 B x matches: exceeds the HBM peak because most "
+                                           "visits are never loaded — not a roofline fraction"}
+    # (5) N > 1, table-sharded: what a rank's step consists of — the part every rank repeats for all Q queries (descriptor
+    # build, home-cell sort, GroupRows, the plan), the part that shrinks with the shard (the sweep and the passes over
+    # its records), and the exchange (export + all_gather + merge, timed alone) — and what they predict
+    scaling_parts = None
+    if mode == "table":
+        pre_ms = kern_ms["ms_build"] + kern_ms["ms_sort"]
+        shard_ms = kern_ms["ms_probe"] + kern_ms["ms_votes"] + kern_ms["ms_topk"] + kern_ms["ms_count"] + kern_ms["ms_scan"] + kern_ms["ms_write"]
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            gather_and_merge(sm._bufs[0], sm._bufs[1], sm.cand_num)
+        barrier()
+        ex_ms = 1000.0 * (time.perf_counter() - t0) / 10
+        mine = torch.tensor([pre_ms, shard_ms, ex_ms], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        parts = np.array([p_.cpu().numpy() for p_ in parts])
+        one_gpu_ms = float(parts[:, 0].mean() + parts[:, 1].sum())          # the replicated part once + every shard's sweep
+        pred_ms = float((parts[:, 0] + parts[:, 1]).max() + parts[:, 2].max())
+        scaling_parts = {"per_rank_ms": {"replicated_build_sort_plan": parts[:, 0].tolist(), "sharded_sweep_and_record_passes": parts[:, 1].tolist(),
+                                         "exchange_all_gather_merge": parts[:, 2].tolist()},
+                         "predicted_ms_per_step": pred_ms, "predicted_one_gpu_ms_per_step": one_gpu_ms,
+                         "predicted_speedup_over_one_gpu": one_gpu_ms / pred_ms,
+                         "speedup_ceiling_if_the_sharded_part_vanished": one_gpu_ms / float(parts[:, 0].mean() + parts[:, 2].max()),
+                         "note": "strong scaling at a fixed map: the build, sort and plan of all Q query frames are repeated on every rank "
+                                 "(every rank needs every query descriptor), only the sweep and the passes over its match records shrink "
+                                 "with the shard; kernel times by HIP events on each rank's stream, the exchange timed alone"}
+    step(-1); mgr.sync()          # back on the warm-up batch
 
     res = mgr.results()
     # ---- next stage of the reference's SearchLoop (STDesc.cpp:105-146), reported separately
@@ -546,7 +700,7 @@ def main():
         tq_xyz, tq_lab = to_dev(queries.xyz[:Q], queries.label[:Q])
         tmerged = {}
 
-        def tstep():
+        def tstep(i=-1):
             tmerged["out"] = sm.query(tq_xyz, tq_lab)
         t_el = timed(tstep, sm.mgr)
         ref_f, ref_v = merged["out"]
@@ -564,7 +718,7 @@ def main():
         rq_xyz, rq_lab = to_dev(queries.xyz[rank * Q:(rank + 1) * Q], queries.label[rank * Q:(rank + 1) * Q])
         rmerged = {}
 
-        def rstep():
+        def rstep(i=-1):
             rmerged["out"] = rm.query(rq_xyz, rq_lab, Q * world)
         r_el = timed(rstep, rm.mgr)
         tf, tv_ = merged["out"]
@@ -582,18 +736,33 @@ def main():
     # (the reference itself cannot hold it: MAX_FRAME_N = 20 000, STDesc.h:33)
     cfg4 = None
     if world > 1 and (args.cfg4 == "on" or (args.cfg4 == "auto" and world == 8)) and F != 100000:
+        # Only rank-local work sits under try/except; the ranks agree on its success (host-side) before every stage
+        # that contains a collective, so that one rank's failure (an allocation, a damaged cache file) skips the leg
+        # on EVERY rank instead of leaving the others inside an all_gather.
+        F4, Q4 = 100000, 256
+        lo4, hi4 = shard_range(F4, world, rank)
+        m4 = q4 = s4 = x4 = l4 = None
+        err4 = None
         try:
-            F4, Q4 = 100000, 256
-            lo4, hi4 = shard_range(F4, world, rank)
-            m4 = make_map_once(F4, N, 4)                  # every rank holds the world, keeps its frames
-            q4 = synth.make_queries(m4, Q4, stream=4)
-            s4 = ShardedMap(F4, rank, world, device_id=local_rank)
-            s4.mgr.set_stream(stream.cuda_stream)
-            s4.add_shard_frames(*to_dev(m4.xyz[lo4:hi4], m4.label[lo4:hi4]))
-            x4, l4 = to_dev(q4.xyz, q4.label)
+            m4 = make_map_once(F4, N, 4)                  # every rank holds the world, keeps its frames (its barrier is always reached)
+        except Exception as exc:
+            err4 = exc
+        if all_ok(err4 is None):
+            try:
+                q4 = synth.make_queries(m4, Q4, stream=4)
+                s4 = ShardedMap(F4, rank, world, device_id=local_rank)
+                s4.mgr.set_stream(stream.cuda_stream)
+                s4.add_shard_frames(*to_dev(m4.xyz[lo4:hi4], m4.label[lo4:hi4]))
+                x4, l4 = to_dev(q4.xyz, q4.label)
+                for _ in range(2):                       # the shard's own sweep without the exchange: work buffers reach their size here
+                    s4.mgr.query_frames(x4, l4, fetch=False)
+                    s4.mgr.sync()
+            except Exception as exc:
+                err4 = exc
+        if all_ok(err4 is None):
             out4 = {}
 
-            def step4():
+            def step4(i=-1):
                 out4["out"] = s4.query(x4, l4)
             e4 = timed(step4, s4.mgr)
             top1 = out4["out"][0][:, 0].cpu().numpy()
@@ -601,9 +770,9 @@ def main():
                     "value": Q4 * args.steps / e4, "unit": "frames/s", "ms_per_step": 1000.0 * e4 / args.steps,
                     "queries_per_step": Q4, "table_entries_per_rank": entries_of(s4.mgr), "collective": collective,
                     "recall": recall(m4, q4, top1)}
-            del s4, m4, q4, x4, l4
-        except Exception as exc:
-            cfg4 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        else:
+            cfg4 = {"error": "skipped on every rank: %s" % ("%s: %s" % (type(err4).__name__, err4) if err4 is not None else "another rank failed")}
+        del s4, m4, q4, x4, l4
 
     # ---- N > 1: ONE process over all N devices (sgtd_create_multi: frame blocks dealt to the devices,
     # concurrent sweeps, host-side merge with the same rule) — the form the reference's C++ caller uses.
@@ -629,12 +798,13 @@ def main():
                 same = bool(ref_f is not None and np.array_equal(rg.cand_frame[:, :ref_f.shape[1]], ref_f))
                 multi_handle = {"value": Q * args.steps / tm, "unit": "frames/s", "ms_per_step": 1000.0 * tm / args.steps,
                                 "devices": gm.device_count, "queries_per_step": Q,
-                                "note": "one process, host pointers in (PCIe inside the timed region), per-device sweeps concurrent, host merge",
+                                "note": "one process, host pointers in (PCIe inside the timed region), per-device sweeps concurrent, host merge; "
+                                        "the other ranks' processes idle on the host meanwhile, their tables still resident",
                                 "candidates_equal_headline_list": same}
                 gm.close()
             except Exception as exc:
                 multi_handle = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        barrier()
+        host_barrier()      # (the other ranks wait on the host: no barrier kernel spins on the devices rank 0 is timing)
 
     # ---- other map sizes (same batch, same pipeline), N = 1 only
     sweep = None
@@ -744,7 +914,13 @@ def main():
                        "ranks_in_collective": ranks_seen, "table_entries_per_rank": entries_per_rank,
                        "table_entries_this_rank": st["n_entries"], "table_buckets_this_rank": st["n_buckets"]},
             "roofline": roofline,
+            "timed_region": dict(timed_info, warmup_batch="a batch of its own: no timed step repeats it",
+                                 note="the timed steps rotate through %d distinct synthetic batches; re-runs (a work buffer overflowed) and "
+                                      "moved match lists inside the timed region are counted, not asserted away; same_batch_ms_per_step = "
+                                      "rounds 1-3's measurement (one batch over and over) in the same run" % n_rot),
         }
+        if scaling_parts is not None:
+            out["scaling_parts"] = scaling_parts
         if cold:
             out["cold_start"] = cold
         if sweep is not None:

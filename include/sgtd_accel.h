@@ -101,7 +101,12 @@ typedef struct sgtd_stats {
                               appended entries while they fit the tail segment              */
   float reserved2;
   /* since the handle was created (what a caller sees over a stream of DIFFERENT batches): */
-  int64_t batches_total;     /* query batches completed                                       */
+  int64_t batches_total;     /* launches of a query batch's pipeline, counted on the device (re-runs included) —
+                                the count includes batches that were enqueued and overwritten by the next one
+                                without a sgtd_sync / sgtd_result_* call in between                   */
+  int64_t overflow_launches_total; /* ... of them, launches that raised a work-buffer flag (their results are
+                                incomplete until sgtd_sync has re-run them): a caller that enqueues batch after
+                                batch without synchronising checks that this did not move            */
   int64_t reruns_total;      /* launches of a whole batch beyond the first (a work buffer
                                 overflowed: match records, pass pool, GroupRows, undecided queue) */
   int64_t rewrites_total;    /* re-runs of the list pass alone (candidate-pair buffer too small) */

@@ -68,7 +68,7 @@ class Stats(C.Structure):
         ("ms_total", C.c_float), ("overflowed", C.c_int32), ("select_form", C.c_int32),
         ("last_P_swept", C.c_int64), ("bucket_len_sq_over_E", C.c_double),
         ("tail_entries", C.c_int64), ("ms_finalize", C.c_float), ("reserved2", C.c_float),
-        ("batches_total", C.c_int64), ("reruns_total", C.c_int64), ("rewrites_total", C.c_int64),
+        ("batches_total", C.c_int64), ("overflow_launches_total", C.c_int64), ("reruns_total", C.c_int64), ("rewrites_total", C.c_int64),
         ("list_moves_total", C.c_int64), ("last_list_moves", C.c_int64),
     ]
 

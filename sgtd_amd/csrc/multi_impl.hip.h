@@ -410,7 +410,7 @@ int get_stats(sgtd_engine *e, sgtd_stats *out) {
     t.hbm_bytes_table += x.hbm_bytes_table;
     t.overflowed |= x.overflowed;
     t.select_form = x.select_form;
-    t.batches_total = x.batches_total;
+    t.batches_total = x.batches_total; t.overflow_launches_total += x.overflow_launches_total;
     t.reruns_total += x.reruns_total; t.rewrites_total += x.rewrites_total;
     t.list_moves_total += x.list_moves_total; t.last_list_moves += x.last_list_moves;
     t.ms_total = std::max(t.ms_total, x.ms_total);

@@ -1756,6 +1756,14 @@ __global__ __launch_bounds__(64) void block_scan_kernel(u32 *blk_count, int bloc
   }
 }
 
+// behind a batch's last kernel: the handle's running totals (never reset: they also see the batches a caller enqueues
+// one after the other without synchronising) — launches, launches that raised an overflow flag, match lists that moved
+__global__ void batch_totals_kernel(const u32 *ctr, unsigned long long *tot) {
+  tot[0] += 1ull;
+  tot[1] += (ctr[10] | ctr[11]) ? 1ull : 0ull;
+  tot[2] += (unsigned long long)ctr[9];
+}
+
 // exclusive scan of q_pairs over queries: q_pair_base[q], [n] = total
 __global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32 *q_pair_base, int n_queries,
                                                          u32 pair_cap, int *overflow) {

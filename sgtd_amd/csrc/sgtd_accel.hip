@@ -120,6 +120,7 @@ struct sgtd_engine {
   std::vector<long long> last_kp_off;
   int last_max_n = 0;
   u32 last_qframe = 0;  // current_frame_id_ when the batch was enqueued (a re-run stamps the same id)
+  DevBuf totals;        // 3 x u64, zeroed once: batch_totals_kernel's running counts
   DevBuf cursors, list, n_visit, votes, slot_of;   // cursors: the batch's counters, overflow flags and ticket heads (ProbeBuffers::ctr)
   DevBuf q_M, q_P, q_pairs, q_pair_base, blk_count, rec, rec_cell, rec_dis;
   DevBuf c_pair, c_blk;           // compact candidate-match lists between block_count and block_write
@@ -235,6 +236,21 @@ int xfer_sync(sgtd_engine *e) {
   e->pin_used = 0;
   return SGTD_OK;
 }
+
+// d2h queues {destination, pinned offset}; only xfer_sync applies the queue.  A function that returns early (a failed
+// HIP call between its d2h calls and its xfer_sync) must not leave entries behind whose destinations are its own
+// locals: PinScope drops whatever is still queued when the function is left.
+struct PinScope {
+  sgtd_engine *e;
+  explicit PinScope(sgtd_engine *e_) : e(e_) {}
+  ~PinScope() {
+    if (e && !e->pin_pending.empty()) {
+      (void)hipStreamSynchronize(e->stream);      // (the copies into the pinned buffer may still be in flight)
+      e->pin_pending.clear();
+      e->pin_used = 0;
+    }
+  }
+};
 
 int pin_room(sgtd_engine *e, size_t bytes, size_t *off) {
   if (!e->pin) {
@@ -811,6 +827,10 @@ int launch_select(sgtd_engine *e) {
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
   const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
   CHK(ensure(e, e->cursors, kCtrWords * sizeof(u32)));
+  if (!e->totals.p) {
+    CHK(ensure(e, e->totals, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(e->totals.p, 0, 4 * sizeof(unsigned long long), e->stream));
+  }
   CHK(ensure(e, e->list, (size_t)std::max<long long>(n_slots, 1) * sizeof(uint2)));
   CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->votes, (size_t)nq * span * sizeof(u32)));
@@ -1041,6 +1061,8 @@ int launch_select(sgtd_engine *e) {
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
     CHK(launch_pairs_query(e, v));
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
+    batch_totals_kernel<<<1, 1, 0, e->stream>>>(v.B.ctr, e->totals.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
     e->pairs_per_query = true;
     e->stats.select_form = fused_votes ? 2 : 1;
     e->batch_valid = true;
@@ -1091,6 +1113,8 @@ int launch_select(sgtd_engine *e) {
   CHK(launch_block_write(e, v, CL, agrid, blocks));
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
+  batch_totals_kernel<<<1, 1, 0, e->stream>>>(v.B.ctr, e->totals.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
   e->batch_valid = true;
   e->verified = false;
   e->batch_synced = false;
@@ -1141,6 +1165,7 @@ int rerun_write(sgtd_engine *e) {
 }
 
 int sync_batch(sgtd_engine *e) {
+  PinScope pin_scope(e);
   if (!e->batch_valid) return SGTD_ERR_STATE;
   if (e->batch_synced) return SGTD_OK;
   e->stats.overflowed = 0;
@@ -1152,16 +1177,17 @@ int sync_batch(sgtd_engine *e) {
     u32 total = 0, pool_used = 0;
     u32 ctr[12];     // ProbeBuffers::ctr, one copy
     u32 n_groups = 0;
+    unsigned long long tot[3] = {0, 0, 0};
     CHK(d2h(e, ctr, e->cursors.p, sizeof(ctr)));
+    if (e->totals.p) CHK(d2h(e, tot, e->totals.p, sizeof(tot)));
     if (e->n_groups.p) CHK(d2h(e, &n_groups, e->n_groups.p, sizeof(u32)));
     CHK(d2h(e, &total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32)));
     CHK(xfer_sync(e));
     std::memcpy(&cursor, ctr, 8); std::memcpy(&need, ctr + 4, 8); std::memcpy(&swept, ctr + 6, 8);
     pool_used = ctr[8]; ovf[0] = (int)ctr[10]; ovf[1] = (int)ctr[11];
     e->stats.last_list_moves = ctr[9];
+    e->stats.batches_total = (int64_t)tot[0]; e->stats.overflow_launches_total = (int64_t)tot[1]; e->stats.list_moves_total = (int64_t)tot[2];
     if (!ovf[0] && !ovf[1]) {
-      e->stats.batches_total++;
-      e->stats.list_moves_total += ctr[9];
       // slab use varies a little from run to run (which wave sweeps what): when a batch comes within
       // a tenth of the capacity, make room for half as much again (reallocated at the next launch)
       const size_t lim0 = 0xFFFFFFF0ull;
@@ -1441,7 +1467,7 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
-                    &e->cand_votes, &e->pair_off, &e->pairs};
+                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals};
   for (DevBuf *b : bufs) free_buf(*b);
   for (auto &b : e->scan_lvl) free_buf(b);
   if (e->pin) (void)hipHostFree(e->pin);
@@ -1454,6 +1480,9 @@ int sgtd_destroy(sgtd_handle e) {
 int sgtd_set_stream(sgtd_handle e, void *hip_stream) {
   if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e) return SGTD_ERR_INVALID;
+  // what is queued on the old stream (copies out of the pinned staging buffer included) finishes there first: the
+  // staging bytes are reused as soon as the new stream has been waited for
+  CHK(xfer_sync(e));
   e->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return SGTD_OK;
 }
@@ -1480,6 +1509,7 @@ int64_t sgtd_max_descs(sgtd_handle e, int n_keypoints) {
 
 int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sgtd_desc_soa *out,
                int64_t capacity, int64_t *n_out) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::build(e, xyz, label, n, out, capacity, n_out);
   if (!e || !out || !n_out || n < 0 || (n > 0 && (!xyz || !label))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1664,6 +1694,7 @@ int sgtd_sync(sgtd_handle e) {
 
 int sgtd_result_candidates(sgtd_handle e, int32_t *n_cand, int32_t *cand_frame, int32_t *cand_votes,
                            int64_t *pair_off) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::result_candidates(e, n_cand, cand_frame, cand_votes, pair_off);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1703,6 +1734,7 @@ int sgtd_result_query_desc_count(sgtd_handle e, int q, int64_t *n) {
 
 int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, int64_t capacity,
                       int64_t *n_pairs) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::result_pairs(e, q, q_idx, db_entry, capacity, n_pairs);
   if (!e || !n_pairs) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1724,6 +1756,7 @@ int sgtd_result_pairs(sgtd_handle e, int q, int32_t *q_idx, int64_t *db_entry, i
 }
 
 int sgtd_result_query_descs(sgtd_handle e, int q, sgtd_desc_soa *out, int64_t capacity, int64_t *n_out) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::result_query_descs(e, q, out, capacity, n_out);
   if (!e || !out || !n_out) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1735,6 +1768,7 @@ int sgtd_result_query_descs(sgtd_handle e, int q, sgtd_desc_soa *out, int64_t ca
 }
 
 int sgtd_result_votes(sgtd_handle e, int q, uint32_t *votes, int64_t capacity, uint32_t *frame_lo, int64_t *n) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::result_votes(e, q, votes, capacity, frame_lo, n);
   if (!e || !n) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1752,6 +1786,7 @@ int sgtd_result_votes(sgtd_handle e, int q, uint32_t *votes, int64_t capacity, u
 
 int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64_t *db_entry, uint32_t *frame,
                       double *dis, int64_t capacity, int64_t *n_rough) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e || !n_rough) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1848,6 +1883,7 @@ int sgtd_verify(sgtd_handle e) {
 }
 
 int sgtd_result_verify(sgtd_handle e, int q, double *score, double *pose) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::result_verify(e, q, score, pose);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1872,6 +1908,7 @@ int sgtd_export_verify_dev(sgtd_handle e, double *d_score, double *d_pose) {
 }
 
 int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t capacity, int64_t *n) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::result_inliers(e, q, cand, idx, capacity, n);
   if (!e || !n) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1896,6 +1933,7 @@ int sgtd_result_inliers(sgtd_handle e, int q, int cand, int32_t *idx, int64_t ca
 
 int sgtd_result_inlier_pairs(sgtd_handle e, int q, int64_t *cand_off, int32_t *q_idx, int64_t *db_entry, int64_t capacity,
                              int64_t *n_pairs) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::result_inlier_pairs(e, q, cand_off, q_idx, db_entry, capacity, n_pairs);
   if (!e || !n_pairs || !cand_off) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -1928,6 +1966,7 @@ int sgtd_result_inlier_pairs(sgtd_handle e, int q, int64_t *cand_off, int32_t *q
 
 int sgtd_result_inlier_entries(sgtd_handle e, int q, int64_t *cand_off, int32_t *q_idx, sgtd_desc_soa *entries, int64_t capacity,
                                int64_t *n_pairs) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (!e || !n_pairs || !cand_off) return SGTD_ERR_INVALID;
   if (e->grp) {
     // several devices: the pairs from the devices that own the candidates, then their entries (db_entry ids name the owner)
@@ -1972,6 +2011,7 @@ int sgtd_result_inlier_entries(sgtd_handle e, int q, int64_t *cand_off, int32_t 
 }
 
 int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, int32_t *best_frame, double *best_score) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::search_loop(e, icp_threshold, best_cand, best_frame, best_score);
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -2125,6 +2165,7 @@ int sgtd_host_free(void *p) {
 }
 
 int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_desc_soa *out) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) return multi::fetch_entries(e, db_entry, n, out);
   if (!e || n < 0 || (n > 0 && (!db_entry || !out))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
@@ -2146,6 +2187,7 @@ int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_d
 
 int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *entry_ids,
                     int64_t cap_buckets, int64_t cap_entries) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
   if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));

@@ -104,6 +104,9 @@ def _observe(landmarks, labels, tree, pose, n_kp, sigma, rng, tie_k=10):
     return out, labels[idx].astype(np.uint32)
 
 
+GEN_VERSION = 2     # bump whenever _trajectory, _observe or the landmark model change: cached maps of older code are then ignored
+
+
 def _cache_path(kind, key):
     """generated sets are deterministic functions of their parameters: large ones are kept under
     SGTD_SYNTH_CACHE (default /tmp/sgtd_synth_cache; empty = off) so that the test session and the
@@ -112,7 +115,9 @@ def _cache_path(kind, key):
     root = os.environ.get("SGTD_SYNTH_CACHE", "/tmp/sgtd_synth_cache")
     if not root:
         return None
-    h = hashlib.sha256(repr((kind, BASE_SEED, key, np.__version__)).encode()).hexdigest()[:24]
+    import scipy
+    # (the generator's own version and scipy's: cKDTree's tie order and any change to _trajectory / _observe give other frames)
+    h = hashlib.sha256(repr((kind, BASE_SEED, GEN_VERSION, key, np.__version__, scipy.__version__)).encode()).hexdigest()[:24]
     return os.path.join(root, "%s_%s.npz" % (kind, h))
 
 
