@@ -10,9 +10,15 @@
 //   {"nodes":[int...], "edges":[[..]], "weights":[..], "centers":[[x,y,z]...],
 //    "poses":[12 floats], "volumes":[..], "densitys":[..]}
 // Only "nodes", "centers", "poses" are read (fromJSON :157-164); every other key is skipped.
-// Numbers: nlohmann::json parses a number to double (strtod) and get<float>() / get<int>()
-// casts it — the same two steps here.
+// Numbers as nlohmann::json (3.1.1, the header this image carries; tests/cpp/test_ingest_nlohmann.cpp
+// compares with it bit for bit) reads them: a token without fraction and exponent is an integer —
+// strtoull for a non-negative one, strtoll for a negative one ("-0" is the integer 0: +0.0f, not
+// -0.0f), and only if that overflows a double — every other token goes through strtod; get<float>() /
+// get<int>() are static_casts of whichever of the three was stored.  A key that occurs twice keeps its
+// FIRST value (that version's parser emplaces; newer versions assign, i.e. keep the last — the producer,
+// get_json.cpp:332-341, never writes a key twice).
 #pragma once
+#include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,6 +67,26 @@ struct Scanner {
     ws();
     return p < end && *p == c;
   }
+  static void utf8(std::string *out, unsigned cp) {
+    if (cp < 0x80) out->push_back((char)cp);
+    else if (cp < 0x800) { out->push_back((char)(0xC0 | (cp >> 6))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) { out->push_back((char)(0xE0 | (cp >> 12))); out->push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+    else { out->push_back((char)(0xF0 | (cp >> 18))); out->push_back((char)(0x80 | ((cp >> 12) & 0x3F))); out->push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+  }
+  bool hex4(unsigned *cp) {
+    if (p + 4 > end) return fail("bad \\u escape");
+    unsigned v = 0;
+    for (int k = 0; k < 4; k++) {
+      const char c = p[k];
+      const int d = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+      if (d < 0) return fail("bad \\u escape");
+      v = v * 16 + (unsigned)d;
+    }
+    p += 4;
+    *cp = v;
+    return true;
+  }
+  // a string with its escapes decoded (a key may be spelled "no\u0064es": the reference's parser compares decoded keys)
   bool string(std::string *out) {
     ws();
     if (p >= end || *p != '"') return fail("string expected");
@@ -68,8 +94,21 @@ struct Scanner {
     while (p < end && *p != '"') {
       if (*p == '\\') {
         if (p + 1 >= end) return fail("bad escape");
-        if (out) out->push_back(p[1]);   // keys of this format carry no escapes; keep the raw char
+        const char c = p[1];
         p += 2;
+        if (c == 'u') {
+          unsigned cp;
+          if (!hex4(&cp)) return false;
+          if (cp >= 0xD800 && cp < 0xDC00 && p + 1 < end && p[0] == '\\' && p[1] == 'u') {     // surrogate pair
+            p += 2;
+            unsigned lo;
+            if (!hex4(&lo)) return false;
+            cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+          }
+          if (out) utf8(out, cp);
+        } else if (out) {
+          out->push_back(c == 'n' ? '\n' : c == 't' ? '\t' : c == 'r' ? '\r' : c == 'b' ? '\b' : c == 'f' ? '\f' : c);   // (", \\, / stand for themselves)
+        }
       } else {
         if (out) out->push_back(*p);
         p++;
@@ -79,14 +118,57 @@ struct Scanner {
     p++;
     return true;
   }
-  bool number(double *out) {
+  // a JSON number as nlohmann::json stores it: unsigned, signed or floating
+  struct Num {
+    int kind = 2;            // 0 number_unsigned, 1 number_integer, 2 number_float
+    uint64_t u = 0;
+    int64_t i = 0;
+    double d = 0.0;
+    float as_float() const { return kind == 0 ? static_cast<float>(u) : kind == 1 ? static_cast<float>(i) : static_cast<float>(d); }
+    int as_int() const { return kind == 0 ? static_cast<int>(u) : kind == 1 ? static_cast<int>(i) : static_cast<int>(d); }
+  };
+  bool number(Num *out) {
     ws();
     if (p >= end) return fail("number expected");
-    char *q = nullptr;
-    const double v = strtod(p, &q);      // what nlohmann's lexer uses for floating numbers
-    if (q == p) return fail("number expected");
+    // the token by JSON's grammar: -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?
+    const char *q = p;
+    bool is_float = false;
+    const bool neg = *q == '-';
+    if (neg) q++;
+    if (q >= end || *q < '0' || *q > '9') return fail("number expected");
+    if (*q == '0') q++;
+    else while (q < end && *q >= '0' && *q <= '9') q++;
+    if (q < end && *q == '.') {
+      q++;
+      if (q >= end || *q < '0' || *q > '9') return fail("digit expected after the decimal point");
+      while (q < end && *q >= '0' && *q <= '9') q++;
+      is_float = true;
+    }
+    if (q < end && (*q == 'e' || *q == 'E')) {
+      q++;
+      if (q < end && (*q == '+' || *q == '-')) q++;
+      if (q >= end || *q < '0' || *q > '9') return fail("digit expected in the exponent");
+      while (q < end && *q >= '0' && *q <= '9') q++;
+      is_float = true;
+    }
+    const std::string tok(p, q);
     p = q;
-    if (out) *out = v;
+    if (!out) return true;
+    Num n;
+    if (!is_float) {
+      errno = 0;
+      char *e = nullptr;
+      if (neg) {
+        const long long x = strtoll(tok.c_str(), &e, 10);
+        if (errno == 0) { n.kind = 1; n.i = x; *out = n; return true; }
+      } else {
+        const unsigned long long x = strtoull(tok.c_str(), &e, 10);
+        if (errno == 0) { n.kind = 0; n.u = x; *out = n; return true; }
+      }
+    }
+    n.kind = 2;
+    n.d = strtod(tok.c_str(), nullptr);
+    *out = n;
     return true;
   }
   // nesting is bounded (nlohmann's recursive-descent parser has no such bound, a hostile
@@ -141,24 +223,24 @@ inline bool parse_graph(const char *text, size_t len, OneGraph &g) {
     std::string key;
     if (!s.string(&key) || !s.expect(':')) { g.error = s.err; return false; }
     bool ok;
-    if (key == "nodes") {                       // vector<int> (fromJSON :157)
+    if (key == "nodes" && !have_nodes) {        // vector<int> (fromJSON :157)
       have_nodes = true;
       g.label.clear();
-      ok = s.array([&] { double v; if (!s.number(&v)) return false; g.label.push_back((uint32_t)(int)v); return true; });
-    } else if (key == "centers") {              // vector<Vector3f> (:160, jsonToVector3f :147-153)
+      ok = s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; g.label.push_back((uint32_t)v.as_int()); return true; });
+    } else if (key == "centers" && !have_centers) {   // vector<Vector3f> (:160, jsonToVector3f :147-153)
       have_centers = true;
       g.xyz.clear();
       ok = s.array([&] {
         int k = 0;
-        const bool in = s.array([&] { double v; if (!s.number(&v)) return false; if (k < 3) g.xyz.push_back((float)v); k++; return true; });
+        const bool in = s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; if (k < 3) g.xyz.push_back(v.as_float()); k++; return true; });
         if (in && k < 3) return s.fail("a center needs three coordinates");
         return in;
       });
-    } else if (key == "poses") {                // vector<float> (:161)
+    } else if (key == "poses" && !have_poses) {  // vector<float> (:161)
       have_poses = true;
       g.n_pose = 0;
-      ok = s.array([&] { double v; if (!s.number(&v)) return false; if (g.n_pose < 12) g.pose[g.n_pose] = (float)v; g.n_pose++; return true; });
-    } else {
+      ok = s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; if (g.n_pose < 12) g.pose[g.n_pose] = v.as_float(); g.n_pose++; return true; });
+    } else {                                    // another key, or a second occurrence of one of the three
       ok = s.skip_value();
     }
     if (!ok) { g.error = s.err; return false; }

@@ -111,3 +111,27 @@ def test_map_from_json_equals_map_from_arrays(tmp_path):
         mgr.close()
     for a, c in zip(out[0], out[1]):
         assert np.array_equal(a, c)
+
+
+NLOHMANN = "/opt/conda/include/json.hpp"
+
+
+@pytest.mark.skipif(not os.path.exists(NLOHMANN), reason="nlohmann/json.hpp (the reference's JSON library) is not in this image")
+def test_ingest_equals_the_references_json_library_bit_for_bit():
+    """tests/cpp/test_ingest_nlohmann.cpp: 1500 fuzzed documents parsed with nlohmann::json exactly as
+    Semantic_Graph.hpp:122-184 does (operator>>, get<std::vector<int>>, item[k].get<float>(),
+    get<std::vector<float>>) and with sgtd_graphs_load — xyz, labels, poses and frame offsets equal bit
+    for bit: exponents, -0 (an integer token: +0.0f), integers written as 11.0, integers beyond 2^24 /
+    2^53 / 2^64, denormals, nested unknown keys, keys spelled with \\u escapes, keys that occur twice"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from sgtd_amd import _lib
+    _lib.build_library()
+    exe = os.path.join(root, "tests", "cpp", "test_ingest_nlohmann")
+    lib_dir = os.path.join(root, "sgtd_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "cpp", "test_ingest_nlohmann.cpp"), "-I" + os.path.join(root, "include"),
+                           "-o", exe, "-L" + lib_dir, "-lsgtd_accel", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-pthread"])
+    out = subprocess.run([exe, "1500"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ingest equals nlohmann::json" in out.stdout
