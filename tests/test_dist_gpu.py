@@ -51,3 +51,20 @@ def test_two_rank_bench_shards_and_replicas_agree():
     if torch.cuda.device_count() >= 2:     # one process over both devices (sgtd_create_multi)
         mh = two["multi_device_handle"]
         assert mh["devices"] == 2 and mh["candidates_equal_headline_list"] is True
+
+
+@pytest.mark.gpu
+def test_sharded_search_loop_over_the_collective_backend():
+    """ShardedMap.search_loop in two processes: over RCCL, one GPU per rank, whenever two devices are visible; on a
+    one-GPU box both ranks share cuda:0 and the same collectives run over gloo.  Ranks are child processes of
+    torch.distributed.run, started before anything here touches a GPU."""
+    import socket
+    n_dev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip() or 0)
+    backend = "nccl" if n_dev >= 2 else "gloo"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGTD_TEST_BACKEND=backend)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "tests", "_sharded_search_loop_worker.py")],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "sharded search_loop ok: 2 ranks over %s" % backend in out.stdout

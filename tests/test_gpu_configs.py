@@ -239,3 +239,65 @@ def test_cfg4_100k_frame_map_sharded_eight_ways_behind_one_handle(mods):
         for f in ("side", "frame", "label", "node_id"):
             np.testing.assert_array_equal(getattr(got, f), getattr(ents[k], f))
     multi.close()
+
+
+def test_cfg5_two_50k_frame_sessions_wild_labels_at_cfg4s_size(mods):
+    """BASELINE configs[4] at configs[3]'s size: two sessions of 50 000 frames of ONE world (the second an independent
+    noise draw of the first's observations), 13 "wild" label classes (get_json_wild.cpp:10-12), appended one behind
+    the other in one handle (100 000 frames) and, the same frames, as EIGHT frame-block shards behind one handle on this
+    GPU.  The shard merge must equal the single table (candidates, votes, offsets, match lists), a place must come
+    back from BOTH sessions, the lists must have the properties every candidate_selector result has, and the product
+    sweep's counters of visited entries and rough matches must equal the diagnostic sweep's (the reference's distance
+    test verbatim in f64 on every visited entry) on a sample.  The oracle cannot hold this map."""
+    _, manager, synth = mods
+    F, N, Q = 50000, 200, 48
+    s1 = synth.make_map(F, N, stream=5, label_lo=0, label_hi=12)
+    rng = np.random.Generator(np.random.PCG64(20251121 + 55))
+    x2 = (s1.xyz.astype(np.float64) + rng.normal(0.0, 0.03, size=s1.xyz.shape)).astype(np.float32)      # the same places seen again
+    qs = synth.make_queries(s1, Q, stream=55)
+    single = manager.STDescManager(max_frame_n=2 * F + 1)
+    single.add_frames(s1.xyz, s1.label)
+    single.add_frames(x2, s1.label)               # second session appended: frames F .. 2F-1
+    assert single.current_frame_id_ == 2 * F
+    sres = single.query_frames(qs.xyz, qs.label)
+    st = single.stats()
+    assert st["n_entries"] > 4e8
+    both = 0
+    for q in range(Q):
+        nc = _list_properties(single, sres, q)
+        cf = sres.cand_frame[q, :nc]
+        assert nc > 0
+        both += int(np.any(cf < F) and np.any(cf >= F))
+        assert np.linalg.norm(s1.pose[cf[0] % F, :2] - qs.pose[q, :2]) < 5.0
+    assert both >= 0.9 * Q                       # a place is retrieved from both sessions
+    pairs = [single.result_pairs(q, sres) for q in range(0, Q, 12)]
+    for k, q in enumerate(range(0, Q, 12)):       # a list's entries belong to its candidate's frame, q_idx ascends
+        lo, hi = sres.pair_off[q, 0], sres.pair_off[q, 1]
+        assert np.all(np.diff(pairs[k][0][lo:hi]) >= 0)
+        assert np.all(single.fetch_entries(pairs[k][1][lo:hi][:128]).frame == sres.cand_frame[q, 0])
+    # product sweep (f32 pre-test, sub-cell pruning, four descriptors per visit list) against the diagnostic sweep
+    # (one descriptor at a time, the reference's f64 test on every entry of every gated cell) on two of the queries
+    sub = single.query_frames(qs.xyz[:2], qs.label[:2])
+    prod = single.stats()
+    rough = single.result_rough(0)                # re-runs the two-query batch with the diagnostic sweep
+    diag = single.stats()
+    assert diag["last_P"] == prod["last_P"] and diag["last_M"] == prod["last_M"] and prod["last_M"] > 0
+    assert len(rough["q_idx"]) > 0 and np.array_equal(sub.cand_frame, sres.cand_frame[:2])
+    lo_v, v = single.result_votes(0)
+    counts = np.bincount(rough["frame"].astype(np.int64) - lo_v, minlength=len(v))
+    assert np.array_equal(counts[:len(v)], v)     # the diagnostic list's frames add up to the vote histogram
+    single.close()
+    del single
+    multi = manager.STDescManager(max_frame_n=2 * F + 1, devices=[0] * 8)
+    multi.add_frames(s1.xyz, s1.label)
+    multi.add_frames(x2, s1.label)
+    assert multi.stats()["n_entries"] == st["n_entries"]
+    mres = multi.query_frames(qs.xyz, qs.label)
+    np.testing.assert_array_equal(mres.n_cand, sres.n_cand)
+    np.testing.assert_array_equal(mres.cand_frame, sres.cand_frame)
+    np.testing.assert_array_equal(mres.cand_votes, sres.cand_votes)
+    np.testing.assert_array_equal(mres.pair_off, sres.pair_off)
+    for k, q in enumerate(range(0, Q, 12)):
+        mq, me = multi.result_pairs(q, mres)
+        np.testing.assert_array_equal(mq, pairs[k][0])
+    multi.close()
