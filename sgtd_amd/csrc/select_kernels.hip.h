@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void cand_prefix_kernel(const int *n_cand, con
 #define SGTD_PQ_DESCS SGTD_PQ_THREADS                     // descriptors per super-block: one list per thread
 #define SGTD_PQ_RANK_BITS 17                              // image words: slot << 26 | descriptor in super-block << 17 | rank in frame
 static_assert(SGTD_PQ_DESCS <= 512 && SGTD_MAX_CAND <= 64, "an image word holds 6 slot bits and 9 descriptor bits");
-static_assert(SGTD_PQ_WAVE_RECS * 4 >= 8 * 64 * 8 && SGTD_PQ_WAVES == 8, "a wave's region of the image holds the ranking masks of eight dense words; image positions rotate over eight regions");
+static_assert(SGTD_PQ_WAVE_RECS * 4 >= 4 * 64 * 8 && SGTD_PQ_WAVES == 8, "a wave's region of the image holds the ranking masks of four dense words; image positions rotate over eight regions");
 
 // One non-empty list of the super-block as the tiles see it: its first quad in the super-block's stream of
 // quads, its first record, its records, its descriptor (index inside the super-block).
@@ -234,7 +234,7 @@ struct __attribute__((aligned(16))) PqList { u32 pre, first, n, desc; };
 
 // dynamic LDS: u32 image[SGTD_PQ_TILE_RECS] | slot table u8[span rounded to 16, + 16] (SLOT_TABLE)
 template <bool SLOT_TABLE>
-__global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
+__global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void pairs_query_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
                                                                        const int *cand_frame, int cand_num,
                                                                        const long long *pair_off, const u32 *q_pair_base,
                                                                        u64 *pairs, IdMap map, u32 frame_span, u32 frame_lo) {
@@ -362,74 +362,98 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView 
 #endif
       // ---- the wave's candidate records, in stream order (word, lane, record of the quad), as image words
       // in its own region of the image
-      s_cnt[wid][lane] = 0;
       u32 nd = 0;      // wave-uniform: dense words so far
+      static_assert(QW % 2 == 0, "the candidates of two quad-words are counted by one wave scan (16-bit halves)");
 #pragma unroll
-      for (int u = 0; u < QW; u++) {
-        const u32 w4[4] = {rc[u].x, rc[u].y, rc[u].z, rc[u].w};
-        u32 sl[4], mine = 0;
+      for (int u0 = 0; u0 < QW; u0 += 2) {
+        u32 sl[2][4], mine[2] = {0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const u32 lf = w4[i] >> id_bits;                 // local frame (a dead record's is beyond every span)
-          if (SLOT_TABLE) {
-            sl[i] = (u32)s_slot8[min(lf, frame_span)];
-            sl[i] = (u32)i < kk[u] ? sl[i] : 0xFFu;
-          } else {
-            sl[i] = 0xFFu;
-            if ((u32)i < kk[u] && lf < frame_span) sl[i] = cand_slot(s_cand, lf + frame_lo);
+        for (int h = 0; h < 2; h++) {
+          const int u = u0 + h;
+          const u32 w4[4] = {rc[u].x, rc[u].y, rc[u].z, rc[u].w};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 lf = w4[i] >> id_bits;                 // local frame (a dead record's is beyond every span)
+            if (SLOT_TABLE) {
+              sl[h][i] = (u32)s_slot8[min(lf, frame_span)];
+              sl[h][i] = (u32)i < kk[u] ? sl[h][i] : 0xFFu;
+            } else {
+              sl[h][i] = 0xFFu;
+              if ((u32)i < kk[u] && lf < frame_span) sl[h][i] = cand_slot(s_cand, lf + frame_lo);
+            }
+            mine[h] += sl[h][i] != 0xFFu ? 1u : 0u;
           }
-          mine += sl[i] != 0xFFu ? 1u : 0u;
         }
-        const u32 inc = wave_incl_scan(mine);
-        u32 at = nd + inc - mine;
+        // (a wave's candidates of one quad-word are at most 256: the two counts travel in the halves of one word)
+        const u32 both = mine[0] | (mine[1] << 16);
+        const u32 inc = wave_incl_scan(both);
+        const u32 tot2 = (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
+        u32 at[2] = {nd + ((inc - both) & 0xFFFFu), nd + (tot2 & 0xFFFFu) + ((inc - both) >> 16)};
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (sl[i] != 0xFFu) my_img[at++] = (sl[i] << 26) | dd[u] | (w4[i] & rank_mask);
-        nd += (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
+        for (int h = 0; h < 2; h++) {
+          const int u = u0 + h;
+          const u32 w4[4] = {rc[u].x, rc[u].y, rc[u].z, rc[u].w};
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (sl[h][i] != 0xFFu) my_img[at[h]++] = (sl[h][i] << 26) | dd[u] | (w4[i] & rank_mask);
+        }
+        nd += (tot2 & 0xFFFFu) + (tot2 >> 16);
       }
+#if defined(SGTD_EXP_PQ) && SGTD_EXP_PQ == 3
+      if (nd == 0xFFFFFFFFu) pairs[0] = 0;     // experiment build (never shipped): locate, loads and the candidates' dense words alone
+      continue;
+#endif
       __builtin_amdgcn_wave_barrier();
       // ---- dense words back into registers; the wave's region of the image then serves as scratch for the
       // ranking: per batch of eight dense words and slot the lanes of the word that carry the slot (commutative
       // LDS ORs: the result does not depend on the order the hardware applies them in).  A record's rank among the
       // wave's records of its slot = the slot's records in the words before (lane s counts slot s) + the lanes
       // before it in its own word's mask: stable in stream order.
-      constexpr int MAXD = SGTD_PQ_WAVE_RECS / SGTD_WAVE, BATCH = 8;
+      constexpr int MAXD = SGTD_PQ_WAVE_RECS / SGTD_WAVE, GRP = 4;     // (one branch per group of four dense words: a wave has 3.5 on average)
       u32 dw[MAXD], rk[MAXD];
       const u32 ndw = (nd + SGTD_WAVE - 1) / SGTD_WAVE;
 #pragma unroll
-      for (int w = 0; w < MAXD; w++) {
-        dw[w] = 0xFFFFFFFFu; rk[w] = 0;
-        if ((u32)w < ndw && (u32)(w * SGTD_WAVE + lane) < nd) dw[w] = my_img[w * SGTD_WAVE + lane];
+      for (int g0 = 0; g0 < MAXD; g0 += GRP) {
+#pragma unroll
+        for (int w = g0; w < g0 + GRP; w++) { dw[w] = 0xFFFFFFFFu; rk[w] = 0; }
+        if ((u32)g0 < ndw) {
+#pragma unroll
+          for (int w = g0; w < g0 + GRP; w++) {
+            const u32 v = my_img[w * SGTD_WAVE + lane];          // (inside the wave's region whatever nd is)
+            dw[w] = (u32)(w * SGTD_WAVE + lane) < nd ? v : 0xFFFFFFFFu;
+          }
+        }
       }
       u32 run_s = 0;        // lane s: the wave's records of slot s so far
-      u64 *m = reinterpret_cast<u64 *>(my_img);      // [BATCH][64]
+      u64 *m = reinterpret_cast<u64 *>(my_img);      // [GRP][64]
 #pragma unroll
-      for (int b0 = 0; b0 < MAXD; b0 += BATCH) {
-        if ((u32)b0 < ndw) {
+      for (int g0 = 0; g0 < MAXD; g0 += GRP) {
+        if ((u32)g0 < ndw) {
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int w = 0; w < BATCH; w++)
-            if ((u32)(b0 + w) < ndw) m[w * SGTD_WAVE + lane] = 0;
+          for (int w = 0; w < GRP; w++) m[w * SGTD_WAVE + lane] = 0;
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int w = 0; w < BATCH; w++)
-            if ((u32)(b0 + w) < ndw && dw[b0 + w] != 0xFFFFFFFFu) atomicOr(&m[w * SGTD_WAVE + (dw[b0 + w] >> 26)], lane_bit);
+          for (int w = 0; w < GRP; w++)
+            if (dw[g0 + w] != 0xFFFFFFFFu) atomicOr(&m[w * SGTD_WAVE + (dw[g0 + w] >> 26)], lane_bit);
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int w = 0; w < BATCH; w++) {
-            if ((u32)(b0 + w) < ndw) {
-              const u64 own = m[w * SGTD_WAVE + lane];
-              const u32 s = (dw[b0 + w] >> 26) & 63u;
-              const u64 gm = m[w * SGTD_WAVE + s];
-              const u32 before = (u32)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)run_s);
-              rk[b0 + w] = before + __builtin_amdgcn_mbcnt_hi((u32)(gm >> 32), __builtin_amdgcn_mbcnt_lo((u32)gm, 0u));
-              run_s += (u32)__builtin_popcountll(own);
-            }
+          for (int w = 0; w < GRP; w++) {
+            const u64 own = m[w * SGTD_WAVE + lane];
+            const u32 s = (dw[g0 + w] >> 26) & 63u;
+            const u64 gm = m[w * SGTD_WAVE + s];
+            const u32 before = (u32)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)run_s);
+            rk[g0 + w] = before + __builtin_amdgcn_mbcnt_hi((u32)(gm >> 32), __builtin_amdgcn_mbcnt_lo((u32)gm, 0u));
+            run_s += (u32)__builtin_popcountll(own);
           }
         }
       }
       s_cnt[wid][lane] = run_s;
       __syncthreads();
+#if defined(SGTD_EXP_PQ) && SGTD_EXP_PQ == 4
+      if (rk[0] == 0xFFFFFFF1u) pairs[0] = 0;     // experiment build (never shipped): everything up to the ranking and the first barrier
+      continue;
+#endif
       // ---- where the wave's records of slot s go in the image: behind the slots before s and the waves before it
       u32 tot = 0, mine_before = 0;
 #pragma unroll
@@ -446,14 +470,21 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) void pairs_query_kernel(QueryView 
       // flushes the 64-record chunks of its own region — nobody else reads them, so the next tile's dense words
       // can follow without a barrier
 #pragma unroll
-      for (int w = 0; w < MAXD; w++) {
-        if ((u32)w < ndw) {
-          const u32 pos = (u32)__builtin_amdgcn_ds_bpermute((int)((dw[w] >> 26) << 2), (int)my_base) + rk[w];
-          if (dw[w] != 0xFFFFFFFFu)
-            s_img[((pos >> 6) & (NW - 1)) * SGTD_PQ_WAVE_RECS + ((pos >> 9) << 6) + (pos & 63u)] = dw[w];
+      for (int g0 = 0; g0 < MAXD; g0 += GRP) {
+        if ((u32)g0 < ndw) {
+#pragma unroll
+          for (int w = g0; w < g0 + GRP; w++) {
+            const u32 pos = (u32)__builtin_amdgcn_ds_bpermute((int)((dw[w] >> 26) << 2), (int)my_base) + rk[w];
+            if (dw[w] != 0xFFFFFFFFu)
+              s_img[((pos >> 6) & (NW - 1)) * SGTD_PQ_WAVE_RECS + ((pos >> 9) << 6) + (pos & 63u)] = dw[w];
+          }
         }
       }
       __syncthreads();
+#if defined(SGTD_EXP_PQ) && SGTD_EXP_PQ == 5
+      out_next += tot;      // experiment build (never shipped): everything but the flush
+      continue;
+#endif
       // ---- the image goes out: position e of slot s's run continues candidate s's list
       for (u32 c = (u32)wid; c * SGTD_WAVE < n_img; c += NW) {      // (wave-uniform: the permutes read lanes 0..63)
         const u32 e = c * SGTD_WAVE + lane;

@@ -14,6 +14,9 @@ from oracle import oracle  # noqa: E402
 from sgtd_amd import manager, synth  # noqa: E402
 
 
+FORMS = {}
+
+
 def one_round(rng, rnd):
     k = int(rng.integers(3, 13))
     cfg = dict(descriptor_near_num=k, std_side_resolution=float(rng.choice([0.25, 0.5, 1.0, 2.0])),
@@ -38,6 +41,11 @@ def one_round(rng, rnd):
     sigma = float(rng.choice([0.0, 0.02, 0.3]))          # 0.0: re-observed frames are exact copies (many twins)
     m = synth.make_map(n_frames, n_kp, stream=stream, label_lo=labels[0], label_hi=labels[1], sigma=max(sigma, 1e-4))
     q = synth.make_queries(m, 3, stream=stream)
+    # the passes over the match records: the five-kernel form, or one workgroup per query (select_kernels.hip.h) —
+    # production picks the latter only for batches with a query per CU, the hook forces it on these small ones
+    form = "2" if rng.random() < 0.6 else "1"
+    __import__("os").environ["SGTD_SELECT_MODE"] = form
+    FORMS[form] = FORMS.get(form, 0) + 1
     g = manager.STDescManager(devices=[0, 0, 0] if multi else None, **cfg)
     o = oracle.OracleManager(**cfg)
     desc = "round %d: K=%d res=%g rough=%g cand=%d n_kp=%d F=%d labels=%s %s%s sigma=%g" % (
@@ -122,7 +130,8 @@ def main():
         except Exception:
             head = ""
         with open(sys.argv[3], "a") as fh:
-            fh.write(json.dumps({"rounds_without_a_difference": rnd, "seconds": round(time.time() - t0, 1), "seed": seed, "git_head": head,
+            fh.write(json.dumps({"rounds_without_a_difference": rnd, "rounds_per_query_workgroups": FORMS.get("2", 0), "rounds_block_passes": FORMS.get("1", 0),
+                                 "seconds": round(time.time() - t0, 1), "seed": seed, "git_head": head,
                                  "compared": "candidates, votes, ordered match lists, P/M counters, ordered rough list (q, cell, entry, frame, dis) against oracle/sgtd_oracle.cpp",
                                  "last_round": d}) + "\n")
 
