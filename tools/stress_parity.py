@@ -125,10 +125,11 @@ def main():
         import json
         import subprocess
         root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+        head = __import__("os").environ.get("STRESS_HEAD", "")      # (the GPU box's copy of the tree has no .git)
         try:
-            head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+            head = head or subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
         except Exception:
-            head = ""
+            pass
         with open(sys.argv[3], "a") as fh:
             fh.write(json.dumps({"rounds_without_a_difference": rnd, "rounds_per_query_workgroups": FORMS.get("2", 0), "rounds_block_passes": FORMS.get("1", 0),
                                  "seconds": round(time.time() - t0, 1), "seed": seed, "git_head": head,
