@@ -226,6 +226,49 @@ __device__ unsigned long long g_vstat[8];
 #endif
 typedef const __attribute__((address_space(4))) f32x2 *sgtd_const_f32x2;
 typedef const __attribute__((address_space(4))) double *sgtd_const_f64;
+// The (pair, hypothesis) combinations the f32 tests could not decide, per lane as bit masks: all three vertices in f64
+// with the exact squared threshold (vertex_close), votes straight into the workgroup's LDS counters.  Behind the vote loop:
+// its f64 temporaries are live only where the loop's own (the hypothesis, the distances) are dead.
+__device__ __forceinline__ void verify_pending(const VerifyParams &P, sgtd_const_f64 hyp64, const f32x2 (&v)[3][3], const f32x2 (&w)[3][3],
+                                                         u64 (&pend)[SGTD_VERIFY_PPT], u64 (&passed)[SGTD_VERIFY_PPT], u32 *s_votes) {
+#pragma unroll
+  for (int u = 0; u < SGTD_VERIFY_PPT; u++) {
+    while (pend[u]) {
+      const int h = __builtin_ctzll(pend[u]);
+      pend[u] &= pend[u] - 1ull;
+      // (R, t) of the hypothesis row by row, re-read for every vertex (volatile: twelve doubles held across the three
+      // vertices would not fit beside the loop's vertex registers); the operations and their order are vertex_close's
+      const volatile double *hp = reinterpret_cast<const volatile double *>((unsigned long long)hyp64) + (size_t)h * SGTD_HYP_F64;
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < 3; m++) {
+        const double a0 = (double)(u ? v[m][0].y : v[m][0].x), a1 = (double)(u ? v[m][1].y : v[m][1].x), a2 = (double)(u ? v[m][2].y : v[m][2].x);
+        double d2;
+        {
+          const double r0 = hp[0], r1 = hp[1], r2 = hp[2], t = hp[9];
+          const double dx = ((r0 * a0 + r1 * a1 + r2 * a2) + t) - (double)(u ? w[m][0].y : w[m][0].x);
+          d2 = dx * dx;
+        }
+        {
+          const double r0 = hp[3], r1 = hp[4], r2 = hp[5], t = hp[10];
+          const double dy = ((r0 * a0 + r1 * a1 + r2 * a2) + t) - (double)(u ? w[m][1].y : w[m][1].x);
+          d2 = d2 + dy * dy;
+        }
+        {
+          const double r0 = hp[6], r1 = hp[7], r2 = hp[8], t = hp[11];
+          const double dz = ((r0 * a0 + r1 * a1 + r2 * a2) + t) - (double)(u ? w[m][2].y : w[m][2].x);
+          d2 = d2 + dz * dz;
+        }
+        ok = ok && (d2 < P.thr2);
+      }
+      if (ok) {
+        passed[u] |= 1ull << h;
+        atomicAdd(&s_votes[h], 1u);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_kernel(VerifyParams P) {
   __shared__ u32 s_votes[SGTD_VERIFY_MAX_HYP];
   __shared__ u32 s_best, s_count;
@@ -294,13 +337,16 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
 #ifdef SGTD_EXP_VSTAT
     u64 any0 = 0, any1 = 0;
 #endif
+    // A vertex test that f32 cannot decide does not interrupt the loop: the pair stays in for the hypothesis and is marked;
+    // a pair that comes through all three vertices with a mark is decided afterwards, outside the loop, exactly as the
+    // reference computes it (f64, all three vertices).  The loop itself holds no f64 value: no scratch.
+    u64 pend[PPT] = {0ull, 0ull};          // bit h: (this pair, hypothesis h) passed the f32 tests only with a mark
     for (int h = 0; h < use_size; h++) {
       f32x2 R[12];      // R00 R01 R02 R10 R11 R12 R20 R21 R22 t0 t1 t2, each in both halves (scalar registers)
 #pragma unroll
       for (int k = 0; k < 12; k++) R[k] = hyp32[h * 12 + k];
-      // vertex m of both pairs: certainly close (stays in), certainly far (leaves), or undecided in
-      // f32 — then decided exactly, as the reference computes it
-      auto vertex = [&](int m, u64 &in0, u64 &in1) {
+      // vertex m of both pairs: certainly far (leaves), certainly close, or undecided in f32 (stays in, marked)
+      auto vertex = [&](int m, u64 &in0, u64 &in1, u64 &mark0, u64 &mark1) {
         const f32x2 px = __builtin_elementwise_fma(R[0], v[m][0], __builtin_elementwise_fma(R[1], v[m][1], __builtin_elementwise_fma(R[2], v[m][2], R[9])));
         const f32x2 py = __builtin_elementwise_fma(R[3], v[m][0], __builtin_elementwise_fma(R[4], v[m][1], __builtin_elementwise_fma(R[5], v[m][2], R[10])));
         const f32x2 pz = __builtin_elementwise_fma(R[6], v[m][0], __builtin_elementwise_fma(R[7], v[m][1], __builtin_elementwise_fma(R[8], v[m][2], R[11])));
@@ -308,52 +354,38 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
         const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
         const u64 sure0 = __builtin_amdgcn_ballot_w64(d2.x < lo2.x), sure1 = __builtin_amdgcn_ballot_w64(d2.y < lo2.y);
         const u64 far0 = __builtin_amdgcn_ballot_w64(d2.x > hi2.x), far1 = __builtin_amdgcn_ballot_w64(d2.y > hi2.y);
-        u64 amb0 = in0 & ~sure0 & ~far0, amb1 = in1 & ~sure1 & ~far1;     // (a NaN is neither sure nor far)
-        in0 &= sure0; in1 &= sure1;
-        if (amb0 | amb1) {     // rare
-          double Rt[12];
-#pragma unroll
-          for (int k = 0; k < 12; k++) Rt[k] = hyp64[h * 12 + k];
-          bool ex0 = false, ex1 = false;
-          if ((amb0 >> lane) & 1ull) {
-            const double qa[3] = {(double)v[m][0].x, (double)v[m][1].x, (double)v[m][2].x};
-            const double ea[3] = {(double)w[m][0].x, (double)w[m][1].x, (double)w[m][2].x};
-            ex0 = vertex_close(Rt, qa, ea, P.thr2);
-          }
-          if ((amb1 >> lane) & 1ull) {
-            const double qa[3] = {(double)v[m][0].y, (double)v[m][1].y, (double)v[m][2].y};
-            const double ea[3] = {(double)w[m][0].y, (double)w[m][1].y, (double)w[m][2].y};
-            ex1 = vertex_close(Rt, qa, ea, P.thr2);
-          }
-          in0 |= __builtin_amdgcn_ballot_w64(ex0);
-          in1 |= __builtin_amdgcn_ballot_w64(ex1);
-        }
+        in0 &= ~far0; in1 &= ~far1;                       // (a NaN is neither sure nor far)
+        mark0 |= in0 & ~sure0; mark1 |= in1 & ~sure1;
       };
-      u64 in0 = valid0, in1 = valid1;
+      u64 in0 = valid0, in1 = valid1, mark0 = 0, mark1 = 0;
       VSTAT(0, 1); VSTAT(7, __builtin_popcountll(in0) + __builtin_popcountll(in1));
-      vertex(0, in0, in1);
+      vertex(0, in0, in1, mark0, mark1);
       VSTAT(2, __builtin_popcountll(in0) + __builtin_popcountll(in1));
 #ifdef SGTD_EXP_VSTAT
       any0 |= in0; any1 |= in1;
 #endif
       if (in0 | in1) {       // wrong hypotheses fail at vertex A for the whole wave
         VSTAT(1, 1);
-        vertex(1, in0, in1);
+        vertex(1, in0, in1, mark0, mark1);
         VSTAT(3, __builtin_popcountll(in0) + __builtin_popcountll(in1));
-        if (in0 | in1) vertex(2, in0, in1);
+        if (in0 | in1) vertex(2, in0, in1, mark0, mark1);
         VSTAT(4, __builtin_popcountll(in0) + __builtin_popcountll(in1));
         if (in0 | in1) {
-          if ((in0 >> lane) & 1ull) passed[0] |= 1ull << h;
-          if ((in1 >> lane) & 1ull) passed[1] |= 1ull << h;
-          const u32 cnt = (u32)__builtin_popcountll(in0) + (u32)__builtin_popcountll(in1);
+          mark0 &= in0; mark1 &= in1;
+          const u64 yes0 = in0 & ~mark0, yes1 = in1 & ~mark1;
+          if ((yes0 >> lane) & 1ull) passed[0] |= 1ull << h;
+          if ((yes1 >> lane) & 1ull) passed[1] |= 1ull << h;
+          const u32 cnt = (u32)__builtin_popcountll(yes0) + (u32)__builtin_popcountll(yes1);
           if (lane == h) acc += cnt;
+          if (mark0 | mark1) {     // rare
+            if ((mark0 >> lane) & 1ull) pend[0] |= 1ull << h;
+            if ((mark1 >> lane) & 1ull) pend[1] |= 1ull << h;
+          }
         }
       }
     }
-#ifdef SGTD_EXP_VSTAT
-    VSTAT(5, __builtin_popcountll(valid0) + __builtin_popcountll(valid1));
-    VSTAT(6, __builtin_popcountll(any0) + __builtin_popcountll(any1));
-#endif
+    // ---- the marked (pair, hypothesis) combinations, decided as the reference decides them (:488-505)
+    if (__builtin_amdgcn_ballot_w64((pend[0] | pend[1]) != 0ull)) verify_pending(P, hyp64, v, w, pend, passed, s_votes);
     // what the inlier pass needs of this pair: no second walk over the vertices
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
