@@ -226,44 +226,47 @@ __device__ unsigned long long g_vstat[8];
 #endif
 typedef const __attribute__((address_space(4))) f32x2 *sgtd_const_f32x2;
 typedef const __attribute__((address_space(4))) double *sgtd_const_f64;
-// The (pair, hypothesis) combinations the f32 tests could not decide, per lane as bit masks: all three vertices in f64
-// with the exact squared threshold (vertex_close), votes straight into the workgroup's LDS counters.  Behind the vote loop:
-// its f64 temporaries are live only where the loop's own (the hypothesis, the distances) are dead.
-__device__ __forceinline__ void verify_pending(const VerifyParams &P, sgtd_const_f64 hyp64, const f32x2 (&v)[3][3], const f32x2 (&w)[3][3],
-                                                         u64 (&pend)[SGTD_VERIFY_PPT], u64 (&passed)[SGTD_VERIFY_PPT], u32 *s_votes) {
+// OR over the 64 lanes, the same value in every lane (the DPP steps of wave_incl_scan with | for +)
+__device__ __forceinline__ u32 wave_or(u32 v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (u32)__builtin_amdgcn_readlane(x, SGTD_WAVE - 1);
+}
+
+// The (pair, hypothesis) combinations the f32 tests could not decide (per lane: bit masks), hypothesis by hypothesis
+// for the whole wave: (R, t) in f64 through the scalar data path, the marked lanes test all three vertices with the exact
+// squared threshold — the operations and their order are vertex_close's — and vote straight into the workgroup's LDS
+// counters.  Behind the vote loop, and on vertices read again from memory: nothing of the loop's registers is live here.
+__device__ __forceinline__ void verify_pending(const VerifyParams &P, sgtd_const_f64 hyp64, const float *const (&qp)[SGTD_VERIFY_PPT],
+                                               const float *const (&ep)[SGTD_VERIFY_PPT], u64 (&pend)[SGTD_VERIFY_PPT],
+                                               u64 (&passed)[SGTD_VERIFY_PPT], u32 *s_votes) {
+  const u64 mine = pend[0] | pend[1];
+  u64 any = ((u64)wave_or((u32)(mine >> 32)) << 32) | (u64)wave_or((u32)mine);
+  while (any) {
+    const int h = __builtin_ctzll(any);
+    any &= any - 1ull;
+    double Rt[12];
 #pragma unroll
-  for (int u = 0; u < SGTD_VERIFY_PPT; u++) {
-    while (pend[u]) {
-      const int h = __builtin_ctzll(pend[u]);
-      pend[u] &= pend[u] - 1ull;
-      // (R, t) of the hypothesis row by row, re-read for every vertex (volatile: twelve doubles held across the three
-      // vertices would not fit beside the loop's vertex registers); the operations and their order are vertex_close's
-      const volatile double *hp = reinterpret_cast<const volatile double *>((unsigned long long)hyp64) + (size_t)h * SGTD_HYP_F64;
-      bool ok = true;
+    for (int k = 0; k < 12; k++) Rt[k] = hyp64[h * SGTD_HYP_F64 + k];
 #pragma unroll
-      for (int m = 0; m < 3; m++) {
-        const double a0 = (double)(u ? v[m][0].y : v[m][0].x), a1 = (double)(u ? v[m][1].y : v[m][1].x), a2 = (double)(u ? v[m][2].y : v[m][2].x);
-        double d2;
-        {
-          const double r0 = hp[0], r1 = hp[1], r2 = hp[2], t = hp[9];
-          const double dx = ((r0 * a0 + r1 * a1 + r2 * a2) + t) - (double)(u ? w[m][0].y : w[m][0].x);
-          d2 = dx * dx;
+    for (int u = 0; u < SGTD_VERIFY_PPT; u++) {
+      if ((pend[u] >> h) & 1ull) {
+        bool ok = true;
+#pragma unroll 1
+        for (int m = 0; m < 3; m++) {
+          const double qa[3] = {(double)qp[u][3 * m], (double)qp[u][3 * m + 1], (double)qp[u][3 * m + 2]};
+          const double ea[3] = {(double)ep[u][3 * m], (double)ep[u][3 * m + 1], (double)ep[u][3 * m + 2]};
+          ok = ok && vertex_close(Rt, qa, ea, P.thr2);
         }
-        {
-          const double r0 = hp[3], r1 = hp[4], r2 = hp[5], t = hp[10];
-          const double dy = ((r0 * a0 + r1 * a1 + r2 * a2) + t) - (double)(u ? w[m][1].y : w[m][1].x);
-          d2 = d2 + dy * dy;
+        if (ok) {
+          passed[u] |= 1ull << h;
+          atomicAdd(&s_votes[h], 1u);
         }
-        {
-          const double r0 = hp[6], r1 = hp[7], r2 = hp[8], t = hp[11];
-          const double dz = ((r0 * a0 + r1 * a1 + r2 * a2) + t) - (double)(u ? w[m][2].y : w[m][2].x);
-          d2 = d2 + dz * dz;
-        }
-        ok = ok && (d2 < P.thr2);
-      }
-      if (ok) {
-        passed[u] |= 1ull << h;
-        atomicAdd(&s_votes[h], 1u);
       }
     }
   }
@@ -278,9 +281,9 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
   if (c >= P.n_cand[q]) { if (tid == 0) *score = -1.0; return; }
   const long long *po = P.pair_off + (size_t)q * (P.cand_num + 1);
   const u32 base = P.q_pair_base[q] + (u32)po[c];
-  const long long n = po[c + 1] - po[c];
-  const int skip_len = (int)(n / 50) + 1;          // :467
-  const int use_size = (int)(n / skip_len);        // :468
+  const u32 n = (u32)(po[c + 1] - po[c]);          // (a batch's pairs are indexed with 32 bits)
+  const int skip_len = (int)(n / 50u) + 1;         // :467
+  const int use_size = (int)(n / (u32)skip_len);   // :468
   const size_t qslot0 = (size_t)q * (size_t)P.q_stride;
   const sgtd_const_f32x2 hyp32 = (sgtd_const_f32x2)(unsigned long long)(P.hyp32 + (size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F32);
   const sgtd_const_f64 hyp64 = (sgtd_const_f64)(unsigned long long)(P.hyp64 + (size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F64);
@@ -291,10 +294,10 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
 
   // ---- votes of every hypothesis (:488-505).  f32 pre-test of a vertex, both pairs of a thread
   // in the halves of packed operations (vertex B only where A passed, C only where B passed): p^ = fma chain of the f32-rounded (R, t) on the exact f32
-  // vertices.  With u = 2^-24, |p^_i - p_i| <= 4 u (Rmax |v|_1 + |t|_1) (one rounding of R and t,
-  // three fused operations), the difference and the sum of squares add relative errors of a
-  // few u, so | ||d^|| - ||d|| | <= E = 16 u (Rmax |v|_1 + tmax + thr) with room to spare (the
-  // f64 evaluation of the reference is within 1e-15 relative of the exact value):
+  // vertices, d^ = fma(R0, v0, fma(R1, v1, fma(R2, v2, t - w))).  With u = 2^-24, |d^_i - d_i| <= 5 u (Rmax |v|_1 + |t|_1 + |w|_1)
+  // (one rounding of R and t, one subtraction, three fused operations, every partial sum below that magnitude), the sum
+  // of squares adds relative errors of a few u, so | ||d^|| - ||d|| | <= E = 16 u (Rmax |v|_1 + tmax + |w|_1 + thr) with room
+  // to spare (the f64 evaluation of the reference is within 1e-15 relative of the exact value):
   //   d2^ < (thr - E)^2 (1 - 8u)  ==>  the reference's test passes
   //   d2^ > (thr + E)^2 (1 + 8u)  ==>  it fails;  anything else (NaN included) is decided in f64.
   u32 acc = 0;   // lane h of every wave: votes of hypothesis h seen by this wave
@@ -303,28 +306,29 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
   const float uf = 5.9604644775390625e-08f;
   const float rmaxf = __uint_as_float(P.bound[2 * (size_t)blockIdx.x]), tmaxf = __uint_as_float(P.bound[2 * (size_t)blockIdx.x + 1]);
   const float thrf = (float)(sqrt(P.thr2) * 1.000001);
-  for (long long j0 = 0; j0 < n; j0 += (long long)PPT * SGTD_VERIFY_THREADS) {
+  for (u32 j0 = 0; j0 < n; j0 += (u32)PPT * SGTD_VERIFY_THREADS) {
     bool valid[PPT];
     f32x2 v[3][3], w[3][3];        // [vertex A, B, C][x, y, z], the two pairs in the halves (f32 as stored)
     f32x2 lo2, hi2;                // the two squared f32 thresholds of each pair (from its largest vertex)
-    u64 passed[PPT] = {0ull, 0ull};        // bit h: the pair votes for hypothesis h
+    u64 passed[PPT];                       // bit h: the pair votes for hypothesis h
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
-      const long long j = j0 + (long long)u * SGTD_VERIFY_THREADS + tid;
+      const u32 j = j0 + (u32)u * SGTD_VERIFY_THREADS + (u32)tid;
       valid[u] = j < n;
-      const u64 pr = P.pairs[base + (valid[u] ? j : 0)];
+      const u64 pr = P.pairs[base + (valid[u] ? j : 0u)];
       const float *qp = P.q_vertex + (qslot0 + (size_t)(pr >> 32)) * 9, *ep = P.t_vertex + (size_t)(pr & 0xFFFFFFFFull) * 9;
-      float vmax = 0.0f;
+      float vmax = 0.0f, wmax = 0.0f;
 #pragma unroll
       for (int m = 0; m < 3; m++) {
         const float a0 = qp[3 * m], a1 = qp[3 * m + 1], a2 = qp[3 * m + 2];
         const float b0 = ep[3 * m], b1 = ep[3 * m + 1], b2 = ep[3 * m + 2];
-        const float s1 = (fabsf(a0) + fabsf(a1)) + fabsf(a2);
+        const float s1 = (fabsf(a0) + fabsf(a1)) + fabsf(a2), s2 = (fabsf(b0) + fabsf(b1)) + fabsf(b2);
         vmax = !(s1 <= vmax) ? s1 : vmax;                           // max that keeps a NaN
+        wmax = !(s2 <= wmax) ? s2 : wmax;
         if (u == 0) { v[m][0].x = a0; v[m][1].x = a1; v[m][2].x = a2; w[m][0].x = b0; w[m][1].x = b1; w[m][2].x = b2; }
         else { v[m][0].y = a0; v[m][1].y = a1; v[m][2].y = a2; w[m][0].y = b0; w[m][1].y = b1; w[m][2].y = b2; }
       }
-      const float E = 16.0f * uf * (rmaxf * vmax + tmaxf + thrf);
+      const float E = 16.0f * uf * (rmaxf * vmax + tmaxf + wmax + thrf);
       const float lo = thrf * 0.999998f - E, hi = thrf + E;     // (thrf was rounded up by 1e-6: take it back for lo)
       const float l2 = lo > 0.0f ? lo * lo * (1.0f - 8.0f * uf) : 0.0f;  // NaN E: lo2 = 0 (never certainly in) ...
       const float h2 = hi * hi * (1.0f + 8.0f * uf);                     // ... and hi2 = NaN (never certainly out)
@@ -337,59 +341,72 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
 #ifdef SGTD_EXP_VSTAT
     u64 any0 = 0, any1 = 0;
 #endif
-    // A vertex test that f32 cannot decide does not interrupt the loop: the pair stays in for the hypothesis and is marked;
-    // a pair that comes through all three vertices with a mark is decided afterwards, outside the loop, exactly as the
-    // reference computes it (f64, all three vertices).  The loop itself holds no f64 value: no scratch.
-    u64 pend[PPT] = {0ull, 0ull};          // bit h: (this pair, hypothesis h) passed the f32 tests only with a mark
-    for (int h = 0; h < use_size; h++) {
-      f32x2 R[12];      // R00 R01 R02 R10 R11 R12 R20 R21 R22 t0 t1 t2, each in both halves (scalar registers)
+    // One step = one hypothesis against the wave's 2 x 64 pairs: the three vertices' squared f32 distances, their maximum
+    // against the pair's two thresholds — certainly far (some vertex is: no vote), certainly close (all three are: a vote),
+    // or undecided in f32: the pair is marked for the hypothesis and decided behind the loop, exactly as the reference
+    // computes it (f64, all three vertices).  A pair with a NaN or an infinity anywhere has lo2 = 0 and hi2 = NaN / inf
+    // (E above): never sure, never far.  The loop holds no f64 value.
+    u64 pend[PPT] = {0ull, 0ull};          // bit h: (this pair, hypothesis h) is undecided in f32
+    u32 pw[PPT][2] = {{0u, 0u}, {0u, 0u}}; // passed[u], low and high word
+    auto steps = [&](int h_lo, int h_hi, u32 &p0, u32 &p1) {
+      for (int h = h_lo; h < h_hi; h++) {
+        f32x2 R[12];      // R00 R01 R02 R10 R11 R12 R20 R21 R22 t0 t1 t2, each in both halves (scalar registers)
 #pragma unroll
-      for (int k = 0; k < 12; k++) R[k] = hyp32[h * 12 + k];
-      // vertex m of both pairs: certainly far (leaves), certainly close, or undecided in f32 (stays in, marked)
-      auto vertex = [&](int m, u64 &in0, u64 &in1, u64 &mark0, u64 &mark1) {
-        const f32x2 px = __builtin_elementwise_fma(R[0], v[m][0], __builtin_elementwise_fma(R[1], v[m][1], __builtin_elementwise_fma(R[2], v[m][2], R[9])));
-        const f32x2 py = __builtin_elementwise_fma(R[3], v[m][0], __builtin_elementwise_fma(R[4], v[m][1], __builtin_elementwise_fma(R[5], v[m][2], R[10])));
-        const f32x2 pz = __builtin_elementwise_fma(R[6], v[m][0], __builtin_elementwise_fma(R[7], v[m][1], __builtin_elementwise_fma(R[8], v[m][2], R[11])));
-        const f32x2 dx = px - w[m][0], dy = py - w[m][1], dz = pz - w[m][2];
-        const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        const u64 sure0 = __builtin_amdgcn_ballot_w64(d2.x < lo2.x), sure1 = __builtin_amdgcn_ballot_w64(d2.y < lo2.y);
-        const u64 far0 = __builtin_amdgcn_ballot_w64(d2.x > hi2.x), far1 = __builtin_amdgcn_ballot_w64(d2.y > hi2.y);
-        in0 &= ~far0; in1 &= ~far1;                       // (a NaN is neither sure nor far)
-        mark0 |= in0 & ~sure0; mark1 |= in1 & ~sure1;
-      };
-      u64 in0 = valid0, in1 = valid1, mark0 = 0, mark1 = 0;
-      VSTAT(0, 1); VSTAT(7, __builtin_popcountll(in0) + __builtin_popcountll(in1));
-      vertex(0, in0, in1, mark0, mark1);
-      VSTAT(2, __builtin_popcountll(in0) + __builtin_popcountll(in1));
+        for (int k = 0; k < 12; k++) R[k] = hyp32[h * 12 + k];
+        f32x2 d2[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+          // d = R v + (t - w): the table vertex goes into the chain's first addend (one operation per coordinate less
+          // than (R v + t) - w; the scalar t and the vector w make one packed subtraction)
+          const f32x2 dx = __builtin_elementwise_fma(R[0], v[m][0], __builtin_elementwise_fma(R[1], v[m][1], __builtin_elementwise_fma(R[2], v[m][2], R[9] - w[m][0])));
+          const f32x2 dy = __builtin_elementwise_fma(R[3], v[m][0], __builtin_elementwise_fma(R[4], v[m][1], __builtin_elementwise_fma(R[5], v[m][2], R[10] - w[m][1])));
+          const f32x2 dz = __builtin_elementwise_fma(R[6], v[m][0], __builtin_elementwise_fma(R[7], v[m][1], __builtin_elementwise_fma(R[8], v[m][2], R[11] - w[m][2])));
+          d2[m] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        }
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(d2[0].x, d2[1].x), d2[2].x), my = __builtin_fmaxf(__builtin_fmaxf(d2[0].y, d2[1].y), d2[2].y);
+        const u64 sure0 = __builtin_amdgcn_ballot_w64(mx < lo2.x), sure1 = __builtin_amdgcn_ballot_w64(my < lo2.y);
+        const u64 far0 = __builtin_amdgcn_ballot_w64(mx > hi2.x), far1 = __builtin_amdgcn_ballot_w64(my > hi2.y);
+        const u64 in0 = valid0 & ~far0, in1 = valid1 & ~far1;
+        const u64 yes0 = in0 & sure0, yes1 = in1 & sure1, mark0 = in0 & ~sure0, mark1 = in1 & ~sure1;
+        VSTAT(0, 1); VSTAT(7, __builtin_popcountll(valid0) + __builtin_popcountll(valid1)); VSTAT(4, __builtin_popcountll(yes0) + __builtin_popcountll(yes1));
 #ifdef SGTD_EXP_VSTAT
-      any0 |= in0; any1 |= in1;
+        any0 |= in0; any1 |= in1;
 #endif
-      if (in0 | in1) {       // wrong hypotheses fail at vertex A for the whole wave
-        VSTAT(1, 1);
-        vertex(1, in0, in1, mark0, mark1);
-        VSTAT(3, __builtin_popcountll(in0) + __builtin_popcountll(in1));
-        if (in0 | in1) vertex(2, in0, in1, mark0, mark1);
-        VSTAT(4, __builtin_popcountll(in0) + __builtin_popcountll(in1));
-        if (in0 | in1) {
-          mark0 &= in0; mark1 &= in1;
-          const u64 yes0 = in0 & ~mark0, yes1 = in1 & ~mark1;
-          if ((yes0 >> lane) & 1ull) passed[0] |= 1ull << h;
-          if ((yes1 >> lane) & 1ull) passed[1] |= 1ull << h;
-          const u32 cnt = (u32)__builtin_popcountll(yes0) + (u32)__builtin_popcountll(yes1);
-          if (lane == h) acc += cnt;
-          if (mark0 | mark1) {     // rare
-            if ((mark0 >> lane) & 1ull) pend[0] |= 1ull << h;
-            if ((mark1 >> lane) & 1ull) pend[1] |= 1ull << h;
-          }
+        // the pair's bit of the hypothesis: the lane mask selects it (one v_cndmask and one v_or per pair)
+        const u32 hb = 1u << (h & 31);
+        u32 hv, t0, t1;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(hv) : "s"(hb));
+        asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(t0) : "v"(hv), "s"(yes0));
+        asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(t1) : "v"(hv), "s"(yes1));
+        p0 |= t0; p1 |= t1;
+        const u32 cnt = (u32)__builtin_popcountll(yes0) + (u32)__builtin_popcountll(yes1);
+        if (lane == h) acc += cnt;
+        if (mark0 | mark1) {     // rare
+          if ((mark0 >> lane) & 1ull) pend[0] |= 1ull << h;
+          if ((mark1 >> lane) & 1ull) pend[1] |= 1ull << h;
         }
       }
-    }
+    };
+    steps(0, use_size < 32 ? use_size : 32, pw[0][0], pw[1][0]);
+    steps(32, use_size, pw[0][1], pw[1][1]);
+#pragma unroll
+    for (int u = 0; u < PPT; u++) passed[u] = ((u64)pw[u][1] << 32) | (u64)pw[u][0];
     // ---- the marked (pair, hypothesis) combinations, decided as the reference decides them (:488-505)
-    if (__builtin_amdgcn_ballot_w64((pend[0] | pend[1]) != 0ull)) verify_pending(P, hyp64, v, w, pend, passed, s_votes);
+    if (__builtin_amdgcn_ballot_w64((pend[0] | pend[1]) != 0ull)) {      // rare: the pairs' vertices once more, from memory
+      const float *qp[PPT], *ep[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; u++) {
+        const u32 j = j0 + (u32)u * SGTD_VERIFY_THREADS + (u32)tid;
+        const u64 pr = P.pairs[base + (j < n ? j : 0u)];
+        qp[u] = P.q_vertex + (qslot0 + (size_t)(pr >> 32)) * 9;
+        ep[u] = P.t_vertex + (size_t)(pr & 0xFFFFFFFFull) * 9;
+      }
+      verify_pending(P, hyp64, qp, ep, pend, passed, s_votes);
+    }
     // what the inlier pass needs of this pair: no second walk over the vertices
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
-      const long long j = j0 + (long long)u * SGTD_VERIFY_THREADS + tid;
+      const u32 j = j0 + (u32)u * SGTD_VERIFY_THREADS + (u32)tid;
       if (j < n) P.passed[base + j] = passed[u];
     }
   }
@@ -408,12 +425,12 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
   const u32 best = s_best;
   if (best == 0xFFFFFFFFu) {
     if (tid == 0) *score = -1.0;                    // :541
-    for (long long j = tid; j < n; j += SGTD_VERIFY_THREADS) P.inlier[base + j] = 0;
+    for (u32 j = tid; j < n; j += SGTD_VERIFY_THREADS) P.inlier[base + j] = 0;
     return;
   }
   // ---- inliers of the best hypothesis (:516-539): the pairs that voted for it
   u32 mine = 0;
-  for (long long j = tid; j < n; j += SGTD_VERIFY_THREADS) {
+  for (u32 j = tid; j < n; j += SGTD_VERIFY_THREADS) {
     const bool in = (P.passed[base + j] >> best) & 1ull;
     P.inlier[base + j] = in ? 1 : 0;
     mine += in ? 1u : 0u;
