@@ -117,7 +117,9 @@ struct ProbeBuffers {
 #define SGTD_REC_SLAB 8192u     // match records a wave takes from the global cursor at once
 #define SGTD_SUB_DESCS 32       // descriptors per prefix sub-block inside an assemble block
 #ifndef SGTD_VOTE_WORDS
-#define SGTD_VOTE_WORDS 2        // 64-quad words of records in flight per wave in the vote pass
+#define SGTD_VOTE_WORDS 6        // 64-quad words of records in flight per wave in the vote pass (votes_topk_kernel, 2048 queries on the
+                                 // 10 000-frame map: 2 / 3 / 4 / 6 / 8 words: 1.55-1.62 / 1.52 / 1.49 / 1.39 / 1.49 ms — one 16-wave workgroup
+                                 // per CU with 6 KB in flight per wave beats two with 2 KB)
 #endif
 #ifndef SGTD_WRITE_WORDS
 #define SGTD_WRITE_WORDS 4       // 64-pair words of the compact list per step of a wave in block_write (their slot masks take ONE
