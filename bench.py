@@ -806,6 +806,24 @@ def main():
                 multi_handle = {"error": "%s: %s" % (type(exc).__name__, exc)}
         host_barrier()      # (the other ranks wait on the host: no barrier kernel spins on the devices rank 0 is timing)
 
+    # ---- another batch size on the same map (beside the headline, which stays at --queries): 4096 query frames per step
+    # amortise the per-batch work (sort, plan, passes of four descriptors per home cell) over twice the frames
+    batch_sweep = None
+    if mode == "single" and args.sweep not in ("", "none") and Q == 2048:
+        try:
+            qb = [synth.make_queries(smap, 4096, stream=2000 + b) for b in range(2)]
+            db = [to_dev(x.xyz, x.label) for x in qb]
+
+            def sb(i=-1):
+                mgr.query_frames(*db[i % 2], fetch=False)
+            eb = timed(sb, mgr, steps=max(3, args.steps // 2))
+            batch_sweep = {"4096": {"frames_per_s": 4096 * max(3, args.steps // 2) / eb, "ms_per_step": 1000.0 * eb / max(3, args.steps // 2)},
+                           str(Q): {"frames_per_s": Q * args.steps / elapsed, "ms_per_step": 1000.0 * elapsed / args.steps}}
+            del db, qb
+            step(-1); mgr.sync()
+        except Exception as exc:
+            batch_sweep = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     # ---- other map sizes (same batch, same pipeline), N = 1 only
     sweep = None
     if mode == "single" and args.sweep not in ("", "none"):
@@ -925,6 +943,8 @@ def main():
             out["cold_start"] = cold
         if sweep is not None:
             out["map_size_sweep"] = sweep
+        if batch_sweep is not None:
+            out["batch_size_sweep"] = batch_sweep
         if verify is not None:
             out["verify"] = verify
         if boundary is not None:

@@ -219,7 +219,12 @@ __global__ __launch_bounds__(256) void cand_prefix_kernel(const int *n_cand, con
 // ---------------------------------------------------------------------------
 #define SGTD_PQ_THREADS 512
 #define SGTD_PQ_WAVES (SGTD_PQ_THREADS / SGTD_WAVE)
+#ifndef SGTD_PQ_WORDS
 #define SGTD_PQ_WORDS 4                                   // quad-words (64 lanes x 4 consecutive records of one list) per wave and tile
+#endif
+#ifndef SGTD_PQ_OCC
+#define SGTD_PQ_OCC 4
+#endif
 #define SGTD_PQ_TILE_QUADS (SGTD_PQ_WAVES * SGTD_PQ_WORDS * SGTD_WAVE)
 #define SGTD_PQ_WAVE_RECS (SGTD_PQ_WORDS * SGTD_WAVE * 4)  // records of a wave's share of a tile: its region of the dense image
 #define SGTD_PQ_TILE_RECS (SGTD_PQ_WAVES * SGTD_PQ_WAVE_RECS)
@@ -234,7 +239,7 @@ struct __attribute__((aligned(16))) PqList { u32 pre, first, n, desc; };
 
 // dynamic LDS: u32 image[SGTD_PQ_TILE_RECS] | slot table u8[span rounded to 16, + 16] (SLOT_TABLE)
 template <bool SLOT_TABLE>
-__global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void pairs_query_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
+__global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu(SGTD_PQ_OCC, SGTD_PQ_OCC))) void pairs_query_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
                                                                        const int *cand_frame, int cand_num,
                                                                        const long long *pair_off, const u32 *q_pair_base,
                                                                        u64 *pairs, IdMap map, u32 frame_span, u32 frame_lo) {

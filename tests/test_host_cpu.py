@@ -150,7 +150,36 @@ def test_bench_finds_the_committed_traffic_row_of_its_default_workload():
         sys.argv = argv
     row = bench.load_traffic(args.frames, args.keypoints, args.queries, 1)
     assert row is not None, "no row for the default workload in profiles/r*_traffic.json"
-    assert row["bytes_per_launch"] == int(2 * row["FETCH_SIZE_KB"] * 1024 + row["WRITE_SIZE_KB"] * 1024)
+    k = row["kernels"][row["kernel"]]        # the sweep's bytes: 2 x FETCH_SIZE + WRITE_SIZE, per launch
+    assert row["bytes_per_launch"] == int(k["read_bytes"] + k["write_bytes"]) and k["launches_per_step"] == 1
     assert 0.0 < row["valu_issue_frac"] <= 1.0
     assert abs(row["valu_issue_frac"] - row["SQ_INSTS_VALU"] * 4.0 / (row["kernel_cycles"] * 1024.0)) < 1e-9
     assert os.path.exists(os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % row["profile_tag"]))
+
+
+def test_committed_traffic_row_describes_the_kernels_the_bench_launches():
+    """bench.py refuses a PMC row that was taken on other kernels than the ones the run launches: the row committed
+    under profiles/ for the default workload must carry the kernels of the per-query form (sgtd_stats.select_form 2),
+    every kernel name bench.py expects must exist in the sources, and a row of another form must be refused"""
+    import importlib.util
+    import json
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = "".join(open(os.path.join(ROOT, "sgtd_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "sgtd_amd", "csrc")) if f.endswith((".h", ".hip")))
+    for form, names in bench.STEP_KERNELS.items():
+        for n in names:
+            assert ("void %s(" % n) in src or ("%s(" % n) in src, n
+    row = bench.load_traffic(10000, 200, 2048, 1)
+    assert row is not None and row["select_form"] == 2 and row.get("commit")
+    bench.check_traffic_row(row, 2)                       # accepted
+    with pytest.raises(SystemExit):
+        bench.check_traffic_row(row, 0)                   # the five-kernel form was not what the row measured
+    renamed = dict(row, select_form=None, kernels={k.replace("pairs_query_kernel", "pairs_kernel_v2"): v for k, v in row["kernels"].items()})
+    with pytest.raises(SystemExit):
+        bench.check_traffic_row(renamed, 2)               # a kernel of the step is missing from the row
+    # every stage the row's kernels fall into is one of sgtd_stats' per-kernel times
+    assert {bench.stage_of(k) for k in row["kernels"] if not k.startswith(("__amd", "at::"))} <= set(bench.KERNEL_KEYS)
+    total = sum((v.get("read_bytes") or 0) + (v.get("write_bytes") or 0) for v in row["kernels"].values())
+    assert abs(total - row["step"]["bytes"]) < 1e-6 * total
