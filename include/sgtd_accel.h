@@ -297,8 +297,10 @@ int sgtd_load_table(sgtd_handle h, const char *path);
 /* ---- graph-JSON ingest (host code, no device needed) ----
  * readGraphFromFile / fromJSON (include/Semantic_Graph.hpp:122-184) + Graph2CloudL
  * (include/utility.hpp:646-659) for many files at once: {"nodes":[int], "centers":[[x,y,z]],
- * "poses":[12 floats], ...} (producer get_json.cpp:332-341; only these three keys are read,
- * numbers go through strtod and a cast like nlohmann::json's get<float>/get<int>) parsed on
+ * "poses":[12 floats], ...} (producer get_json.cpp:332-341; only these three keys are read;
+ * numbers as nlohmann::json stores and casts them — integer tokens through strtoull / strtoll, the rest through
+ * strtod, then get<float>() / get<int>() — pinned bit for bit against that library by
+ * tests/cpp/test_ingest_nlohmann.cpp; a key that occurs twice keeps its first value) parsed on
  * n_threads host threads into the arrays sgtd_add_frames / sgtd_query_frames take.  Frames
  * keep the order of `paths`.  On SGTD_ERR_IO *out still holds an object whose
  * sgtd_graphs_error() names the file ("Error opening file: ..." like Semantic_Graph.hpp:173);
