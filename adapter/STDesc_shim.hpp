@@ -127,7 +127,10 @@ struct PinnedSoa {
   ~PinnedSoa() { delete plain; }
 };
 inline PinnedSoa &fetched_entries() { static thread_local PinnedSoa p; return p; }
-// gives the calling thread's page-locked buffers back (before the thread ends or the handle is destroyed)
+// Gives the calling thread's page-locked buffers back.  MANDATORY before a thread that has called SearchLoop or
+// candidate_selector ends (its thread_local destructor no longer calls into the HIP runtime: the seven blocks, some
+// 130 B per fetched entry, would stay page-locked until the process exits); ~STDescManager calls it for the thread
+// that destroys the manager.  The reference calls every method from its main thread (not re-entrant).
 inline void release_thread_buffers() { fetched_entries().release(); }
 
 template <class Desc>
@@ -240,7 +243,13 @@ template <class F>
 void deal_lists(int n, const int64_t *off, F &&fill) {
   const int64_t total = off[n] - off[0];
   const int n_thr = total > 8192 ? (int)std::min<unsigned>(SGTD_SHIM_FILL_THREADS, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  std::vector<std::thread> team;
+  // (joined on every way out: a fill that throws — std::bad_alloc on a match list of 10^5 pairs — or a thread that cannot be
+  // started must not leave joinable threads behind, whose destructors would end the process)
+  struct Team {
+    std::vector<std::thread> t;
+    ~Team() { for (auto &th : t) if (th.joinable()) th.join(); }
+  } joined;
+  std::vector<std::thread> &team = joined.t;
   int k0 = 0;
   for (int t = 0; t < n_thr; t++) {
     int k1 = k0;
