@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256) void cand_prefix_kernel(const int *n_cand, con
 // ---------------------------------------------------------------------------
 // match lists of one query by ONE workgroup (:434-449)
 // ---------------------------------------------------------------------------
+#ifndef SGTD_PQ_THREADS
 #define SGTD_PQ_THREADS 512
+#endif
 #define SGTD_PQ_WAVES (SGTD_PQ_THREADS / SGTD_WAVE)
 #ifndef SGTD_PQ_WORDS
 #define SGTD_PQ_WORDS 4                                   // quad-words (64 lanes x 4 consecutive records of one list) per wave and tile
@@ -229,9 +231,10 @@ __global__ __launch_bounds__(256) void cand_prefix_kernel(const int *n_cand, con
 #define SGTD_PQ_WAVE_RECS (SGTD_PQ_WORDS * SGTD_WAVE * 4)  // records of a wave's share of a tile: its region of the dense image
 #define SGTD_PQ_TILE_RECS (SGTD_PQ_WAVES * SGTD_PQ_WAVE_RECS)
 #define SGTD_PQ_DESCS SGTD_PQ_THREADS                     // descriptors per super-block: one list per thread
-#define SGTD_PQ_RANK_BITS 17                              // image words: slot << 26 | descriptor in super-block << 17 | rank in frame
-static_assert(SGTD_PQ_DESCS <= 512 && SGTD_MAX_CAND <= 64, "an image word holds 6 slot bits and 9 descriptor bits");
-static_assert(SGTD_PQ_WAVE_RECS * 4 >= 4 * 64 * 8 && SGTD_PQ_WAVES == 8, "a wave's region of the image holds the ranking masks of four dense words; image positions rotate over eight regions");
+#define SGTD_PQ_RANK_BITS (SGTD_PQ_DESCS <= 512 ? 17 : 16)  // image words: slot << 26 | descriptor in super-block << RANK_BITS | rank in frame
+static_assert(SGTD_PQ_DESCS <= 1024 && SGTD_MAX_CAND <= 64, "an image word holds 6 slot bits and 26 - RANK_BITS descriptor bits");
+static_assert(SGTD_PQ_WAVE_RECS * 4 >= 4 * 64 * 8 && (SGTD_PQ_WAVES & (SGTD_PQ_WAVES - 1)) == 0 && SGTD_PQ_WAVES >= 2,
+              "a wave's region of the image holds the ranking masks of four dense words; image positions rotate over a power of two of regions");
 
 // One non-empty list of the super-block as the tiles see it: its first quad in the super-block's stream of
 // quads, its first record, its records, its descriptor (index inside the super-block).
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu
     if (n) { s_ne[kx] = PqList{pre, p, n, (u32)tid}; s_start[kx] = pre; }
     if ((u32)tid >= K) s_start[tid] = 0xFFFFFFFFu;
     if (tid < SGTD_WAVE + 8) s_start[SGTD_PQ_DESCS + tid] = 0xFFFFFFFFu;
+    static_assert(SGTD_PQ_THREADS >= SGTD_WAVE + 8, "the end markers behind the list starts are written by the first 72 threads");
     __syncthreads();
     if (RQ == 0) continue;
     const u32 n_tiles = (RQ + SGTD_PQ_TILE_QUADS - 1) / SGTD_PQ_TILE_QUADS;
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu
           for (int w = g0; w < g0 + GRP; w++) {
             const u32 pos = (u32)__builtin_amdgcn_ds_bpermute((int)((dw[w] >> 26) << 2), (int)my_base) + rk[w];
             if (dw[w] != 0xFFFFFFFFu)
-              s_img[((pos >> 6) & (NW - 1)) * SGTD_PQ_WAVE_RECS + ((pos >> 9) << 6) + (pos & 63u)] = dw[w];
+              s_img[((pos >> 6) & (NW - 1)) * SGTD_PQ_WAVE_RECS + (((pos >> 6) / NW) << 6) + (pos & 63u)] = dw[w];
           }
         }
       }
