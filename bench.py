@@ -379,7 +379,8 @@ def main():
     # (`queries`, which the parity and recall legs use): a node never sees the same frames twice
     # (semantic_graph_localization.cpp:567-604), and the room a match list is given is predicted from the batch BEFORE.
     n_rot = max(1, args.rotate)
-    rot_sets = [synth.make_queries(smap, n_q_total, stream=1000 + b) for b in range(n_rot)]
+    n_rot_q = Q * world if mode == "query" else Q        # (query mode: every rank takes its own slice of each set)
+    rot_sets = [synth.make_queries(smap, n_rot_q, stream=1000 + b) for b in range(n_rot)]
 
     def to_dev(xyz, label):
         return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
