@@ -128,3 +128,37 @@ def test_batch_with_a_query_per_cu_takes_the_per_query_passes_and_equals_the_blo
     for q in (0, 77, 319):
         P._check_query(ga, o, ra, q, o.build(qs.xyz[q], qs.label[q]), check_rough=False)
     ga.close(); gb.close()
+
+
+def test_frame_spans_beyond_lds_take_the_tiled_votes_and_the_candidates_hash(mods):
+    """frame ids spread over 150 000 (caller-stamped): the vote histogram of a query does not fit LDS — votes in frame
+    tiles by votes_query_kernel, top-k by topk_kernel, the lists' offsets by cand_prefix_kernel — and neither does the
+    frame -> slot byte table of pairs_query_kernel, which looks the candidates up in their 256-entry hash instead"""
+    oracle, manager, synth = mods
+    g = manager.STDescManager(max_frame_n=200000)
+    o = oracle.OracleManager(max_frame_n=200000)
+    m = synth.make_map(24, 150, stream=144)
+    for f in range(24):
+        d = g.BuildSingleScanSTD(m.xyz[f], m.label[f])
+        od = o.build(m.xyz[f], m.label[f])
+        fid = 11 + f * 6521                      # ascending, up to 149 994
+        d.frame[:] = fid; od.frame[:] = fid
+        g.AddSTDescs(d); o.add(od)
+    qs = synth.make_queries(m, 4, stream=144)
+    res = g.query_frames(qs.xyz, qs.label)
+    st = g.stats()
+    assert st["select_form"] == 1                # the lists by one workgroup per query, votes and top-k by their own kernels
+    for q in range(4):
+        o.build(qs.xyz[q], qs.label[q], export=False)
+        r = o.select()
+        nc = int(res.n_cand[q])
+        assert nc > 0
+        np.testing.assert_array_equal(res.cand_frame[q, :nc], r["cand_frame"])
+        np.testing.assert_array_equal(res.cand_votes[q, :nc], r["cand_votes"])
+        np.testing.assert_array_equal(res.pair_off[q, :nc + 1], r["cand_off"])
+        qi, de = g.result_pairs(q, res)
+        np.testing.assert_array_equal(qi, r["q_idx"])
+        np.testing.assert_array_equal(de, r["db_entry"])
+        lo, v = g.result_votes(q)
+        ov = o.votes()
+        np.testing.assert_array_equal(v.astype(np.float64), ov[lo:lo + len(v)])
