@@ -715,9 +715,11 @@ int do_finalize(sgtd_engine *e, bool force_merge = false) {
 // ---------------------------------------------------------------------------
 // the query pipeline on descriptors already in e->qd (strided)
 // ---------------------------------------------------------------------------
-int rec_alloc(sgtd_engine *e) {
+int rec_alloc(sgtd_engine *e, bool compact_lists) {
   CHK(ensure(e, e->rec, (e->rec_cap + 4) * sizeof(u32)));      // + a quad: the vote pass reads four records at the last list's tail
-  CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));   // every block reserves room for all of its records
+  // (the compact candidate lists between block_count and block_write: every block reserves room for all of its records —
+  // twice the record buffer; the per-query list pass needs none)
+  if (compact_lists) CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));
   if (e->diag) {
     CHK(ensure(e, e->rec_cell, e->rec_cap));
     CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
@@ -845,7 +847,6 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->cand_frame, (size_t)nq * cn * sizeof(int)));
   CHK(ensure(e, e->cand_votes, (size_t)nq * cn * sizeof(int)));
   CHK(ensure(e, e->pair_off, (size_t)nq * (cn + 1) * sizeof(long long)));
-  CHK(rec_alloc(e));
 
   // Which passes over the match records (STDesc.cpp:404-453): one workgroup per query (select_kernels.hip.h) when
   // the batch has a query for every CU — votes + top-k in one launch while the query's vote histogram fits LDS,
@@ -853,9 +854,13 @@ int launch_select(sgtd_engine *e) {
   // five-kernel form with one wave per 128-descriptor block.
   const u32 tile_span = span <= 36 * 1024 ? span : 36 * 1024;
   const u32 n_tiles = (span + tile_span - 1) / tile_span;
-  const bool per_query = e->select_mode == 2 || (e->select_mode == 0 && nq >= e->n_cus);
+  // (automatic choice only where a query's vote histogram fits LDS: with the candidates' hash instead of the frame -> slot
+  // byte table the list pass is slower than the block passes — 100 000-frame map, 256 queries: 6.1 against 2.9 ms)
+  const bool votes_fit = votes_topk_lds_bytes(span) <= 150 * 1024;
+  const bool per_query = e->select_mode == 2 || (e->select_mode == 0 && nq >= e->n_cus && votes_fit);
   const bool fused_pairs = per_query && !e->wide_pairs && (e->id_bits ? e->id_bits : 13) <= SGTD_PQ_RANK_BITS;
-  const bool fused_votes = fused_pairs && votes_topk_lds_bytes(span) <= 150 * 1024;     // (block_count_kernel wants topk_kernel's slot table)
+  const bool fused_votes = fused_pairs && votes_fit;     // (block_count_kernel wants topk_kernel's slot table)
+  CHK(rec_alloc(e, !fused_pairs));
   const bool votes_per_query = n_tiles == 1 ? nq >= e->n_cus : ((long long)nq * n_tiles >= e->n_cus / 4 && n_tiles <= 8);
   HIPCHK(hipMemsetAsync(e->cursors.p, 0, kCtrWords * sizeof(u32), e->stream));
   if (!fused_votes) {
@@ -1795,7 +1800,7 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
     // the ordered rough list (cell index, distance, reference order inside a cell) comes from the
     // diagnostic probe build: switch it on and re-run the batch
     e->diag = true;
-    CHK(rec_alloc(e));
+    CHK(rec_alloc(e, false));     // (the diagnostic arrays; the re-run below sizes the rest)
     CHK(rerun(e));
   }
   CHK(sync_batch(e));
