@@ -29,6 +29,9 @@ def pmc_means(pattern, reduce="mean"):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    if tag[:3] >= "r04":      # round 4 on: per kernel and per step (profiles/collect_r04.sh), summarised by summarize_step.py
+        import summarize_step
+        return summarize_step.main()
     here = os.path.dirname(os.path.abspath(__file__))
     stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
     if stats:
