@@ -39,6 +39,13 @@ def test_two_rank_bench_shards_and_replicas_agree():
     assert cfg["collective_backend"] == ("gloo" if "SGTD_BENCH_BACKEND" in env else "nccl")
     assert ("NOT RCCL" in cfg["sharding"]) == (cfg["collective_backend"] == "gloo")      # the line says what really ran
     assert two["merged_list_equals_single_table"] is True
+    # what a rank's step consists of and what that predicts (the replicated part bounds the strong-scaling curve)
+    sp = two["scaling_parts"]
+    for key in ("replicated_build_sort_plan", "sharded_sweep_and_record_passes", "exchange_all_gather_merge"):
+        assert len(sp["per_rank_ms"][key]) == 2 and min(sp["per_rank_ms"][key]) > 0
+    assert sp["predicted_speedup_over_one_gpu"] > 0 and sp["speedup_ceiling_if_the_sharded_part_vanished"] >= sp["predicted_speedup_over_one_gpu"]
+    tr = two["timed_region"]
+    assert tr["batch_launches_in_timed_region"] >= 2 and tr["launches_that_overflowed_a_work_buffer"] == tr["reruns_in_timed_region"] + tr["list_pass_reruns_in_timed_region"]
     rp = two["replicated"]        # beside it: every rank a full replica, 24 queries each (weak scaling)
     assert rp["ranks_in_collective"] == 2 and rp["scaling"] == "weak" and rp["queries_per_step"] == 48
     assert rp["equals_table_sharded_list"] is True

@@ -183,3 +183,25 @@ def test_committed_traffic_row_describes_the_kernels_the_bench_launches():
     assert {bench.stage_of(k) for k in row["kernels"] if not k.startswith(("__amd", "at::"))} <= set(bench.KERNEL_KEYS)
     total = sum((v.get("read_bytes") or 0) + (v.get("write_bytes") or 0) for v in row["kernels"].values())
     assert abs(total - row["step"]["bytes"]) < 1e-6 * total
+
+
+def test_step_summariser_cuts_steps_out_of_a_dispatch_sequence(tmp_path):
+    """profiles/summarize_step.py: a step runs from the first build_frames_kernel after the previous step's last kernel to
+    pairs_query_kernel / block_write_kernel; a kernel's launches inside a step are summed, the map's own build launches
+    and a first-batch re-run in front do not count (the median over the last steps is taken)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("summarize_step", os.path.join(ROOT, "profiles", "summarize_step.py"))
+    ss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ss)
+    seq = ["build_frames_kernel<true, 10>"] * 3 + ["slice_assign_kernel"]                      # map construction: no step closes
+    one = ["build_frames_kernel<true, 10>", "radix_scatter_kernel<unsigned int>", "radix_scatter_kernel<unsigned int>",
+           "probe_sorted_kernel<false, false, false>", "votes_topk_kernel", "pairs_query_kernel<true>"]
+    rows = [dict(name=n, v=1.0) for n in seq]
+    for k in range(6):
+        rows += [dict(name=n, v=float(10 * (k + 1) if n.startswith("probe") else 2.0)) for n in one]
+    steps = ss.steps_of(rows, lambda r: r["v"])
+    assert len(steps) == 6 and len(steps[0]["build_frames_kernel<true, 10>"]) == 4       # (the map's launches fall into the first, discarded, step)
+    pk = ss.per_kernel(steps)
+    assert pk["radix_scatter_kernel<unsigned int>"] == {"launches_per_step": 2, "per_step": 4.0}
+    assert pk["probe_sorted_kernel<false, false, false>"]["per_step"] == 50.0            # median of the last four steps: 30, 40, 50, 60
+    assert pk["build_frames_kernel<true, 10>"]["launches_per_step"] == 1
