@@ -908,6 +908,9 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
 #pragma unroll
       for (int k = 0; k < K; k++) test(std::false_type{}, u, k, DIAG ? 0.0f : d2[k], matches[k]);
     }
+#ifdef SGTD_EXP_NOSTORE
+    amb_any = 0;      // (experiment build: nothing was stored, nothing to decide again)
+#endif
     if (!DIAG && amb_any) {   // rare: about one in 10^4 matches
       u32 back[K];
 #pragma unroll
@@ -1007,6 +1010,9 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
 #pragma unroll
     for (int k = 1; k < K; k++)
       if (lane == k) { r_ptr = next0[k]; r_match = matches[k]; }
+#ifdef SGTD_EXP_NOSTORE
+    r_match = 0;      // (experiment build: no record was stored — the lists stay empty for the kernels behind)
+#endif
     if ((u32)lane < pv.k_real) B.list[r_slot] = make_uint2(r_ptr, fits ? r_match : 0u);
   }
   static_for<K>([&](auto kc) {
