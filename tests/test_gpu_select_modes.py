@@ -130,6 +130,36 @@ def test_batch_with_a_query_per_cu_takes_the_per_query_passes_and_equals_the_blo
     ga.close(); gb.close()
 
 
+def test_frame_span_that_nearly_fills_lds(mods):
+    """frame ids spread over 28 761 (caller-stamped): the query's vote histogram takes 115 KB of the 160 KB of LDS and
+    votes_topk_kernel still runs it (140 KB with its top-k scratch), pairs_query_kernel's byte table 28 KB"""
+    oracle, manager, synth = mods
+    g = manager.STDescManager(max_frame_n=32000)
+    o = oracle.OracleManager(max_frame_n=32000)
+    m = synth.make_map(24, 150, stream=145)
+    for f in range(24):
+        d = g.BuildSingleScanSTD(m.xyz[f], m.label[f])
+        od = o.build(m.xyz[f], m.label[f])
+        fid = 11 + f * 1250
+        d.frame[:] = fid; od.frame[:] = fid
+        g.AddSTDescs(d); o.add(od)
+    qs = synth.make_queries(m, 3, stream=145)
+    res = g.query_frames(qs.xyz, qs.label)
+    assert g.stats()["select_form"] == 2
+    for q in range(3):
+        o.build(qs.xyz[q], qs.label[q], export=False)
+        r = o.select()
+        nc = int(res.n_cand[q])
+        assert nc > 0
+        np.testing.assert_array_equal(res.cand_frame[q, :nc], r["cand_frame"])
+        np.testing.assert_array_equal(res.cand_votes[q, :nc], r["cand_votes"])
+        qi, de = g.result_pairs(q, res)
+        np.testing.assert_array_equal(qi, r["q_idx"])
+        np.testing.assert_array_equal(de, r["db_entry"])
+        lo, v = g.result_votes(q)
+        np.testing.assert_array_equal(v.astype(np.float64), o.votes()[lo:lo + len(v)])
+
+
 def test_frame_spans_beyond_lds_take_the_tiled_votes_and_the_candidates_hash(mods):
     """frame ids spread over 150 000 (caller-stamped): the vote histogram of a query does not fit LDS — votes in frame
     tiles by votes_query_kernel, top-k by topk_kernel, the lists' offsets by cand_prefix_kernel — and neither does the
