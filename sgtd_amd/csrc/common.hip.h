@@ -188,6 +188,13 @@ __device__ __forceinline__ u32 gate_mask(double q0, double q1, double q2) {
 //   d2f < lo2 = rounddown_f32((thr - m)^2)  ==>  the reference's dis < thr
 //   d2f > hi2 = roundup_f32((thr + m)^2)    ==>  the reference's dis >= thr
 // anything else (including NaN) is decided exactly.
+// The product sweep does not keep lo2 and hi2 in registers: it starts the sum from -hi2,
+//   acc = fma(dz, dz, fma(dy, dy, fma(dx, dx, -hi2)))        (from +inf - hi2 = +inf where the cell fails the gate),
+// and tests acc > 0 (certainly outside) and acc < -g, g >= hi2 - lo2 (certainly inside; one g for the up to four
+// descriptors of a pass: a larger g only sends more entries to the exact test).  acc differs from d2* - hi2 (d2* = the
+// exact sum of the three squared f32 differences) by three roundings of partial sums of magnitude <= max(hi2, d2*):
+// at either threshold at most 3 u hi2, i.e. 1.5 u thr on the distance, where the three rounded additions of the form
+// above cost 2 u thr — both inside the 16 u thr that m reserves beyond the bound it needs.
 __device__ __forceinline__ void f32_bounds(double q0, double q1, double q2, double thr, float &lo2, float &hi2) {
   const double u = 5.9604644775390625e-08;   // 2^-24
   const double a0 = u * (4.0 * fabs(q0) + 16.0), a1 = u * (4.0 * fabs(q1) + 16.0), a2 = u * (4.0 * fabs(q2) + 16.0);

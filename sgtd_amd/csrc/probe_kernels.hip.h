@@ -666,6 +666,13 @@ __device__ __forceinline__ u32 write_lane(u32 vec, u32 val) {
   return vec;
 }
 
+// a wave-uniform float computed by vector instructions, pinned to its vector register
+__device__ __forceinline__ u32 in_vgpr_f(float x) {
+  u32 v = __float_as_uint(x);
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // a wave-uniform value held in a vector register (operand of v_cmp / v_pk_* without taking scalar registers)
 __device__ __forceinline__ u32 in_vgpr(u32 x) {
   u32 v;
@@ -702,9 +709,26 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     thr = norm3(dq0, dq1, dq2) * rough;
   }
   // per lane: the gate penalties of its range (0 / +inf per descriptor) and its cell
+  // ... and, in the product sweep, MINUS the column's upper squared threshold: the sums then run to d2 - hi2, "certainly
+  // outside" is a compare with zero and "not certainly inside" a compare with -(hi2 - lo2) — one wave-uniform value for
+  // all columns (the largest gap: an entry that is called undecided without being so is decided exactly like the others) —
+  // so that no threshold stays in a register through the pass (eight vector registers less: six waves per SIMD)
   float penc[K];
 #pragma unroll
-  for (int k = 0; k < K; k++) penc[k] = __uint_as_float((pv.meta >> (8 + k)) & 1u ? 0x7F800000u : 0u);
+  for (int k = 0; k < K; k++) {
+    penc[k] = __uint_as_float((pv.meta >> (8 + k)) & 1u ? 0x7F800000u : 0u);
+    if constexpr (!DIAG) penc[k] = penc[k] - __uint_as_float(pv.word(PH_HI2, k));      // (+inf stays +inf; hi2 is finite)
+  }
+  float ngap = 0.0f;      // -(largest hi2 - lo2 of the pass's columns), rounded away from zero
+  if constexpr (!DIAG) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const float g = __uint_as_float(pv.word(PH_HI2, k)) - __uint_as_float(pv.word(PH_LO2, k));
+      ngap = !(g <= ngap) ? g : ngap;           // (max that keeps a NaN: then nothing is certainly inside)
+    }
+    ngap = -(ngap * 1.0001f + 1e-30f);
+  }
+  const u32 ngapv = in_vgpr_f(ngap);
   const u32 cellc = pv.meta & 0xFFu;
   // narrow layout: the address delta in bytes, so that an entry's byte offset is ONE three-operand add
   const u32 dlc_sel = WIDE ? pv.dlc : pv.dlc << 4;
@@ -756,12 +780,10 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     list_base[k] = reinterpret_cast<char *>(B.rec + next0[k]);
   }
   // wave-uniform constants of the columns in vector registers
-  u32 lo2v[K], hi2v[K], qfv[K];
+  u32 qfv[K];
 #pragma unroll
-  for (int k = 0; k < K; k++) {
-    lo2v[k] = in_vgpr(pv.word(PH_LO2, k)); hi2v[k] = in_vgpr(pv.word(PH_HI2, k));
-    qfv[k] = (FRAMES || DIAG) ? in_vgpr(pv.word(PH_FRAME, k)) : 0u;
-  }
+  for (int k = 0; k < K; k++) qfv[k] = (FRAMES || DIAG) ? in_vgpr(pv.word(PH_FRAME, k)) : 0u;
+  const float nhi0 = -__uint_as_float(pv.word(PH_HI2, 0));      // (one column: the sum starts from it)
   f32x2 qx[KP], qy[KP], qz[KP];
   if constexpr (K >= 2) {
 #pragma unroll
@@ -841,7 +863,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         }
       } else {
         const float dx = q0s - v[u].x, dy = q1s - v[u].y, dz = q2s - v[u].z;
-        d2[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        d2[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nhi0)));
       }
     };
     // one (word, column) test; PUSH = false: store the matches — `count` runs up; true: replay of
@@ -868,9 +890,9 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         m = __builtin_amdgcn_ballot_w64(hit);
       } else {
         // (sentinel entries and gated-out cells: d2 = +inf, above every hi2 — f32_bounds keeps it finite)
-        const bool near = !(d2 > __uint_as_float(hi2v[k]));     // not certainly outside (NaN stays in)
+        const bool near = !(d2 > 0.0f);                         // d2 is the squared distance MINUS hi2: not certainly outside (NaN stays in)
         hit = near && other;
-        amb = hit && !(d2 < __uint_as_float(lo2v[k]));          // not certainly inside either: provisional
+        amb = hit && !(d2 < __uint_as_float(ngapv));            // not certainly inside either: provisional
         m = FRAMES ? __builtin_amdgcn_ballot_w64(near) & __builtin_amdgcn_ballot_w64(other)   // two plain compares: no mask round trip
                    : __builtin_amdgcn_ballot_w64(near);
       }
@@ -890,7 +912,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         // (left to the scheduler, the masks of a whole group wait in scalar registers for this)
         if (!DIAG)
           asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n\ts_and_b64 vcc, vcc, %3\n\ts_or_b64 %0, %0, vcc"
-                       : "+s"(amb_any) : "v"(lo2v[k]), "v"(d2), "s"(m) : "vcc");
+                       : "+s"(amb_any) : "v"(ngapv), "v"(d2), "s"(m) : "vcc");
         count += (u32)__builtin_popcountll(m);
       } else {
         if (amb && fits) {
