@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(SGTD_PROBE_THREADS) SGTD_SWEEP_WAVES void probe_sor
   const u32 n_slots = pass_slot_count(*n_valid_p, *n_groups_p, !DIAG && SGTD_PAIR >= 2);
   // Every WAVE dequeues `chunk` consecutive pass slots at a time (no workgroup barrier).
   // Small chunks keep the passes in flight on one XCD — and with them the buckets it is
-  // reading — within that XCD's 4 MB L2; the host sizes a ticket to about 3k entry visits.
+  // reading — within that XCD's 4 MB L2; the host sizes a ticket to about 1.5k entry visits.
   // Software pipeline per wave: the ticket after next is in flight, the next ticket's record
   // offsets are in flight, the next pass's header and ranges are in flight while the current
   // pass is swept.

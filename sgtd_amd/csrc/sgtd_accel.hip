@@ -950,13 +950,15 @@ int launch_select(sgtd_engine *e) {
     pass_slots_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), e->group_first.as<u32>(), nv,
                                                                        e->pos_of_slot.as<u32>(), n_slots, pair ? 1 : 0);
     HIPCHK(hipGetLastError());
-    // pass slots per wave ticket: about 3k entry visits, from the visits per descriptor the
+    // pass slots per wave ticket: about 1.5k entry visits (neighbouring home cells then go to different waves of one XCD at
+    // about the same time and find each other's buckets in its L2: at six waves per SIMD tickets of 4 / 3 / 2 pass slots
+    // fetch 8.0 / 6.0 / 4.2 GB per sweep of the default batch in the same 4.8-5.0 ms; 1: 3.1 GB in 6.0 ms), from the visits per descriptor the
     // previous batch measured (2 until there is one); SGTD_SORTED_CHUNK overrides
     u32 chunk = 2;
     if (e->stats.last_D > 0 && e->stats.last_P_swept > 0) {
       // last_P_swept counts a pass's shared list once: visits per pass ~ P_swept / (D / descriptors per pass)
       const double per_pass = (double)e->stats.last_P_swept / ((double)e->stats.last_D / (pair ? (SGTD_PAIR >= 4 ? 3.2 : 1.9) : 1.0));
-      chunk = (u32)std::min(8.0, std::max(1.0, std::floor(3072.0 / per_pass + 0.5)));
+      chunk = (u32)std::min(8.0, std::max(1.0, std::floor(1536.0 / per_pass + 0.5)));
     }
     if (e->sorted_chunk > 0) chunk = (u32)std::min(SGTD_TICKET_MAX, e->sorted_chunk);
     // the grid is sized by resident waves, not by work items: every wave pulls tickets
