@@ -402,45 +402,84 @@ __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int 
 }
 
 // One lane per pass slot.  The lanes of a wave hold consecutive slots, i.e. passes of consecutive
-// groups: the wave stages the GroupRows of SGTD_PLAN_GROUPS groups at a time in LDS (coalesced
-// copies instead of 64 scattered 16-B loads per lane and cell) and the lanes of those groups
-// walk their group's 27 directory rows there ONCE, writing the ranges as they go: a record's room
-// is taken from the pool beforehand (one atomic per wave) for an upper bound of its ranges — two
-// per gated cell that has a bucket, one more where the bucket has an overflow slice (the masks
-// group_resolve_kernel left behind the rows).  A pass without a single entry to visit gets no
-// record and its (empty) results are written here.
+// groups.  Per trip of a workgroup (256 slots):
+//   1. every lane reads its pass (positions, descriptors, its group's masks: which of the 27 cells have a
+//      bucket / an overflow slice — group_resolve_kernel left them behind the rows — and the descriptors'
+//      records) and bounds its record: two ranges per gated cell that has a bucket, one more where the
+//      bucket has an overflow slice;
+//   2. room for all 256 records with ONE add to the pool's cursor (a scan per wave, the waves' sums through
+//      LDS);
+//   3. wave by wave, SGTD_PLAN_GROUPS groups at a time: the rows of the cells that HAVE a bucket (10 of 27
+//      on the synthetic maps) are staged in LDS, packed, behind a zero row that stands for all others (a
+//      set = one group's rows in one segment; lane q < 54 copies quarter q of a set; groups that do not
+//      fit the wave's 7 KB wait for the next round), and the lanes of those groups walk THEIR cells there
+//      — gated by one of their descriptors and holding a bucket — writing the ranges as they go.
+// A pass without a single entry to visit gets no record and its (empty) results are written here.
 #ifndef SGTD_PLAN_GROUPS
 #define SGTD_PLAN_GROUPS 16   // (4 / 6 / 8 / 12 groups per round measured +1.07 / +0.50 / +0.24 / +0 ms: a round costs a whole walk)
 #endif
-#define SGTD_PLAN_THREADS 128
+#define SGTD_PLAN_THREADS 256
+#ifndef SGTD_PLAN_WAVES
+#define SGTD_PLAN_WAVES __attribute__((amdgpu_waves_per_eu(5)))
+#endif
+#ifndef SGTD_EXP_PLAN_STAGE
+// Experiment builds (never shipped): the planner stops behind stage 1 .. 5 (slot -> positions and descriptors -> the
+// group's masks -> the descriptors' records and reach -> room) or, 6, does everything but the walk; with the product
+// build, the differences are what each stage costs.
+#define SGTD_EXP_PLAN_STAGE 0
+#endif
+#ifndef SGTD_PLAN_INFLIGHT
+#define SGTD_PLAN_INFLIGHT 4u   // sets whose rows are in flight together in the staging copy
+#endif
+#ifndef SGTD_PLAN_SPARSE
+#define SGTD_PLAN_SPARSE 1
+#endif
+#ifndef SGTD_PLAN_QUADS
+#define SGTD_PLAN_QUADS 448    // staging room per wave, 16-B quarters: the rows of the cells that HAVE a bucket (10 of a group's 27 on
+                               // the synthetic maps) of up to SGTD_PLAN_GROUPS groups; groups that do not fit wait for the next round
+#endif
 #define SGTD_ROW_QUADS (2 * SGTD_NCELL + 1)     // 16-B quarters of one GroupRow: 27 rows + the masks
 // TAIL: the table has a tail segment — a GroupRow slot holds two sets of rows, half as many groups are
 // staged per round, and a cell's ranges are the main segment's followed by the tail's (the reference's
 // bucket holds the appended entries behind the older ones).
 template <bool PAIR, bool TAIL>
-__global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableView T, QueryView Q, const u32 *order, const u32 *gid,
+__global__ __launch_bounds__(SGTD_PLAN_THREADS) SGTD_PLAN_WAVES void plan_passes_kernel(TableView T, QueryView Q, const u32 *order, const u32 *gid,
                                                           const u32 *pos_of_slot, const u32 *n_valid_p,
                                                           const u32 *n_groups_p, const unsigned char *rows, u32 rows_cap, PassPool P,
                                                           u32 *n_visit, uint2 *list, int *overflow) {
   constexpr u32 SEGS = TAIL ? 2u : 1u;
-  constexpr u32 GQ = SEGS * SGTD_ROW_QUADS;                   // staged quarters per group
   constexpr u32 NG = SGTD_PLAN_GROUPS / SEGS;                 // groups staged per round
   constexpr size_t ROWB = (size_t)SEGS * SGTD_GROUP_ROW_BYTES;
-  __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][NG * GQ];
+  // staged per wave: a zero row (the cells without a bucket) + the rows of the cells that have one, set after set
+  // (a set = one group's rows in one segment)
+  __shared__ uint4 s_rows[SGTD_PLAN_THREADS / SGTD_WAVE][SGTD_PLAN_QUADS + 2];
   const int lane = lane_id();
   uint4 *my_rows = s_rows[threadIdx.x >> 6];
+  if (lane < 2) my_rows[lane] = make_uint4(0u, 0u, 0u, 0u);
+  __builtin_amdgcn_wave_barrier();
   const u32 nv = *n_valid_p;
   const u32 n_pass = pass_slot_count(nv, *n_groups_p, PAIR);
   const bool no_rows = *n_groups_p > rows_cap;      // group_resolve_kernel raised the overflow flag: no pass gets a record
-  // every wave takes 64 consecutive slots at a time, grid-stride (the grid is sized by resident waves)
-  for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; (s & ~63u) < n_pass; s += gridDim.x * blockDim.x) {
+  // every wave takes 64 consecutive slots at a time, the workgroup SGTD_PLAN_THREADS, grid-stride (the grid is sized by
+  // resident workgroups); the trip count is the same for all waves of a workgroup (barriers below)
+  __shared__ u32 s_units[SGTD_PLAN_THREADS / SGTD_WAVE], s_base[SGTD_PLAN_THREADS / SGTD_WAVE], s_room;
+  for (u32 s_wg = blockIdx.x * blockDim.x; s_wg < n_pass; s_wg += gridDim.x * blockDim.x) {
+  const u32 s = s_wg + threadIdx.x;
   const u32 p = (s < n_pass && !no_rows) ? pos_of_slot[s] : SGTD_NO_PASS;
+#if SGTD_EXP_PLAN_STAGE == 1
+  if (p == 0x12345678u) overflow[1] = 1;
+  if (s < n_pass) P.rec_off[s] = SGTD_NO_PASS;
+  continue;
+#endif
   constexpr int KM = SGTD_PASS_KMAX;
   int K = 0;
   u32 g = 0, d[KM];
 #pragma unroll
   for (int k = 0; k < KM; k++) d[k] = 0;
   bool act = p != SGTD_NO_PASS;
+  u32 ex_g[SEGS], ov_g[SEGS];     // the group's masks: cells that have a bucket / an overflow slice, per segment
+#pragma unroll
+  for (u32 sg = 0; sg < SEGS; sg++) { ex_g[sg] = 0; ov_g[sg] = 0; }
   if (act) {
     g = gid[p];
     K = 1;
@@ -452,9 +491,13 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
     for (int k = 0; k < KM; k++) d[k] = order[p + (k < K ? k : 0)];
     // a home cell none of whose 27 buckets exists in the table: nothing to plan or sweep — before
     // anything of the descriptors is read
-    const u32 *gr = reinterpret_cast<const u32 *>(rows + (size_t)g * ROWB);
-    u32 any = gr[8 * SGTD_NCELL];
-    if (TAIL) any |= gr[SGTD_GROUP_ROW_BYTES / 4 + 8 * SGTD_NCELL];
+    u32 any = SGTD_EXP_PLAN_STAGE == 2 ? 1u : 0u;
+#pragma unroll
+    for (u32 sg = 0; sg < (SGTD_EXP_PLAN_STAGE == 2 ? 0u : SEGS); sg++) {
+      const uint2 m = *reinterpret_cast<const uint2 *>(rows + (size_t)g * ROWB + (size_t)sg * SGTD_GROUP_ROW_BYTES + 32 * SGTD_NCELL);
+      ex_g[sg] = m.x; ov_g[sg] = m.y;
+      any |= m.x;
+    }
     if (any == 0u) {
 #pragma unroll
       for (int k = 0; k < KM; k++)
@@ -463,6 +506,11 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
     }
   }
   u32 hq[KM][5];   // q0, q1, q2 (f32), lo2, hi2 as words
+#if SGTD_EXP_PLAN_STAGE == 3 || SGTD_EXP_PLAN_STAGE == 2
+  if ((ex_g[0] ^ d[0] ^ d[1] ^ d[2] ^ d[3]) == 0x12345678u) overflow[1] = 1;
+  if (s < n_pass) P.rec_off[s] = SGTD_NO_PASS;
+  continue;
+#endif
   if (!act) K = 0;
   u32 qfr[KM], gate[KM];
   // per descriptor and offset -1, 0, +1: the halves (second side) and thirds (third side) its
@@ -497,6 +545,54 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
   u32 gate_any = 0;
 #pragma unroll
   for (int k = 0; k < KM; k++) gate_any |= gate[k];
+#if SGTD_EXP_PLAN_STAGE == 4
+  { u32 x = gate_any; for (int k = 0; k < KM; k++) x ^= reach[k] ^ hq[k][0] ^ hq[k][4] ^ qfr[k]; if (x == 0x12345678u) overflow[1] = 1; }
+  if (s < n_pass) P.rec_off[s] = SGTD_NO_PASS;
+  continue;
+#endif
+  // Room for the records, for all 64 x waves passes of the workgroup at once: an upper bound of a pass's ranges — two
+  // per gated cell that has a bucket, one more where the bucket has an overflow slice — from the masks alone, one
+  // scan per wave and ONE add to the pool's cursor per workgroup and trip (an address takes 88 M atomic adds per
+  // second, tools/atomic_rate.hip: one add per wave and staging round, 8 x 10^4 a batch, were 0.9 of this kernel's
+  // 1.1 ms)
+  u32 n_ex = 0, n_ov = 0;
+#pragma unroll
+  for (u32 sg = 0; sg < SEGS; sg++) {
+    n_ex += (u32)__builtin_popcount(gate_any & ex_g[sg]);
+    n_ov += (u32)__builtin_popcount(gate_any & ov_g[sg]);
+  }
+  u32 ub = act ? 2u * n_ex + n_ov : 0u;
+  // more ranges than the sweep has lanes (only with many overflow slices): the halves of a cell as
+  // ONE unpruned range, all six sub-cells — a superset of what the descriptors reach; with a tail
+  // segment even that can be too many: then every bucket is one range, overflow slice included (it
+  // follows the halves)
+  const bool coarse = ub > T.coarse_at;
+  if (coarse) ub = n_ex + n_ov;
+  const bool whole = TAIL && coarse && ub > T.whole_at;
+  if (whole) ub = n_ex;
+  const u32 units = ub ? SGTD_PASS_HDR_UNITS + ((ub + 1u) * 12u + 15u) / 16u : 0u;
+  const u32 inc = wave_incl_scan(units);
+  if (lane == SGTD_WAVE - 1) s_units[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tot = 0;
+#pragma unroll
+    for (int w = 0; w < SGTD_PLAN_THREADS / SGTD_WAVE; w++) { s_base[w] = tot; tot += s_units[w]; }
+    const u32 base = tot ? atomicAdd(P.cursor, tot) : 0u;
+#pragma unroll
+    for (int w = 0; w < SGTD_PLAN_THREADS / SGTD_WAVE; w++) s_base[w] += base;
+    const bool fits = (u64)base + tot <= (u64)P.cap;
+    s_room = fits ? 1u : 0u;
+    if (!fits) overflow[0] = 1;                 // the host grows the pool and re-runs the batch
+  }
+  __syncthreads();
+  const bool room = s_room != 0u;
+  const u32 off = s_base[threadIdx.x >> 6] + inc - units;
+#if SGTD_EXP_PLAN_STAGE == 5
+  { u32 x = gate_any ^ off; for (int k = 0; k < KM; k++) x ^= reach[k] ^ hq[k][0] ^ hq[k][4] ^ qfr[k]; if (x == 0x12345678u) overflow[1] = 1; }
+  if (s < n_pass) P.rec_off[s] = SGTD_NO_PASS;
+  continue;
+#endif
   // the wave's groups are consecutive ids (slots grow with the sorted position): first and last active lane
   const u64 act_mask = __builtin_amdgcn_ballot_w64(act);
   if (!act_mask) {
@@ -506,59 +602,50 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
   const u32 g_lo = (u32)__builtin_amdgcn_readlane((int)g, __builtin_ctzll(act_mask));
   const u32 g_hi = (u32)__builtin_amdgcn_readlane((int)g, 63 - __builtin_clzll(act_mask));
   u32 my_off = SGTD_NO_PASS;
-  for (u32 gc = g_lo; gc <= g_hi; gc += NG) {
-    const u32 ng = min(NG, g_hi - gc + 1u);
-    __builtin_amdgcn_wave_barrier();
-    {   // flat copy of ng x 55 (110) quarters, four loads in flight per lane
-      const u32 n_quads = ng * GQ;
-      for (u32 i0 = 0; i0 < n_quads; i0 += 4 * SGTD_WAVE) {
-        uint4 t[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const u32 i = min(i0 + u * SGTD_WAVE + lane, n_quads - 1u);
-          const u32 gg = i / GQ, q = i - gg * GQ;
-          // (the tail's rows start at the slot's second KB, quarter 64)
-          const u32 src = TAIL && q >= SGTD_ROW_QUADS ? q - SGTD_ROW_QUADS + SGTD_GROUP_ROW_BYTES / 16 : q;
-          t[u] = reinterpret_cast<const uint4 *>(rows + (size_t)(gc + gg) * ROWB)[src];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const u32 i = i0 + u * SGTD_WAVE + lane;
-          if (i < n_quads) my_rows[i] = t[u];
-        }
-      }
+  for (u32 gc = g_lo, ng = 0; gc <= g_hi; gc += ng) {
+    // the masks of the next (up to) NG groups' sets, one lane each; then as many whole groups as the staging room takes
+    const u32 ng_max = min(NG, g_hi - gc + 1u);
+    u32 ex_l = 0;
+    if ((u32)lane < ng_max * SEGS) {
+      const u32 gi = gc + (u32)lane / SEGS, sg = (u32)lane % SEGS;
+      ex_l = *reinterpret_cast<const u32 *>(rows + (size_t)gi * ROWB + (size_t)sg * SGTD_GROUP_ROW_BYTES + 32 * SGTD_NCELL);
+    }
+    const u32 sz = 2u * (u32)__builtin_popcount(ex_l);            // quarters of the set's rows
+    const u32 incl = wave_incl_scan(sz);
+    const u32 pre_l = incl - sz + 2u;                              // its first quarter (behind the zero row)
+    {
+      const u64 fitm = __builtin_amdgcn_ballot_w64(incl <= (u32)SGTD_PLAN_QUADS);      // (leading ones: incl grows with the lane)
+      const u32 n_fit = ~fitm ? (u32)__builtin_ctzll(~fitm) : 64u;
+      ng = min(n_fit, ng_max * SEGS) / SEGS;                       // (at least one: a group's sets are 54 SEGS quarters)
     }
     __builtin_amdgcn_wave_barrier();
-    const bool mine = act && g - gc < NG;      // (g >= gc for every lane not yet served)
-    const u32 *row = reinterpret_cast<const u32 *>(my_rows + (mine ? g - gc : 0u) * GQ);
-    // room for the record: an upper bound of the ranges
-    u32 n_ex = 0, n_ov = 0;
+    // set after set: lane q < 54 copies quarter q of the set's rows if its cell has a bucket; four sets' loads in flight
+    for (u32 s0 = 0; s0 < ng * SEGS; s0 += SGTD_PLAN_INFLIGHT) {
+      uint4 t[SGTD_PLAN_INFLIGHT];
+      u32 dst[SGTD_PLAN_INFLIGHT];
+#pragma unroll
+      for (u32 u = 0; u < SGTD_PLAN_INFLIGHT; u++) {
+        const u32 st = min(s0 + u, ng * SEGS - 1u);
+        const u32 ex_s = (u32)__builtin_amdgcn_readlane((int)ex_l, (int)st), pre_s = (u32)__builtin_amdgcn_readlane((int)pre_l, (int)st);
+        const u32 c = (u32)lane >> 1;
+        const bool on = s0 + u < ng * SEGS && lane < 2 * SGTD_NCELL && ((ex_s >> c) & 1u);
+        dst[u] = on ? pre_s + 2u * (u32)__builtin_popcount(ex_s & ((1u << c) - 1u)) + ((u32)lane & 1u) : 0xFFFFFFFFu;
+        // (lanes without a row read the set's mask quarter: one line for all of them, nothing stored)
+        t[u] = reinterpret_cast<const uint4 *>(rows + (size_t)(gc + st / SEGS) * ROWB + (size_t)(st % SEGS) * SGTD_GROUP_ROW_BYTES)[on ? lane : 2 * SGTD_NCELL];
+      }
+#pragma unroll
+      for (u32 u = 0; u < SGTD_PLAN_INFLIGHT; u++)
+        if (dst[u] != 0xFFFFFFFFu) my_rows[dst[u]] = t[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool mine = act && g - gc < ng;      // (g >= gc for every lane not yet served)
+    // the first quarters of the lane's sets, from the lanes that hold them
+    u32 pre_m[SEGS], rk[SEGS];
 #pragma unroll
     for (u32 sg = 0; sg < SEGS; sg++) {
-      const u32 *m = row + sg * 4 * SGTD_ROW_QUADS + 8 * SGTD_NCELL;
-      n_ex += (u32)__builtin_popcount(gate_any & m[0]);
-      n_ov += (u32)__builtin_popcount(gate_any & m[1]);
+      pre_m[sg] = (u32)__builtin_amdgcn_ds_bpermute((int)(((mine ? g - gc : 0u) * SEGS + sg) << 2), (int)pre_l);
+      rk[sg] = 0;
     }
-    u32 ub = mine ? 2u * n_ex + n_ov : 0u;
-    // more ranges than the sweep has lanes (only with many overflow slices): the halves of a cell as
-    // ONE unpruned range, all six sub-cells — a superset of what the descriptors reach; with a tail
-    // segment even that can be too many: then every bucket is one range, overflow slice included (it
-    // follows the halves)
-    const bool coarse = ub > T.coarse_at;
-    if (coarse) ub = n_ex + n_ov;
-    const bool whole = TAIL && coarse && ub > T.whole_at;
-    if (whole) ub = n_ex;
-    const u32 units = ub ? SGTD_PASS_HDR_UNITS + ((ub + 1u) * 12u + 15u) / 16u : 0u;
-    const u32 inc = wave_incl_scan(units);
-    const u32 wave_units = (u32)__builtin_amdgcn_readlane((int)inc, SGTD_WAVE - 1);
-    u32 base = 0;
-    if (wave_units) {
-      if (lane == 0) base = atomicAdd(P.cursor, wave_units);
-      base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-    }
-    const bool room = (u64)base + wave_units <= (u64)P.cap;
-    if (!room && lane == 0) overflow[0] = 1;                 // the host grows the pool and re-runs the batch
-    const u32 off = base + inc - units;
     u32 n = 0, total = 0, visits[KM];
 #pragma unroll
     for (int k = 0; k < KM; k++) visits[k] = 0;
@@ -572,12 +659,12 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
           n++;
         }
       };
-#pragma unroll 1
-      for (int cs = 0; cs < (int)(SGTD_NCELL * SEGS); cs++) {     // (unrolled, the compiler keeps 54 gate predicates in scalar registers)
-        const int c = TAIL ? cs >> 1 : cs;
+      // one cell of one segment: its ranges, its visits
+      auto cell = [&](int c, u32 sgi, u32 rank) {
         const int oy = (c / 3) % 3, oz = c % 3;
-        const u32 *rc = row + 8 * c + (TAIL && (cs & 1) ? 4 * SGTD_ROW_QUADS : 0);             // {start, cum0 .. cum6}
-        const u32 cum6 = rc[7], cum5 = rc[6], start = rc[0] + (TAIL && (cs & 1) ? T.tail_off : 0u);
+        const u32 has = (ex_g[sgi] >> c) & 1u;                                                 // (no bucket: the zero row)
+        const u32 *rc = reinterpret_cast<const u32 *>(my_rows + (has ? pre_m[sgi] + 2u * rank : 0u));   // {start, cum0 .. cum6}
+        const u32 cum6 = rc[7], cum5 = rc[6], start = rc[0] + (TAIL && sgi ? T.tail_off : 0u);
         // sub-cells reached by any gated descriptor: bits 0..2 the thirds of the lower half, 3..5 of the upper
         u32 sub = 0, meta = (u32)c;
 #pragma unroll
@@ -593,7 +680,7 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
         sub |= (sub & (sub >> 2) & 0x9u) << 1;   // per half the thirds from the first to the last reached one
         if (whole) {
           put(start, live ? cum6 : 0u, meta);                   // the whole bucket
-          continue;
+          return;
         }
         if (!coarse) {
           // half h: entries before its first reached third (cum[i - 1], 0 for i = 0) and up to its last
@@ -608,7 +695,30 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) void plan_passes_kernel(TableVie
           put(start, live ? cum5 : 0u, meta);                   // both halves
         }
         put(start + cum5, live ? cum6 - cum5 : 0u, meta);         // the overflow slice follows both halves
+      };
+#if SGTD_PLAN_SPARSE
+      // every lane walks ITS cells — gated by one of its descriptors and holding a bucket in one of the segments, 7 of
+      // the 27 on the synthetic maps — in ascending order; the wave runs as many trips as its busiest lane has cells
+      u32 todo = gate_any & (ex_g[0] | ex_g[SEGS - 1]);
+#if SGTD_EXP_PLAN_STAGE == 6
+      todo = todo == 0x12345u ? 1u : 0u;
+#endif
+#pragma unroll 1
+      while (todo) {
+        const int c = __builtin_ctz(todo);
+        todo &= todo - 1u;
+#pragma unroll
+        for (u32 sgi = 0; sgi < SEGS; sgi++) cell(c, sgi, (u32)__builtin_popcount(ex_g[sgi] & ((1u << c) - 1u)));
       }
+#else
+#pragma unroll 1
+      for (int cs = 0; cs < (int)(SGTD_NCELL * SEGS); cs++) {
+        const int c = TAIL ? cs >> 1 : cs;
+        const u32 sgi = TAIL ? (u32)(cs & 1) : 0u;
+        cell(c, sgi, rk[sgi]);
+        rk[sgi] += (ex_g[sgi] >> c) & 1u;
+      }
+#endif
       const bool rec = emit && n != 0u;
       if (rec) {
         my_off = off;

@@ -762,11 +762,15 @@ Views make_views(sgtd_engine *e) {
   B.rec = e->rec.as<u32>(); B.id_bits = e->id_bits ? e->id_bits : 13;
   B.ctr = e->cursors.as<u32>();
   // the smallest slab: the streams of all resident waves hold one each (8192 waves x SGTD_PAIR streams) — together
-  // at most a quarter of the record buffer (a 33 M-record buffer of a small batch: 512-record slabs)
+  // at most a quarter of the record buffer (a 33 M-record buffer of a small batch: 512-record slabs).  (A slab is one
+  // atomic add to the cursor, and ONE address takes 88 M of them per second, tools/atomic_rate.hip: the 1.8 G records
+  // of the default batch in slabs of 8 K are 2.4 ms of the cursor's time inside a 5 ms sweep — but slabs of 32 K or
+  // 128 K run no faster, SGTD_REC_SLAB: the waves do not wait for it.)
   {
     const size_t streams = (size_t)e->n_cus * 32 * SGTD_PAIR;
     u32 slab = SGTD_REC_SLAB;
     while (slab > 512u && (size_t)slab * streams * 4 > e->rec_cap) slab >>= 1;
+    if (const char *o = getenv("SGTD_REC_SLAB")) slab = (u32)std::max(512, atoi(o));   // experiment knob
     B.rec_slab = slab;
   }
   // room a list gets when its pass starts (ProbeBuffers::rec_rate): three times the matches per visited entry
@@ -974,8 +978,11 @@ int launch_select(sgtd_engine *e) {
       group_resolve_kernel<<<e->n_cus * 16, 256, 0, e->stream>>>(vs.T, vs.Q, vin, e->group_first.as<u32>(),
                                                                   e->n_groups.as<u32>(), nv, e->cell_rows.as<unsigned char>(), rows_cap, vs.B.overflow());
       HIPCHK(hipGetLastError());
-      // resident workgroups (LDS: 880 B per staged group and wave) x 4 rounds, grid-stride over the slots
-      const int pgrid = (int)std::min<long long>(grid_for((long long)max_pass_slots, SGTD_PLAN_THREADS), (long long)e->n_cus * 20);
+      // resident workgroups (five waves per SIMD: 100 vector registers, 7 KB of staged rows per wave) x 4 rounds,
+      // grid-stride over the slots
+      int plan_per_cu = 20;
+      if (const char *o = getenv("SGTD_PLAN_BLOCKS_PER_CU")) plan_per_cu = std::max(1, atoi(o));   // experiment knob
+      const int pgrid = (int)std::min<long long>(grid_for((long long)max_pass_slots, SGTD_PLAN_THREADS), (long long)e->n_cus * plan_per_cu);
 #define SGTD_LAUNCH_PLAN(PR, TL)                                                                               \
   plan_passes_kernel<PR, TL><<<pgrid, SGTD_PLAN_THREADS, 0, e->stream>>>(vs.T, vs.Q, vin, e->gid.as<u32>(), e->pos_of_slot.as<u32>(), nv, \
                                                        e->n_groups.as<u32>(), rows, rows_cap, PP, vs.B.n_visit, vs.B.list,          \
