@@ -252,8 +252,12 @@ __global__ void group_first_kernel(const u32 *gid, const u32 *n_valid_p, u32 *gr
 }
 
 // One GroupRow per home cell of the batch: the 27 ungated bucket lookups (STDesc.cpp:358-371
-// minus the gate), each answered with the bucket's directory row {start, cum[5]} (all zero if
-// the table has no such bucket): 27 x 32 B at rows + g * SGTD_GROUP_ROW_BYTES.
+// minus the gate), each answered with the bucket's directory row {start, cum[0..6]} if the table
+// has such a bucket: at rows + g * SGTD_GROUP_ROW_BYTES a quarter of masks (cells with a bucket,
+// cells whose bucket has an overflow slice) and the rows of the cells that have one, packed in
+// cell order — 10 of 27 on the synthetic maps: the kernel is bound by its traffic (4.8 TB/s with
+// all 27 rows written; two or four groups per trip and half-wave, every link of the dependent chain
+// issued for all of them first: no faster).
 // 32 lanes per group, grid-stride.
 __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryView Q, const u32 *order,
                                                             const u32 *group_first, const u32 *n_groups_p,
@@ -307,14 +311,19 @@ __global__ __launch_bounds__(256) void group_resolve_kernel(TableView T, QueryVi
           h = (h + 1) & mask;
         }
       }
-      uint4 *out = reinterpret_cast<uint4 *>(rows + (size_t)g * group_row_bytes(T) + (size_t)sg * SGTD_GROUP_ROW_BYTES) + 2 * c;
-      out[0] = lo;     // start, cum[0..2]
-      out[1] = hi;     // cum[3..6]
-      // behind the 27 rows: which cells have a bucket at all, and which of those an overflow slice
-      // (plan_passes_kernel bounds a pass's number of ranges with them before it walks the rows)
+      // the set's first quarter: which cells have a bucket at all, and which of those an overflow slice
+      // (plan_passes_kernel bounds a pass's number of ranges with them before it walks the rows); behind it
+      // the rows of the cells that have one, packed in cell order (two quarters each)
       const u64 ex = __builtin_amdgcn_ballot_w64(hi.w != 0u), ov = __builtin_amdgcn_ballot_w64(hi.w != hi.z);
       const int sh = (int)(threadIdx.x & 32);
-      if (c == 0) out[2 * SGTD_NCELL] = make_uint4((u32)(ex >> sh) & 0x7FFFFFFu, (u32)(ov >> sh) & 0x7FFFFFFu, 0u, 0u);
+      const u32 exh = (u32)(ex >> sh) & 0x7FFFFFFu;
+      uint4 *out = reinterpret_cast<uint4 *>(rows + (size_t)g * group_row_bytes(T) + (size_t)sg * SGTD_GROUP_ROW_BYTES);
+      if (hi.w != 0u) {
+        const u32 r = 1u + 2u * (u32)__builtin_popcount(exh & ((1u << c) - 1u));
+        out[r] = lo;         // start, cum[0..2]
+        out[r + 1] = hi;     // cum[3..6]
+      }
+      if (c == 0) out[0] = make_uint4(exh, (u32)(ov >> sh) & 0x7FFFFFFu, 0u, 0u);
     }
   }
 }
@@ -411,7 +420,7 @@ __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int 
 //      LDS);
 //   3. wave by wave, SGTD_PLAN_GROUPS groups at a time: the rows of the cells that HAVE a bucket (10 of 27
 //      on the synthetic maps) are staged in LDS, packed, behind a zero row that stands for all others (a
-//      set = one group's rows in one segment; lane q < 54 copies quarter q of a set; groups that do not
+//      set = one group's rows in one segment, packed like that by group_resolve_kernel: a flat copy; groups that do not
 //      fit the wave's 7 KB wait for the next round), and the lanes of those groups walk THEIR cells there
 //      — gated by one of their descriptors and holding a bucket — writing the ranges as they go.
 // A pass without a single entry to visit gets no record and its (empty) results are written here.
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) SGTD_PLAN_WAVES void plan_passes
     u32 any = SGTD_EXP_PLAN_STAGE == 2 ? 1u : 0u;
 #pragma unroll
     for (u32 sg = 0; sg < (SGTD_EXP_PLAN_STAGE == 2 ? 0u : SEGS); sg++) {
-      const uint2 m = *reinterpret_cast<const uint2 *>(rows + (size_t)g * ROWB + (size_t)sg * SGTD_GROUP_ROW_BYTES + 32 * SGTD_NCELL);
+      const uint2 m = *reinterpret_cast<const uint2 *>(rows + (size_t)g * ROWB + (size_t)sg * SGTD_GROUP_ROW_BYTES);
       ex_g[sg] = m.x; ov_g[sg] = m.y;
       any |= m.x;
     }
@@ -608,7 +617,7 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) SGTD_PLAN_WAVES void plan_passes
     u32 ex_l = 0;
     if ((u32)lane < ng_max * SEGS) {
       const u32 gi = gc + (u32)lane / SEGS, sg = (u32)lane % SEGS;
-      ex_l = *reinterpret_cast<const u32 *>(rows + (size_t)gi * ROWB + (size_t)sg * SGTD_GROUP_ROW_BYTES + 32 * SGTD_NCELL);
+      ex_l = *reinterpret_cast<const u32 *>(rows + (size_t)gi * ROWB + (size_t)sg * SGTD_GROUP_ROW_BYTES);
     }
     const u32 sz = 2u * (u32)__builtin_popcount(ex_l);            // quarters of the set's rows
     const u32 incl = wave_incl_scan(sz);
@@ -619,19 +628,18 @@ __global__ __launch_bounds__(SGTD_PLAN_THREADS) SGTD_PLAN_WAVES void plan_passes
       ng = min(n_fit, ng_max * SEGS) / SEGS;                       // (at least one: a group's sets are 54 SEGS quarters)
     }
     __builtin_amdgcn_wave_barrier();
-    // set after set: lane q < 54 copies quarter q of the set's rows if its cell has a bucket; four sets' loads in flight
+    // set after set: lane q copies quarter q of the set's packed rows; SGTD_PLAN_INFLIGHT sets' loads in flight
     for (u32 s0 = 0; s0 < ng * SEGS; s0 += SGTD_PLAN_INFLIGHT) {
       uint4 t[SGTD_PLAN_INFLIGHT];
       u32 dst[SGTD_PLAN_INFLIGHT];
 #pragma unroll
       for (u32 u = 0; u < SGTD_PLAN_INFLIGHT; u++) {
         const u32 st = min(s0 + u, ng * SEGS - 1u);
-        const u32 ex_s = (u32)__builtin_amdgcn_readlane((int)ex_l, (int)st), pre_s = (u32)__builtin_amdgcn_readlane((int)pre_l, (int)st);
-        const u32 c = (u32)lane >> 1;
-        const bool on = s0 + u < ng * SEGS && lane < 2 * SGTD_NCELL && ((ex_s >> c) & 1u);
-        dst[u] = on ? pre_s + 2u * (u32)__builtin_popcount(ex_s & ((1u << c) - 1u)) + ((u32)lane & 1u) : 0xFFFFFFFFu;
-        // (lanes without a row read the set's mask quarter: one line for all of them, nothing stored)
-        t[u] = reinterpret_cast<const uint4 *>(rows + (size_t)(gc + st / SEGS) * ROWB + (size_t)(st % SEGS) * SGTD_GROUP_ROW_BYTES)[on ? lane : 2 * SGTD_NCELL];
+        const u32 sz_s = (u32)__builtin_amdgcn_readlane((int)sz, (int)st), pre_s = (u32)__builtin_amdgcn_readlane((int)pre_l, (int)st);
+        const bool on = s0 + u < ng * SEGS && (u32)lane < sz_s;
+        dst[u] = on ? pre_s + (u32)lane : 0xFFFFFFFFu;
+        // (lanes beyond the set's rows read its mask quarter: one line for all of them, nothing stored)
+        t[u] = reinterpret_cast<const uint4 *>(rows + (size_t)(gc + st / SEGS) * ROWB + (size_t)(st % SEGS) * SGTD_GROUP_ROW_BYTES)[on ? 1 + lane : 0];
       }
 #pragma unroll
       for (u32 u = 0; u < SGTD_PLAN_INFLIGHT; u++)
