@@ -22,3 +22,18 @@ def test_library_rebuilt_on_the_gpu_box_passes_smoke(tmp_path):
     run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "smoke ok" in run.stdout
+
+
+@pytest.mark.gpu
+def test_planner_with_room_for_two_groups_per_round(tmp_path):
+    """plan_passes_kernel stages as many groups per round as its LDS room takes (probe_kernels.hip.h, SGTD_PLAN_QUADS:
+    448 quarters, all 16 groups of a round on the synthetic maps).  Built with room for two groups (one with a tail
+    segment), every wave needs many rounds and the groups left over wait: the parity tests of the batch path, the tail
+    segment and the per-query record passes must not notice."""
+    out = str(tmp_path / "libsgtd_accel_small_room.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "sgtd_amd", "csrc"), "-s", "-B", "OUT=" + out, "EXTRA=-DSGTD_PLAN_QUADS=112"])
+    env = dict(os.environ, SGTD_ACCEL_LIB=out)
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "select_parity or tail or append or twins"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]
+    assert " passed" in run.stdout
