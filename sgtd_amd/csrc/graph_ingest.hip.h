@@ -127,35 +127,76 @@ struct Scanner {
     float as_float() const { return kind == 0 ? static_cast<float>(u) : kind == 1 ? static_cast<float>(i) : static_cast<float>(d); }
     int as_int() const { return kind == 0 ? static_cast<int>(u) : kind == 1 ? static_cast<int>(i) : static_cast<int>(d); }
   };
+  // The double strtod returns, without calling it, for tokens of at most 19 significant digits and a decimal exponent of
+  // at most 27 in magnitude (every number the producer writes: floats dumped with 17 digits): the digits as an integer
+  // (exact in the 64-bit significand of x87 extended precision) times or divided by a power of ten (exact there too:
+  // 5^27 < 2^63) is ONE correctly rounded extended operation; rounding that to double gives the correctly rounded
+  // double unless the extended result sits exactly on a midpoint of the double grid (low eleven significand bits
+  // 100 0000 0000: the exact value decides) — then, and for every other token, strtod it is.
+  // tests/cpp/test_ingest_numbers.cpp compares the two on millions of tokens.
+  static bool fast_double(uint64_t m, int e10, bool neg, double *out) {
+    static const long double p10[28] = {1e0L,  1e1L,  1e2L,  1e3L,  1e4L,  1e5L,  1e6L,  1e7L,  1e8L,  1e9L,  1e10L, 1e11L, 1e12L, 1e13L,
+                                        1e14L, 1e15L, 1e16L, 1e17L, 1e18L, 1e19L, 1e20L, 1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+    if (__LDBL_MANT_DIG__ != 64) return false;    // (no x87 extended precision here — e.g. this header's device pass: strtod)
+    if (e10 < -27 || e10 > 27) return false;
+    if (m == 0) { *out = neg ? -0.0 : 0.0; return true; }
+    const long double x = e10 < 0 ? static_cast<long double>(m) / p10[-e10] : static_cast<long double>(m) * p10[e10];
+    uint64_t sig;
+    memcpy(&sig, &x, 8);                          // the 64-bit significand (explicit leading one)
+    if ((sig & 0x7FFu) == 0x400u) return false;
+    const double d = static_cast<double>(x);
+    *out = neg ? -d : d;
+    return true;
+  }
   bool number(Num *out) {
     ws();
     if (p >= end) return fail("number expected");
     // the token by JSON's grammar: -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?
+    // — and, on the way, its significant digits as an integer (the first 19) and its decimal exponent
     const char *q = p;
     bool is_float = false;
     const bool neg = *q == '-';
     if (neg) q++;
     if (q >= end || *q < '0' || *q > '9') return fail("number expected");
+    uint64_t m = 0;
+    int nd = 0, e10 = 0;
+    bool all_digits = true;      // every significant digit is in m
     if (*q == '0') q++;
-    else while (q < end && *q >= '0' && *q <= '9') q++;
+    else
+      for (; q < end && *q >= '0' && *q <= '9'; q++) {
+        if (nd < 19) { m = m * 10 + (uint64_t)(*q - '0'); nd++; }
+        else { all_digits = false; e10++; }
+      }
     if (q < end && *q == '.') {
       q++;
       if (q >= end || *q < '0' || *q > '9') return fail("digit expected after the decimal point");
-      while (q < end && *q >= '0' && *q <= '9') q++;
+      for (; q < end && *q >= '0' && *q <= '9'; q++) {
+        if (nd == 0 && *q == '0') { e10--; continue; }     // zeros in front of the first significant digit
+        if (nd < 19) { m = m * 10 + (uint64_t)(*q - '0'); nd++; e10--; }
+        else all_digits = false;
+      }
       is_float = true;
     }
     if (q < end && (*q == 'e' || *q == 'E')) {
       q++;
-      if (q < end && (*q == '+' || *q == '-')) q++;
+      bool eneg = false;
+      if (q < end && (*q == '+' || *q == '-')) { eneg = *q == '-'; q++; }
       if (q >= end || *q < '0' || *q > '9') return fail("digit expected in the exponent");
-      while (q < end && *q >= '0' && *q <= '9') q++;
+      int ex = 0;
+      for (; q < end && *q >= '0' && *q <= '9'; q++)
+        if (ex < 100000) ex = ex * 10 + (*q - '0');
+      e10 += eneg ? -ex : ex;
       is_float = true;
     }
-    const std::string tok(p, q);
+    const char *tok_begin = p;
     p = q;
     if (!out) return true;
     Num n;
     if (!is_float) {
+      // (no fraction, no exponent: all_digits means at most 19 digits — below 2^64; 18 fit a negative 64-bit integer)
+      if (!neg && all_digits) { n.kind = 0; n.u = m; *out = n; return true; }
+      if (neg && nd <= 18) { n.kind = 1; n.i = -static_cast<int64_t>(m); *out = n; return true; }
+      const std::string tok(tok_begin, q);
       errno = 0;
       char *e = nullptr;
       if (neg) {
@@ -167,7 +208,7 @@ struct Scanner {
       }
     }
     n.kind = 2;
-    n.d = strtod(tok.c_str(), nullptr);
+    if (!(is_float && all_digits && fast_double(m, e10, neg, &n.d))) n.d = strtod(std::string(tok_begin, q).c_str(), nullptr);
     *out = n;
     return true;
   }

@@ -135,3 +135,17 @@ def test_ingest_equals_the_references_json_library_bit_for_bit():
     out = subprocess.run([exe, "1500"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ingest equals nlohmann::json" in out.stdout
+
+
+def test_number_scanner_equals_strtod_and_the_integer_conversions(tmp_path):
+    """tests/cpp/test_ingest_numbers.cpp: the scanner's numbers on 3 M random tokens — float32 values dumped with 17
+    digits (what the producer writes), coordinates of 9-17 digits, random digit strings with exponents, any finite
+    double, integers around 2^63 / 2^64 — against strtod / strtoull / strtoll bit for bit (the scanner reaches most
+    doubles through one x87 extended-precision operation instead of strtod: graph_ingest.hip.h, fast_double)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_ingest_numbers")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-x", "c++", os.path.join(root, "tests", "cpp", "test_ingest_numbers.cpp"), "-o", exe, "-pthread"])
+    out = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "number scanner equals the C library" in out.stdout
