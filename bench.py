@@ -13,20 +13,28 @@ KITTI-00 length).
 
 N > 1: `python bench.py --gpus N` starts N ranks itself (child processes under
 torch.distributed.run, before anything touches a GPU); when it is already
-running under a launcher (RANK/WORLD_SIZE set) it is one rank.  The headline
-`value` for N > 1 is the form BASELINE.json's north_star names:
-  table  (default) the map's hash table is sharded by frame range over the ranks,
-         every rank sweeps its shard with the same Q queries, the local top-50
-         tables are all-gathered (RCCL) and merged with the reference's rule
-         (STDesc.cpp:423-433; sgtd_amd/dist.py::ShardedMap) — strong scaling: the
-         same F-frame map and Q queries per step whatever N is;
-  query  (--shard query; also measured beside the headline as `replicated` when the
-         map fits one GPU) the map is replicated, every rank serves its own Q query
-         frames per step — weak scaling, no data-path collective, one all_gather of
-         the result tables per step.
-Beside them, N > 1: `multi_device_handle` — ONE process (rank 0) driving all N
-devices through sgtd_create_multi, the form the reference's C++ caller uses; and,
-at N = 8, `cfg4`: BASELINE configs[3]'s 100 000-frame map sharded the same way.
+running under a launcher (RANK/WORLD_SIZE set) it is one rank.  The N ranks form
+a grid of R_t table shards x R_q query groups (sgtd_amd/dist.py::Map2D):
+  auto   (default) R_t = the smallest count whose shard fits one GPU's envelope
+         (dist.plan_2d), R_q = N / R_t: every query group holds one copy of the
+         (sharded) table and serves `--queries` query frames per step, so a step
+         serves R_q x `--queries` frames — weak scaling in the query groups.  A
+         10 000-frame map fits one GPU: R_t = 1, no data-path collective, one
+         all_gather of the result tables per step (on a side stream).
+  table  R_t = N: the form BASELINE.json's north_star names — the map's hash table
+         sharded by frame range over all ranks, every rank sweeps its shard with the
+         same `--queries` frames, ONE all_gather of the packed local top-50 tables and
+         the merge kernel (STDesc.cpp:423-433) on a side stream while the match lists
+         are written — strong scaling; also measured beside the headline
+         (`table_sharded`) whenever the headline is another form, with the ceiling
+         its replicated per-query work puts on it (`scaling_parts`).
+  query  R_t = 1 whatever the map size.
+Beside them, N > 1: `fixed_total_batch` (the headline's grid with `--queries` frames
+per step in TOTAL: strong scaling), `multi_device_handle` — ONE process (rank 0)
+driving all N devices through sgtd_create_multi, the form the reference's C++
+caller uses; and, at N = 8, `cfg4`: BASELINE configs[3]'s 100 000-frame map.
+N = 1 also carries `scaling_prediction`: what rank 0 of an 8-rank job does, measured
+here part by part, for both forms.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -58,9 +66,18 @@ def parse():
     ap.add_argument("--queries", type=int, default=2048,
                     help="query frames per step (per rank in query mode); 512 / 1024 / 2048 / 4096 give 81 / 92 / 98 / 101 k frames/s at F = 10 k")
     ap.add_argument("--shard", choices=["auto", "table", "query"], default="auto",
-                    help="N>1: what `value` measures; auto = table (the map's hash table sharded by frame range)")
-    ap.add_argument("--also-replicated", choices=["on", "off"], default="on",
-                    help="N>1, table mode: also measure the replicated-map / sharded-queries mode (and check that both give the same lists)")
+                    help="N>1: the grid of table shards x query groups `value` is measured on; auto = dist.plan_2d (the smallest number of "
+                         "table shards whose shard fits one GPU), table = N shards, query = N replicas")
+    ap.add_argument("--rt", type=int, default=None, help="N>1: table shards per query group, explicitly (must divide N)")
+    ap.add_argument("--lists", choices=["all", "winners"], default="all",
+                    help="N>1, table shards: match lists of every local candidate, written while the exchange runs (all), or of the merge's "
+                         "winners only, written behind the exchange (winners)")
+    ap.add_argument("--also-table", choices=["on", "off"], default="on",
+                    help="N>1: also measure the pure table-sharded form beside a headline of another form (and check that both give the same lists)")
+    ap.add_argument("--predict-world", type=int, default=8,
+                    help="N=1: ranks of the job whose rank 0 is measured part by part for `scaling_prediction` (0 = off)")
+    ap.add_argument("--skew", choices=["on", "off"], default="on", help="N=1: also measure the skewed, reference-shaped workload (workload_skew)")
+    ap.add_argument("--cfg1", choices=["on", "off"], default="on", help="N=1: also run BASELINE configs[0] (graph JSON in, 100-frame map) with its CPU timing")
     ap.add_argument("--multi-handle", choices=["auto", "on", "off"], default="auto",
                     help="N>1: also drive all N devices from ONE process through sgtd_create_multi (auto: when N real devices exist)")
     ap.add_argument("--cfg4", choices=["auto", "on", "off"], default="auto",
@@ -285,24 +302,194 @@ def run_steps(step, sync, steps):
     return time.perf_counter() - t0
 
 
+def claim_stdout():
+    """The result line must be the ONLY thing on stdout, and c10d / gloo print from C++ to fd 1 ("[Gloo] Rank 0 is
+    connected to ..."): keep the real stdout aside for the result, point fd 1 (and Python's sys.stdout) at stderr."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(os.dup(2), "w")
+    return os.fdopen(real, "w")
+
+
+def last_result_line(text):
+    """the last line of `text` that is a bench result (a JSON object with a metric), or None"""
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                json.loads(line)
+                return line
+            except ValueError:
+                continue
+    return None
+
+
+def modelled_all_gather_ms(bytes_per_rank, ranks):
+    """ring all_gather over xGMI, MODELLED (no multi-GPU box here): ranks - 1 steps of bytes_per_rank over one link at
+    48 GB/s effective (an xGMI link moves about 64 GB/s one way, MI355X_MICROARCH.md), 8 us per step of latency"""
+    if ranks <= 1:
+        return 0.0
+    return (ranks - 1) * (bytes_per_rank / 48e9 * 1e3 + 0.008)
+
+
+def skew_leg(args, dev, stream, local_rank, to_dev_flat):
+    """the same pipeline on a skewed, reference-shaped workload — Zipf-distributed labels over the 13
+    wild classes (get_json_wild.cpp:10-12), 50-400 keypoints per frame, clustered landmarks; F = --frames."""
+    import torch
+    from sgtd_amd import synth
+    from sgtd_amd.manager import STDescManager
+    F = args.frames
+    smap, world = synth.make_skewed_map(F, stream=31)
+    g = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 1))
+    g.set_stream(stream.cuda_stream)
+    t0 = time.perf_counter()
+    g.add_frames(*to_dev_flat(smap), kp_off=smap.kp_off)
+    g.finalize()
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    # the largest batch the 32-bit record index and the memory allow (long buckets: more matches per query than the
+    # uniform maps give — the estimate from the bucket statistics runs low here, so a small batch is measured first)
+    probe = synth.make_skewed_queries(world, 64, stream=3099)
+    g.query_frames(*to_dev_flat(probe), kp_off=probe.kp_off, fetch=False)
+    g.sync()
+    probe_reruns = int(g.stats()["reruns_total"])
+    q_safe = int(g.max_batch(int(np.mean(np.diff(smap.kp_off)))))
+    Q = max(64, min(args.queries, q_safe // 64 * 64 if q_safe >= 64 else 64))
+    sets = [synth.make_skewed_queries(world, Q, stream=3100 + b) for b in range(3)]
+    dsets = [(to_dev_flat(s), s.kp_off) for s in sets]
+
+    def step(i):
+        (x, l), off = dsets[i % len(dsets)]
+        g.query_frames(x, l, kp_off=off, fetch=False)
+    for i in range(3):          # work buffers reach their size (re-runs happen here, not in the timed steps)
+        step(i); g.sync()
+    s0 = g.stats()
+    torch.cuda.synchronize()
+    k = max(3, args.steps // 2)
+    t0 = time.perf_counter()
+    for i in range(k):
+        step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    g.sync()
+    s1 = g.stats()
+    res = g.results()
+    top1 = res.top1()
+    last = sets[(k - 1) % len(sets)]
+    ok = top1 >= 0
+    d = np.linalg.norm(smap.pose[np.clip(top1, 0, F - 1), :2] - last.pose[:, :2], axis=1)
+    out = {"workload": "synthetic skewed: Zipf(1.2) labels over 13 classes, 50-400 keypoints/frame, 70 % of the landmarks in clusters; %d-frame map" % F,
+           "frames_per_s": Q * k / el, "ms_per_step": 1000.0 * el / k, "queries_per_step": Q, "max_batch_the_record_index_allows": q_safe,
+           "keypoints_per_frame_mean": float(np.mean(np.diff(smap.kp_off))), "table_entries": int(s1["n_entries"]), "table_buckets": int(s1["n_buckets"]),
+           "bucket_len_sq_over_E": s1["bucket_len_sq_over_E"], "map_build_s": t_build,
+           "P_visited_per_query": s1["last_P"] / Q, "P_swept_per_query": s1["last_P_swept"] / Q, "M_matches_per_query": s1["last_M"] / Q,
+           "D_descs_per_query": s1["last_D"] / Q, "select_form": int(s1["select_form"]),
+           "reruns_in_timed_steps": int(s1["reruns_total"] - s0["reruns_total"]),
+           "launches_that_overflowed_in_timed_steps": int(s1["overflow_launches_total"] - s0["overflow_launches_total"]),
+           "list_moves_in_timed_steps": int(s1["list_moves_total"] - s0["list_moves_total"]),
+           "reruns_while_the_buffers_grew": int(s0["reruns_total"]), "reruns_of_the_first_64_query_batch": probe_reruns,
+           "top1_pose_within_5m": float(np.mean(ok & (d < 5.0)))}
+    g.close()
+    return out
+
+
+def cfg1_leg(args, dev, stream, local_rank):
+    """BASELINE configs[0] / BASELINE.md §2's F = 100 point: graph JSON files in (the producer's format, get_json.cpp:332-341;
+    synthetic stand-in, KITTI-00 is not in the image), a 100-frame map, the scans localized one per call on the CPU
+    restatement (10 warm-up + 200 timed) and on the GPU (per-frame calls and one batch)."""
+    import tempfile
+    import torch
+    from oracle.oracle import OracleManager
+    from sgtd_amd import evaluate as ev, ingest, synth
+    from sgtd_amd.manager import STDescManager
+    F, NQ, N = 100, 210, args.keypoints
+    smap = synth.make_map(F, N, stream=11)
+    qs = synth.make_queries(smap, NQ, stream=11)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp, qp = [], []
+        for f in range(F):
+            p = os.path.join(tmp, "map_%04d.json" % f)
+            ingest.write_graph_json(p, smap.xyz[f], smap.label[f], ev.pose_row(*smap.pose[f]))
+            mp.append(p)
+        for q in range(NQ):
+            p = os.path.join(tmp, "scan_%04d.json" % q)
+            ingest.write_graph_json(p, qs.xyz[q], qs.label[q], ev.pose_row(*qs.pose[q]))
+            qp.append(p)
+        t0 = time.perf_counter()
+        gm = ingest.load_graphs(mp)
+        gq = ingest.load_graphs(qp)
+        t_ingest = time.perf_counter() - t0
+    assert gm.n_frames == F and gq.n_frames == NQ and np.array_equal(gm.xyz.reshape(F, N, 3), smap.xyz)
+    g = STDescManager(device_id=local_rank)
+    g.set_stream(stream.cuda_stream)
+    g.add_frames(gm.xyz, gm.label, kp_off=gm.kp_off)
+    g.finalize()
+    # one scan per call, host pointers in, candidates out (the reference's call pattern)
+    qx, ql = gq.xyz.reshape(NQ, N, 3), gq.label.reshape(NQ, N)
+    for q in range(10):
+        g.query_frames(qx[q:q + 1], ql[q:q + 1])
+    t0 = time.perf_counter()
+    per = [g.query_frames(qx[q:q + 1], ql[q:q + 1]) for q in range(10, NQ)]
+    t_per = (time.perf_counter() - t0) / (NQ - 10)
+    g.query_frames(qx[10:], ql[10:])
+    t0 = time.perf_counter()
+    res = g.query_frames(qx[10:], ql[10:])
+    t_batch = time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
+    cpu_threads = ncpu - 4 if ncpu > 4 else (2 if ncpu > 3 else 1)       # MP_PROC_NUM rule, CMakeLists.txt:22-41
+    o = OracleManager(num_threads=cpu_threads)
+    o.add_frames(gm.xyz.reshape(F, N, 3), gm.label.reshape(F, N))
+    ms, ident = [], 0
+    for q in range(NQ):
+        t1 = time.perf_counter()
+        o.build(qx[q], ql[q], export=False)
+        r = o.select()
+        if q >= 10:
+            ms.append(1000.0 * (time.perf_counter() - t1))
+            k = q - 10
+            nc = int(res.n_cand[k])
+            same = np.array_equal(res.cand_frame[k, :nc], r["cand_frame"]) and np.array_equal(res.cand_votes[k, :nc], r["cand_votes"])
+            same = same and np.array_equal(per[k].cand_frame[0, :nc], r["cand_frame"]) and int(per[k].n_cand[0]) == nc
+            if same:
+                qi, de = g.result_pairs(k, res)
+                same = np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
+            ident += int(same)
+    g.close()
+    return {"workload": "BASELINE configs[0]: one scan per call vs a 100-frame map, graph JSON in (synthetic stand-in in the producer's format)",
+            "map_frames": F, "scans": NQ - 10, "ms_ingest_json_%d_files" % (F + NQ): 1000.0 * t_ingest,
+            "cpu": {"ms_per_scan": pct(ms), "frames_per_s": 1000.0 / float(np.mean(ms)), "threads": cpu_threads,
+                    "kind": "port", "protocol": "BASELINE.md §2: 10 warm-up + 200 timed, build + candidate_selector per scan"},
+            "gpu_one_scan_per_call": {"ms_per_scan": 1000.0 * t_per, "frames_per_s": 1.0 / t_per, "note": "host pointers in, candidates out, python ctypes adapter"},
+            "gpu_one_batch_of_200": {"ms_per_scan": 1000.0 * t_batch / (NQ - 10), "frames_per_s": (NQ - 10) / t_batch},
+            "identical_candidates_votes_matchlists": "%d/%d" % (ident, NQ - 10)}
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         # start the ranks BEFORE anything touches a GPU (no exec after GPU init on this pool):
-        # child processes under torch.distributed.run, this process only relays the result
+        # child processes under torch.distributed.run; this process relays the ONE result line and nothing else
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        sys.exit(subprocess.call(cmd, env=env))
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        line = last_result_line(p.stdout)
+        if line is not None:
+            print(line)
+        else:
+            sys.stderr.write(p.stdout)
+        sys.exit(p.returncode if (p.returncode or line is not None) else 1)
     world = int(env_world or "1")
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    result_out = claim_stdout()
 
     import torch
     import torch.distributed as dist
     from sgtd_amd import synth
-    from sgtd_amd.dist import ReplicatedMap, ShardedMap, gather_and_merge, shard_range
+    from sgtd_amd.dist import Map2D, plan_2d, shard_range
     from sgtd_amd.manager import STDescManager
 
     rank = int(os.environ.get("RANK", "0"))
@@ -367,24 +554,30 @@ def main():
     smap = make_map_once(F, N, 1)
     # cold + probe layout of the whole table: ~155 B per descriptor, <= 36*N per frame
     table_bytes = 155.0 * 36 * N * F
-    mode = "single"
-    if world > 1:
-        mode = args.shard if args.shard != "auto" else "table"
     fits_one_gpu = table_bytes < HBM_BYTES / 4
-    # the replicated leg serves Q queries per rank: the first Q of them are the table mode's batch
-    n_q_total = Q * world if (mode == "query" or (mode == "table" and args.also_replicated == "on" and fits_one_gpu)) else Q
-    queries = synth.make_queries(smap, n_q_total, stream=1)
-    n_q_value = Q * world if mode == "query" else Q     # query frames one step of the headline mode serves
+    if world > 1:
+        forced = args.rt if args.rt is not None else {"auto": None, "table": world, "query": 1}[args.shard]
+        r_t, r_q = plan_2d(world, F, Q, N, r_t=forced)
+        mode = "table" if r_t == world else ("query" if r_t == 1 else "2d")
+    else:
+        r_t, r_q, mode = 1, 1, "single"
+    g_idx = rank // r_t
+    # query group g serves frames [g Q, (g + 1) Q) of every set; a step serves Q x R_q frames
+    n_q_value = Q * r_q
+    queries = synth.make_queries(smap, n_q_value, stream=1)
     # The timed region rotates through n_rot batches that differ from each other AND from the warm-up batch
     # (`queries`, which the parity and recall legs use): a node never sees the same frames twice
     # (semantic_graph_localization.cpp:567-604), and the room a match list is given is predicted from the batch BEFORE.
     n_rot = max(1, args.rotate)
-    n_rot_q = Q * world if mode == "query" else Q        # (query mode: every rank takes its own slice of each set)
-    rot_sets = [synth.make_queries(smap, n_rot_q, stream=1000 + b) for b in range(n_rot)]
+    rot_sets = [synth.make_queries(smap, n_q_value, stream=1000 + b) for b in range(n_rot)]
+    q_lo, q_hi = g_idx * Q, (g_idx + 1) * Q
 
     def to_dev(xyz, label):
         return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
                 torch.from_numpy(np.ascontiguousarray(label).astype(np.int64)).to(dev).to(torch.int32).contiguous())
+
+    def to_dev_flat(fr):
+        return to_dev(fr.xyz, fr.label)
 
     stream = torch.cuda.current_stream()
     merged = {}
@@ -398,38 +591,57 @@ def main():
 
     def timed(step, mgr, steps=None, info=None):
         """warm-up on the warm-up batch (incl. work-buffer growth), then K steps between barrier + synchronize, max
-        over ranks.  step(i): i < 0 the warm-up batch, i >= 0 the i-th timed step (batch i % n_rot of the rotation)"""
+        over ranks.  step(i): i < 0 the warm-up batch, i >= 0 the i-th timed step (batch i % n_rot of the rotation).
+        Steps are enqueued back to back without a host synchronisation, so a batch that outgrew a work buffer inside
+        the region would be overwritten, incomplete, by the next one: such a region does not count — the buffers have
+        grown by then, the region is timed again (three attempts, then the run fails)."""
         steps = args.steps if steps is None else steps
-        for _ in range(max(args.warmup, 1)):
+        for attempt in range(3):
+            for _ in range(max(args.warmup, 1)):
+                step(-1)
+            mgr.sync()          # grows work buffers if the first batch overflowed them
             step(-1)
-        mgr.sync()          # grows work buffers if the first batch overflowed them
-        step(-1)
-        mgr.sync()
-        s0 = mgr.stats()
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        mgr.sync()
-        s1 = mgr.stats()
-        if info is not None:
-            # nothing is asserted about fresh data: re-runs and list moves inside the timed region are counted and reported
-            # (counted on the device: the steps are enqueued one after the other without a host synchronisation)
-            info.update(batch_launches_in_timed_region=int(s1["batches_total"] - s0["batches_total"]),
-                        launches_that_overflowed_a_work_buffer=int(s1["overflow_launches_total"] - s0["overflow_launches_total"]),
-                        reruns_in_timed_region=int(s1["reruns_total"] - s0["reruns_total"]),
-                        list_pass_reruns_in_timed_region=int(s1["rewrites_total"] - s0["rewrites_total"]),
-                        list_moves_in_timed_region=int(s1["list_moves_total"] - s0["list_moves_total"]),
-                        distinct_batches_in_timed_region=min(n_rot, steps))
-        return elapsed
+            mgr.sync()
+            s0 = mgr.stats()
+            barrier()
+            t0 = time.perf_counter()
+            marks = []
+            for i in range(steps):
+                step(i)
+                marks.append(time.perf_counter())
+            barrier()
+            elapsed = time.perf_counter() - t0
+            if os.environ.get("SGTD_BENCH_TRACE"):      # host-side enqueue times of the steps, then the wait for the devices
+                sys.stderr.write("[trace rank %d] enqueue ms %s, drain %.2f\n" % (
+                    rank, ["%.2f" % (1000.0 * (b - a)) for a, b in zip([t0] + marks[:-1], marks)], 1000.0 * (t0 + elapsed - marks[-1])))
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            mgr.sync()
+            s1 = mgr.stats()
+            overflowed = int(s1["overflow_launches_total"] - s0["overflow_launches_total"])
+            if world > 1:
+                t = torch.tensor([overflowed], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                any_overflow = int(t.item())
+            else:
+                any_overflow = overflowed
+            if info is not None:
+                info.update(batch_launches_in_timed_region=int(s1["batches_total"] - s0["batches_total"]),
+                            launches_that_overflowed_a_work_buffer=overflowed,
+                            reruns_in_timed_region=int(s1["reruns_total"] - s0["reruns_total"]),
+                            list_pass_reruns_in_timed_region=int(s1["rewrites_total"] - s0["rewrites_total"]),
+                            list_moves_in_timed_region=int(s1["list_moves_total"] - s0["list_moves_total"]),
+                            device_allocations_in_timed_region=int(s1["device_allocs_total"] - s0["device_allocs_total"]),
+                            distinct_batches_in_timed_region=min(n_rot, steps), timed_region_attempts=attempt + 1)
+            if any_overflow == 0:
+                return elapsed
+        sys.exit("bench.py: every attempt at the timed region had a batch that outgrew a work buffer (%d launches in the last): "
+                 "its results would have been overwritten incomplete — no valid measurement" % any_overflow)
 
     cold = {}
+    m2 = None
     if mode == "single":
         mgr = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 1))
         mgr.set_stream(stream.cuda_stream)
@@ -440,7 +652,6 @@ def main():
         cold["map_build_s"] = time.perf_counter() - t0
         d_qxyz, d_qlab = to_dev(queries.xyz, queries.label)
         d_rot = [to_dev(r.xyz, r.label) for r in rot_sets]
-        q_lo, q_hi = 0, Q
 
         def step(i=-1):
             x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
@@ -452,31 +663,20 @@ def main():
         cold["first_batch_ms"] = 1000.0 * (time.perf_counter() - t0)
         cold["first_batch_overflowed"] = int(mgr.stats()["overflowed"])
         cold["bucket_len_sq_over_E"] = mgr.stats()["bucket_len_sq_over_E"]
-    elif mode == "table":
-        sm = ShardedMap(F, rank, world, device_id=local_rank)
-        mgr = sm.mgr
-        mgr.set_stream(stream.cuda_stream)
-        lo, hi = shard_range(F, world, rank)
-        sm.add_shard_frames(*to_dev(smap.xyz[lo:hi], smap.label[lo:hi]))
-        d_qxyz, d_qlab = to_dev(queries.xyz[:Q], queries.label[:Q])
-        d_rot = [to_dev(r.xyz[:Q], r.label[:Q]) for r in rot_sets]
-        q_lo, q_hi = 0, Q
-
-        def step(i=-1):
-            x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
-            merged["out"] = sm.query(x, l)[:2]
     else:
-        rm = ReplicatedMap(F, rank, world, device_id=local_rank)
-        mgr = rm.mgr
-        mgr.set_stream(stream.cuda_stream)
-        rm.add_frames(*to_dev(smap.xyz, smap.label))
-        q_lo, q_hi = rank * Q, (rank + 1) * Q
+        m2 = Map2D(F, rank, world, r_t=r_t, device_id=local_rank, lists=args.lists, max_frame_n=max(20000, F + 1))
+        mgr = m2.mgr
+        m2.add_shard_frames(*to_dev(smap.xyz[m2.lo:m2.hi], smap.label[m2.lo:m2.hi]))
         d_qxyz, d_qlab = to_dev(queries.xyz[q_lo:q_hi], queries.label[q_lo:q_hi])
         d_rot = [to_dev(r.xyz[q_lo:q_hi], r.label[q_lo:q_hi]) for r in rot_sets]
 
         def step(i=-1):
+            """the shard's pipeline on the main stream; exchange (all_gather + merge kernel inside the table group) and the
+            gather of the groups' result tables on the side stream: nothing waits on the host"""
             x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
-            merged["out"] = rm.query(x, l, n_q_total)
+            m2.query_async(x, l)
+            with torch.cuda.stream(m2.side):
+                merged["out"] = m2.gather_groups()
 
     elapsed = timed(step, mgr, info=timed_info)
     # the same measurement the way rounds 1-3 took it — ONE batch over and over (the room prediction is then exact, no
@@ -485,7 +685,25 @@ def main():
     same_elapsed = timed(lambda i: step(-1), mgr, steps=k_same)
     timed_info.update(same_batch_ms_per_step=1000.0 * same_elapsed / k_same, same_batch_steps=k_same,
                       rotating_over_same_batch=(elapsed / args.steps) / (same_elapsed / k_same))
-    step(-1); mgr.sync()          # leave the handle on the warm-up batch: the parity, recall and profile legs read its results
+    # ... and a step that DELIVERS: the host waits for the batch (a batch that outgrew a work buffer is re-run there) and
+    # takes the candidate tables and the lists' offsets into page-locked arrays before the next batch is enqueued
+    delivered = None
+    if mode == "single":
+        def dstep(i):
+            step(i)
+            return mgr.results()
+        dstep(-1)
+        torch.cuda.synchronize()
+        kd = max(3, args.steps // 2)
+        t0 = time.perf_counter()
+        for i in range(kd):
+            rd = dstep(i)
+        td = time.perf_counter() - t0
+        delivered = {"frames_per_s": Q * kd / td, "ms_per_step": 1000.0 * td / kd, "steps": kd,
+                     "bytes_to_host_per_step": int(rd.n_cand.nbytes + rd.cand_frame.nbytes + rd.cand_votes.nbytes + rd.pair_off.nbytes),
+                     "note": "every step ends with sgtd_sync + sgtd_result_candidates (n_cand, candidate frames, votes, list offsets through "
+                             "page-locked staging); a batch that outgrew a work buffer would be re-run inside the step"}
+    step(-1); mgr.sync(); torch.cuda.synchronize()          # leave the handle on the warm-up batch: the parity, recall and profile legs read its results
     backend_ran = dist.get_backend() if world > 1 else None
     collective = {"nccl": "RCCL (torch.distributed backend nccl)", "gloo": "gloo (NOT RCCL: test fallback)"}.get(backend_ran, backend_ran)
     st = mgr.stats()
@@ -500,6 +718,7 @@ def main():
         for k in KERNEL_KEYS:
             acc.setdefault(k, []).append(s[k])
     mgr.set_timing(False)
+    torch.cuda.synchronize()
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
     st = mgr.stats()
     P, M, D = st["last_P"], st["last_M"], st["last_D"]
@@ -509,7 +728,7 @@ def main():
     entry_bytes = st["hbm_bytes_table"] // max(st["n_entries"], 1)   # probe-layout bytes per loaded entry
     P_swept = st.get("last_P_swept") or P
     # (1) The dominant kernel (the sweep) against the HBM roof: bytes per launch from the committed PMC passes of this
-    # very command (profiles/collect_r04.sh: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE; both counters sit on
+    # very command (profiles/collect_r05.sh: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE; both counters sit on
     # the L2's fabric side and count Infinity-Cache hits, so they bound the HBM bytes from above) over the kernel's
     # average launch duration measured live (HIP events on the launch stream).  A row measured on other kernels than
     # the ones this run launches is refused.
@@ -522,7 +741,7 @@ def main():
                 "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs is not None else None, "traffic": traffic,
                 "traffic_profile": tr.get("profile_tag") if tr else None, "traffic_profile_commit": tr.get("commit") if tr else None,
                 "traffic_note": "PMC bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md §HBM), committed under profiles/ by "
-                                "profiles/collect_r04.sh for this command; both counters include Infinity-Cache hits: an upper bound on HBM bytes",
+                                "profiles/collect_r05.sh for this command; both counters include Infinity-Cache hits: an upper bound on HBM bytes",
                 "avg_launch_ms": kern_ms["ms_probe"], "select_form": select_form,
                 "l2_frac": l2_gbs / L2_PEAK_GBS, "l2_GBps_moved_by_the_waves": l2_gbs,
                 "valu_issue_frac": tr.get("valu_issue_frac") if tr else None,
@@ -570,34 +789,76 @@ def main():
                                    "reference_visits_per_s": P / t_probe if t_probe > 0 else 0.0,
                                    "note": "28 B x reference visits + 64 B x descriptors + 8 B x matches: exceeds the HBM peak because most "
                                            "visits are never loaded — not a roofline fraction"}
-    # (5) N > 1, table-sharded: what a rank's step consists of — the part every rank repeats for all Q queries (descriptor
-    # build, home-cell sort, GroupRows, the plan), the part that shrinks with the shard (the sweep and the passes over
-    # its records), and the exchange (export + all_gather + merge, timed alone) — and what they predict
-    scaling_parts = None
-    if mode == "table":
-        pre_ms = kern_ms["ms_build"] + kern_ms["ms_sort"]
-        shard_ms = kern_ms["ms_probe"] + kern_ms["ms_votes"] + kern_ms["ms_topk"] + kern_ms["ms_count"] + kern_ms["ms_scan"] + kern_ms["ms_write"]
+
+    def parts_of(km):
+        """a rank's step by what scales how: the part every rank of a table group repeats for all of the group's queries
+        (descriptor build, home-cell sort, GroupRows, the plan) and the part that shrinks with the shard (the sweep and
+        the passes over its records)"""
+        return (km["ms_build"] + km["ms_sort"],
+                km["ms_probe"] + km["ms_votes"] + km["ms_topk"] + km["ms_count"] + km["ms_scan"] + km["ms_write"])
+
+    def measure_parts(map2d, xl_sets, steps):
+        """scaling_parts of a Map2D form: per-rank kernel parts (HIP events on each rank's stream), the exchange timed
+        alone (side-stream work of one step), and how much of it the step really waits for: step with exchange minus the
+        same step without"""
+        mg = map2d.mgr
+        mg.set_timing(True)
+        a = {}
+        for j in range(max(2, args.profile_steps)):
+            map2d.query_async(*xl_sets[j % len(xl_sets)])
+            mg.sync()
+            s_ = mg.stats()
+            for k in KERNEL_KEYS:
+                a.setdefault(k, []).append(s_[k])
+        mg.set_timing(False)
+        km = {k: float(np.mean(v)) for k, v in a.items()}
+        pre_ms, shard_ms = parts_of(km)
         barrier()
         t0 = time.perf_counter()
         for _ in range(10):
-            gather_and_merge(sm._bufs[0], sm._bufs[1], sm.cand_num)
+            map2d._exchange()
+            with torch.cuda.stream(map2d.side):
+                map2d.gather_groups()
+        map2d.side.synchronize()
         barrier()
         ex_ms = 1000.0 * (time.perf_counter() - t0) / 10
-        mine = torch.tensor([pre_ms, shard_ms, ex_ms], dtype=torch.float64, device=dev)
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        parts = np.array([p_.cpu().numpy() for p_ in parts])
-        one_gpu_ms = float(parts[:, 0].mean() + parts[:, 1].sum())          # the replicated part once + every shard's sweep
-        pred_ms = float((parts[:, 0] + parts[:, 1]).max() + parts[:, 2].max())
-        scaling_parts = {"per_rank_ms": {"replicated_build_sort_plan": parts[:, 0].tolist(), "sharded_sweep_and_record_passes": parts[:, 1].tolist(),
-                                         "exchange_all_gather_merge": parts[:, 2].tolist()},
-                         "predicted_ms_per_step": pred_ms, "predicted_one_gpu_ms_per_step": one_gpu_ms,
-                         "predicted_speedup_over_one_gpu": one_gpu_ms / pred_ms,
-                         "speedup_ceiling_if_the_sharded_part_vanished": one_gpu_ms / float(parts[:, 0].mean() + parts[:, 2].max()),
-                         "note": "strong scaling at a fixed map: the build, sort and plan of all Q query frames are repeated on every rank "
-                                 "(every rank needs every query descriptor), only the sweep and the passes over its match records shrink "
-                                 "with the shard; kernel times by HIP events on each rank's stream, the exchange timed alone"}
-    step(-1); mgr.sync()          # back on the warm-up batch
+
+        def with_x(i):
+            map2d.query_async(*xl_sets[i % len(xl_sets)])
+            with torch.cuda.stream(map2d.side):
+                map2d.gather_groups()
+
+        def without_x(i):
+            mg.query_frames(*xl_sets[i % len(xl_sets)], fetch=False)
+            if map2d.lists == "winners":
+                mg.finish_lists(None)
+        t_with = timed(with_x, mg, steps=steps) / steps
+        t_without = timed(without_x, mg, steps=steps) / steps
+        mine = torch.tensor([pre_ms, shard_ms, ex_ms, 1000.0 * t_with, 1000.0 * t_without], dtype=torch.float64, device=dev)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        pr = np.array([p_.cpu().numpy() for p_ in allp])
+        rt, rq = map2d.r_t, map2d.r_q
+        # the same work on ONE GPU: R_q batches, each the replicated part once and every shard's part of group 0
+        one_gpu_ms = float(rq * (pr[:rt, 0].mean() + pr[:rt, 1].sum()))
+        exposed = float(max(0.0, (pr[:, 3] - pr[:, 4]).max()))
+        pred_ms = float((pr[:, 0] + pr[:, 1]).max() + exposed)
+        return {"table_shards_R_t": rt, "query_groups_R_q": rq, "lists": map2d.lists,
+                "per_rank_ms": {"replicated_build_sort_plan": pr[:, 0].tolist(), "sharded_sweep_and_record_passes": pr[:, 1].tolist(),
+                                "exchange_alone_all_gather_merge_result_gather": pr[:, 2].tolist(),
+                                "step_with_exchange": pr[:, 3].tolist(), "step_without_exchange": pr[:, 4].tolist()},
+                "exchange_exposed_ms": exposed, "predicted_ms_per_step": pred_ms, "predicted_one_gpu_ms_for_the_same_frames": one_gpu_ms,
+                "predicted_speedup_over_one_gpu": one_gpu_ms / pred_ms,
+                "speedup_ceiling_if_the_sharded_part_vanished": one_gpu_ms / float(pr[:, 0].max() + exposed) if rt > 1 else float(rq),
+                "note": "kernel times by HIP events on each rank's stream; the build, sort and plan of a group's query frames are repeated on "
+                        "every rank of its table group, only the sweep and the passes over its match records shrink with the shard; "
+                        "exchange_exposed = step with exchange - step without (the exchange runs on a side stream beside the list pass)"}
+
+    # (5) N > 1: what a rank's step consists of and what that predicts
+    scaling_parts = None
+    if m2 is not None:
+        scaling_parts = measure_parts(m2, [d_rot[b] for b in range(n_rot)], max(3, args.steps // 2))
+    step(-1); mgr.sync(); torch.cuda.synchronize()          # back on the warm-up batch
 
     res = mgr.results()
     # ---- next stage of the reference's SearchLoop (STDesc.cpp:105-146), reported separately
@@ -683,65 +944,72 @@ def main():
         step(); mgr.sync()   # leave the handle on the headline batch
         res = mgr.results()
 
-    # ---- N > 1: the other multi-GPU form of the same map beside the headline, and the check that
-    # the table-sharded merged list IS the single-table list (every replica holds the whole table)
-    table_sharded, replicated = None, None
-
     def entries_of(m):
         ent = torch.tensor([m.stats()["n_entries"]], dtype=torch.int64, device=dev)
         ents = [torch.zeros_like(ent) for _ in range(world)]
         dist.all_gather(ents, ent)
         return [int(e.item()) for e in ents]
 
-    if mode == "query" and fits_one_gpu:
-        sm = ShardedMap(F, rank, world, device_id=local_rank)
-        sm.mgr.set_stream(stream.cuda_stream)
-        lo, hi = shard_range(F, world, rank)
-        sm.add_shard_frames(*to_dev(smap.xyz[lo:hi], smap.label[lo:hi]))
-        tq_xyz, tq_lab = to_dev(queries.xyz[:Q], queries.label[:Q])
-        tmerged = {}
+    # ---- N > 1: the pure table-sharded form of the same map beside a headline of another form (north_star's wording), with
+    # its own scaling parts, and the check that its merged list IS the list of a rank that holds the whole table
+    table_sharded, fixed_total, merged_equal = None, None, None
+    if m2 is not None:
+        step(-1); mgr.sync(); torch.cuda.synchronize()
+        head_f, head_v = merged["out"][0][:Q].clone(), merged["out"][1][:Q].clone()      # query group 0's lists of queries[:Q]
+        if mode != "table" and args.also_table == "on" and fits_one_gpu:
+            ts = Map2D(F, rank, world, r_t=world, device_id=local_rank, lists=args.lists, max_frame_n=max(20000, F + 1))
+            ts.add_shard_frames(*to_dev(smap.xyz[ts.lo:ts.hi], smap.label[ts.lo:ts.hi]))
+            tq = to_dev(queries.xyz[:Q], queries.label[:Q])
+            trot = [to_dev(r.xyz[:Q], r.label[:Q]) for r in rot_sets]
 
-        def tstep(i=-1):
-            tmerged["out"] = sm.query(tq_xyz, tq_lab)
-        t_el = timed(tstep, sm.mgr)
-        ref_f, ref_v = merged["out"]
-        tf, tv_, _ = tmerged["out"]
-        same = bool(torch.equal(tf, ref_f[:Q]) and torch.equal(tv_, ref_v[:Q]))
-        table_sharded = {"value": Q * args.steps / t_el, "unit": "frames/s", "ms_per_step": 1000.0 * t_el / args.steps,
-                         "queries_per_step": Q, "scaling": "strong", "ranks_in_collective": dist.get_world_size(),
-                         "collective": collective, "table_entries_per_rank": entries_of(sm.mgr),
-                         "merged_list_equals_single_table": same}
-        del sm
-    elif mode == "table" and args.also_replicated == "on" and fits_one_gpu:
-        rm = ReplicatedMap(F, rank, world, device_id=local_rank)
-        rm.mgr.set_stream(stream.cuda_stream)
-        rm.add_frames(*to_dev(smap.xyz, smap.label))
-        rq_xyz, rq_lab = to_dev(queries.xyz[rank * Q:(rank + 1) * Q], queries.label[rank * Q:(rank + 1) * Q])
-        rmerged = {}
+            def tstep(i=-1):
+                ts.query_async(*(tq if i < 0 else trot[i % n_rot]))
+            t_el = timed(tstep, ts.mgr)
+            tparts = measure_parts(ts, trot, max(3, args.steps // 2))
+            tf, tv_, _ = ts.query(*tq)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(tf, head_f) and torch.equal(tv_, head_v))
+            table_sharded = {"value": Q * args.steps / t_el, "unit": "frames/s", "ms_per_step": 1000.0 * t_el / args.steps,
+                             "queries_per_step": Q, "scaling": "strong", "ranks_in_collective": dist.get_world_size(),
+                             "collective": collective, "table_entries_per_rank": entries_of(ts.mgr), "scaling_parts": tparts,
+                             "merged_list_equals_headline_list": same}
+            if mode == "query":
+                merged_equal = same          # (the headline's ranks hold the whole table)
+            ts.mgr.close()
+            del ts
+        elif mode == "table" and fits_one_gpu and args.also_table == "on":
+            # explicit --shard table: the replica-per-rank form beside it, the same check the other way round
+            rp = Map2D(F, rank, world, r_t=1, device_id=local_rank, max_frame_n=max(20000, F + 1))
+            rp.add_shard_frames(*to_dev(smap.xyz, smap.label))
+            rq_ = to_dev(queries.xyz[:Q], queries.label[:Q])
+            rf, rv, _ = rp.query(*rq_)
+            torch.cuda.synchronize()
+            merged_equal = bool(torch.equal(rf, head_f) and torch.equal(rv, head_v))
+            rp.mgr.close()
+            del rp
+        # ---- the headline's grid with --queries frames per step in TOTAL (strong scaling of a fixed batch)
+        if r_q > 1 and Q // r_q >= 1:
+            qs_ = Q // r_q
+            fq = [to_dev(r.xyz[g_idx * qs_:(g_idx + 1) * qs_], r.label[g_idx * qs_:(g_idx + 1) * qs_]) for r in [queries] + rot_sets]
 
-        def rstep(i=-1):
-            rmerged["out"] = rm.query(rq_xyz, rq_lab, Q * world)
-        r_el = timed(rstep, rm.mgr)
-        tf, tv_ = merged["out"]
-        rf, rv = rmerged["out"]
-        same = bool(torch.equal(tf, rf[:Q]) and torch.equal(tv_, rv[:Q]))     # rank 0's replica served the table mode's Q queries
-        replicated = {"value": Q * world * args.steps / r_el, "unit": "frames/s", "ms_per_step": 1000.0 * r_el / args.steps,
-                      "queries_per_step": Q * world, "queries_per_rank": Q, "scaling": "weak",
-                      "ranks_in_collective": dist.get_world_size(), "collective": collective,
-                      "table_entries_per_rank": entries_of(rm.mgr), "equals_table_sharded_list": same}
-        replicated["recall"] = recall(smap, queries, rf[:, 0].cpu().numpy())
-        del rm
-    merged_equal = (replicated or {}).get("equals_table_sharded_list", (table_sharded or {}).get("merged_list_equals_single_table"))
+            def fstep(i=-1):
+                m2.query_async(*fq[0 if i < 0 else 1 + i % n_rot])
+                with torch.cuda.stream(m2.side):
+                    m2.gather_groups()
+            f_el = timed(fstep, mgr)
+            fixed_total = {"value": qs_ * r_q * args.steps / f_el, "unit": "frames/s", "ms_per_step": 1000.0 * f_el / args.steps,
+                           "queries_per_step_total": qs_ * r_q, "queries_per_group": qs_, "scaling": "strong"}
+            step(-1); mgr.sync(); torch.cuda.synchronize()
 
-    # ---- N > 1: BASELINE configs[3], the 100 000-frame map sharded by frame range the same way
-    # (the reference itself cannot hold it: MAX_FRAME_N = 20 000, STDesc.h:33)
+    # ---- N > 1: BASELINE configs[3], the 100 000-frame map on the grid dist.plan_2d gives it (the reference itself cannot
+    # hold it: MAX_FRAME_N = 20 000, STDesc.h:33)
     cfg4 = None
     if world > 1 and (args.cfg4 == "on" or (args.cfg4 == "auto" and world == 8)) and F != 100000:
         # Only rank-local work sits under try/except; the ranks agree on its success (host-side) before every stage
         # that contains a collective, so that one rank's failure (an allocation, a damaged cache file) skips the leg
         # on EVERY rank instead of leaving the others inside an all_gather.
         F4, Q4 = 100000, 256
-        lo4, hi4 = shard_range(F4, world, rank)
+        rt4, rq4 = plan_2d(world, F4, Q4, N)
         m4 = q4 = s4 = x4 = l4 = None
         err4 = None
         try:
@@ -750,11 +1018,10 @@ def main():
             err4 = exc
         if all_ok(err4 is None):
             try:
-                q4 = synth.make_queries(m4, Q4, stream=4)
-                s4 = ShardedMap(F4, rank, world, device_id=local_rank)
-                s4.mgr.set_stream(stream.cuda_stream)
-                s4.add_shard_frames(*to_dev(m4.xyz[lo4:hi4], m4.label[lo4:hi4]))
-                x4, l4 = to_dev(q4.xyz, q4.label)
+                q4 = synth.make_queries(m4, Q4 * rq4, stream=4)
+                s4 = Map2D(F4, rank, world, r_t=rt4, device_id=local_rank, lists=args.lists, max_frame_n=F4 + 1)
+                s4.add_shard_frames(*to_dev(m4.xyz[s4.lo:s4.hi], m4.label[s4.lo:s4.hi]))
+                x4, l4 = to_dev(q4.xyz[s4.g * Q4:(s4.g + 1) * Q4], q4.label[s4.g * Q4:(s4.g + 1) * Q4])
                 for _ in range(2):                       # the shard's own sweep without the exchange: work buffers reach their size here
                     s4.mgr.query_frames(x4, l4, fetch=False)
                     s4.mgr.sync()
@@ -764,12 +1031,15 @@ def main():
             out4 = {}
 
             def step4(i=-1):
-                out4["out"] = s4.query(x4, l4)
+                s4.query_async(x4, l4)
+                with torch.cuda.stream(s4.side):
+                    out4["out"] = s4.gather_groups()
             e4 = timed(step4, s4.mgr)
             top1 = out4["out"][0][:, 0].cpu().numpy()
-            cfg4 = {"workload": "synthetic %d keypoints/frame, %d-frame map hash-sharded by frame range over %d GPUs, candidate gather" % (N, F4, world),
-                    "value": Q4 * args.steps / e4, "unit": "frames/s", "ms_per_step": 1000.0 * e4 / args.steps,
-                    "queries_per_step": Q4, "table_entries_per_rank": entries_of(s4.mgr), "collective": collective,
+            cfg4 = {"workload": "synthetic %d keypoints/frame, %d-frame map: %d table shards (frame ranges) x %d query groups over %d GPUs" % (N, F4, rt4, rq4, world),
+                    "value": Q4 * rq4 * args.steps / e4, "unit": "frames/s", "ms_per_step": 1000.0 * e4 / args.steps,
+                    "queries_per_step": Q4 * rq4, "table_shards_R_t": rt4, "query_groups_R_q": rq4,
+                    "table_entries_per_rank": entries_of(s4.mgr), "collective": collective,
                     "recall": recall(m4, q4, top1)}
         else:
             cfg4 = {"error": "skipped on every rank: %s" % ("%s: %s" % (type(err4).__name__, err4) if err4 is not None else "another rank failed")}
@@ -795,8 +1065,8 @@ def main():
                     gm.sync()
                 tm = time.perf_counter() - t0
                 rg = gm.results()
-                ref_f = merged["out"][0][:Q].cpu().numpy() if mode != "single" else None
-                same = bool(ref_f is not None and np.array_equal(rg.cand_frame[:, :ref_f.shape[1]], ref_f))
+                ref_f = merged["out"][0][:Q].cpu().numpy()
+                same = bool(np.array_equal(rg.cand_frame[:, :ref_f.shape[1]], ref_f))
                 multi_handle = {"value": Q * args.steps / tm, "unit": "frames/s", "ms_per_step": 1000.0 * tm / args.steps,
                                 "devices": gm.device_count, "queries_per_step": Q,
                                 "note": "one process, host pointers in (PCIe inside the timed region), per-device sweeps concurrent, host merge; "
@@ -825,6 +1095,75 @@ def main():
         except Exception as exc:
             batch_sweep = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
+    # ---- N = 1: what rank 0 of a --predict-world job does, measured here part by part (no multi-GPU box in this round's
+    # builder runs: the per-rank parts are measured, the all_gather's time is modelled and says so)
+    prediction = None
+    if mode == "single" and args.predict_world > 1 and args.sweep != "none":
+        try:
+            W = args.predict_world
+            cn = mgr.config_setting_["candidate_num"]
+            pre1, shard1 = parts_of(kern_ms)
+            forms = {}
+            for name, rt in (("auto_2d", plan_2d(W, F, Q, N)[0]), ("pure_table", W)):
+                rq = W // rt
+                if rt == 1:
+                    pre_r, shard_r, entries_r = pre1, shard1, int(st["n_entries"])
+                    mm = None
+                else:
+                    lo, hi = shard_range(F, rt, 0)
+                    mm = STDescManager(device_id=local_rank, max_frame_n=max(20000, F + 1))     # rank 0's shard as a table of its own
+                    mm.set_stream(stream.cuda_stream)
+                    mm.add_frames(*to_dev(smap.xyz[lo:hi], smap.label[lo:hi]))
+                    mm.finalize()
+                    for j in range(3):
+                        mm.query_frames(*d_rot[j % n_rot], fetch=False); mm.sync()
+                    mm.set_timing(True)
+                    a = {}
+                    for j in range(3):
+                        mm.query_frames(*d_rot[j % n_rot], fetch=False); mm.sync()
+                        s_ = mm.stats()
+                        for k in KERNEL_KEYS:
+                            a.setdefault(k, []).append(s_[k])
+                    mm.set_timing(False)
+                    pre_r, shard_r = parts_of({k: float(np.mean(v)) for k, v in a.items()})
+                    entries_r = int(mm.stats()["n_entries"])
+                # the merge kernel over rt packed tables of Q queries, timed alone on this GPU
+                ints = 2 * Q * cn + 4
+                fake = torch.zeros(rt * ints, dtype=torch.int32, device=dev)
+                for t_ in range(rt):
+                    fake[t_ * ints + 2 * Q * cn + 1] = Q
+                    fake[t_ * ints + 2 * Q * cn + 2] = cn
+                outs = [torch.empty((Q, cn), dtype=torch.int32, device=dev) for _ in range(3)] + \
+                       [torch.empty(Q, dtype=torch.int32, device=dev), torch.empty(Q, dtype=torch.int64, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    mgr.merge_candidates_dev(stream.cuda_stream, fake, rt, 0, Q, outs[0], outs[1], outs[3], outs[2], outs[4], outs[5])
+                torch.cuda.synchronize()
+                merge_ms = 1000.0 * (time.perf_counter() - t0) / 20
+                ag_ms = modelled_all_gather_ms(ints * 4, rt) + modelled_all_gather_ms(2 * Q * cn * 4, rq)
+                one_gpu_ms = rq * (pre1 + shard1)
+                # the exchange runs beside the list pass (lists "all"): only what outlasts that pass would be waited for
+                exposed = max(0.0, merge_ms + ag_ms - kern_ms["ms_write"] * (shard_r / shard1 if rt > 1 else 1.0)) if rt > 1 else 0.0
+                pred_ms = pre_r + shard_r + exposed
+                forms[name] = {"table_shards_R_t": rt, "query_groups_R_q": rq, "frames_per_step": Q * rq, "table_entries_rank0": entries_r,
+                               "rank0_ms": {"replicated_build_sort_plan": pre_r, "sharded_sweep_and_record_passes": shard_r,
+                                            "merge_kernel_alone": merge_ms, "all_gathers_MODELLED": ag_ms, "exchange_exposed": exposed},
+                               "predicted_ms_per_step": pred_ms, "predicted_frames_per_s": Q * rq / pred_ms * 1e3,
+                               "one_gpu_ms_for_the_same_frames": one_gpu_ms, "predicted_speedup_over_one_gpu": one_gpu_ms / pred_ms,
+                               "scaling": "weak" if rq > 1 else "strong"}
+                if mm is not None:
+                    mm.close()
+                    del mm
+            prediction = {"world": W, "forms": forms,
+                          "note": "rank 0's kernel parts measured on THIS GPU (its shard, the group's %d query frames per step; the other ranks' shards "
+                                  "are the same size); the merge kernel timed alone; the all_gathers' times are a MODEL of a ring over xGMI "
+                                  "(48 GB/s per link, 8 us per step), not a measurement — no step of this path has run on two physical GPUs "
+                                  "from the builder's side; the driver's SCALE run measures it" % Q}
+            step(-1); mgr.sync()
+        except Exception as exc:
+            prediction = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     # ---- other map sizes (same batch, same pipeline), N = 1 only
     sweep = None
     if mode == "single" and args.sweep not in ("", "none"):
@@ -833,11 +1172,11 @@ def main():
             if f2 == F:
                 continue
             try:
-                m2 = synth.make_map(f2, N, stream=1)
-                q2 = synth.make_queries(m2, Q, stream=1)
+                m2_ = synth.make_map(f2, N, stream=1)
+                q2 = synth.make_queries(m2_, Q, stream=1)
                 g2 = STDescManager(device_id=local_rank, max_frame_n=max(20000, f2 + 1))
                 g2.set_stream(stream.cuda_stream)
-                g2.add_frames(*to_dev(m2.xyz, m2.label))
+                g2.add_frames(*to_dev(m2_.xyz, m2_.label))
                 g2.finalize()
                 x2, l2 = to_dev(q2.xyz, q2.label)
 
@@ -850,12 +1189,25 @@ def main():
                 t2 = run_steps(s2, torch.cuda.synchronize, k2)
                 r2 = g2.results()
                 sweep[str(f2)] = {"frames_per_s": Q * k2 / t2, "ms_per_step": 1000.0 * t2 / k2,
-                                  "top1_pose_within_5m": recall(m2, q2, r2.top1())["top1_pose_within_5m"],
+                                  "top1_pose_within_5m": recall(m2_, q2, r2.top1())["top1_pose_within_5m"],
                                   "table_entries": g2.stats()["n_entries"]}
                 g2.close()
                 del g2, x2, l2
             except Exception as exc:
                 sweep[str(f2)] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if args.cfg1 == "on":
+            try:
+                sweep["100_cfg1_json_in"] = cfg1_leg(args, dev, stream, local_rank)
+            except Exception as exc:
+                sweep["100_cfg1_json_in"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    # ---- the skewed, reference-shaped workload (N = 1)
+    skew = None
+    if mode == "single" and args.skew == "on" and args.sweep != "none":
+        try:
+            skew = skew_leg(args, dev, stream, local_rank, to_dev_flat)
+        except Exception as exc:
+            skew = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ---- incremental insert: 100 frames appended to the finalized map are
     # sorted into a tail segment (cost proportional to the appended entries), the batch then
@@ -907,45 +1259,55 @@ def main():
         one = torch.ones(1, dtype=torch.int64, device=dev)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
-        ent = torch.tensor([st["n_entries"]], dtype=torch.int64, device=dev)
-        ents = [torch.zeros_like(ent) for _ in range(world)]
-        dist.all_gather(ents, ent)
-        entries_per_rank = [int(e.item()) for e in ents]
+        entries_per_rank = entries_of(mgr)
 
     out = None
     if rank == 0:
         value = n_q_value * args.steps / elapsed
-        sharding = {"single": "none",
-                    "table": "map frames range-sharded over %d GPUs, every rank sweeps all queries, all_gather + merge of top-50 over %s" % (world, collective),
-                    "query": "map replicated on %d GPUs, %d query frames per rank and step, all_gather of the result tables over %s" % (world, Q, collective)}[mode]
+        if mode == "single":
+            sharding = "none"
+        else:
+            sharding = ("%d table shards (map frames by range) x %d query groups over %d GPUs: every rank sweeps its shard with its group's %d query frames; "
+                        "per group one all_gather of the packed top-50 tables + the merge kernel on a side stream, one all_gather of the groups' "
+                        "result tables; collectives over %s" % (r_t, r_q, world, Q, collective))
         out = {
             "metric": "query frames/sec vs map size (descriptor build + candidate selection)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong" if mode == "table" else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if (world == 1 or r_q > 1) else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "arithmetic": "every decision equals the reference's f64 result: the sweep pre-tests in f32 against two "
                           "conservative thresholds and decides the few entries between them on the exact f64 sides",
             "config": {"workload": "synthetic %d keypoints/frame, %d-frame map, descriptor build+match (BASELINE north-star point: 10k-frame map, 1 GPU)" % (N, F)
                        if F == 10000 else "synthetic %d keypoints/frame, %d-frame map, descriptor build+match" % (N, F),
-                       "map_frames": F, "keypoints_per_frame": N, "queries_per_step": n_q_value,
+                       "map_frames": F, "keypoints_per_frame": N, "queries_per_step": n_q_value, "queries_per_query_group": Q,
+                       "table_shards_R_t": r_t, "query_groups_R_q": r_q, "lists": args.lists if world > 1 else None,
                        "sharding": sharding, "mode": mode, "collective_backend": backend_ran, "queries_this_rank": q_hi - q_lo,
                        "ranks_in_collective": ranks_seen, "table_entries_per_rank": entries_per_rank,
-                       "table_entries_this_rank": st["n_entries"], "table_buckets_this_rank": st["n_buckets"]},
+                       "table_entries_this_rank": st["n_entries"], "table_buckets_this_rank": st["n_buckets"],
+                       # (under `config` so that a parser that keeps only the contract's keys still carries them)
+                       "timed_region": dict(timed_info, warmup_batch="a batch of its own: no timed step repeats it",
+                                            note="the timed steps rotate through %d distinct synthetic batches; a region in which a batch outgrew a work "
+                                                 "buffer is discarded and timed again (timed_region_attempts); moved match lists are counted; "
+                                                 "same_batch_ms_per_step = rounds 1-3's measurement (one batch over and over) in the same run" % n_rot),
+                       "delivered": delivered},
             "roofline": roofline,
-            "timed_region": dict(timed_info, warmup_batch="a batch of its own: no timed step repeats it",
-                                 note="the timed steps rotate through %d distinct synthetic batches; re-runs (a work buffer overflowed) and "
-                                      "moved match lists inside the timed region are counted, not asserted away; same_batch_ms_per_step = "
-                                      "rounds 1-3's measurement (one batch over and over) in the same run" % n_rot),
         }
+        out["timed_region"] = out["config"]["timed_region"]
         if scaling_parts is not None:
             out["scaling_parts"] = scaling_parts
+        if prediction is not None:
+            out["scaling_prediction"] = prediction
+        if delivered is not None:
+            out["delivered"] = delivered
         if cold:
             out["cold_start"] = cold
         if sweep is not None:
             out["map_size_sweep"] = sweep
         if batch_sweep is not None:
             out["batch_size_sweep"] = batch_sweep
+        if skew is not None:
+            out["workload_skew"] = skew
         if verify is not None:
             out["verify"] = verify
         if boundary is not None:
@@ -954,8 +1316,8 @@ def main():
             out["incremental_insert"] = incremental
         if table_sharded is not None:
             out["table_sharded"] = table_sharded
-        if replicated is not None:
-            out["replicated"] = replicated
+        if fixed_total is not None:
+            out["fixed_total_batch"] = fixed_total
         if merged_equal is not None:
             out["merged_list_equals_single_table"] = merged_equal
         if cfg4 is not None:
@@ -983,7 +1345,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
 
 
 if __name__ == "__main__":

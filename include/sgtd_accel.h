@@ -113,6 +113,8 @@ typedef struct sgtd_stats {
   int64_t list_moves_total;  /* match lists that outgrew the room they were given and moved to a
                                 fresh slab during the sweep (probe_kernels.hip.h make_room)      */
   int64_t last_list_moves;   /* ... of the last batch                                         */
+  int64_t device_allocs_total; /* hipMalloc calls of the handle's work and table buffers so far (a buffer that grows is
+                                freed and allocated again, which synchronises the device: a timed region should see none) */
 } sgtd_stats;
 
 typedef struct sgtd_engine *sgtd_handle;
@@ -217,6 +219,45 @@ int sgtd_result_candidates(sgtd_handle h, int32_t *n_cand, int32_t *cand_frame,
  * unused slots hold frame -1 / votes 0), enqueued on the handle's stream
  * without synchronising: the multi-GPU path all-gathers them with RCCL. */
 int sgtd_export_candidates_dev(sgtd_handle h, int32_t *d_cand_frame, int32_t *d_cand_votes);
+/* ---- the multi-GPU step (one process per GPU, sgtd_amd/dist.py): every rank holds the table of a
+ * frame range (sgtd_config.first_frame_id), sweeps it with the query batch and takes its local top-candidate_num; the
+ * local tables travel in ONE all-gather (RCCL) per table group and every rank merges them with the reference's rule
+ * (the largest vote count first, ties -> the lowest frame id, >= 5 votes: STDesc.cpp:423-433) — the list a single table
+ * gives.  The calls below keep that exchange off the critical path:
+ *   sgtd_set_candidate_export   registers a device buffer of sgtd_candidate_export_ints(n_queries, candidate_num) int32;
+ *                               from then on every batch writes its local tables there, packed [frames | votes | 4 flag
+ *                               words], as soon as they are final — BEFORE its match lists are written (NULL: off)
+ *   sgtd_export_wait            makes side_stream wait (on the device) for the last enqueued batch's packed table
+ *   sgtd_export_release         recorded on side_stream behind the last reader of the packed table (the all-gather): the
+ *                               next batch's export waits for it — neither call blocks the host
+ *   sgtd_merge_candidates_dev   the merge as one kernel on `stream`: d_gathered = n_tables packed tables back to back (an
+ *                               all-gather's output); outputs int32 [n_queries*candidate_num] frames / votes (unused: -1 / 0)
+ *                               and src (table << 8 | slot in the owner's local list, -1 unused), n_cand [n_queries], keep
+ *                               u64 [n_queries] (bit s: slot s of table my_table's local list survived; my_table -1: none)
+ *                               and flags[0] (bit 0: some table came from a batch that outgrew a work buffer — sgtd_sync
+ *                               every rank and exchange again; bit 1: tables of different shapes)
+ *   sgtd_set_deferred_lists /   a batch stops behind its candidate tables; sgtd_finish_lists writes the match lists — of the
+ *   sgtd_finish_lists           candidates in d_keep only (NULL: all).  Repeatable (the match records stay intact).  Batches
+ *                               whose lists come from the per-block passes (small batches, sgtd_stats.select_form 0) ignore
+ *                               both: they always hold every local candidate's list.
+ *   sgtd_verify_masked          sgtd_verify for the candidates in d_keep only (the others score -1)
+ *   sgtd_gather_verified_dev    verification results of the merged candidates out of the owners' tables: d_gathered =
+ *                               n_tables x [score f64 n_queries*cn | pose f64 n_queries*cn*12] (every rank's
+ *                               sgtd_export_verify_dev output, all-gathered), d_src = the merge's src
+ * Not available on a multi-device handle (that one merges on the host). */
+int64_t sgtd_candidate_export_ints(int n_queries, int cand_num);
+int sgtd_set_candidate_export(sgtd_handle h, int32_t *d_packed, int64_t capacity_ints);
+int sgtd_export_wait(sgtd_handle h, void *side_stream);
+int sgtd_export_release(sgtd_handle h, void *side_stream);
+int sgtd_merge_candidates_dev(sgtd_handle h, void *stream, const int32_t *d_gathered, int n_tables, int my_table, int n_queries,
+                              int32_t *d_frame, int32_t *d_votes, int32_t *d_n_cand, int32_t *d_src, uint64_t *d_keep,
+                              int32_t *d_flags);
+int sgtd_gather_verified_dev(sgtd_handle h, void *stream, const double *d_gathered, int n_tables, const int32_t *d_src,
+                             int n_queries, double *d_score, double *d_pose);
+int sgtd_set_deferred_lists(sgtd_handle h, int on);
+int sgtd_finish_lists(sgtd_handle h, const uint64_t *d_keep);
+int sgtd_verify_masked(sgtd_handle h, const uint64_t *d_keep);
+
 /* number of query descriptors of query q (stds_vec.size()) */
 int sgtd_result_query_desc_count(sgtd_handle h, int q, int64_t *n);
 /* match_list_ pairs of query q, candidate after candidate, each in the

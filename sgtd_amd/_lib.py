@@ -27,6 +27,8 @@ SYMBOLS = [
     "sgtd_verify", "sgtd_export_verify_dev", "sgtd_result_verify", "sgtd_result_inliers", "sgtd_result_inlier_pairs", "sgtd_result_inlier_entries", "sgtd_search_loop",
     "sgtd_graphs_load", "sgtd_graphs_save_cache", "sgtd_graphs_load_cache", "sgtd_graphs_view",
     "sgtd_graphs_error", "sgtd_graphs_free", "sgtd_save_table", "sgtd_load_table",
+    "sgtd_candidate_export_ints", "sgtd_set_candidate_export", "sgtd_export_wait", "sgtd_export_release", "sgtd_merge_candidates_dev",
+    "sgtd_gather_verified_dev", "sgtd_set_deferred_lists", "sgtd_finish_lists", "sgtd_verify_masked",
 ]
 
 
@@ -69,7 +71,7 @@ class Stats(C.Structure):
         ("last_P_swept", C.c_int64), ("bucket_len_sq_over_E", C.c_double),
         ("tail_entries", C.c_int64), ("ms_finalize", C.c_float), ("reserved2", C.c_float),
         ("batches_total", C.c_int64), ("overflow_launches_total", C.c_int64), ("reruns_total", C.c_int64), ("rewrites_total", C.c_int64),
-        ("list_moves_total", C.c_int64), ("last_list_moves", C.c_int64),
+        ("list_moves_total", C.c_int64), ("last_list_moves", C.c_int64), ("device_allocs_total", C.c_int64),
     ]
 
 
@@ -165,6 +167,16 @@ def lib():
     L.sgtd_graphs_error.restype = C.c_char_p
     L.sgtd_graphs_free.argtypes = [vp]
     L.sgtd_graphs_free.restype = None
+    L.sgtd_candidate_export_ints.argtypes = [C.c_int, C.c_int]
+    L.sgtd_candidate_export_ints.restype = i64
+    L.sgtd_set_candidate_export.argtypes = [vp, vp, i64]
+    L.sgtd_export_wait.argtypes = [vp, vp]
+    L.sgtd_export_release.argtypes = [vp, vp]
+    L.sgtd_merge_candidates_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.sgtd_gather_verified_dev.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
+    L.sgtd_set_deferred_lists.argtypes = [vp, C.c_int]
+    L.sgtd_finish_lists.argtypes = [vp, vp]
+    L.sgtd_verify_masked.argtypes = [vp, vp]
     L.sgtd_save_table.argtypes = [vp, C.c_char_p]
     L.sgtd_load_table.argtypes = [vp, C.c_char_p]
     for name in SYMBOLS:

@@ -245,7 +245,8 @@ template <bool SLOT_TABLE>
 __global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu(SGTD_PQ_OCC, SGTD_PQ_OCC))) void pairs_query_kernel(QueryView Q, ProbeBuffers B, const int *n_cand,
                                                                        const int *cand_frame, int cand_num,
                                                                        const long long *pair_off, const u32 *q_pair_base,
-                                                                       u64 *pairs, IdMap map, u32 frame_span, u32 frame_lo) {
+                                                                       u64 *pairs, IdMap map, u32 frame_span, u32 frame_lo,
+                                                                       const u64 *keep) {
   constexpr int NW = SGTD_PQ_WAVES, QW = SGTD_PQ_WORDS;
   extern __shared__ __attribute__((aligned(16))) u32 s_img[];   // [SGTD_PQ_TILE_RECS]: per wave its dense candidates, then the tile's slot-sorted image
                                                                 // (16-byte aligned: the ranking masks in it are 64-bit words)
@@ -261,15 +262,19 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu
   const u32 cnt = Q.count[q];
   const int nc = n_cand[q];
   if (nc == 0 || cnt == 0) return;     // (workgroup-uniform)
+  // lists only for the candidates in the mask (the multi-GPU step's winners, sgtd_finish_lists): the others get no
+  // slot, their records pass like those of any other frame; pair_off holds the masked offsets
+  const u64 kept = keep ? keep[q] : ~0ull;
+  if (kept == 0) return;
   // frame -> candidate slot (the byte behind the span answers for the ids of dead records)
   if (SLOT_TABLE) {
     for (u32 f = tid; f < (((frame_span + 15u) & ~15u) + 16u) / 4u; f += SGTD_PQ_THREADS) reinterpret_cast<u32 *>(s_slot8)[f] = 0xFFFFFFFFu;
     __syncthreads();
-    if (tid < nc) s_slot8[(u32)cand_frame[(size_t)q * cand_num + tid] - frame_lo] = (unsigned char)tid;
+    if (tid < nc && ((kept >> tid) & 1ull)) s_slot8[(u32)cand_frame[(size_t)q * cand_num + tid] - frame_lo] = (unsigned char)tid;
   } else {
     s_cand[tid & (SGTD_CAND_HASH - 1)] = SGTD_CAND_EMPTY;
     __syncthreads();
-    if (tid < nc) {
+    if (tid < nc && ((kept >> tid) & 1ull)) {
       const u32 f = (u32)cand_frame[(size_t)q * cand_num + tid];
       u32 h = (f * 0x9E3779B1u) >> 24;
       while (atomicCAS(&s_cand[h], SGTD_CAND_EMPTY, ((u64)f << 8) | (u64)tid) != SGTD_CAND_EMPTY) h = (h + 1) & (SGTD_CAND_HASH - 1);

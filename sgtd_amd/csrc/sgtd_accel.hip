@@ -18,6 +18,7 @@
 #include "probe_kernels.hip.h"
 #include "select_kernels.hip.h"
 #include "verify_kernels.hip.h"
+#include "exchange_kernels.hip.h"
 #include "graph_ingest.hip.h"
 
 namespace {
@@ -40,6 +41,35 @@ struct DescStore {
     a.qrec = with_thr2 ? qrec.as<QueryRec>() : nullptr;
     return a;
   }
+};
+
+// A host array in page-locked memory (grow-only): the per-batch result tables land here by direct DMA — a copy into
+// pageable memory goes through the runtime's staging at about a third of the rate (and ~150 us each on this runtime).
+template <class T>
+struct PinnedVec {
+  T *p = nullptr;
+  size_t n = 0, cap = 0;
+  PinnedVec() = default;
+  PinnedVec(const PinnedVec &) = delete;
+  PinnedVec &operator=(const PinnedVec &) = delete;
+  ~PinnedVec() { if (p) (void)hipHostFree(p); }
+  bool resize(size_t want) {
+    if (want > cap) {
+      void *np = nullptr;
+      const size_t c = std::max<size_t>(want + want / 4, 64);
+      if (hipHostMalloc(&np, c * sizeof(T), hipHostMallocDefault) != hipSuccess) return false;
+      if (p) (void)hipHostFree(p);      // (contents are not kept: every user refills after a resize)
+      p = static_cast<T *>(np);
+      cap = c;
+    }
+    n = want;
+    return true;
+  }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
 };
 
 constexpr size_t kCtrWords = 1024 + 8 * 1024;   // ProbeBuffers::ctr: counters + the sweep's ticket-queue heads
@@ -130,6 +160,21 @@ struct sgtd_engine {
   DevBuf inl_pairs, inl_off;                  // sgtd_result_inlier_pairs staging
   DevBuf v_hyp64, v_hyp32, v_bound;           // hypotheses between the two passes of sgtd_verify
   bool verified = false;
+  // ---- multi-GPU step (exchange_kernels.hip.h): the batch's local candidate tables are written, packed, into a caller
+  // device buffer as soon as they are final (behind votes_topk_kernel / topk_kernel) and ev_cand is recorded; a side
+  // stream waits for it (sgtd_export_wait), all-gathers and merges while the match lists are written, and records
+  // ev_export_free (sgtd_export_release): the next batch's export waits for that before it overwrites the buffer
+  int *export_packed = nullptr;
+  size_t export_cap = 0;                      // ints the caller's buffer holds
+  hipEvent_t ev_cand = nullptr, ev_export_free = nullptr;
+  bool export_busy = false;
+  u32 batch_serial = 0;
+  bool defer_lists = false;                   // sgtd_set_deferred_lists: a batch stops behind the candidate tables, sgtd_finish_lists writes the lists
+  bool lists_pending = false;                 // ... and has not been called for the batch yet
+  bool lists_masked = false;                  // the batch's lists were written for a subset of its candidates (pair_off holds the masked offsets)
+  bool fused_votes_last = false;              // the batch's candidate tables came from votes_topk_kernel (it also wrote the unmasked offsets)
+  const u64 *verify_keep = nullptr;           // sgtd_verify_masked: device mask of the candidates to verify (one launch)
+  const u64 *list_keep = nullptr;             // the mask the batch's lists were last written with (a re-run of the list pass: the same)
   bool pairs_per_query = false;               // the batch's match lists were written by pairs_query_kernel (a re-run of the write pass: the same)
   DevBuf rough_qi, rough_entry, rough_frame, rough_cell, rough_dis;
   size_t rec_cap = (size_t)1 << 25;    // match records (grown on overflow)
@@ -145,10 +190,10 @@ struct sgtd_engine {
   int select_mode = 0;                 // SGTD_SELECT_MODE (test hook): 0 auto, 1 the five-kernel passes over the records, 2 the per-query
                                        // workgroups (select_kernels.hip.h) wherever they are supported, whatever the batch size
   // host copies after sync
-  std::vector<u32> h_count, h_pair_base, h_q_M;
-  std::vector<unsigned long long> h_q_P;
-  std::vector<int> h_n_cand, h_cand_frame, h_cand_votes;
-  std::vector<long long> h_pair_off;
+  PinnedVec<u32> h_count, h_pair_base, h_q_M;
+  PinnedVec<unsigned long long> h_q_P;
+  PinnedVec<int> h_n_cand, h_cand_frame, h_cand_votes;
+  PinnedVec<long long> h_pair_off;
   sgtd_stats stats{};
   // pinned host staging of the small transfers (see d2h / h2d below)
   char *pin = nullptr;
@@ -182,6 +227,7 @@ int ensure(sgtd_engine *e, DevBuf &b, size_t bytes, bool keep = false) {
   size_t want = keep ? std::max(bytes, b.bytes + b.bytes / 2) : (b.p ? bytes + bytes / 4 : bytes);
   void *np = nullptr;
   HIPCHK(hipMalloc(&np, want));
+  e->stats.device_allocs_total++;
   if (keep && b.p && b.bytes) {
     HIPCHK(hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -808,7 +854,7 @@ int launch_block_write(sgtd_engine *e, const Views &v, const CompactLists &CL, i
 
 // the match lists of every query by a workgroup of its own (select_kernels.hip.h); the slot of a record's frame
 // from a byte table in LDS while the frame span fits, else from the hash of the candidates
-int launch_pairs_query(sgtd_engine *e, const Views &v) {
+int launch_pairs_query(sgtd_engine *e, const Views &v, const u64 *keep = nullptr) {
   const int cn = e->dc.cand_num;
   const size_t img = (size_t)SGTD_PQ_TILE_RECS * sizeof(u32);
   const size_t tab = (((size_t)v.span + 15) & ~(size_t)15) + 16;     // (+ the bytes that answer for dead records)
@@ -816,13 +862,69 @@ int launch_pairs_query(sgtd_engine *e, const Views &v) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_query_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img + tab)));
     pairs_query_kernel<true><<<e->nq, SGTD_PQ_THREADS, img + tab, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
                                                                                 e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
-                                                                                e->pairs.as<u64>(), v.T.map, v.span, v.T.frame_lo);
+                                                                                e->pairs.as<u64>(), v.T.map, v.span, v.T.frame_lo, keep);
   } else {
     pairs_query_kernel<false><<<e->nq, SGTD_PQ_THREADS, img, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
                                                                            e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
-                                                                           e->pairs.as<u64>(), v.T.map, v.span, v.T.frame_lo);
+                                                                           e->pairs.as<u64>(), v.T.map, v.span, v.T.frame_lo, keep);
   }
   HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
+// the batch's local candidate tables, packed, into the buffer a multi-GPU caller registered (exchange_kernels.hip.h);
+// enqueued as soon as they are final, before the match lists are written
+int export_candidates(sgtd_engine *e, const Views &v) {
+  if (!e->export_packed) return SGTD_OK;
+  const int nq = e->nq, cn = e->dc.cand_num;
+  if (xchg_packed_ints(nq, cn) > e->export_cap) {
+    e->err = "the registered candidate-export buffer is too small for this batch";
+    return SGTD_ERR_CAPACITY;
+  }
+  if (e->export_busy) {     // a side stream may still be reading the table of the batch before
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_export_free, 0));
+    e->export_busy = false;
+  }
+  export_candidates_kernel<<<std::min(grid_for((long long)nq * cn, 256), 512), 256, 0, e->stream>>>(
+      e->cand_frame.as<int>(), e->cand_votes.as<int>(), v.B.overflow(), nq, cn, ++e->batch_serial, e->export_packed);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev_cand, e->stream));
+  return SGTD_OK;
+}
+
+// The match lists of a batch whose candidate tables are final, by one workgroup per query (select_kernels.hip.h):
+// offsets (the prefix sums of the candidates' votes — of the candidates in `keep` only, when a mask is given), the
+// queries' bases, the lists.  Runs once per batch inside launch_select, or later and repeatedly through
+// sgtd_finish_lists (the records stay intact: a list pass can be repeated with another mask).
+int launch_lists(sgtd_engine *e, const Views &v, const u64 *keep, bool first) {
+  const int nq = e->nq, cn = e->dc.cand_num;
+  if (keep) {
+    cand_prefix_masked_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->n_cand.as<int>(), e->cand_votes.as<int>(), keep, cn, nq,
+                                                                          e->pair_off.as<long long>(), e->q_pairs.as<u32>());
+    HIPCHK(hipGetLastError());
+  } else if (!e->fused_votes_last || e->lists_masked) {
+    // (votes_topk_kernel leaves the unmasked offsets itself)
+    cand_prefix_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->n_cand.as<int>(), e->cand_votes.as<int>(), cn, nq,
+                                                                   e->pair_off.as<long long>(), e->q_pairs.as<u32>());
+    HIPCHK(hipGetLastError());
+  }
+  e->lists_masked = keep != nullptr;
+  e->list_keep = keep;
+  if (e->timing && first) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
+  if (!first) HIPCHK(hipMemsetAsync(v.B.overflow() + 1, 0, sizeof(int), e->stream));
+  query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
+                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
+  HIPCHK(hipGetLastError());
+  if (e->timing && first) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
+  CHK(launch_pairs_query(e, v, keep));
+  if (e->timing && first) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
+  if (first) {
+    batch_totals_kernel<<<1, 1, 0, e->stream>>>(v.B.ctr, e->totals.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
+  }
+  e->lists_pending = false;
+  e->verified = false;
+  e->batch_synced = false;
   return SGTD_OK;
 }
 
@@ -862,7 +964,10 @@ int launch_select(sgtd_engine *e) {
   // byte table the list pass is slower than the block passes — 100 000-frame map, 256 queries: 6.1 against 2.9 ms)
   const bool votes_fit = votes_topk_lds_bytes(span) <= 150 * 1024;
   const bool per_query = e->select_mode == 2 || (e->select_mode == 0 && nq >= e->n_cus && votes_fit);
-  const bool fused_pairs = per_query && !e->wide_pairs && (e->id_bits ? e->id_bits : 13) <= SGTD_PQ_RANK_BITS;
+  // (an image word of the list pass is slot(6) | descriptor(9) | rank: with 64 candidates AND ranks of the full width the
+  // word of slot 63, descriptor 511, rank 2^17 - 1 would be the pass's "no record" marker — that corner takes the block form)
+  const bool fused_pairs = per_query && !e->wide_pairs && (e->id_bits ? e->id_bits : 13) <= SGTD_PQ_RANK_BITS &&
+                           !(cn == SGTD_MAX_CAND && (e->id_bits ? e->id_bits : 13) == SGTD_PQ_RANK_BITS);
   const bool fused_votes = fused_pairs && votes_fit;     // (block_count_kernel wants topk_kernel's slot table)
   CHK(rec_alloc(e, !fused_pairs));
   const bool votes_per_query = n_tiles == 1 ? nq >= e->n_cus : ((long long)nq * n_tiles >= e->n_cus / 4 && n_tiles <= 8);
@@ -1061,28 +1166,27 @@ int launch_select(sgtd_engine *e) {
     HIPCHK(hipGetLastError());
   }
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_TOPK], e->stream));
+  CHK(export_candidates(e, v));      // (multi-GPU step: the local tables start travelling before the lists are written)
+  e->lists_pending = false;
+  e->lists_masked = false;
+  e->fused_votes_last = fused_votes;
   if (fused_pairs) {
     // the lists' offsets are the prefix sums of the candidates' votes; the lists themselves by one workgroup per query
-    if (!fused_votes) {
-      cand_prefix_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->n_cand.as<int>(), e->cand_votes.as<int>(), cn, nq,
-                                                                     e->pair_off.as<long long>(), e->q_pairs.as<u32>());
-      HIPCHK(hipGetLastError());
-    }
-    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
-    query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
-                                                 (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
-    HIPCHK(hipGetLastError());
-    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
-    CHK(launch_pairs_query(e, v));
-    if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
-    batch_totals_kernel<<<1, 1, 0, e->stream>>>(v.B.ctr, e->totals.as<unsigned long long>());
-    HIPCHK(hipGetLastError());
     e->pairs_per_query = true;
     e->stats.select_form = fused_votes ? 2 : 1;
     e->batch_valid = true;
-    e->verified = false;
-    e->batch_synced = false;
-    return SGTD_OK;
+    if (e->defer_lists) {
+      // the caller writes the lists itself once it knows which candidates survive the merge (sgtd_finish_lists)
+      if (e->timing)
+        for (int k : {EV_COUNT_T, EV_SCAN, EV_WRITE}) HIPCHK(hipEventRecord(e->ev[k], e->stream));
+      batch_totals_kernel<<<1, 1, 0, e->stream>>>(v.B.ctr, e->totals.as<unsigned long long>());
+      HIPCHK(hipGetLastError());
+      e->lists_pending = true;
+      e->verified = false;
+      e->batch_synced = false;
+      return SGTD_OK;
+    }
+    return launch_lists(e, v, nullptr, /*first=*/true);
   }
   e->pairs_per_query = false;
   e->stats.select_form = 0;
@@ -1161,12 +1265,7 @@ int rerun_write(sgtd_engine *e) {
   CHK(ensure(e, e->pairs, e->pair_cap * sizeof(u64)));
   Views v = make_views(e);
   HIPCHK(hipMemsetAsync(v.B.overflow() + 1, 0, sizeof(int), e->stream));
-  if (e->pairs_per_query) {
-    query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
-                                                 (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
-    HIPCHK(hipGetLastError());
-    return launch_pairs_query(e, v);
-  }
+  if (e->pairs_per_query) return launch_lists(e, v, e->lists_masked ? e->list_keep : nullptr, /*first=*/false);
   CompactLists CL;
   CL.pair = e->c_pair.as<u64>();
   CL.blk_start = e->c_blk.as<u32>(); CL.blk_n = e->c_blk.as<u32>() + (size_t)nq * blocks;
@@ -1192,6 +1291,8 @@ int sync_batch(sgtd_engine *e) {
     u32 ctr[12];     // ProbeBuffers::ctr, one copy
     u32 n_groups = 0;
     unsigned long long tot[3] = {0, 0, 0};
+    // (deferred lists that nobody finished, or a re-run that changed the candidates: the lists of all of them)
+    if (e->lists_pending) CHK(launch_lists(e, make_views(e), nullptr, /*first=*/false));
     CHK(d2h(e, ctr, e->cursors.p, sizeof(ctr)));
     if (e->totals.p) CHK(d2h(e, tot, e->totals.p, sizeof(tot)));
     if (e->n_groups.p) CHK(d2h(e, &n_groups, e->n_groups.p, sizeof(u32)));
@@ -1239,17 +1340,22 @@ int sync_batch(sgtd_engine *e) {
     CHK(rerun(e));
   }
   const int nq = e->nq, cn = e->dc.cand_num;
-  e->h_count.resize(nq); e->h_pair_base.resize(nq + 1); e->h_q_M.resize(nq); e->h_q_P.resize(nq);
-  e->h_n_cand.resize(nq); e->h_cand_frame.resize((size_t)nq * cn); e->h_cand_votes.resize((size_t)nq * cn);
-  e->h_pair_off.resize((size_t)nq * (cn + 1));
-  CHK(d2h(e, e->h_count.data(), e->q_count.p, nq * sizeof(u32)));
-  CHK(d2h(e, e->h_pair_base.data(), e->q_pair_base.p, (nq + 1) * sizeof(u32)));
-  CHK(d2h(e, e->h_q_M.data(), e->q_M.p, nq * sizeof(u32)));
-  CHK(d2h(e, e->h_q_P.data(), e->q_P.p, nq * sizeof(unsigned long long)));
-  CHK(d2h(e, e->h_n_cand.data(), e->n_cand.p, nq * sizeof(int)));
-  CHK(d2h(e, e->h_cand_frame.data(), e->cand_frame.p, (size_t)nq * cn * sizeof(int)));
-  CHK(d2h(e, e->h_cand_votes.data(), e->cand_votes.p, (size_t)nq * cn * sizeof(int)));
-  CHK(d2h(e, e->h_pair_off.data(), e->pair_off.p, (size_t)nq * (cn + 1) * sizeof(long long)));
+  if (!(e->h_count.resize(nq) && e->h_pair_base.resize(nq + 1) && e->h_q_M.resize(nq) && e->h_q_P.resize(nq) &&
+        e->h_n_cand.resize(nq) && e->h_cand_frame.resize((size_t)nq * cn) && e->h_cand_votes.resize((size_t)nq * cn) &&
+        e->h_pair_off.resize((size_t)nq * (cn + 1)))) {
+    e->err = "hipHostMalloc of the result tables failed";
+    return SGTD_ERR_HIP;
+  }
+  // the batch's result tables: eight direct DMA transfers into page-locked arrays the handle keeps
+  auto pull = [&](void *dst, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream) : hipSuccess; };
+  HIPCHK(pull(e->h_count.data(), e->q_count.p, nq * sizeof(u32)));
+  HIPCHK(pull(e->h_pair_base.data(), e->q_pair_base.p, (nq + 1) * sizeof(u32)));
+  HIPCHK(pull(e->h_q_M.data(), e->q_M.p, nq * sizeof(u32)));
+  HIPCHK(pull(e->h_q_P.data(), e->q_P.p, nq * sizeof(unsigned long long)));
+  HIPCHK(pull(e->h_n_cand.data(), e->n_cand.p, nq * sizeof(int)));
+  HIPCHK(pull(e->h_cand_frame.data(), e->cand_frame.p, (size_t)nq * cn * sizeof(int)));
+  HIPCHK(pull(e->h_cand_votes.data(), e->cand_votes.p, (size_t)nq * cn * sizeof(int)));
+  HIPCHK(pull(e->h_pair_off.data(), e->pair_off.p, (size_t)nq * (cn + 1) * sizeof(long long)));
   CHK(xfer_sync(e));
   sgtd_stats &s = e->stats;
   s.last_queries = nq;
@@ -1446,6 +1552,8 @@ int sgtd_create(const sgtd_config *cfg, sgtd_handle *out) {
   if (const char *o = getenv("SGTD_PAIR_CAP")) { e->pair_cap = (size_t)std::max(64ll, atoll(o)); e->rec_cap_fixed = true; }
   for (int i = 0; i < EV_COUNT; i++)
     if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
+  if (hipEventCreateWithFlags(&e->ev_cand, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_export_free, hipEventDisableTiming) != hipSuccess) { delete e; return SGTD_ERR_HIP; }
   *out = e;
   return SGTD_OK;
 }
@@ -1487,6 +1595,8 @@ int sgtd_destroy(sgtd_handle e) {
   if (e->pin) (void)hipHostFree(e->pin);
   for (int i = 0; i < EV_COUNT; i++)
     if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+  if (e->ev_cand) (void)hipEventDestroy(e->ev_cand);
+  if (e->ev_export_free) (void)hipEventDestroy(e->ev_export_free);
   delete e;
   return SGTD_OK;
 }
@@ -1736,6 +1846,95 @@ int sgtd_export_candidates_dev(sgtd_handle e, int32_t *d_cand_frame, int32_t *d_
   return SGTD_OK;
 }
 
+int64_t sgtd_candidate_export_ints(int n_queries, int cand_num) {
+  if (n_queries < 0 || cand_num < 0) return 0;
+  return (int64_t)xchg_packed_ints(n_queries, cand_num);
+}
+
+#define SGTD_NO_GROUP(e)                                                                                                   \
+  if ((e) && (e)->grp) { (e)->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
+
+int sgtd_set_candidate_export(sgtd_handle e, int32_t *d_packed, int64_t capacity_ints) {
+  SGTD_NO_GROUP(e);
+  if (!e || capacity_ints < 0 || (d_packed && capacity_ints < SGTD_XCHG_FLAG_WORDS)) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  // (what is enqueued may still write the buffer registered before)
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->export_packed = d_packed;
+  e->export_cap = d_packed ? (size_t)capacity_ints : 0;
+  e->export_busy = false;
+  return SGTD_OK;
+}
+
+int sgtd_export_wait(sgtd_handle e, void *side_stream) {
+  SGTD_NO_GROUP(e);
+  if (!e) return SGTD_ERR_INVALID;
+  if (!e->export_packed || !e->batch_valid) return SGTD_ERR_STATE;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  HIPCHK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(side_stream), e->ev_cand, 0));
+  return SGTD_OK;
+}
+
+int sgtd_export_release(sgtd_handle e, void *side_stream) {
+  SGTD_NO_GROUP(e);
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  HIPCHK(hipEventRecord(e->ev_export_free, reinterpret_cast<hipStream_t>(side_stream)));
+  e->export_busy = true;
+  return SGTD_OK;
+}
+
+int sgtd_merge_candidates_dev(sgtd_handle e, void *stream, const int32_t *d_gathered, int n_tables, int my_table, int n_queries,
+                              int32_t *d_frame, int32_t *d_votes, int32_t *d_n_cand, int32_t *d_src, uint64_t *d_keep, int32_t *d_flags) {
+  SGTD_NO_GROUP(e);
+  if (!e || !d_gathered || !d_frame || !d_votes || !d_n_cand || !d_src || !d_keep || !d_flags || n_tables < 1 || n_queries < 0 ||
+      my_table < -1 || my_table >= n_tables)
+    return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num;
+  if ((long long)n_tables * cn > (long long)SGTD_MERGE_PER_LANE * SGTD_WAVE || n_tables > 0x7FFFFF) return SGTD_ERR_UNSUPPORTED;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  // (min_votes 5: max_vote >= 5, STDesc.cpp:433)
+  merge_candidates_kernel<<<std::max(1, grid_for(n_queries, 4)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+      d_gathered, (long long)xchg_packed_ints(n_queries, cn), n_tables, my_table, n_queries, cn, 5, d_frame, d_votes, d_n_cand, d_src,
+      reinterpret_cast<u64 *>(d_keep), d_flags);
+  HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
+int sgtd_gather_verified_dev(sgtd_handle e, void *stream, const double *d_gathered, int n_tables, const int32_t *d_src, int n_queries,
+                             double *d_score, double *d_pose) {
+  SGTD_NO_GROUP(e);
+  if (!e || !d_gathered || !d_src || !d_score || !d_pose || n_tables < 1 || n_queries < 0) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num;
+  if (n_queries == 0) return SGTD_OK;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  gather_verified_kernel<<<grid_for((long long)n_queries * cn, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+      d_gathered, (long long)n_queries * cn * 13, d_src, n_queries, cn, d_score, d_pose);
+  HIPCHK(hipGetLastError());
+  return SGTD_OK;
+}
+
+int sgtd_set_deferred_lists(sgtd_handle e, int on) {
+  SGTD_NO_GROUP(e);
+  if (!e) return SGTD_ERR_INVALID;
+  e->defer_lists = on != 0;
+  return SGTD_OK;
+}
+
+int sgtd_finish_lists(sgtd_handle e, const uint64_t *d_keep) {
+  SGTD_NO_GROUP(e);
+  if (!e) return SGTD_ERR_INVALID;
+  if (!e->batch_valid) return SGTD_ERR_STATE;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (!e->pairs_per_query) {
+    // the lists of this batch came from the passes of one wave per 128-descriptor block (small batches, frame spans
+    // beyond LDS): they hold every local candidate already; a mask only matters to sgtd_verify_masked
+    return SGTD_OK;
+  }
+  return launch_lists(e, make_views(e), reinterpret_cast<const u64 *>(d_keep), /*first=*/false);
+}
+#undef SGTD_NO_GROUP
+
 int sgtd_result_query_desc_count(sgtd_handle e, int q, int64_t *n) {
   if (e && e->grp) return multi::result_query_desc_count(e, q, n);
   if (!e || !n) return SGTD_ERR_INVALID;
@@ -1847,6 +2046,15 @@ int sgtd_result_rough(sgtd_handle e, int q, int32_t *q_idx, int32_t *cell, int64
   return SGTD_OK;
 }
 
+int sgtd_verify_masked(sgtd_handle e, const uint64_t *d_keep) {
+  if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
+  if (!e) return SGTD_ERR_INVALID;
+  e->verify_keep = reinterpret_cast<const u64 *>(d_keep);
+  const int st = sgtd_verify(e);
+  e->verify_keep = nullptr;
+  return st;
+}
+
 int sgtd_verify(sgtd_handle e) {
   if (e && e->grp) return multi::verify(e);
   if (!e) return SGTD_ERR_INVALID;
@@ -1877,6 +2085,7 @@ int sgtd_verify(sgtd_handle e) {
   CHK(ensure(e, e->v_hyp32, (size_t)nq * cn * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F32 * sizeof(float)));
   CHK(ensure(e, e->v_bound, (size_t)nq * cn * 2 * sizeof(u32)));
   P.hyp64 = e->v_hyp64.as<double>(); P.hyp32 = e->v_hyp32.as<float>(); P.bound = e->v_bound.as<u32>();
+  P.keep = e->verify_keep;
   verify_solve_kernel<<<nq * cn, SGTD_WAVE, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
   verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);

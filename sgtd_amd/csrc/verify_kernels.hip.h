@@ -51,6 +51,8 @@ struct VerifyParams {
   u32 *bound;                  // [nq * cand_num][2] largest |rot entry| and |t|_1 of the candidate's hypotheses (float bits)
   double thr2;                 // smallest y with sqrt_rn(y) >= 3.0 (dis_threshold, :469)
   int exact_only;              // test hook (SGTD_VERIFY_EXACT=1): no f32 pre-test, every vertex A test in f64
+  const u64 *keep;             // [nq] or NULL: bit c = verify candidate c of the query (sgtd_verify_masked: the candidates that
+                               // survived a multi-GPU merge); the others score -1 like a rejected candidate
 };
 
 // One-sided (Hestenes) Jacobi SVD of a 3x3, H = U diag(s) V^T; columns of (near) zero
@@ -174,7 +176,7 @@ __device__ __forceinline__ bool vertex_close(const double *Rt, const double v[3]
 __global__ __launch_bounds__(SGTD_WAVE) void verify_solve_kernel(VerifyParams P) {
   const int tid = threadIdx.x;
   const int q = blockIdx.x / P.cand_num, c = blockIdx.x % P.cand_num;
-  if (c >= P.n_cand[q]) return;
+  if (c >= P.n_cand[q] || (P.keep && !((P.keep[q] >> c) & 1ull))) return;
   const long long *po = P.pair_off + (size_t)q * (P.cand_num + 1);
   const u32 base = P.q_pair_base[q] + (u32)po[c];
   const long long n = po[c + 1] - po[c];
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
   const int tid = threadIdx.x, lane = lane_id();
   const int q = blockIdx.x / P.cand_num, c = blockIdx.x % P.cand_num;
   double *score = P.score + (size_t)q * P.cand_num + c;
-  if (c >= P.n_cand[q]) { if (tid == 0) *score = -1.0; return; }
+  if (c >= P.n_cand[q] || (P.keep && !((P.keep[q] >> c) & 1ull))) { if (tid == 0) *score = -1.0; return; }
   const long long *po = P.pair_off + (size_t)q * (P.cand_num + 1);
   const u32 base = P.q_pair_base[q] + (u32)po[c];
   const u32 n = (u32)(po[c + 1] - po[c]);          // (a batch's pairs are indexed with 32 bits)

@@ -1,22 +1,28 @@
 """Multi-GPU forms of candidate_selector, one process per GPU, RCCL collectives.
 
-Two modes (bench.py --shard auto|table|query):
-* table-sharded (below): the map's hash table is sharded by frame range — for maps
-  that do not fit, or should not be replicated on, one GPU;
-* query-sharded (`ReplicatedMap`): the table is replicated and every rank serves a
-  slice of each query batch — the throughput mode for maps that fit one GPU.
+The N ranks of a job form a grid of R_t table shards x R_q query groups (R_t * R_q = N, `Map2D`):
+* inside a query group the map's hash table is sharded by frame range over R_t ranks:
+  rank t owns map frames [lo_t, hi_t) and holds a complete table for them, so every vote of a frame
+  is counted on exactly one rank and the final vote of each of its frames is local.  Per batch each
+  rank probes its shard with the group's queries and takes its local top-`candidate_num` (votes
+  desc, frame id asc, >= 5 votes — STDesc.cpp:423-433); ONE all_gather of the packed tables inside
+  the group and an identical merge on every rank (a kernel: sgtd_merge_candidates_dev) reproduce the
+  single-table candidate list bit for bit: the global top-k of disjoint frame sets is the top-k of
+  the union of the local top-k lists.  The match lists of the winners stay on their owner.
+* the R_q query groups each serve their own queries against their own copy of the (sharded) table;
+  one all_gather across the groups hands every rank the result tables of the whole step.
+R_t = N is the pure table-sharded form BASELINE.json's north_star names (`ShardedMap`), R_t = 1 the
+replicated map with sharded queries (`ReplicatedMap`); `plan_2d` picks the smallest R_t whose shard
+fits one GPU's envelope, because everything a rank does per QUERY (descriptor build, home-cell sort,
+GroupRows, the plan) is repeated on all R_t ranks of a group and only the sweep shrinks with the shard.
 
-Sharding: rank r owns map frames [lo_r, hi_r) and holds a
-complete table for them, so every vote of a frame is counted on exactly one
-rank and the final vote of each of its frames is local.  Per query batch each
-rank probes its shard with all queries, takes its local top-`candidate_num`
-(votes desc, frame id asc, >= 5 votes — STDesc.cpp:423-433), then ONE
-all_gather of the (frame, votes) tables (candidate_num * 8 B per query and
-rank) and an identical merge on every rank reproduce the single-table
-candidate list bit for bit: the global top-k of disjoint frame sets is the
-top-k of the union of the local top-k lists.  The match lists of the winners
-stay on their owner rank (`owner_of`).
+The exchange is off the critical path: the packed local tables leave the pipeline right behind
+votes_topk_kernel (sgtd_set_candidate_export), a side stream all-gathers and merges them while the
+main stream writes the match lists (`lists="all"`), or the main stream waits for the merge and
+writes the lists of the winners only (`lists="winners"`).  Either way sgtd_verify_masked verifies
+only the candidates that survived the merge.
 """
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -119,52 +125,185 @@ def search_loop_choice(global_frames, n_cand, scores, icp_threshold):
             torch.where(ok, best, torch.zeros_like(best)))
 
 
-class ShardedMap:
-    """one rank's shard of the map + the collective query (one process per GPU)"""
 
-    def __init__(self, n_frames_total, rank, world, device_id=0, **cfg):
+def plan_2d(world, n_frames, queries_per_group, keypoints=200, span_limit=32000, record_limit=3.2e9, r_t=None):
+    """(R_t, R_q) for `world` ranks: the smallest R_t (a divisor of world) whose shard of an n_frames map fits one GPU's
+    envelope — the per-query vote histogram of votes_topk_kernel in LDS (span_limit frames), the batch's match records
+    under the 32-bit record index (about 0.37 rough matches per keypoint, map frame and query on the synthetic maps:
+    0.74 M per 200-keypoint query at 10 000 frames), the table in HBM (36 descriptors per keypoint, 155 B each, a
+    quarter of 288 GB)."""
+    if r_t is not None:
+        assert world % r_t == 0
+        return int(r_t), world // int(r_t)
+    for t in [d for d in range(1, world + 1) if world % d == 0]:
+        f = -(-n_frames // t)
+        if f > span_limit and t < world:
+            continue
+        if 0.37 * keypoints * f * queries_per_group > record_limit and t < world:
+            continue
+        if 155.0 * 36 * keypoints * f > 288e9 / 4 and t < world:
+            continue
+        return t, world // t
+    return world, 1
+
+
+class Map2D:
+    """one rank of an R_t x R_q grid: rank = g * R_t + t serves query group g with table shard t"""
+
+    def __init__(self, n_frames_total, rank, world, r_t=None, device_id=0, lists="all", **cfg):
+        from . import _lib
         from .manager import STDescManager
+        assert lists in ("all", "winners")
         self.n_frames, self.rank, self.world = n_frames_total, rank, world
-        self.lo, self.hi = shard_range(n_frames_total, world, rank)
+        self.r_t = world if r_t is None else int(r_t)
+        assert self.r_t >= 1 and world % self.r_t == 0
+        self.r_q = world // self.r_t
+        self.t, self.g = rank % self.r_t, rank // self.r_t
+        self.lo, self.hi = shard_range(n_frames_total, self.r_t, self.t)
+        self.lists = lists
         cfg.setdefault("max_frame_n", max(20000, n_frames_total + 1))
         self.mgr = STDescManager(first_frame_id=self.lo, device_id=device_id, **cfg)
         self.cand_num = self.mgr.config_setting_["candidate_num"]
-        self._bufs = None
+        self._L = _lib.lib()
+        self.dev = torch.device("cuda", device_id)
+        # every rank creates every group, in the same order (torch.distributed's rule)
+        self.table_group, self.col_group = None, None
+        if dist.is_initialized() and world > 1:
+            assert dist.get_world_size() == world and dist.get_rank() == rank
+            for g in range(self.r_q):
+                grp = dist.new_group(list(range(g * self.r_t, (g + 1) * self.r_t))) if 1 < self.r_t < world else None
+                if g == self.g:
+                    self.table_group = grp
+            for t in range(self.r_t):
+                grp = dist.new_group(list(range(t, world, self.r_t))) if 1 < self.r_q < world else None
+                if t == self.t:
+                    self.col_group = grp
+        self.main = torch.cuda.current_stream(self.dev)
+        self.mgr.set_stream(self.main.cuda_stream)
+        self.side = torch.cuda.Stream(self.dev)
+        self._nq_buf = -1
+        self.merged = None
+        self.exchanges = 0
+        if lists == "winners":
+            self.mgr.set_deferred_lists(True)
 
+    # ---- map construction ---------------------------------------------------------------
     def add_shard_frames(self, xyz, label, kp_off=None):
         """xyz/label of THIS rank's frames [lo, hi) in frame order"""
         self.mgr.add_frames(xyz, label, kp_off)
         self.mgr.finalize()
 
-    def query(self, xyz, label, kp_off=None):
-        """all ranks pass the same query batch; returns the global candidate list
-        (frames, votes, n_cand) as device tensors, identical on every rank"""
-        self.mgr.query_frames(xyz, label, kp_off, fetch=False)
+    # ---- buffers --------------------------------------------------------------------------
+    def _buffers(self, nq):
+        if nq == self._nq_buf:
+            return
+        cn, rt, dev = self.cand_num, self.r_t, self.dev
+        ints = int(self._L.sgtd_candidate_export_ints(nq, cn))
+        self.packed = torch.empty(ints, dtype=torch.int32, device=dev)
+        self.gathered = torch.empty(rt * ints, dtype=torch.int32, device=dev)
+        self.m_frame = torch.empty((nq, cn), dtype=torch.int32, device=dev)
+        self.m_votes = torch.empty((nq, cn), dtype=torch.int32, device=dev)
+        self.m_src = torch.empty((nq, cn), dtype=torch.int32, device=dev)
+        self.m_n = torch.empty(nq, dtype=torch.int32, device=dev)
+        self.m_keep = torch.empty(nq, dtype=torch.int64, device=dev)
+        self.m_flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.v_local = torch.empty(nq * cn * 13, dtype=torch.float64, device=dev)        # [score | pose] of the local candidates
+        self.v_gathered = torch.empty(rt * nq * cn * 13, dtype=torch.float64, device=dev)
+        self.v_score = torch.empty((nq, cn), dtype=torch.float64, device=dev)
+        self.v_pose = torch.empty((nq, cn, 12), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        self.mgr.set_candidate_export(self.packed)
+        self._nq_buf = nq
+
+    def _table_collective(self):
+        return self.r_t > 1 and dist.is_initialized()
+
+    # ---- the step ---------------------------------------------------------------------------
+    def _exchange(self):
+        """side stream: wait for the packed local table, all-gather it inside the table group, merge"""
         nq = self.mgr._nq
-        dev = torch.device("cuda", self.mgr.config_setting_["device_id"])
-        if self._bufs is None or self._bufs[0].shape[0] != nq:
-            self._bufs = (torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev),
-                          torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev))
-        self.mgr.export_candidates(*self._bufs)
-        return gather_and_merge(self._bufs[0], self._bufs[1], self.cand_num)
+        self.mgr.export_wait(self.side.cuda_stream)
+        with torch.cuda.stream(self.side):
+            if self._table_collective():
+                dist.all_gather_into_tensor(self.gathered, self.packed, group=self.table_group)
+                src = self.gathered
+            else:
+                src = self.packed
+        self.mgr.merge_candidates_dev(self.side.cuda_stream, src, self.r_t, self.t, nq, self.m_frame, self.m_votes, self.m_n,
+                                      self.m_src, self.m_keep, self.m_flags)
+        self.mgr.export_release(self.side.cuda_stream)
+        self.exchanges += 1
+
+    def query_async(self, xyz, label, kp_off=None):
+        """enqueue one step for this rank's query group: the shard's sweep and the passes over its records on the main
+        stream, the exchange (all_gather + merge kernel) on the side stream.  Nothing waits on the host; the merged tables
+        (self.m_frame / m_votes / m_n / m_src / m_keep) are valid once both streams are, and self.m_flags[0] != 0 says
+        that some rank's batch outgrew a work buffer (query() repairs that; a caller of query_async checks it)."""
+        nq = self.mgr.frames_in(xyz, kp_off)
+        self._buffers(nq)
+        self.mgr.query_frames(xyz, label, kp_off, fetch=False)
+        self._exchange()
+        if self.lists == "winners":
+            self.main.wait_stream(self.side)                 # (device-side wait)
+            self.mgr.finish_lists(self.m_keep)
+
+    def query(self, xyz, label, kp_off=None):
+        """all ranks of a table group pass the same query batch; returns the group's merged candidate list
+        (frames, votes, n_cand) as device tensors, identical on every rank of the group"""
+        self.query_async(xyz, label, kp_off)
+        for _ in range(4):
+            self.side.synchronize()
+            if int(self.m_flags[0].item()) == 0:
+                break
+            if int(self.m_flags[0].item()) & 2:
+                raise RuntimeError("sgtd_amd.dist: the ranks of a table group passed batches of different shapes")
+            # some rank's batch outgrew a work buffer (every rank of the group sees the same flag): sgtd_sync re-runs it
+            # where that happened — the re-run exports again — and the group exchanges once more
+            self.mgr.sync()
+            self._exchange()
+            if self.lists == "winners":
+                self.main.wait_stream(self.side)
+                self.mgr.finish_lists(self.m_keep)
+        else:
+            raise RuntimeError("sgtd_amd.dist: a batch kept outgrowing its work buffers")
+        self.main.wait_stream(self.side)
+        return self.m_frame, self.m_votes, self.m_n
+
+    def gather_groups(self):
+        """the merged tables of ALL query groups (group-major): (frames, votes) [R_q * nq, cn] on every rank"""
+        if self.r_q == 1 or not dist.is_initialized():
+            return self.m_frame, self.m_votes
+        packed = torch.stack([self.m_frame, self.m_votes]).contiguous()
+        out = torch.empty((self.r_q * 2,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(out, packed, group=self.col_group)
+        out = out.view((self.r_q, 2) + tuple(packed.shape[1:]))
+        return out[:, 0].reshape(-1, self.cand_num), out[:, 1].reshape(-1, self.cand_num)
 
     def search_loop(self, xyz, label, kp_off=None, icp_threshold=None, group=None):
-        """SearchLoop over the sharded map: query + merge, candidate_verify of the local
-        candidates on every rank, one all_gather of (frames, scores, poses), SearchLoop's
-        choice on the merged list.  Returns (frames, votes, n_cand, scores, poses, best_cand,
-        best_frame, best_score), identical on every rank."""
+        """SearchLoop over the sharded map: query + merge, candidate_verify of this rank's WINNERS only
+        (sgtd_verify_masked), one all_gather of (scores, poses) inside the table group, the merged candidates'
+        results out of their owners' tables (sgtd_gather_verified_dev), SearchLoop's choice on the merged list.
+        Returns (frames, votes, n_cand, scores, poses, best_cand, best_frame, best_score), identical on every rank."""
         frames, votes, n_cand = self.query(xyz, label, kp_off)
-        self.mgr.verify()
         nq, cn = frames.shape
-        dev = frames.device
-        score = torch.empty((nq, cn), dtype=torch.float64, device=dev)
-        pose = torch.empty((nq, cn, 12), dtype=torch.float64, device=dev)
-        self.mgr.export_verify(score, pose)
-        sf, ss, sp = gather_verified(self._bufs[0], score, pose, group)
-        scores, poses = merge_verified(frames, sf, ss, sp)
+        self.mgr.verify_masked(self.m_keep)
+        self.mgr.export_verify(self.v_local[:nq * cn], self.v_local[nq * cn:])
+        if self._table_collective():
+            dist.all_gather_into_tensor(self.v_gathered, self.v_local, group=self.table_group)
+            src = self.v_gathered
+        else:
+            src = self.v_local
+        self.mgr.gather_verified_dev(self.main.cuda_stream, src, self.r_t, self.m_src, nq, self.v_score, self.v_pose)
         thr = self.mgr.icp_threshold_ if icp_threshold is None else icp_threshold
-        bc, bf, bs = search_loop_choice(frames, n_cand, scores, thr)
-        return frames, votes, n_cand, scores, poses, bc, bf, bs
+        bc, bf, bs = search_loop_choice(frames, n_cand, self.v_score, thr)
+        return frames, votes, n_cand, self.v_score, self.v_pose, bc, bf, bs
+
+
+class ShardedMap(Map2D):
+    """the pure table-sharded form (R_t = world): one rank's shard of the map + the collective query"""
+
+    def __init__(self, n_frames_total, rank, world, device_id=0, **cfg):
+        super().__init__(n_frames_total, rank, world, r_t=world, device_id=device_id, **cfg)
 
 
 def query_slice(n_queries, world, rank):
@@ -196,34 +335,22 @@ def gather_query_slices(local_frames, local_votes, n_queries, group=None):
     return torch.cat(frames), torch.cat(votes)
 
 
-class ReplicatedMap:
-    """multi-GPU mode for maps that fit one GPU: every rank holds the whole table and
-    serves its slice of each query batch (no collective on the data path but the
-    gather of the results)"""
+class ReplicatedMap(Map2D):
+    """R_t = 1: every rank holds the whole table and serves its own query group (no collective on the data path but
+    the gather of the results)"""
 
     def __init__(self, n_frames_total, rank, world, device_id=0, **cfg):
-        from .manager import STDescManager
-        self.rank, self.world = rank, world
-        cfg.setdefault("max_frame_n", max(20000, n_frames_total + 1))
-        self.mgr = STDescManager(device_id=device_id, **cfg)
-        self.cand_num = self.mgr.config_setting_["candidate_num"]
-        self._bufs = None
+        super().__init__(n_frames_total, rank, world, r_t=1, device_id=device_id, **cfg)
 
     def add_frames(self, xyz, label, kp_off=None):
-        self.mgr.add_frames(xyz, label, kp_off)
-        self.mgr.finalize()
+        self.add_shard_frames(xyz, label, kp_off)
 
-    def query(self, xyz_slice, label_slice, n_queries_total):
-        """xyz_slice/label_slice: THIS rank's slice of the batch (uniform frames [n, N, 3]);
-        returns (frames, votes) [n_queries_total, cn] on every rank"""
-        self.mgr.query_frames(xyz_slice, label_slice, fetch=False)
-        nq = self.mgr._nq
-        dev = torch.device("cuda", self.mgr.config_setting_["device_id"])
-        if self._bufs is None or self._bufs[0].shape[0] != nq:
-            self._bufs = (torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev),
-                          torch.empty((nq, self.cand_num), dtype=torch.int32, device=dev))
-        self.mgr.export_candidates(*self._bufs)
-        return gather_query_slices(self._bufs[0], self._bufs[1], n_queries_total)
+    def query_group(self, xyz_group, label_group):
+        """xyz_group/label_group: THIS rank's queries; returns (frames, votes) [world * nq, cn] on every rank"""
+        self.query_async(xyz_group, label_group)
+        self.main.wait_stream(self.side)
+        with torch.cuda.stream(self.main):
+            return self.gather_groups()
 
 
 # ---------------------------------------------------------------------------

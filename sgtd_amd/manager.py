@@ -234,6 +234,47 @@ class STDescManager:
         self._check(self._L.sgtd_export_candidates_dev(self._h, C.c_void_p(d_frame.data_ptr()),
                                                        C.c_void_p(d_votes.data_ptr())))
 
+    # ---- the multi-GPU step (include/sgtd_accel.h, sgtd_amd/dist.py) -----------------------------------------
+    @staticmethod
+    def frames_in(xyz, kp_off=None):
+        """query frames a batch call carries"""
+        return int(xyz.shape[0]) if kp_off is None else len(kp_off) - 1
+
+    def set_candidate_export(self, d_packed):
+        """every batch writes its packed local candidate tables into this torch.cuda int32 tensor as soon as they are
+        final (None: off)"""
+        if d_packed is None:
+            self._check(self._L.sgtd_set_candidate_export(self._h, None, 0))
+        else:
+            self._check(self._L.sgtd_set_candidate_export(self._h, C.c_void_p(d_packed.data_ptr()), d_packed.numel()))
+        self._export_keep = d_packed
+
+    def export_wait(self, side_stream_ptr):
+        self._check(self._L.sgtd_export_wait(self._h, C.c_void_p(side_stream_ptr)))
+
+    def export_release(self, side_stream_ptr):
+        self._check(self._L.sgtd_export_release(self._h, C.c_void_p(side_stream_ptr)))
+
+    def merge_candidates_dev(self, stream_ptr, gathered, n_tables, my_table, nq, frame, votes, n_cand, src, keep, flags):
+        """the merge of STDesc.cpp:423-433 over n_tables packed tables as one kernel on `stream_ptr` (torch.cuda tensors)"""
+        self._check(self._L.sgtd_merge_candidates_dev(self._h, C.c_void_p(stream_ptr), C.c_void_p(gathered.data_ptr()), n_tables, my_table, nq,
+                                                      C.c_void_p(frame.data_ptr()), C.c_void_p(votes.data_ptr()), C.c_void_p(n_cand.data_ptr()),
+                                                      C.c_void_p(src.data_ptr()), C.c_void_p(keep.data_ptr()), C.c_void_p(flags.data_ptr())))
+
+    def gather_verified_dev(self, stream_ptr, gathered, n_tables, src, nq, score, pose):
+        self._check(self._L.sgtd_gather_verified_dev(self._h, C.c_void_p(stream_ptr), C.c_void_p(gathered.data_ptr()), n_tables,
+                                                     C.c_void_p(src.data_ptr()), nq, C.c_void_p(score.data_ptr()), C.c_void_p(pose.data_ptr())))
+
+    def set_deferred_lists(self, on):
+        self._check(self._L.sgtd_set_deferred_lists(self._h, int(bool(on))))
+
+    def finish_lists(self, keep=None):
+        """write the match lists of the last batch — of the candidates in the u64-per-query device mask only (None: all)"""
+        self._check(self._L.sgtd_finish_lists(self._h, None if keep is None else C.c_void_p(keep.data_ptr())))
+
+    def verify_masked(self, keep):
+        self._check(self._L.sgtd_verify_masked(self._h, None if keep is None else C.c_void_p(keep.data_ptr())))
+
     def result_pairs(self, q, res):
         cn = self.config_setting_["candidate_num"]
         n = int(res.pair_off[q, cn])

@@ -222,3 +222,114 @@ def has_knn_ties(xyz, k):
     d2 = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
     part = np.sort(d2, axis=1)[:, :k + 1]
     return bool(np.any(part[:, 1:] == part[:, :-1]))
+
+
+# ---------------------------------------------------------------------------
+# A skewed, reference-shaped workload: what the reference's producers emit differs from the
+# uniform generator above in three ways that all lengthen buckets — class frequencies are heavily skewed
+# (get_json.cpp:10-12,287-293 maps SemanticKITTI classes to node labels, a handful of classes carry most instances;
+# the wild mapping get_json_wild.cpp:10-12 has 13 classes), the number of instances per scan varies by almost an
+# order of magnitude, and instances come in clusters (parked cars, tree rows, poles along a road).
+# ---------------------------------------------------------------------------
+@dataclass
+class RaggedFrames:
+    xyz: np.ndarray        # (total, 3) float32, sensor frame, frame after frame
+    label: np.ndarray      # (total,) uint32
+    kp_off: np.ndarray     # (F + 1,) int64
+    pose: np.ndarray       # (F, 3) x, y, yaw
+    gt_frame: np.ndarray   # (F,) int64 (queries: the map frame re-observed; maps: arange)
+
+    @property
+    def n_frames(self):
+        return len(self.kp_off) - 1
+
+    def frame(self, f):
+        a, b = int(self.kp_off[f]), int(self.kp_off[f + 1])
+        return self.xyz[a:b], self.label[a:b]
+
+    def take(self, frames):
+        """the given frames as a new set (offsets rebuilt)"""
+        frames = np.asarray(frames, np.int64)
+        n = (self.kp_off[frames + 1] - self.kp_off[frames]).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        idx = np.concatenate([np.arange(self.kp_off[f], self.kp_off[f + 1]) for f in frames]) if len(frames) else np.zeros(0, np.int64)
+        return RaggedFrames(self.xyz[idx], self.label[idx], off, self.pose[frames], self.gt_frame[frames])
+
+
+@dataclass
+class SkewWorld:
+    landmarks: np.ndarray       # (L, 3) world
+    landmark_label: np.ndarray  # (L,) uint32
+    pose: np.ndarray            # (F, 3) map poses
+
+
+def zipf_class_probs(n_classes=13, s=1.2):
+    p = 1.0 / np.arange(1, n_classes + 1) ** s
+    return p / p.sum()
+
+
+def _observe_ragged(landmarks, labels, tree, pose, n_kp, sigma, rng, tie_k=10):
+    """frame i = the n_kp[i] landmarks nearest to pose i (sensor frame, noisy, f32, shuffled); frames with duplicate
+    points or exact f32 k-NN distance ties are redrawn like _observe's"""
+    n_kp = np.asarray(n_kp, np.int64)
+    F = len(n_kp)
+    out_xyz, out_lab = [None] * F, [None] * F
+    for n in np.unique(n_kp):
+        sel = np.nonzero(n_kp == n)[0]
+        sub = np.random.Generator(np.random.PCG64(np.random.SeedSequence([BASE_SEED, 104729, int(n), int(rng.integers(1 << 30))])))
+        x, l = _observe(landmarks, labels, tree, pose[sel], int(n), sigma, sub, tie_k=tie_k if n > tie_k else 0)
+        for j, f in enumerate(sel):
+            out_xyz[f], out_lab[f] = x[j], l[j]
+    off = np.concatenate([[0], np.cumsum(n_kp)]).astype(np.int64)
+    return np.concatenate(out_xyz).astype(np.float32), np.concatenate(out_lab).astype(np.uint32), off
+
+
+def make_skewed_map(n_frames, stream=1, kp_lo=50, kp_hi=400, n_classes=13, zipf_s=1.2, spacing=2.0, swath=100.0,
+                    radius=50.0, sigma=0.02, z_sigma=1.5, cluster_frac=0.7, cluster_mean=12.0, cluster_sigma=6.0):
+    """-> (RaggedFrames map, SkewWorld).  Labels Zipf-distributed over `n_classes` classes (label = class index, the most
+    frequent first), kp_lo..kp_hi keypoints per frame (uniform), landmarks clustered: `cluster_frac` of them in
+    Gaussian clusters of `cluster_mean` members on average (sigma `cluster_sigma` m; a cluster's members share its class
+    with probability 0.8), the rest uniform.  Mean density = the uniform generator's ((kp_lo + kp_hi) / 2 in a
+    `radius` view)."""
+    from scipy.spatial import cKDTree
+    rng = _rng(stream, 40)
+    pose, amp = _trajectory(n_frames, spacing, swath)
+    mean_kp = 0.5 * (kp_lo + kp_hi)
+    rho = mean_kp / (np.pi * radius * radius)
+    half = amp + 2.5 * radius
+    n_land = int(rho * (2 * half) ** 2)
+    n_cl_members = int(cluster_frac * n_land)
+    n_clusters = max(1, int(n_cl_members / cluster_mean))
+    probs = zipf_class_probs(n_classes, zipf_s)
+    centre = rng.uniform(-half, half, (n_clusters, 2))
+    centre_class = rng.choice(n_classes, n_clusters, p=probs)
+    member_of = rng.integers(0, n_clusters, n_cl_members)
+    xy_c = centre[member_of] + rng.normal(0.0, cluster_sigma, (n_cl_members, 2))
+    own = rng.random(n_cl_members) < 0.8
+    lab_c = np.where(own, centre_class[member_of], rng.choice(n_classes, n_cl_members, p=probs))
+    n_bg = n_land - n_cl_members
+    xy_b = rng.uniform(-half, half, (n_bg, 2))
+    lab_b = rng.choice(n_classes, n_bg, p=probs)
+    landmarks = np.empty((n_land, 3))
+    landmarks[:, :2] = np.concatenate([xy_c, xy_b])
+    landmarks[:, 2] = rng.normal(0.0, z_sigma, n_land)
+    lab = np.concatenate([lab_c, lab_b]).astype(np.uint32)
+    tree = cKDTree(landmarks[:, :2])
+    n_kp = rng.integers(kp_lo, kp_hi + 1, n_frames)
+    xyz, label, off = _observe_ragged(landmarks, lab, tree, pose, n_kp, sigma, rng)
+    world = SkewWorld(landmarks=landmarks, landmark_label=lab, pose=pose)
+    world._tree = tree
+    world._kp = (kp_lo, kp_hi)
+    return RaggedFrames(xyz, label, off, pose, np.arange(n_frames, dtype=np.int64)), world
+
+
+def make_skewed_queries(world, n_queries, stream=1, sigma=0.05, shift_sigma=0.5):
+    """queries re-observing random map poses of a skewed world from perturbed poses, each with its own keypoint count"""
+    rng = _rng(stream, 41)
+    gt = rng.integers(0, world.pose.shape[0], n_queries)
+    pose = world.pose[gt].copy()
+    pose[:, :2] += rng.normal(0.0, shift_sigma, (n_queries, 2))
+    pose[:, 2] = rng.uniform(-np.pi, np.pi, n_queries)
+    n_kp = rng.integers(world._kp[0], world._kp[1] + 1, n_queries)
+    xyz, label, off = _observe_ragged(world.landmarks, world.landmark_label, world._tree, pose, n_kp, sigma, rng)
+    return RaggedFrames(xyz, label, off, pose, gt.astype(np.int64))

@@ -16,7 +16,7 @@ def main():
     import torch
     import torch.distributed as dist
     from sgtd_amd import synth
-    from sgtd_amd.dist import ShardedMap, shard_range
+    from sgtd_amd.dist import Map2D
     from sgtd_amd.manager import STDescManager
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("SGTD_TEST_BACKEND", "nccl")
@@ -30,10 +30,12 @@ def main():
     F, N, Q = 240, 150, 12
     smap = synth.make_map(F, N, stream=171)
     qs = synth.make_queries(smap, Q, stream=171)
-    lo, hi = shard_range(F, world, rank)
-    sm = ShardedMap(F, rank, world, device_id=local)
-    sm.add_shard_frames(smap.xyz[lo:hi], smap.label[lo:hi])
+    # SGTD_TEST_RT table shards per query group (default: all ranks one group), SGTD_TEST_LISTS all | winners; every group is
+    # handed the same queries here, so all ranks must end with the same result
+    sm = Map2D(F, rank, world, r_t=int(os.environ.get("SGTD_TEST_RT", world)), device_id=local, lists=os.environ.get("SGTD_TEST_LISTS", "all"))
+    sm.add_shard_frames(smap.xyz[sm.lo:sm.hi], smap.label[sm.lo:sm.hi])
     frames, votes, n_cand, scores, poses, bc, bf, bs = sm.search_loop(qs.xyz, qs.label)
+    torch.cuda.synchronize()
     # every rank holds the same merged result
     probe = torch.cat([frames.double().flatten(), votes.double().flatten(), scores.flatten(), poses.flatten(), bf.double(), bs]).contiguous()
     ref = probe.clone()
@@ -41,13 +43,14 @@ def main():
     assert torch.equal(ref, probe), "rank %d holds another merged result than rank 0" % rank
     ok = 1
     if rank == 0:
-        single = STDescManager(device_id=local)
-        single.add_frames(smap.xyz, smap.label)
-        want = single.query_frames(qs.xyz, qs.label)
-        single.verify()
-        w_bc, w_bf, w_bs = single.search_loop()
-        cn = single.config_setting_["candidate_num"]
+        single = None
         try:
+            single = STDescManager(device_id=local)
+            single.add_frames(smap.xyz, smap.label)
+            want = single.query_frames(qs.xyz, qs.label)
+            single.verify()
+            w_bc, w_bf, w_bs = single.search_loop()
+            cn = single.config_setting_["candidate_num"]
             for i in range(Q):
                 nc = int(want.n_cand[i])
                 assert int(n_cand[i]) == nc
@@ -59,10 +62,13 @@ def main():
                 assert np.array_equal(got[:, :9].reshape(cn, 3, 3), w_rot) and np.array_equal(got[:, 9:], w_t)
             assert np.array_equal(bc.cpu().numpy(), w_bc) and np.array_equal(bf.cpu().numpy(), w_bf) and np.array_equal(bs.cpu().numpy(), w_bs)
             assert int((w_bf >= 0).sum()) >= Q // 2          # loops are found
-        except AssertionError as exc:
+        except Exception as exc:       # (anything: the broadcast and the barrier below must be reached)
+            import traceback
             ok = 0
             print("MISMATCH", exc)
-        single.close()
+            traceback.print_exc()
+        if single is not None:
+            single.close()
     flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
     dist.broadcast(flag, src=0)
     dist.barrier()
