@@ -341,7 +341,8 @@ int sgtd_load_table(sgtd_handle h, const char *path);
  * "poses":[12 floats], ...} (producer get_json.cpp:332-341; only these three keys are read;
  * numbers as nlohmann::json stores and casts them — integer tokens through strtoull / strtoll, the rest through
  * strtod, then get<float>() / get<int>() — pinned bit for bit against that library by
- * tests/cpp/test_ingest_nlohmann.cpp; a key that occurs twice keeps its first value) parsed on
+ * tests/cpp/test_ingest_nlohmann.cpp; a key that occurs twice keeps its LAST value like nlohmann::json 3.2 and later, its
+ * first like 3.1.1 when SGTD_JSON_DUPLICATE_KEYS=first is set in the environment) parsed on
  * n_threads host threads into the arrays sgtd_add_frames / sgtd_query_frames take.  Frames
  * keep the order of `paths`.  On SGTD_ERR_IO *out still holds an object whose
  * sgtd_graphs_error() names the file ("Error opening file: ..." like Semantic_Graph.hpp:173);

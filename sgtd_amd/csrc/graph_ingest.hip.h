@@ -14,9 +14,10 @@
 // compares with it bit for bit) reads them: a token without fraction and exponent is an integer —
 // strtoull for a non-negative one, strtoll for a negative one ("-0" is the integer 0: +0.0f, not
 // -0.0f), and only if that overflows a double — every other token goes through strtod; get<float>() /
-// get<int>() are static_casts of whichever of the three was stored.  A key that occurs twice keeps its
-// FIRST value (that version's parser emplaces; newer versions assign, i.e. keep the last — the producer,
-// get_json.cpp:332-341, never writes a key twice).
+// get<int>() are static_casts of whichever of the three was stored.  A key that occurs twice: nlohmann 3.1.1
+// keeps the FIRST value (its parser emplaces), 3.2 and later keep the LAST (object[key] is assigned; ROS noetic
+// ships 3.7.3) — SGTD_JSON_DUPLICATE_KEYS = first | last chooses, default last; the producer,
+// get_json.cpp:332-341, never writes a key twice.
 #pragma once
 #include <errno.h>
 #include <stdint.h>
@@ -99,11 +100,15 @@ struct Scanner {
         if (c == 'u') {
           unsigned cp;
           if (!hex4(&cp)) return false;
-          if (cp >= 0xD800 && cp < 0xDC00 && p + 1 < end && p[0] == '\\' && p[1] == 'u') {     // surrogate pair
+          if (cp >= 0xD800 && cp < 0xDC00) {     // a high surrogate: \uDC00..\uDFFF must follow (nlohmann: parse error otherwise)
+            if (!(p + 1 < end && p[0] == '\\' && p[1] == 'u')) return fail("a high surrogate without its low surrogate");
             p += 2;
             unsigned lo;
             if (!hex4(&lo)) return false;
+            if (lo < 0xDC00 || lo > 0xDFFF) return fail("a high surrogate without its low surrogate");
             cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+          } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+            return fail("a low surrogate without its high surrogate");
           }
           if (out) utf8(out, cp);
         } else if (out) {
@@ -238,9 +243,10 @@ struct Scanner {
         return expect(']');
       }
     }
-    if (!strncmp(p, "true", 4)) { p += 4; return true; }
-    if (!strncmp(p, "false", 5)) { p += 5; return true; }
-    if (!strncmp(p, "null", 4)) { p += 4; return true; }
+    // (bounded by `end`: the buffer need not be NUL-terminated)
+    if (end - p >= 4 && !memcmp(p, "true", 4)) { p += 4; return true; }
+    if (end - p >= 5 && !memcmp(p, "false", 5)) { p += 5; return true; }
+    if (end - p >= 4 && !memcmp(p, "null", 4)) { p += 4; return true; }
     return number(nullptr);
   }
   template <class F>
@@ -255,40 +261,26 @@ struct Scanner {
   }
 };
 
-inline bool parse_graph(const char *text, size_t len, OneGraph &g) {
-  Scanner s{text, text + len, {}};
-  bool have_nodes = false, have_centers = false, have_poses = false;
-  if (!s.expect('{')) { g.error = s.err; return false; }
-  if (s.peek('}')) { g.error = "missing key \"nodes\""; return false; }
-  while (true) {
-    std::string key;
-    if (!s.string(&key) || !s.expect(':')) { g.error = s.err; return false; }
-    bool ok;
-    if (key == "nodes" && !have_nodes) {        // vector<int> (fromJSON :157)
-      have_nodes = true;
-      g.label.clear();
-      ok = s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; g.label.push_back((uint32_t)v.as_int()); return true; });
-    } else if (key == "centers" && !have_centers) {   // vector<Vector3f> (:160, jsonToVector3f :147-153)
-      have_centers = true;
-      g.xyz.clear();
-      ok = s.array([&] {
-        int k = 0;
-        const bool in = s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; if (k < 3) g.xyz.push_back(v.as_float()); k++; return true; });
-        if (in && k < 3) return s.fail("a center needs three coordinates");
-        return in;
-      });
-    } else if (key == "poses" && !have_poses) {  // vector<float> (:161)
-      have_poses = true;
-      g.n_pose = 0;
-      ok = s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; if (g.n_pose < 12) g.pose[g.n_pose] = v.as_float(); g.n_pose++; return true; });
-    } else {                                    // another key, or a second occurrence of one of the three
-      ok = s.skip_value();
-    }
-    if (!ok) { g.error = s.err; return false; }
-    if (s.peek(',')) { s.p++; continue; }
-    if (!s.expect('}')) { g.error = s.err; return false; }
-    break;
-  }
+// the three typed values (fromJSON :157-164); each returns false on a syntax or type error (s.err says which)
+inline bool parse_nodes(Scanner &s, OneGraph &g) {      // vector<int> (:157)
+  g.label.clear();
+  return s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; g.label.push_back((uint32_t)v.as_int()); return true; });
+}
+inline bool parse_centers(Scanner &s, OneGraph &g) {    // vector<Vector3f> (:160, jsonToVector3f :147-153)
+  g.xyz.clear();
+  return s.array([&] {
+    int k = 0;
+    const bool in = s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; if (k < 3) g.xyz.push_back(v.as_float()); k++; return true; });
+    if (in && k < 3) return s.fail("a center needs three coordinates");
+    return in;
+  });
+}
+inline bool parse_poses(Scanner &s, OneGraph &g) {      // vector<float> (:161)
+  g.n_pose = 0;
+  return s.array([&] { Scanner::Num v; if (!s.number(&v)) return false; if (g.n_pose < 12) g.pose[g.n_pose] = v.as_float(); g.n_pose++; return true; });
+}
+
+inline bool finish_graph(OneGraph &g, bool have_nodes, bool have_centers, bool have_poses) {
   if (!have_nodes) { g.error = "missing key \"nodes\""; return false; }     // json.at()/operator[] would throw
   if (!have_centers) { g.error = "missing key \"centers\""; return false; }
   if (!have_poses) { g.error = "missing key \"poses\""; return false; }
@@ -296,6 +288,74 @@ inline bool parse_graph(const char *text, size_t len, OneGraph &g) {
   if (g.label.size() != g.xyz.size() / 3) { g.error = "nodes and centers differ in length"; return false; }
   for (int k = g.n_pose; k < 12; k++) g.pose[k] = 0.f;
   return true;
+}
+
+// The exact form for documents that repeat one of the three keys (or whose first occurrence cannot be read): walk the
+// top-level object once with every value skipped (any JSON value is legal where the key's other occurrence will be
+// used), remember where the deciding occurrence of each key starts, then read those three.
+inline bool parse_graph_two_pass(const char *text, size_t len, OneGraph &g, bool last_wins) {
+  Scanner s{text, text + len, {}};
+  const char *at[3] = {nullptr, nullptr, nullptr};
+  if (!s.expect('{')) { g.error = s.err; return false; }
+  if (!s.peek('}')) {
+    while (true) {
+      std::string key;
+      if (!s.string(&key) || !s.expect(':')) { g.error = s.err; return false; }
+      s.ws();
+      const int k = key == "nodes" ? 0 : key == "centers" ? 1 : key == "poses" ? 2 : -1;
+      if (k >= 0 && (last_wins || !at[k])) at[k] = s.p;
+      if (!s.skip_value()) { g.error = s.err; return false; }
+      if (s.peek(',')) { s.p++; continue; }
+      if (!s.expect('}')) { g.error = s.err; return false; }
+      break;
+    }
+  } else {
+    s.p++;
+  }
+  bool (*const read[3])(Scanner &, OneGraph &) = {parse_nodes, parse_centers, parse_poses};
+  for (int k = 0; k < 3; k++) {
+    if (!at[k]) continue;
+    Scanner v{at[k], text + len, {}};
+    if (!read[k](v, g)) { g.error = v.err; return false; }
+  }
+  return finish_graph(g, at[0] != nullptr, at[1] != nullptr, at[2] != nullptr);
+}
+
+// last_wins: which occurrence of a repeated key counts.  nlohmann::json 3.1.1 (the header this image carries, the one the
+// differential test runs) emplaces — the FIRST stays; from 3.2 on (the SAX DOM parser; ROS noetic / Ubuntu 20.04 ship 3.7.3,
+// the reference's CMake pins no version) object[key] is assigned — the LAST stays.  The producer (get_json.cpp:332-341) never
+// writes a key twice.  sgtd_graphs_load takes the policy from SGTD_JSON_DUPLICATE_KEYS = first | last (default last).
+inline bool parse_graph(const char *text, size_t len, OneGraph &g, bool last_wins = true) {
+  Scanner s{text, text + len, {}};
+  bool have_nodes = false, have_centers = false, have_poses = false, repeated = false;
+  bool ok = s.expect('{');
+  if (ok && s.peek('}')) { g.error = "missing key \"nodes\""; return false; }
+  while (ok) {
+    std::string key;
+    if (!s.string(&key) || !s.expect(':')) { ok = false; break; }
+    if (key == "nodes" && !have_nodes) { have_nodes = true; ok = parse_nodes(s, g); }
+    else if (key == "centers" && !have_centers) { have_centers = true; ok = parse_centers(s, g); }
+    else if (key == "poses" && !have_poses) { have_poses = true; ok = parse_poses(s, g); }
+    else {                                      // another key, or a second occurrence of one of the three
+      repeated = repeated || key == "nodes" || key == "centers" || key == "poses";
+      ok = s.skip_value();
+    }
+    if (!ok) break;
+    if (s.peek(',')) { s.p++; continue; }
+    ok = s.expect('}');
+    break;
+  }
+  // One pass is exact when every key occurred once and could be read.  Otherwise, if the last occurrence counts, the
+  // two-pass form decides (a first occurrence of another type, or a repeated key: rare, and errors are not on the fast path).
+  if (last_wins && (repeated || !ok)) {
+    OneGraph h;
+    const bool ok2 = parse_graph_two_pass(text, len, h, true);
+    g.xyz = std::move(h.xyz); g.label = std::move(h.label); g.n_pose = h.n_pose; g.error = h.error;
+    memcpy(g.pose, h.pose, sizeof(g.pose));
+    return ok2;
+  }
+  if (!ok) { g.error = s.err; return false; }
+  return finish_graph(g, have_nodes, have_centers, have_poses);
 }
 
 inline bool read_file(const std::string &path, std::string &out) {
@@ -315,12 +375,14 @@ inline bool read_file(const std::string &path, std::string &out) {
 inline bool load(const char *const *paths, int n_files, int n_threads, sgtd_graph_batch &b) {
   std::vector<OneGraph> graphs((size_t)n_files);
   std::atomic<int> next{0};
+  const char *dup = getenv("SGTD_JSON_DUPLICATE_KEYS");
+  const bool last_wins = !(dup && !strcmp(dup, "first"));
   auto work = [&] {
     std::string text;
     for (int i = next++; i < n_files; i = next++) {
       OneGraph g;   // parsed thread-locally: neighbouring slots of `graphs` share cache lines
       if (!read_file(paths[i], text)) g.error = std::string("Error opening file: ") + paths[i];   // Semantic_Graph.hpp:172-174
-      else if (!parse_graph(text.data(), text.size(), g)) g.error = std::string(paths[i]) + ": " + g.error;
+      else if (!parse_graph(text.data(), text.size(), g, last_wins)) g.error = std::string(paths[i]) + ": " + g.error;
       graphs[i] = std::move(g);
     }
   };

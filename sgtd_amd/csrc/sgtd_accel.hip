@@ -20,6 +20,7 @@
 #include "verify_kernels.hip.h"
 #include "exchange_kernels.hip.h"
 #include "graph_ingest.hip.h"
+#include "table_file.h"
 
 namespace {
 
@@ -1439,13 +1440,6 @@ int check_cfg(const sgtd_config *c) {
 // C ABI
 // ===========================================================================
 namespace {
-const char kTableMagic[8] = {'S', 'G', 'T', 'D', 'T', 'B', '0', '1'};
-struct TableHeader {
-  double side_resolution, min_len, max_len;
-  int32_t near_num, have_frames;
-  uint32_t current_frame_id, frame_lo, frame_hi, reserved;
-  int64_t n_entries, n_add_calls;
-};
 // one SoA field <-> file, staged through a bounded host buffer
 template <class T>
 int stream_field(sgtd_engine *e, FILE *f, T *dev, size_t n_items, bool to_file, std::vector<char> &stage) {
@@ -2279,26 +2273,11 @@ int sgtd_load_table(sgtd_handle e, const char *path) {
   CHK(settle_pending(e));
   FILE *f = fopen(path, "rb");
   if (!f) { e->err = std::string("Error opening file: ") + path; return SGTD_ERR_IO; }
-  char magic[8];
   TableHeader h{};
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kTableMagic, 8) || fread(&h, sizeof(h), 1, f) != 1 || h.n_entries < 0) {
-    fclose(f);
-    e->err = std::string(path) + ": not a saved table";
-    return SGTD_ERR_IO;
+  {
+    const int hs = read_table_header(f, path, e->cfg, h, e->err);
+    if (hs != SGTD_OK) { fclose(f); return hs; }
   }
-  if (h.side_resolution != e->cfg.std_side_resolution) {
-    fclose(f);
-    e->err = "saved table was built with another std_side_resolution";
-    return SGTD_ERR_INVALID;
-  }
-  if (h.near_num != e->cfg.descriptor_near_num || h.min_len != e->cfg.descriptor_min_len || h.max_len != e->cfg.descriptor_max_len) {
-    fclose(f);
-    e->err = "saved table was built with another descriptor_near_num / min_len / max_len";
-    return SGTD_ERR_INVALID;
-  }
-  if (h.have_frames && (h.frame_hi >= (u32)e->cfg.max_frame_n || h.frame_lo > h.frame_hi)) { fclose(f); return SGTD_ERR_FRAME_LIMIT; }
-  if (h.n_entries >= (1ll << 32) - 2) { fclose(f); return SGTD_ERR_UNSUPPORTED; }
-  if ((h.n_entries > 0) != (h.have_frames != 0)) { fclose(f); e->err = std::string(path) + ": inconsistent table header"; return SGTD_ERR_IO; }
   int st = ensure_store(e, e->tab, (size_t)std::max<int64_t>(h.n_entries, 1), false);
   if (st == SGTD_OK) st = stream_table(e, f, (size_t)h.n_entries, false);
   fclose(f);
@@ -2329,51 +2308,6 @@ int sgtd_load_table(sgtd_handle e, const char *path) {
   e->batch_valid = false;
   return SGTD_OK;
 }
-
-int sgtd_graphs_load(const char *const *paths, int n_files, int n_threads, sgtd_graph_batch **out) {
-  if (!out || n_files < 0 || (n_files > 0 && !paths)) return SGTD_ERR_INVALID;
-  sgtd_graph_batch *b = new sgtd_graph_batch();
-  *out = b;
-  try {
-    return ingest::load(paths, n_files, n_threads, *b) ? SGTD_OK : SGTD_ERR_IO;
-  } catch (const std::exception &ex) {   // nothing throws across the ABI
-    b->error = std::string("graph ingest: ") + ex.what();
-    return SGTD_ERR_IO;
-  }
-}
-
-int sgtd_graphs_save_cache(const sgtd_graph_batch *b, const char *path) {
-  if (!b || !path) return SGTD_ERR_INVALID;
-  return ingest::save_cache(*b, path) ? SGTD_OK : SGTD_ERR_IO;
-}
-
-int sgtd_graphs_load_cache(const char *path, sgtd_graph_batch **out) {
-  if (!out || !path) return SGTD_ERR_INVALID;
-  sgtd_graph_batch *b = new sgtd_graph_batch();
-  *out = b;
-  try {
-    return ingest::load_cache(path, *b) ? SGTD_OK : SGTD_ERR_IO;
-  } catch (const std::exception &ex) {
-    b->error = std::string(path) + ": " + ex.what();
-    return SGTD_ERR_IO;
-  }
-}
-
-int sgtd_graphs_view(const sgtd_graph_batch *b, int *n_frames, int64_t *n_keypoints, const float **xyz,
-                     const uint32_t **label, const int64_t **kp_off, const float **poses) {
-  if (!b || b->kp_off.empty()) return SGTD_ERR_INVALID;
-  if (n_frames) *n_frames = (int)b->kp_off.size() - 1;
-  if (n_keypoints) *n_keypoints = (int64_t)b->label.size();
-  if (xyz) *xyz = b->xyz.data();
-  if (label) *label = b->label.data();
-  if (kp_off) *kp_off = b->kp_off.data();
-  if (poses) *poses = b->poses.data();
-  return SGTD_OK;
-}
-
-const char *sgtd_graphs_error(const sgtd_graph_batch *b) { return b ? b->error.c_str() : ""; }
-
-void sgtd_graphs_free(sgtd_graph_batch *b) { delete b; }
 
 int sgtd_host_alloc(size_t bytes, void **out) {
   if (!out) return SGTD_ERR_INVALID;
@@ -2462,4 +2396,5 @@ int sgtd_get_stats(sgtd_handle e, sgtd_stats *out) {
 
 }  // extern "C"
 
+#include "graph_ingest_abi.h"
 #include "multi_impl.hip.h"

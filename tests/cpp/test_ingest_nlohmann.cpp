@@ -131,6 +131,8 @@ bool same_bits(const T *a, const T *b, size_t n) { return n == 0 || memcmp(a, b,
 }  // namespace
 
 int main(int argc, char **argv) {
+  // this image's json.hpp is 3.1.1: a repeated key keeps its FIRST value there (the library's default mirrors 3.2+: the last)
+  setenv("SGTD_JSON_DUPLICATE_KEYS", "first", 1);
   const int n_docs = argc > 1 ? atoi(argv[1]) : 1500;
   std::string dir = argc > 2 ? argv[2] : "/tmp/sgtd_ingest_fuzz";
   mkdir(dir.c_str(), 0755);
