@@ -193,6 +193,16 @@ int sgtd_add_frames(sgtd_handle h, const float *xyz, const uint32_t *label,
  * .ms_finalize). */
 int sgtd_finalize(sgtd_handle h);
 
+/* Two (or more) batches in flight over ONE map: `view` — a handle of the same configuration on the same device,
+ * without a table of its own — borrows the finalized table of `owner` (cold entries, probe layout, entry ids) and keeps
+ * its own work buffers, results and stream.  Batches enqueued alternately on the two handles' streams overlap on the
+ * device: the descriptor build, home-cell sort and plan of one run beside the passes over the other's match records.
+ * The owner must outlive its views (sgtd_destroy of an owner with views is SGTD_ERR_STATE); after anything that changes
+ * the owner's table (sgtd_add*, sgtd_load_table, a finalize that merges a tail) a view's next query returns
+ * SGTD_ERR_STATE until it is attached again.  A view cannot add, load or rebuild (SGTD_ERR_STATE).  Neither handle
+ * is thread safe; the table itself is only read by queries, so one host thread per handle is fine. */
+int sgtd_attach_table(sgtd_handle view, sgtd_handle owner);
+
 /* ---- candidate_selector (STDesc.cpp:318-460) ---------------------------- */
 /* Fused query: for every query frame BuildSingleScanSTD (frame id =
  * current_frame_id_, as semantic_graph_localization.cpp:592) followed by

@@ -48,6 +48,26 @@ class OrcCounters(C.Structure):
     ]
 
 
+class OrcAudit(C.Structure):
+    """orc_audit of sgtd_oracle.h (parity-risk audit, tools/parity_audit.py)"""
+    _fields_ = [("gate_tests", C.c_int64), ("gate_flips", C.c_int64 * 3), ("gate_flip_visits", C.c_int64 * 3),
+                ("visits", C.c_int64), ("match_flips", C.c_int64 * 3), ("thr_ulp_flips", C.c_int64 * 2), ("near_calls", C.c_int64),
+                ("min_margin", C.c_double), ("min_margin_ulps", C.c_double), ("min_gate_margin", C.c_double),
+                ("knn_points", C.c_int64), ("knn_tied_points", C.c_int64), ("knn_fma_order_diffs", C.c_int64), ("triplets", C.c_int64),
+                ("side_value_diffs", C.c_int64 * 3), ("build_flips", C.c_int64 * 3), ("min_len_margin", C.c_double), ("min_cell_margin", C.c_double)]
+
+    def __init__(self):
+        super().__init__()
+        self.min_margin = self.min_margin_ulps = self.min_gate_margin = self.min_len_margin = self.min_cell_margin = float("inf")
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
 def build_library(force=False):
     """compile oracle/libsgtd_oracle.so with the committed Makefile"""
     if force or not os.path.exists(_LIB_PATH) or (
@@ -189,6 +209,23 @@ class OracleManager:
 
     def add_last(self):
         lib().orc_add_last(self._h)
+
+    def audit_build(self, xyz, label, acc):
+        """BuildSingleScanSTD of one frame with every inferred piece of arithmetic in its alternatives (accumulates into
+        the OrcAudit `acc`); the frame becomes the last built one"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        label = np.ascontiguousarray(label, dtype=np.uint32)
+        L = lib()
+        L.orc_audit_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OrcAudit)]
+        L.orc_audit_build.restype = None
+        L.orc_audit_build(self._h, _p(xyz), _p(label), xyz.shape[0], C.byref(acc))
+
+    def audit_select(self, acc):
+        """candidate_selector's loop for the last built frame, audited (accumulates into `acc`)"""
+        L = lib()
+        L.orc_audit_select.argtypes = [C.c_void_p, C.POINTER(OrcAudit)]
+        L.orc_audit_select.restype = None
+        L.orc_audit_select(self._h, C.byref(acc))
 
     def add_frames(self, xyz, label):
         """xyz (F, N, 3), label (F, N): what F build + add_last pairs give (builds on all host threads)"""

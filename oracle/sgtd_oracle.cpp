@@ -772,4 +772,164 @@ double orc_verify(orc_manager *m, int cand, double *t_out, double *rot_out,
   return -1;  // :541
 }
 
+// ---------------------------------------------------------------------------
+// parity-risk audit (sgtd_oracle.h): the same loops with every inferred piece of arithmetic evaluated in its
+// plausible alternatives side by side
+// ---------------------------------------------------------------------------
+namespace audit {
+// sum of three squares, reference form and the three variants of sgtd_oracle.h
+inline double ss_ref(double a, double b, double c) { return (a * a + b * b) + c * c; }
+inline double ss_var(int k, double a, double b, double c) {
+  if (k == 0) return a * a + (b * b + c * c);
+  if (k == 1) return std::fma(c, c, std::fma(b, b, a * a));
+  return std::fma(a, a, std::fma(b, b, c * c));
+}
+inline double ulp_of(double x) { return std::nextafter(std::fabs(x), INFINITY) - std::fabs(x); }
+inline void lower(double &m, double v) { if (v < m) m = v; }
+}  // namespace audit
+
+void orc_audit_build(orc_manager *mg, const float *xyz, const uint32_t *label, int n, orc_audit *A) {
+  using namespace audit;
+  orc_build(mg, xyz, label, n);
+  const int K = mg->cfg.descriptor_near_num;
+  if (n < K) return;
+  const double scale = 1.0 / mg->cfg.std_side_resolution, max_len = mg->cfg.descriptor_max_len, min_len = mg->cfg.descriptor_min_len;
+  std::vector<P4> pc(n);
+  for (int i = 0; i < n; i++) pc[i] = P4{xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], label[i]};
+  std::vector<std::pair<float, int>> all(n), allf(n);
+  std::vector<int> nn(K);
+  const int kk = std::min(K + 1, n);
+  for (int i = 0; i < n; i++) {
+    const P4 sp = pc[i];
+    for (int j = 0; j < n; j++) {
+      const float dx = sp.x - pc[j].x, dy = sp.y - pc[j].y, dz = sp.z - pc[j].z;
+      float d = dx * dx;
+      d += dy * dy;
+      d += dz * dz;
+      all[j] = {d, j};
+      allf[j] = {std::fma(dz, dz, std::fma(dy, dy, dx * dx)), j};
+    }
+    std::partial_sort(all.begin(), all.begin() + kk, all.end());
+    std::partial_sort(allf.begin(), allf.begin() + kk, allf.end());
+    A->knn_points++;
+    bool tie = false, order = false;
+    for (int k = 0; k + 1 < kk; k++) tie = tie || all[k].first == all[k + 1].first;
+    for (int k = 0; k < K; k++) order = order || all[k].second != allf[k].second;
+    A->knn_tied_points += tie;
+    A->knn_fma_order_diffs += order;
+    for (int k = 0; k < K; k++) nn[k] = all[k].second;
+    for (int m = 1; m < K - 1; m++)
+      for (int q = m + 1; q < K; q++) {
+        const P4 p1 = sp, p2 = pc[nn[m]], p3 = pc[nn[q]];
+        // the three sides: f32 differences (exact as doubles), then the sum of squares in the reference form and its variants
+        const double d[3][3] = {{(double)(p1.x - p2.x), (double)(p1.y - p2.y), (double)(p1.z - p2.z)},
+                                {(double)(p1.x - p3.x), (double)(p1.y - p3.y), (double)(p1.z - p3.z)},
+                                {(double)(p3.x - p2.x), (double)(p3.y - p2.y), (double)(p3.z - p2.z)}};
+        double ref[3];
+        for (int s = 0; s < 3; s++) ref[s] = std::sqrt(ss_ref(d[s][0], d[s][1], d[s][2]));
+        A->triplets++;
+        // the integer decisions a triplet takes part in, as one signature
+        auto signature = [&](const double *v, bool margins) {
+          unsigned long long sig = 0;
+          for (int s = 0; s < 3; s++) {
+            sig = sig * 4 + (v[s] > max_len ? 1 : 0) * 2 + (v[s] < min_len ? 1 : 0);
+            if (margins) { lower(A->min_len_margin, std::fabs(v[s] - max_len)); lower(A->min_len_margin, std::fabs(v[s] - min_len)); }
+          }
+          double a = v[0], b = v[1], c = v[2];
+          sig = sig * 2 + (a > b);
+          if (a > b) std::swap(a, b);
+          sig = sig * 2 + (b > c);
+          if (b > c) std::swap(b, c);
+          sig = sig * 2 + (a > b);
+          if (a > b) std::swap(a, b);
+          const double srt[3] = {a, b, c};
+          unsigned long long h = 1469598103934665603ull;
+          for (int s = 0; s < 3; s++) {
+            const float kf = (float)(srt[s] * 1000);
+            const double sc = scale * srt[s];
+            const long long parts[3] = {(long long)kf, (long long)(int)(sc + 0.5), (long long)(int)sc};
+            for (long long pv : parts) h = (h ^ (unsigned long long)pv) * 1099511628211ull;
+            if (margins) {
+              const double fr = sc - std::floor(sc);
+              lower(A->min_cell_margin, std::min(fr, 1.0 - fr));
+              lower(A->min_cell_margin, std::fabs(fr - 0.5));
+            }
+          }
+          return sig * 1000003ull + h;
+        };
+        const unsigned long long sig_ref = signature(ref, true);
+        for (int k = 0; k < 3; k++) {
+          double var[3];
+          for (int s = 0; s < 3; s++) {
+            var[s] = std::sqrt(ss_var(k, d[s][0], d[s][1], d[s][2]));
+            A->side_value_diffs[k] += var[s] != ref[s];
+          }
+          A->build_flips[k] += signature(var, false) != sig_ref;
+        }
+      }
+  }
+}
+
+void orc_audit_select(orc_manager *mg, orc_audit *A) {
+  using namespace audit;
+  const std::vector<Desc> &q = mg->last;
+  const double rough = mg->cfg.rough_dis_threshold;
+  auto &db = mg->data_base_;
+  omp_set_num_threads(mg->cfg.num_threads > 0 ? mg->cfg.num_threads : 1);
+  const size_t nq = q.size();
+  std::vector<orc_audit> part((size_t)omp_get_max_threads());
+  for (auto &p : part) { std::memset(&p, 0, sizeof p); p.min_margin = p.min_margin_ulps = p.min_gate_margin = INFINITY; }
+#pragma omp parallel for schedule(dynamic, 16)
+  for (size_t i = 0; i < nq; i++) {
+    orc_audit &T = part[(size_t)omp_get_thread_num()];
+    const Desc &src = q[i];
+    const double s0 = src.side_length_[0], s1 = src.side_length_[1], s2 = src.side_length_[2];
+    const double thr = std::sqrt(ss_ref(s0, s1, s2)) * rough;
+    double thr_v[3];
+    for (int k = 0; k < 3; k++) thr_v[k] = std::sqrt(ss_var(k, s0, s1, s2)) * rough;
+    const double thr_up = std::nextafter(thr, INFINITY), thr_dn = std::nextafter(thr, -INFINITY);
+    const double u = ulp_of(thr);
+    CellKey pos;
+    pos.a = label_code((int)src.vertex_attached_[0], (int)src.vertex_attached_[1], (int)src.vertex_attached_[2]);
+    for (int x = -1; x <= 1; x++)
+      for (int y = -1; y <= 1; y++)
+        for (int z = -1; z <= 1; z++) {
+          pos.x = (int)(s0 + x); pos.y = (int)(s1 + y); pos.z = (int)(s2 + z);
+          const double c0 = s0 - ((double)pos.x + 0.5), c1 = s1 - ((double)pos.y + 0.5), c2 = s2 - ((double)pos.z + 0.5);
+          const double gd = std::sqrt(ss_ref(c0, c1, c2));
+          const bool gate = gd < 1.5;
+          T.gate_tests++;
+          lower(T.min_gate_margin, std::fabs(gd - 1.5));
+          auto it = db.find(pos);
+          const int64_t len = it == db.end() ? 0 : (int64_t)it->second.size();
+          for (int k = 0; k < 3; k++)
+            if ((std::sqrt(ss_var(k, c0, c1, c2)) < 1.5) != gate) { T.gate_flips[k]++; T.gate_flip_visits[k] += len; }
+          if (!gate || it == db.end()) continue;
+          for (const Desc &e : it->second) {
+            if (!((src.frame_id_ - e.frame_id_) > 0)) continue;
+            const double d0 = s0 - e.side_length_[0], d1 = s1 - e.side_length_[1], d2 = s2 - e.side_length_[2];
+            const double dis = std::sqrt(ss_ref(d0, d1, d2));
+            const bool hit = dis < thr;
+            T.visits++;
+            const double mar = std::fabs(dis - thr);
+            if (mar < T.min_margin) { T.min_margin = mar; T.min_margin_ulps = mar / u; }
+            if (mar <= 64 * u) {
+              T.near_calls++;
+              // (only a near call can flip: the variants move dis and the threshold by a few ulps at most)
+              for (int k = 0; k < 3; k++) T.match_flips[k] += (std::sqrt(ss_var(k, d0, d1, d2)) < thr_v[k]) != hit;
+              T.thr_ulp_flips[0] += (dis < thr_up) != hit;
+              T.thr_ulp_flips[1] += (dis < thr_dn) != hit;
+            }
+          }
+        }
+  }
+  for (const orc_audit &p : part) {
+    A->gate_tests += p.gate_tests; A->visits += p.visits; A->near_calls += p.near_calls;
+    for (int k = 0; k < 3; k++) { A->gate_flips[k] += p.gate_flips[k]; A->gate_flip_visits[k] += p.gate_flip_visits[k]; A->match_flips[k] += p.match_flips[k]; }
+    A->thr_ulp_flips[0] += p.thr_ulp_flips[0]; A->thr_ulp_flips[1] += p.thr_ulp_flips[1];
+    if (p.min_margin < A->min_margin) { A->min_margin = p.min_margin; A->min_margin_ulps = p.min_margin_ulps; }
+    lower(A->min_gate_margin, p.min_gate_margin);
+  }
+}
+
 }  // extern "C"

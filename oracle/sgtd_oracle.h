@@ -131,6 +131,42 @@ void orc_get_counters(const orc_manager *m, orc_counters *c);
 double orc_verify(orc_manager *m, int cand, double *t, double *rot,
                   int32_t *success_idx, int32_t *n_success);
 
+/* ---- parity-risk audit (tools/parity_audit.py): how many of the path's DECISIONS would come out differently under
+ * arithmetic the real binary might use where this restatement had to infer it — Eigen's
+ * Vector3d::norm() association, FMA contraction, +-1 ulp on dis_threshold, FLANN's order among exactly tied
+ * neighbours — and how close the closest call is.  Counters accumulate over calls (zero the struct first).
+ * Variants of a 3-term sum of squares: [0] right association  sqrt(v0^2 + (v1^2 + v2^2))
+ *                                       [1] left association with both adds contracted  fma(v2, v2, fma(v1, v1, v0*v0))
+ *                                       [2] right association contracted                fma(v0, v0, fma(v1, v1, v2*v2))
+ * (the reference form is the left association with every operation rounded: sqrt((v0^2 + v1^2) + v2^2)). */
+typedef struct orc_audit {
+  /* candidate_selector's loop (STDesc.cpp:351-400) */
+  int64_t gate_tests;            /* (query descriptor, cell) tests of :366-369                                   */
+  int64_t gate_flips[3];         /* ... whose outcome differs under variant k                                    */
+  int64_t gate_flip_visits[3];   /* table entries in the buckets of those cells                                  */
+  int64_t visits;                /* (query descriptor, table entry) distance tests (:374-378, other frame)       */
+  int64_t match_flips[3];        /* ... whose outcome differs with BOTH norms (dis and dis_threshold) of variant k */
+  int64_t thr_ulp_flips[2];      /* ... with the reference's dis against dis_threshold + 1 ulp / - 1 ulp          */
+  int64_t near_calls;            /* ... with |dis - dis_threshold| <= 64 ulp(dis_threshold)                       */
+  double min_margin;             /* min |dis - dis_threshold| over all visits                                    */
+  double min_margin_ulps;        /* ... in ulps of dis_threshold                                                 */
+  double min_gate_margin;        /* min | ||side - centre|| - 1.5 | over all gate tests                          */
+  /* BuildSingleScanSTD (STDesc.cpp:183-308) */
+  int64_t knn_points;            /* keypoints                                                                    */
+  int64_t knn_tied_points;       /* ... with an exact f32 tie among the squared distances of their K + 1 nearest  */
+  int64_t knn_fma_order_diffs;   /* ... whose ordered K-NN list differs when FLANN's accumulation is contracted   */
+  int64_t triplets;              /* enumerated (i, m, n)                                                         */
+  int64_t side_value_diffs[3];   /* sides (3 per triplet) whose f64 value differs under variant k                */
+  int64_t build_flips[3];        /* triplets where a length limit (:204-208), a sort comparison (:220-243), a millimetre
+                                    key (:246-250), an insert cell (:155-157) or a probe cell (:359-361) differs     */
+  double min_len_margin;         /* closest side to descriptor_min_len / descriptor_max_len                       */
+  double min_cell_margin;        /* closest scaled side to a cell boundary (k for the probe, k + 0.5 for the insert) */
+} orc_audit;
+/* audits BuildSingleScanSTD on one frame (and builds it: the frame becomes "last built") */
+void orc_audit_build(orc_manager *m, const float *xyz, const uint32_t *label, int n, orc_audit *acc);
+/* audits candidate_selector's loop for the last built frame against the table (results are not kept) */
+void orc_audit_select(orc_manager *m, orc_audit *acc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ SYMBOLS = [
     "sgtd_graphs_load", "sgtd_graphs_save_cache", "sgtd_graphs_load_cache", "sgtd_graphs_view",
     "sgtd_graphs_error", "sgtd_graphs_free", "sgtd_save_table", "sgtd_load_table",
     "sgtd_candidate_export_ints", "sgtd_set_candidate_export", "sgtd_export_wait", "sgtd_export_release", "sgtd_merge_candidates_dev",
-    "sgtd_gather_verified_dev", "sgtd_set_deferred_lists", "sgtd_finish_lists", "sgtd_verify_masked",
+    "sgtd_gather_verified_dev", "sgtd_set_deferred_lists", "sgtd_finish_lists", "sgtd_verify_masked", "sgtd_attach_table",
 ]
 
 
@@ -177,6 +177,7 @@ def lib():
     L.sgtd_set_deferred_lists.argtypes = [vp, C.c_int]
     L.sgtd_finish_lists.argtypes = [vp, vp]
     L.sgtd_verify_masked.argtypes = [vp, vp]
+    L.sgtd_attach_table.argtypes = [vp, vp]
     L.sgtd_save_table.argtypes = [vp, C.c_char_p]
     L.sgtd_load_table.argtypes = [vp, C.c_char_p]
     for name in SYMBOLS:

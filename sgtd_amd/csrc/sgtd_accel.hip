@@ -27,6 +27,7 @@ namespace {
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  bool borrowed = false;     // the memory belongs to another handle (sgtd_attach_table): never freed or regrown here
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -90,6 +91,12 @@ struct sgtd_engine {
   bool timing = false;
   hipEvent_t ev[EV_COUNT] = {};
 
+  // ---- a handle may borrow the finalized table of another handle on the same device (sgtd_attach_table): its own
+  // work buffers, results and stream, the owner's table — two batches in flight over one map
+  sgtd_engine *attached_to = nullptr;
+  unsigned long long table_version = 0;   // bumped by everything that changes the table or its probe layout
+  unsigned long long attached_version = 0;
+  int n_views = 0;                        // handles attached to this one's table
   // ---- table, insertion order (cold)
   u32 current_frame_id = 0;
   DescStore tab;
@@ -119,6 +126,8 @@ struct sgtd_engine {
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
   u32 coarse_at = 62, whole_at = 62;     // SGTD_COARSE_AT, SGTD_WHOLE_AT: see TableView
   u32 rec_rate_hook = 0;                 // SGTD_REC_RATE (test hook): ProbeBuffers::rec_rate, 1..256
+  u32 rec_rate_cap = 256;                // upper bound on rec_rate for the pending batch: quartered by every re-run whose RESERVATIONS
+                                         // (not its matches) outgrew the record buffer — long visit lists with few matches, skewed maps
   bool wide_pairs = false;               // SGTD_WIDE_PAIRS (test hook): 8-byte compact words whatever the ids' rank bits
   int tail_batches = 0;                  // query batches swept with the current tail (it is merged after a few: see settle_tail)
   DevBuf slice_of, sq_sum;
@@ -223,6 +232,7 @@ namespace {
 
 int ensure(sgtd_engine *e, DevBuf &b, size_t bytes, bool keep = false) {
   if (bytes <= b.bytes) return SGTD_OK;
+  if (b.borrowed) { e->err = "a table attached from another handle cannot grow here"; return SGTD_ERR_STATE; }
   // (a buffer that grows again gets a quarter more than asked for: the one-frame-per-call pattern would
   // otherwise free and allocate a dozen work buffers on every frame that is a little larger than the last)
   size_t want = keep ? std::max(bytes, b.bytes + b.bytes / 2) : (b.p ? bytes + bytes / 4 : bytes);
@@ -255,9 +265,10 @@ int ensure_store(sgtd_engine *e, DescStore &s, size_t cap, bool keep = false) {
 }
 
 void free_buf(DevBuf &b) {
-  if (b.p) (void)hipFree(b.p);
+  if (b.p && !b.borrowed) (void)hipFree(b.p);
   b.p = nullptr;
   b.bytes = 0;
+  b.borrowed = false;
 }
 void free_store(DescStore &s) {
   free_buf(s.side); free_buf(s.angle); free_buf(s.center); free_buf(s.vertex);
@@ -733,6 +744,8 @@ int build_idmap(sgtd_engine *e, u32 &bits) {
 // segment; force_merge asks for the single-segment form (table dump).
 int do_finalize(sgtd_engine *e, bool force_merge = false) {
   if (e->finalized && !(force_merge && e->n_seg > 1)) return SGTD_OK;
+  if (e->attached_to) { e->err = "the table belongs to another handle (sgtd_attach_table): only its owner rebuilds it"; return SGTD_ERR_STATE; }
+  e->table_version++;
   const long long E = e->n_entries;
   if (E >= (1ll << 32) - 2 - SGTD_SENTINELS) return SGTD_ERR_UNSUPPORTED;
   const auto t0 = std::chrono::steady_clock::now();
@@ -827,6 +840,7 @@ Views make_views(sgtd_engine *e) {
     B.rec_rate = 64;
     if (e->stats.last_P_swept > 0 && e->stats.last_M > 0)
       B.rec_rate = (u32)std::min(256.0, std::max(16.0, std::ceil(3.0 * 256.0 * (double)e->stats.last_M / ((double)e->stats.last_P_swept * per_pass))));
+    B.rec_rate = std::min(B.rec_rate, e->rec_rate_cap);
     if (e->diag) B.rec_rate = 256;
     if (e->rec_rate_hook) B.rec_rate = e->rec_rate_hook;
   }
@@ -1284,7 +1298,7 @@ int sync_batch(sgtd_engine *e) {
   if (e->batch_synced) return SGTD_OK;
   e->stats.overflowed = 0;
   unsigned long long swept = 0;
-  for (int attempt = 0; attempt < 8; attempt++) {
+  for (int attempt = 0; attempt < 12; attempt++) {
     int ovf[2] = {0, 0};
     unsigned long long cursor = 0, need = 0;
     swept = 0;
@@ -1315,7 +1329,7 @@ int sync_batch(sgtd_engine *e) {
     if (getenv("SGTD_DEBUG"))
       fprintf(stderr, "sgtd: batch re-run (attempt %d): flags %d %d, records %llu of %zu (+%llu wanted), pass pool %u of %zu units, home cells %u of %zu rows, pairs %u of %zu\n",
               attempt, ovf[0], ovf[1], cursor, e->rec_cap, need, pool_used, e->pool_units, n_groups, e->group_cap, total, e->pair_cap);
-    if (attempt == 7) return SGTD_ERR_CAPACITY;
+    if (attempt == 11) return SGTD_ERR_CAPACITY;
     // grow towards the u32 index limit; a batch that does not fit even there must be split
     const size_t lim = 0xFFFFFFF0ull;
     if (ovf[0] && (size_t)n_groups > e->group_cap) {
@@ -1326,12 +1340,20 @@ int sync_batch(sgtd_engine *e) {
       if (e->pool_units >= 0xFFFFFF00ull) return SGTD_ERR_CAPACITY;
       e->pool_units = std::min<size_t>(0xFFFFFF00ull, (size_t)pool_used + (size_t)pool_used / 4 + 65536);
     } else if (ovf[0]) {
-      if (e->rec_cap >= lim) return SGTD_ERR_CAPACITY;
+      // The cursor counts the room the lists RESERVED (rec_rate / 256 of every visit list), `need` the matches that
+      // found none.  Reservations far beyond the buffer with few matches left over: the rate is too generous for
+      // this table (a first batch on long buckets that match little: skewed label frequencies) — a list that
+      // outgrows its room moves, so the rate can drop safely; only when it is at its floor is the batch too large.
+      const bool reservations = (double)cursor > 1.5 * (double)e->rec_cap + 4.0 * (double)need;
+      if (reservations && e->rec_rate_cap > 2) {
+        e->rec_rate_cap = std::max<u32>(2, std::min<u32>(e->rec_rate_cap, 64) / 4);
+      } else if (e->rec_cap >= lim) {
+        return SGTD_ERR_CAPACITY;
+      }
       // what was stored fits rec_cap, `need` matches did not; slabs leave about an eighth unused,
       // every wave strands part of its last slab
       const size_t want = (size_t)((double)(e->rec_cap + need) * 1.4) + (size_t)e->n_cus * 32 * SGTD_PAIR * 512;
-      (void)cursor;
-      e->rec_cap = std::min<size_t>(lim, std::max<size_t>(e->rec_cap * 2, want));
+      e->rec_cap = std::min<size_t>(lim, std::max<size_t>(reservations ? e->rec_cap : e->rec_cap * 2, want));
     } else if (ovf[1]) {
       if (e->pair_cap >= lim) return SGTD_ERR_CAPACITY;
       e->pair_cap = std::min<size_t>(lim, std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536));
@@ -1415,6 +1437,13 @@ int settle_pending(sgtd_engine *e) {
 // (one full build, ~0.25 ms per million entries).
 #define SGTD_TAIL_BATCHES 4
 int settle_tail(sgtd_engine *e) {
+  if (e->attached_to) {
+    if (e->attached_to->table_version != e->attached_version || !e->attached_to->finalized) {
+      e->err = "the owner's table changed since sgtd_attach_table: attach again";
+      return SGTD_ERR_STATE;
+    }
+    return SGTD_OK;
+  }
   if (e->finalized && e->n_seg == 2) {
     if (e->tail_batches >= SGTD_TAIL_BATCHES) { e->tail_batches = 0; return do_finalize(e, /*force_merge=*/true); }
     e->tail_batches++;
@@ -1572,8 +1601,10 @@ sgtd_handle sgtd_device_handle(sgtd_handle e, int k) {
 int sgtd_destroy(sgtd_handle e) {
   if (e && e->grp) return multi::destroy(e);
   if (!e) return SGTD_OK;
+  if (e->n_views > 0) { e->err = "other handles are attached to this handle's table (sgtd_attach_table): destroy them first"; return SGTD_ERR_STATE; }
   (void)hipSetDevice(e->cfg.device_id);
   (void)hipStreamSynchronize(e->stream);
+  if (e->attached_to) { e->attached_to->n_views--; e->attached_to = nullptr; }
   free_store(e->tab); free_store(e->tmp); free_store(e->qd); free_store(e->fetch); free_buf(e->fetch_idx);
   DevBuf *bufs[] = {&e->seg[0].hot, &e->seg[0].perm, &e->seg[0].hash, &e->seg[0].bucket_start, &e->seg[0].bucket_key, &e->seg[0].dir,
                     &e->seg[1].hot, &e->seg[1].perm, &e->seg[1].hash, &e->seg[1].bucket_start, &e->seg[1].bucket_key, &e->seg[1].dir, &e->slice_of, &e->sq_sum,
@@ -1660,7 +1691,9 @@ int sgtd_add(sgtd_handle e, const sgtd_desc_soa *d, int64_t n) {
     hi = std::max(hi, d->frame[i]);
   }
   if (n > 0 && hi >= (u32)e->cfg.max_frame_n) return SGTD_ERR_FRAME_LIMIT;
+  if (e->attached_to) { e->err = "the table belongs to another handle (sgtd_attach_table): add to its owner"; return SGTD_ERR_STATE; }
   CHK(settle_pending(e));
+  e->table_version++;
   e->current_frame_id++;  // STDesc.cpp:151, before anything is inserted
   e->n_add_calls++;
   if (n == 0) return SGTD_OK;
@@ -1680,9 +1713,11 @@ int sgtd_add_frames(sgtd_handle e, const float *xyz, const uint32_t *label, cons
   if (!e || n_frames < 0 || !kp_off) return SGTD_ERR_INVALID;
   if (n_frames == 0) return SGTD_OK;
   HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (e->attached_to) { e->err = "the table belongs to another handle (sgtd_attach_table): add to its owner"; return SGTD_ERR_STATE; }
   if ((uint64_t)e->current_frame_id + (uint64_t)n_frames > (uint64_t)e->cfg.max_frame_n)
     return SGTD_ERR_FRAME_LIMIT;
   CHK(settle_pending(e));
+  e->table_version++;
   const int chunk = 512;
   for (int f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = std::min(chunk, n_frames - f0);
@@ -1719,6 +1754,60 @@ int sgtd_add_frames(sgtd_handle e, const float *xyz, const uint32_t *label, cons
   return SGTD_OK;
 }
 
+int sgtd_attach_table(sgtd_handle v, sgtd_handle o) {
+  if (!v || !o || v == o) return SGTD_ERR_INVALID;
+  if (v->grp || o->grp) { v->err = "not available on a multi-device handle"; return SGTD_ERR_UNSUPPORTED; }
+  sgtd_engine *e = v;
+  if (o->attached_to) { e->err = "attach to the handle that owns the table"; return SGTD_ERR_INVALID; }
+  if (v->cfg.device_id != o->cfg.device_id || v->cfg.descriptor_near_num != o->cfg.descriptor_near_num ||
+      v->cfg.descriptor_min_len != o->cfg.descriptor_min_len || v->cfg.descriptor_max_len != o->cfg.descriptor_max_len ||
+      v->cfg.std_side_resolution != o->cfg.std_side_resolution || v->cfg.rough_dis_threshold != o->cfg.rough_dis_threshold ||
+      v->cfg.max_frame_n != o->cfg.max_frame_n) {
+    e->err = "sgtd_attach_table: the two handles are configured differently";
+    return SGTD_ERR_INVALID;
+  }
+  if (!v->attached_to && (v->n_entries != 0 || v->n_views != 0)) { e->err = "sgtd_attach_table: this handle holds a table of its own"; return SGTD_ERR_STATE; }
+  HIPCHK(hipSetDevice(v->cfg.device_id));
+  CHK(settle_pending(v));
+  HIPCHK(hipStreamSynchronize(v->stream));
+  {
+    const int st = do_finalize(o);      // the probe layout the view borrows
+    if (st != SGTD_OK) { e->err = "sgtd_attach_table: the owner's table could not be finalized"; return st; }
+    if (hipStreamSynchronize(o->stream) != hipSuccess) return SGTD_ERR_HIP;
+  }
+  auto borrow = [](DevBuf &dst, const DevBuf &src) {
+    if (dst.p && !dst.borrowed) (void)hipFree(dst.p);
+    dst = src;
+    dst.borrowed = true;
+  };
+  borrow(v->tab.side, o->tab.side); borrow(v->tab.angle, o->tab.angle); borrow(v->tab.center, o->tab.center);
+  borrow(v->tab.vertex, o->tab.vertex); borrow(v->tab.label, o->tab.label); borrow(v->tab.frame, o->tab.frame);
+  borrow(v->tab.node_id, o->tab.node_id);
+  v->tab.cap = o->tab.cap;
+  for (int k = 0; k < 2; k++) {
+    sgtd_engine::Segment &d = v->seg[k];
+    const sgtd_engine::Segment &s = o->seg[k];
+    borrow(d.hot, s.hot); borrow(d.perm, s.perm); borrow(d.hash, s.hash); borrow(d.bucket_start, s.bucket_start);
+    borrow(d.bucket_key, s.bucket_key); borrow(d.dir, s.dir);
+    d.hash_mask = s.hash_mask; d.n_buckets = s.n_buckets; d.g0 = s.g0; d.g1 = s.g1; d.sum_len_sq = s.sum_len_sq;
+    d.frame_hi = s.frame_hi; d.built = s.built;
+  }
+  borrow(v->frame_first, o->frame_first); borrow(v->by_frame, o->by_frame); borrow(v->id_of_g, o->id_of_g);
+  v->n_seg = o->n_seg; v->id_bits = o->id_bits; v->id_by_frame = o->id_by_frame;
+  v->n_entries = o->n_entries; v->n_add_calls = o->n_add_calls; v->have_frames = o->have_frames;
+  v->frame_lo = o->frame_lo; v->frame_hi = o->frame_hi; v->current_frame_id = o->current_frame_id;
+  v->ms_finalize = o->ms_finalize;
+  v->finalized = true;
+  v->batch_valid = false;
+  if (v->attached_to != o) {
+    if (v->attached_to) v->attached_to->n_views--;
+    o->n_views++;
+  }
+  v->attached_to = o;
+  v->attached_version = o->table_version;
+  return SGTD_OK;
+}
+
 int sgtd_finalize(sgtd_handle e) {
   if (e && e->grp) return multi::finalize(e);
   if (!e) return SGTD_ERR_INVALID;
@@ -1739,6 +1828,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
   e->last_kind = 1; e->last_xyz = dx; e->last_label = dl; e->last_max_n = max_n;
   e->last_qframe = e->current_frame_id;
   e->diag = false;   // a new batch runs the product sweep; sgtd_result_rough re-runs it in the diagnostic form
+  e->rec_rate_cap = 256;
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride * n_queries));
   CHK(ensure(e, e->q_count, (size_t)n_queries * sizeof(u32)));
   if (!e->rec_cap_fixed && e->stats.last_queries == 0) {
@@ -1769,6 +1859,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   e->q_stride = std::max<long long>(nq, 1);
   e->last_kind = 2;
   e->diag = false;
+  e->rec_rate_cap = 256;
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
@@ -1788,7 +1879,7 @@ int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
   if (e && e->grp) return multi::max_batch(e, n_keypoints, max_queries);
   if (!e || !max_queries || n_keypoints < 0) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
-  CHK(do_finalize(e));
+  CHK(settle_tail(e));
   const double per_query = std::max(1.0, est_matches_per_query(e, n_keypoints)) * 2.0;   // margin: slab slack, variation
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
@@ -2270,7 +2361,9 @@ int sgtd_load_table(sgtd_handle e, const char *path) {
   if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e || !path) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (e->attached_to) { e->err = "the table belongs to another handle (sgtd_attach_table): load into its owner"; return SGTD_ERR_STATE; }
   CHK(settle_pending(e));
+  e->table_version++;
   FILE *f = fopen(path, "rb");
   if (!f) { e->err = std::string("Error opening file: ") + path; return SGTD_ERR_IO; }
   TableHeader h{};
@@ -2348,6 +2441,7 @@ int sgtd_table_dump(sgtd_handle e, int64_t *keys, int64_t *bucket_off, int64_t *
   if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }
   if (!e) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
+  if (e->attached_to && e->n_seg > 1) { e->err = "dump the table through its owner"; return SGTD_ERR_STATE; }
   CHK(do_finalize(e, /*force_merge=*/true));   // one segment: the dump shows whole buckets
   const sgtd_engine::Segment &S = e->seg[0];
   const int64_t U = S.n_buckets, E = e->n_entries;

@@ -117,8 +117,11 @@ class STDescManager:
 
     def close(self):
         if self._h is not None:
-            self._L.sgtd_destroy(self._h)
+            st = self._L.sgtd_destroy(self._h)
+            if st != 0:       # (an owner whose table other managers still borrow: close them first)
+                raise SgtdError(st, self._L.sgtd_last_error(self._h).decode())
             self._h = None
+            self._owner = None
 
     def __del__(self):
         try:
@@ -186,6 +189,12 @@ class STDescManager:
 
     def finalize(self):
         self._check(self._L.sgtd_finalize(self._h))
+
+    def attach_table(self, owner):
+        """borrow the finalized table of `owner` (another manager on the same device): this manager then queries the
+        same map with its own work buffers and stream — two batches in flight (include/sgtd_accel.h)"""
+        self._check(self._L.sgtd_attach_table(self._h, owner._h))
+        self._owner = owner         # (the owner must outlive its views)
 
     def _frames_args(self, xyz, label, kp_off):
         is_torch = hasattr(xyz, "data_ptr")

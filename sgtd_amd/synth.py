@@ -285,7 +285,7 @@ def _observe_ragged(landmarks, labels, tree, pose, n_kp, sigma, rng, tie_k=10):
 
 
 def make_skewed_map(n_frames, stream=1, kp_lo=50, kp_hi=400, n_classes=13, zipf_s=1.2, spacing=2.0, swath=100.0,
-                    radius=50.0, sigma=0.02, z_sigma=1.5, cluster_frac=0.7, cluster_mean=12.0, cluster_sigma=6.0):
+                    radius=50.0, sigma=0.02, z_sigma=1.5, cluster_frac=0.5, cluster_mean=6.0, cluster_sigma=15.0):
     """-> (RaggedFrames map, SkewWorld).  Labels Zipf-distributed over `n_classes` classes (label = class index, the most
     frequent first), kp_lo..kp_hi keypoints per frame (uniform), landmarks clustered: `cluster_frac` of them in
     Gaussian clusters of `cluster_mean` members on average (sigma `cluster_sigma` m; a cluster's members share its class

@@ -301,3 +301,48 @@ def test_cfg5_two_50k_frame_sessions_wild_labels_at_cfg4s_size(mods):
         mq, me = multi.result_pairs(q, mres)
         np.testing.assert_array_equal(mq, pairs[k][0])
     multi.close()
+
+
+def test_skewed_reference_shaped_workload_sampled_parity(mods):
+    """Zipf-distributed labels over the 13 wild classes (get_json_wild.cpp:10-12), 50-400 keypoints per
+    frame (ragged batches: CSR offsets, frames beyond the LDS-resident dedup take the global one), clustered landmarks;
+    2 500-frame map.  Long, unevenly filled buckets: the first batch's work buffers are sized from bucket statistics that
+    run far off here and are regrown by re-runs; the oracle is compared on a sample (candidates, votes, ordered lists),
+    properties on the rest, and the P / M counters on the sample as a batch of its own."""
+    oracle, manager, synth = mods
+    F, Q = 2500, 48
+    smap, world = synth.make_skewed_map(F, stream=31)
+    qs = synth.make_skewed_queries(world, Q, stream=3100)
+    n_kp = np.diff(smap.kp_off)
+    assert n_kp.min() >= 50 and n_kp.max() <= 400 and n_kp.max() > 380 and np.bincount(smap.label).max() > 0.3 * len(smap.label)
+    g = manager.STDescManager()
+    g.add_frames(smap.xyz, smap.label, kp_off=smap.kp_off)
+    res = g.query_frames(qs.xyz, qs.label, kp_off=qs.kp_off)
+    st = g.stats()
+    assert st["bucket_len_sq_over_E"] > 300          # (the uniform generator: about 50 at this map size)
+    assert np.all(res.n_cand > 0)
+    # (frames of 50 .. 400 keypoints: the most votes often go to a neighbouring frame that sees more of the place — the
+    # candidate list must contain the place, candidate_verify picks from it)
+    for q in range(Q):
+        nc = _list_properties(g, res, q)
+        near = np.linalg.norm(smap.pose[res.cand_frame[q, :nc], :2] - qs.pose[q, :2], axis=1) < 5.0
+        assert near.any(), "no candidate of query %d lies within 5 m of its place" % q
+    from sgtd_amd.synth import effective_cpus
+    o = oracle.OracleManager(num_threads=max(1, effective_cpus() - 4), max_frame_n=20000)
+    for f in range(F):
+        x, l = smap.frame(f)
+        o.build(x, l, export=False)
+        o.add_last()
+    assert o.counters()["E"] == st["n_entries"]
+    checked = (0, 17, 30, 47)
+    P = M = 0
+    for q in checked:
+        x, l = qs.frame(q)
+        _same_as_oracle(g, o, res, q, x, l)
+        c = o.counters()
+        P += c["P"]; M += c["M"]
+    sub = qs.take(list(checked))
+    rs = g.query_frames(sub.xyz, sub.label, kp_off=sub.kp_off)
+    st = g.stats()
+    assert st["last_P"] == P and st["last_M"] == M and np.array_equal(rs.cand_frame, res.cand_frame[list(checked)])
+    g.close()

@@ -174,3 +174,55 @@ def test_three_shards_through_the_exchange_kernels_equal_a_single_table(mods, mo
         assert np.array_equal(a[0], full_pairs[q][0]) and np.array_equal(a[1], full_pairs[q][1])
     for m in shards + [single]:
         m.close()
+
+
+def test_attached_view_queries_the_owners_table(mods):
+    """sgtd_attach_table: a second handle borrows the finalized table (here with a tail segment) and gives the owner's
+    results for the same batch — candidates, votes, ordered lists, verification — from its own work buffers and stream,
+    while the owner works on another batch; a changed table is noticed; a view cannot add; an owner outlives its views"""
+    import torch
+    from sgtd_amd._lib import SgtdError
+    manager, synth = mods
+    smap = synth.make_map(70, 150, stream=97)
+    qa, qb = synth.make_queries(smap, 7, stream=97), synth.make_queries(smap, 7, stream=98)
+    own = manager.STDescManager()
+    own.add_frames(smap.xyz[:60], smap.label[:60])
+    own.finalize()
+    own.add_frames(smap.xyz[60:], smap.label[60:])        # ... into a tail segment
+    own.finalize()
+    assert own.stats()["tail_entries"] > 0
+    view = manager.STDescManager()
+    s2 = torch.cuda.Stream()
+    view.set_stream(s2.cuda_stream)
+    view.attach_table(own)
+    assert view.stats()["n_entries"] == own.stats()["n_entries"] and view.current_frame_id_ == own.current_frame_id_
+    # two batches in flight: A on the view, B on the owner
+    view.query_frames(qa.xyz, qa.label, fetch=False)
+    own.query_frames(qb.xyz, qb.label, fetch=False)
+    rv, ro_b = view.results(), own.results()
+    pv = [view.result_pairs(q, rv) for q in range(7)]
+    view.verify()
+    sv = [view.result_verify(q) for q in range(7)]
+    ro = own.query_frames(qa.xyz, qa.label)
+    own.verify()
+    assert rv.n_cand.max() > 0 and not np.array_equal(ro_b.cand_frame, ro.cand_frame)
+    assert np.array_equal(rv.n_cand, ro.n_cand) and np.array_equal(rv.cand_frame, ro.cand_frame) and np.array_equal(rv.cand_votes, ro.cand_votes)
+    assert np.array_equal(rv.pair_off, ro.pair_off)
+    for q in range(7):
+        a = own.result_pairs(q, ro)
+        assert np.array_equal(a[0], pv[q][0]) and np.array_equal(a[1], pv[q][1])
+        so = own.result_verify(q)
+        assert all(np.array_equal(x, y) for x, y in zip(so, sv[q]))
+    with pytest.raises(SgtdError):
+        view.add_frames(smap.xyz[:2], smap.label[:2])
+    with pytest.raises(SgtdError):
+        own.close()                                        # a view is still attached
+    own.add_frames(smap.xyz[:3], smap.label[:3])           # the table changes ...
+    with pytest.raises(SgtdError):
+        view.query_frames(qa.xyz, qa.label)                # ... and the view notices
+    view.attach_table(own)
+    r2 = view.query_frames(qa.xyz, qa.label)
+    r3 = own.query_frames(qa.xyz, qa.label)
+    assert np.array_equal(r2.cand_frame, r3.cand_frame) and np.array_equal(r2.cand_votes, r3.cand_votes)
+    view.close()
+    own.close()
