@@ -46,6 +46,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -68,16 +69,18 @@ const std::vector<P> &points_of(const std::vector<P> &pc) { return pc; }
 
 // ---- STDesc <-> sgtd_desc_soa ----------------------------------------------------------
 struct SoaBuf {
-  std::vector<double> side, angle, center;
-  std::vector<float> vertex;
-  std::vector<int32_t> label, node_id;
-  std::vector<uint32_t> frame;
+  // one block, NOT value-initialised (a std::vector would zero a megabyte per frame that is overwritten at once)
+  std::unique_ptr<unsigned char[]> block;
+  size_t n_;
   sgtd_desc_soa v;
-  explicit SoaBuf(size_t n) : side(3 * n), angle(3 * n), center(3 * n), vertex(9 * n), label(3 * n), node_id(3 * n), frame(n) {
-    v.side = side.data(); v.angle = angle.data(); v.center = center.data(); v.vertex = vertex.data();
-    v.label = label.data(); v.frame = frame.data(); v.node_id = node_id.data();
+  explicit SoaBuf(size_t n) : block(new unsigned char[n * 136 + 64]), n_(n) {
+    unsigned char *p = block.get();
+    p += (8 - reinterpret_cast<uintptr_t>(p) % 8) % 8;
+    v.side = reinterpret_cast<double *>(p); v.angle = v.side + 3 * n; v.center = v.angle + 3 * n;
+    v.vertex = reinterpret_cast<float *>(v.center + 3 * n); v.label = reinterpret_cast<int32_t *>(v.vertex + 9 * n);
+    v.frame = reinterpret_cast<uint32_t *>(v.label + 3 * n); v.node_id = reinterpret_cast<int32_t *>(v.frame + n);
   }
-  size_t capacity() const { return frame.size(); }
+  size_t capacity() const { return n_; }
 };
 
 // The same arrays in page-locked memory (sgtd_host_alloc), kept by the calling thread from call to call
@@ -137,13 +140,13 @@ template <class Desc>
 void to_soa(const std::vector<Desc> &in, SoaBuf &b) {
   for (size_t i = 0; i < in.size(); i++) {
     for (int k = 0; k < 3; k++) {
-      b.side[3 * i + k] = in[i].side_length_[k]; b.angle[3 * i + k] = in[i].angle_[k]; b.center[3 * i + k] = in[i].center_[k];
-      b.vertex[9 * i + k] = (float)in[i].vertex_A_[k]; b.vertex[9 * i + 3 + k] = (float)in[i].vertex_B_[k];
-      b.vertex[9 * i + 6 + k] = (float)in[i].vertex_C_[k];
-      b.label[3 * i + k] = (int32_t)in[i].vertex_attached_[k];          // (int) as STDesc.cpp:158-160
-      b.node_id[3 * i + k] = in[i].node_id.size() == 3 ? in[i].node_id[k] : 0;
+      b.v.side[3 * i + k] = in[i].side_length_[k]; b.v.angle[3 * i + k] = in[i].angle_[k]; b.v.center[3 * i + k] = in[i].center_[k];
+      b.v.vertex[9 * i + k] = (float)in[i].vertex_A_[k]; b.v.vertex[9 * i + 3 + k] = (float)in[i].vertex_B_[k];
+      b.v.vertex[9 * i + 6 + k] = (float)in[i].vertex_C_[k];
+      b.v.label[3 * i + k] = (int32_t)in[i].vertex_attached_[k];          // (int) as STDesc.cpp:158-160
+      b.v.node_id[3 * i + k] = in[i].node_id.size() == 3 ? in[i].node_id[k] : 0;
     }
-    b.frame[i] = in[i].frame_id_;
+    b.v.frame[i] = in[i].frame_id_;
   }
 }
 
@@ -352,28 +355,59 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   };
 #define SGTD_LAP(part) lap(&SearchTiming::part, #part)
   Selection s;
-  int st = select(h, stds_vec, candidate_num, s, /*with_pairs=*/false);  // :98
-  if (st != SGTD_OK) return st;
-  CS1 = (int)(std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count() * 1000);
-  SGTD_LAP(select);
-  st = sgtd_verify(h);                             // :105-118 for every candidate
-  if (st != SGTD_OK) return st;
   const int cn = candidate_num;
   std::vector<double> score(cn), pose((size_t)cn * 12);   // rot row-major (9), then t (3)
-  st = sgtd_result_verify(h, 0, score.data(), pose.data());
-  if (st != SGTD_OK) return st;
-  SGTD_LAP(verify);
-  // the inlier pairs of every candidate (sucess_match_vec, :516-539) and the table entries they name, in one call
   std::vector<int64_t> ioff((size_t)cn + 1, 0);
   int64_t n_inl = 0;
   PinnedSoa &pe = fetched_entries();      // page-locked, reused from frame to frame
-  const int64_t most = s.off[s.n_cand];   // every pair of every candidate's list
-  pe.reserve((size_t)most);
-  std::vector<int32_t> iq((size_t)most);
-  st = sgtd_result_inlier_entries(h, 0, ioff.data(), iq.data(), &pe.v, most, &n_inl);
-  if (st != SGTD_OK) return st;
+  static thread_local std::vector<int32_t> iq;            // query side of the inlier pairs, kept like the entries
+  // ONE call for candidate_selector (:98), candidate_verify of every candidate (:105-118) and the inlier pairs of every
+  // candidate (sucess_match_vec, :516-539) with the table entries they name: two waits for the device instead of eight
+  // (sgtd_search_frame).  Room for the inlier pairs: what the frames before needed, with slack; a frame that needs more
+  // says so and its pairs are fetched by the second call below.
+  int st;
+  {
+    SoaBuf qb(stds_vec.size());
+    to_soa(stds_vec, qb);
+    s.frame.assign(cn, -1); s.votes.assign(cn, 0); s.off.assign((size_t)cn + 1, 0);
+    pe.reserve(16384);
+    if (iq.size() < pe.cap) iq.resize(pe.cap);
+    sgtd_frame_search fs{};
+    fs.cand_frame = s.frame.data(); fs.cand_votes = s.votes.data(); fs.pair_off = s.off.data();
+    fs.score = score.data(); fs.pose = pose.data(); fs.inlier_off = ioff.data();
+    fs.inlier_q_idx = iq.data(); fs.entries = pe.v; fs.capacity = (int64_t)pe.cap;
+    st = sgtd_search_frame(h, &qb.v, (int64_t)stds_vec.size(), &fs);
+    s.n_cand = fs.n_cand;
+    n_inl = fs.n_inliers;
+    if (st == SGTD_ERR_CAPACITY) {         // more inlier pairs than there was room for: everything else is there
+      pe.reserve((size_t)n_inl + (size_t)n_inl / 2);
+      iq.resize(pe.cap);
+      st = sgtd_result_inlier_entries(h, 0, ioff.data(), iq.data(), &pe.v, (int64_t)pe.cap, &n_inl);
+    }
+  }
+  if (st == SGTD_ERR_UNSUPPORTED) {        // (a handle over several devices: the calls one after the other)
+    st = select(h, stds_vec, candidate_num, s, /*with_pairs=*/false);  // :98
+    if (st != SGTD_OK) return st;
+    CS1 = (int)(std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count() * 1000);
+    SGTD_LAP(select);
+    st = sgtd_verify(h);                             // :105-118 for every candidate
+    if (st != SGTD_OK) return st;
+    st = sgtd_result_verify(h, 0, score.data(), pose.data());
+    if (st != SGTD_OK) return st;
+    SGTD_LAP(verify);
+    const int64_t most = s.off[s.n_cand];   // every pair of every candidate's list
+    pe.reserve((size_t)most);
+    if (iq.size() < pe.cap) iq.resize(pe.cap);
+    st = sgtd_result_inlier_entries(h, 0, ioff.data(), iq.data(), &pe.v, most, &n_inl);
+    if (st != SGTD_OK) return st;
+    SGTD_LAP(inliers);
+  } else {
+    if (st != SGTD_OK) return st;
+    CS1 = (int)(std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count() * 1000);
+    SGTD_LAP(select);                        // (the whole device side of the call)
+  }
   const sgtd_desc_soa &ent = pe.v;
-  SGTD_LAP(inliers);
+  const int32_t *const iqp = iq.data();      // (a thread_local: the fill threads below must see THIS thread's)
 #ifdef SGTD_SHIM_TIMING
   std::fprintf(stderr, "  [shim] %lld inlier pairs over %d candidates\n", (long long)n_inl, s.n_cand);
 #endif
@@ -409,7 +443,7 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
       std::vector<std::pair<Desc, Desc>> &lp = match_result_list[first + (size_t)k].loop_std_pair;
       lp.reserve((size_t)(ioff[(size_t)k + 1] - ioff[(size_t)k]));
       for (int64_t j = ioff[(size_t)k]; j < ioff[(size_t)k + 1]; j++)
-        lp.emplace_back(stds_vec[(size_t)iq[(size_t)j]], desc_from<Desc>(ent, (size_t)j));
+        lp.emplace_back(stds_vec[(size_t)iqp[(size_t)j]], desc_from<Desc>(ent, (size_t)j));
     }
   });
   SGTD_LAP(fill);

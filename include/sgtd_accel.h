@@ -333,6 +333,32 @@ int sgtd_result_inlier_entries(sgtd_handle h, int q, int64_t *cand_off, int32_t 
 int sgtd_search_loop(sgtd_handle h, double icp_threshold, int32_t *best_cand, int32_t *best_frame,
                      double *best_score);
 
+/* One query frame through candidate_selector (STDesc.cpp:318-460), candidate_verify for every candidate (:462-571) and the
+ * inlier pairs of every candidate with the table entries they name — what SearchLoop (:84-147) needs — in ONE call: the
+ * reference's one-frame-per-call pattern (semantic_graph_localization.cpp:590-603).  Equal, value for value, to
+ * sgtd_query_descs + sgtd_verify + sgtd_result_candidates + sgtd_result_verify(0) + sgtd_result_inlier_entries(0), which
+ * wait for the device eight times and issue some sixty small copies between them; this call enqueues everything behind
+ * the batch, waits once for one packed block of the small results and once for the entries.  Output arrays of
+ * candidate_num (pair_off, inlier_off: candidate_num + 1; pose: candidate_num * 12) elements; any pointer may be NULL.
+ * capacity = room (pairs) in inlier_q_idx / entries; n_inliers = needed.  SGTD_ERR_CAPACITY leaves everything but the
+ * inlier pairs valid — sgtd_result_inlier_entries(h, 0, ...) with more room fetches them.  The handle afterwards is in
+ * the state the five calls leave (every sgtd_result_* call works).  Not on a multi-device handle (SGTD_ERR_UNSUPPORTED). */
+typedef struct sgtd_frame_search {
+  int32_t n_cand;           /* out */
+  int32_t reserved;
+  int32_t *cand_frame;      /* out [candidate_num]: match_id_.second, votes descending / frame ascending            */
+  int32_t *cand_votes;      /* out [candidate_num]                                                                  */
+  int64_t *pair_off;        /* out [candidate_num + 1]: offsets of the candidates' match lists (their lengths)      */
+  double *score;            /* out [candidate_num]: verify_score (-1: rejected)                                     */
+  double *pose;             /* out [candidate_num * 12]: rot row-major (9), t (3)                                   */
+  int64_t *inlier_off;      /* out [candidate_num + 1]: candidate k's inlier pairs are [inlier_off[k], inlier_off[k + 1]) */
+  int32_t *inlier_q_idx;    /* out [capacity]: query descriptor of inlier pair i                                    */
+  sgtd_desc_soa entries;    /* out: table entry of inlier pair i (arrays of capacity descriptors; NULL members skipped) */
+  int64_t capacity;         /* in                                                                                   */
+  int64_t n_inliers;        /* out                                                                                  */
+} sgtd_frame_search;
+int sgtd_search_frame(sgtd_handle h, const sgtd_desc_soa *q, int64_t nq, sgtd_frame_search *io);
+
 /* ---- persistent table ----
  * The reference rebuilds data_base_ from the map files at every start
  * (semantic_graph_localization.cpp:419-458) and only ever appends (STDesc.cpp:149-172).

@@ -28,7 +28,7 @@ SYMBOLS = [
     "sgtd_graphs_load", "sgtd_graphs_save_cache", "sgtd_graphs_load_cache", "sgtd_graphs_view",
     "sgtd_graphs_error", "sgtd_graphs_free", "sgtd_save_table", "sgtd_load_table",
     "sgtd_candidate_export_ints", "sgtd_set_candidate_export", "sgtd_export_wait", "sgtd_export_release", "sgtd_merge_candidates_dev",
-    "sgtd_gather_verified_dev", "sgtd_set_deferred_lists", "sgtd_finish_lists", "sgtd_verify_masked", "sgtd_attach_table",
+    "sgtd_gather_verified_dev", "sgtd_set_deferred_lists", "sgtd_finish_lists", "sgtd_verify_masked", "sgtd_attach_table", "sgtd_search_frame",
 ]
 
 
@@ -57,6 +57,13 @@ class DescSoa(C.Structure):
     _fields_ = [("side", C.c_void_p), ("angle", C.c_void_p), ("center", C.c_void_p),
                 ("vertex", C.c_void_p), ("label", C.c_void_p), ("frame", C.c_void_p),
                 ("node_id", C.c_void_p)]
+
+
+class FrameSearch(C.Structure):
+    """sgtd_frame_search"""
+    _fields_ = [("n_cand", C.c_int32), ("reserved", C.c_int32), ("cand_frame", C.c_void_p), ("cand_votes", C.c_void_p),
+                ("pair_off", C.c_void_p), ("score", C.c_void_p), ("pose", C.c_void_p), ("inlier_off", C.c_void_p),
+                ("inlier_q_idx", C.c_void_p), ("entries", DescSoa), ("capacity", C.c_int64), ("n_inliers", C.c_int64)]
 
 
 class Stats(C.Structure):
@@ -178,6 +185,7 @@ def lib():
     L.sgtd_finish_lists.argtypes = [vp, vp]
     L.sgtd_verify_masked.argtypes = [vp, vp]
     L.sgtd_attach_table.argtypes = [vp, vp]
+    L.sgtd_search_frame.argtypes = [vp, C.POINTER(DescSoa), i64, C.POINTER(FrameSearch)]
     L.sgtd_save_table.argtypes = [vp, C.c_char_p]
     L.sgtd_load_table.argtypes = [vp, C.c_char_p]
     for name in SYMBOLS:

@@ -168,6 +168,12 @@ struct sgtd_engine {
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
   DevBuf inl_pairs, inl_off;                  // sgtd_result_inlier_pairs staging
+  DevBuf inl_counts, frame_pack;              // sgtd_search_frame: inlier pairs per candidate, the packed small results
+  size_t frame_inl_cap = 0;                   // ... entries its gather has room for (grown when a frame has more inlier pairs)
+  const int *frame_qi = nullptr;              // ... the query-descriptor indices of the gathered inlier pairs (inside fetch_idx)
+  DevBuf b_in, b_out;                         // sgtd_build's one-block staging on the device: inputs / all descriptor fields
+  char *pin_build = nullptr;                  // ... and in page-locked host memory
+  size_t pin_build_cap = 0;
   DevBuf v_hyp64, v_hyp32, v_bound;           // hypotheses between the two passes of sgtd_verify
   bool verified = false;
   // ---- multi-GPU step (exchange_kernels.hip.h): the batch's local candidate tables are written, packed, into a caller
@@ -285,7 +291,8 @@ void free_store(DescStore &s) {
 // caller's data into pinned memory at once, queue pinned -> device; the pinned bytes are reused
 // only after the next xfer_sync.  Transfers beyond kPinMax take the direct path (bandwidth-bound).
 // ---------------------------------------------------------------------------
-constexpr size_t kPinMax = (size_t)256 << 10, kPinCap = (size_t)8 << 20;   // (beyond 256 KB a transfer is bandwidth-bound: the extra host copy would cost more than it saves)
+constexpr size_t kPinMax = (size_t)1 << 20, kPinCap = (size_t)16 << 20;   // (a frame's 7 200 descriptors: 172 KB of sides, 259 KB of vertices — one frame's fields all take
+                                                                           // the staged path; beyond 1 MB a transfer is bandwidth-bound and the extra host copy costs more than it saves)
 
 int xfer_sync(sgtd_engine *e) {
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -484,7 +491,7 @@ int copy_out(sgtd_engine *e, const DescStore &s, size_t first, size_t n, sgtd_de
   return SGTD_OK;
 }
 
-int copy_in(sgtd_engine *e, DescStore &s, size_t first, size_t n, const sgtd_desc_soa *in) {
+int copy_in(sgtd_engine *e, DescStore &s, size_t first, size_t n, const sgtd_desc_soa *in, bool wait = true) {
   if (n == 0) return SGTD_OK;
 #define CP(field, T, w)                                                                        \
   if (in->field)                                                                               \
@@ -494,7 +501,9 @@ int copy_in(sgtd_engine *e, DescStore &s, size_t first, size_t n, const sgtd_des
   CP(side, double, 3) CP(angle, double, 3) CP(center, double, 3) CP(vertex, float, 9)
   CP(label, int, 3) CP(frame, u32, 1) CP(node_id, int, 3)
 #undef CP
-  CHK(xfer_sync(e));
+  // (wait = false: every field went through the page-locked staging — at most 256 KB each — or is read from the caller's
+  // memory until the caller's next wait on the stream: sgtd_search_frame, whose inputs stay valid for the call)
+  if (wait) CHK(xfer_sync(e));
   return SGTD_OK;
 }
 
@@ -1614,10 +1623,11 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
-                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals};
+                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals, &e->inl_counts, &e->frame_pack, &e->b_in, &e->b_out};
   for (DevBuf *b : bufs) free_buf(*b);
   for (auto &b : e->scan_lvl) free_buf(b);
   if (e->pin) (void)hipHostFree(e->pin);
+  if (e->pin_build) (void)hipHostFree(e->pin_build);
   for (int i = 0; i < EV_COUNT; i++)
     if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->ev_cand) (void)hipEventDestroy(e->ev_cand);
@@ -1665,6 +1675,53 @@ int sgtd_build(sgtd_handle e, const float *xyz, const uint32_t *label, int n, sg
   *n_out = 0;
   if (n == 0) return SGTD_OK;
   CHK(settle_pending(e));
+  {
+    // One frame, the reference's call pattern: ONE transfer in (offsets, keypoints, labels in one page-locked block), the
+    // build, ONE transfer out (the count and every descriptor field, contiguous on the device) and one wait — the
+    // general path below issues a dozen small copies and three waits.  Frames whose descriptors exceed 4 MB take it.
+    const long long cap = (long long)n * e->dc.tpi;
+    const size_t in_bytes = 16 + (size_t)n * 16, out_bytes = 16 + (size_t)cap * 136;
+    if (out_bytes <= ((size_t)4 << 20) && n >= e->dc.K) {
+      CHK(ensure(e, e->b_in, in_bytes));
+      CHK(ensure(e, e->b_out, out_bytes));
+      const size_t in_room = (in_bytes + 255) & ~(size_t)255;
+      if (e->pin_build_cap < in_room + out_bytes) {
+        if (e->pin_build) (void)hipHostFree(e->pin_build);
+        e->pin_build = nullptr; e->pin_build_cap = 0;
+        void *pp = nullptr;
+        HIPCHK(hipHostMalloc(&pp, (in_room + out_bytes) * 2, hipHostMallocDefault));
+        e->pin_build = static_cast<char *>(pp);
+        e->pin_build_cap = (in_room + out_bytes) * 2;
+      }
+      char *hin = e->pin_build, *hout = e->pin_build + in_room;
+      const long long off2[2] = {0, n};
+      std::memcpy(hin, off2, 16);
+      std::memcpy(hin + 16, xyz, (size_t)n * 12);
+      std::memcpy(hin + 16 + (size_t)n * 12, label, (size_t)n * 4);
+      HIPCHK(hipMemcpyAsync(e->b_in.p, hin, in_bytes, hipMemcpyHostToDevice, e->stream));
+      char *din = e->b_in.as<char>(), *dout = e->b_out.as<char>();
+      DescArrays o;
+      o.side = reinterpret_cast<double *>(dout + 16); o.angle = o.side + cap * 3; o.center = o.angle + cap * 3;
+      o.vertex = reinterpret_cast<float *>(o.center + cap * 3); o.label = reinterpret_cast<int *>(o.vertex + cap * 9);
+      o.frame = reinterpret_cast<u32 *>(o.label + cap * 3); o.node_id = reinterpret_cast<int *>(o.frame + cap);
+      o.qrec = nullptr;
+      CHK(launch_build(e, reinterpret_cast<const float *>(din + 16), reinterpret_cast<const u32 *>(din + 16 + (size_t)n * 12),
+                       reinterpret_cast<const long long *>(din), 1, n, e->current_frame_id, 0, o, cap, reinterpret_cast<u32 *>(dout)));
+      HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      const u32 cnt = *reinterpret_cast<const u32 *>(hout);
+      *n_out = cnt;
+      if ((int64_t)cnt > capacity) return SGTD_ERR_CAPACITY;
+      const char *hp = hout + 16;
+      auto take = [&](void *dst, size_t width, size_t elem) {       // field of `width` elements per descriptor
+        if (dst) std::memcpy(dst, hp, (size_t)cnt * width * elem);
+        hp += (size_t)cap * width * elem;
+      };
+      take(out->side, 3, 8); take(out->angle, 3, 8); take(out->center, 3, 8); take(out->vertex, 9, 4); take(out->label, 3, 4);
+      take(out->frame, 1, 4); take(out->node_id, 3, 4);
+      return SGTD_OK;
+    }
+  }
   int64_t off[2] = {0, n};
   const float *dx; const u32 *dl; int max_n;
   CHK(stage_inputs(e, xyz, label, off, 1, 0, &dx, &dl, &max_n, /*own_set=*/true));
@@ -2140,16 +2197,14 @@ int sgtd_verify_masked(sgtd_handle e, const uint64_t *d_keep) {
   return st;
 }
 
-int sgtd_verify(sgtd_handle e) {
-  if (e && e->grp) return multi::verify(e);
-  if (!e) return SGTD_ERR_INVALID;
-  HIPCHK(hipSetDevice(e->cfg.device_id));
-  CHK(sync_batch(e));
-  if (!e->batch_valid) return SGTD_ERR_INVALID;
+}  // extern "C"
+
+namespace {
+// candidate_verify + triangle_solver (STDesc.cpp:462-571) of every (query, candidate) of the batch, enqueued behind it;
+// total = an upper bound on the pairs of all lists (sizes the per-pair scratch); guard: the kernels look at the batch's
+// overflow flags first (the batch has not been waited for)
+int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
   const int cn = e->dc.cand_num, nq = e->nq;
-  if (nq == 0) { e->verified = true; return SGTD_OK; }
-  int64_t total = 0;
-  for (int q = 0; q < nq; q++) total = std::max<int64_t>(total, (int64_t)e->h_pair_base[q] + e->h_pair_off[(size_t)q * (cn + 1) + cn]);
   CHK(ensure(e, e->v_score, (size_t)nq * cn * sizeof(double)));
   CHK(ensure(e, e->v_pose, (size_t)nq * cn * 12 * sizeof(double)));
   CHK(ensure(e, e->v_inlier, (size_t)std::max<int64_t>(total, 1)));
@@ -2171,6 +2226,7 @@ int sgtd_verify(sgtd_handle e) {
   CHK(ensure(e, e->v_bound, (size_t)nq * cn * 2 * sizeof(u32)));
   P.hyp64 = e->v_hyp64.as<double>(); P.hyp32 = e->v_hyp32.as<float>(); P.bound = e->v_bound.as<u32>();
   P.keep = e->verify_keep;
+  P.overflow = guard ? reinterpret_cast<const int *>(e->cursors.as<u32>() + 10) : nullptr;
   verify_solve_kernel<<<nq * cn, SGTD_WAVE, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
   verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
@@ -2186,6 +2242,23 @@ int sgtd_verify(sgtd_handle e) {
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vstat), z, sizeof(z)));
   }
 #endif
+  return SGTD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sgtd_verify(sgtd_handle e) {
+  if (e && e->grp) return multi::verify(e);
+  if (!e) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(sync_batch(e));
+  if (!e->batch_valid) return SGTD_ERR_INVALID;
+  const int cn = e->dc.cand_num, nq = e->nq;
+  if (nq == 0) { e->verified = true; return SGTD_OK; }
+  int64_t total = 0;
+  for (int q = 0; q < nq; q++) total = std::max<int64_t>(total, (int64_t)e->h_pair_base[q] + e->h_pair_off[(size_t)q * (cn + 1) + cn]);
+  CHK(verify_enqueue(e, total, /*guard=*/false));
   e->verified = true;
   return SGTD_OK;
 }
@@ -2337,6 +2410,138 @@ int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, in
   if (best_score) CHK(d2h(e, best_score, d_score, nq * sizeof(double)));
   CHK(xfer_sync(e));
   return SGTD_OK;
+}
+
+// One query frame through candidate_selector, candidate_verify and the inlier pairs with their table entries in ONE call
+// and (normally) two waits: the reference's per-frame call pattern (semantic_graph_localization.cpp:590-603 ->
+// STDesc.cpp:84-147) as sgtd_query_descs + sgtd_verify + sgtd_result_candidates + sgtd_result_verify +
+// sgtd_result_inlier_entries issue it costs eight waits and some sixty small copies.  Everything is enqueued behind the
+// batch without looking at it — the kernels behind the lists check the batch's overflow flags themselves — the small
+// results come back as one packed block, then the inlier pairs' entries.
+int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_frame_search *io) {
+  PinScope pin_scope(e && !e->grp ? e : nullptr);
+  if (e && e->grp) { e->err = "not available on a multi-device handle"; return SGTD_ERR_UNSUPPORTED; }
+  if (!e || !io || nq < 0 || (nq > 0 && (!q || !q->side || !q->label || !q->frame)) || io->capacity < 0) return SGTD_ERR_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device_id));
+  const int cn = e->dc.cand_num;
+  io->n_cand = 0; io->n_inliers = 0;
+  CHK(settle_tail(e));
+  // ---- sgtd_query_descs without its waits
+  e->nq = 1;
+  e->q_stride = std::max<long long>(nq, 1);
+  e->last_kind = 2;
+  e->diag = false;
+  e->rec_rate_cap = 256;
+  CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
+  CHK(ensure(e, e->q_count, sizeof(u32)));
+  CHK(copy_in(e, e->qd, 0, (size_t)nq, q, /*wait=*/false));
+  if (nq > 0) {
+    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.frame.as<u32>(), e->qd.qrec.as<QueryRec>(), nq,
+                                                           e->dc.rough);
+    HIPCHK(hipGetLastError());
+  }
+  const u32 cnt = (u32)nq;
+  CHK(h2d(e, e->q_count.p, &cnt, sizeof(u32)));      // (staged: the bytes are copied out of `cnt` here)
+  if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));
+  const bool deferred = e->defer_lists;
+  e->defer_lists = false;
+  const int ls = launch_select(e);
+  e->defer_lists = deferred;
+  CHK(ls);
+  // ---- candidate_verify behind it, sized by what the pair buffer holds
+  CHK(verify_enqueue(e, (int64_t)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), /*guard=*/true));
+  // ---- the inlier pairs of every candidate, compacted by one workgroup per candidate, and the entries they name
+  const int *ovf = reinterpret_cast<const int *>(e->cursors.as<u32>() + 10);
+  CHK(ensure(e, e->inl_counts, (size_t)SGTD_MAX_CAND * sizeof(u32)));
+  CHK(ensure(e, e->inl_off, (size_t)(cn + 1) * sizeof(long long)));
+  CHK(ensure(e, e->inl_pairs, std::min<size_t>(e->pair_cap, 0xFFFFFFF0u) * sizeof(u64)));
+  CHK(ensure(e, e->frame_pack, frame_pack_bytes(cn)));
+  inlier_count_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(), e->n_cand.as<int>(), ovf,
+                                                                       e->inl_counts.as<u32>());
+  HIPCHK(hipGetLastError());
+  inlier_compact_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->pairs.as<u64>(), e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(),
+                                                                         e->n_cand.as<int>(), ovf, e->inl_counts.as<u32>(), cn, e->inl_pairs.as<u64>(),
+                                                                         e->inl_off.as<long long>());
+  HIPCHK(hipGetLastError());
+  auto gather = [&](size_t room) -> int {      // index lists + entries of the first `room` inlier pairs (the count is on the device)
+    CHK(ensure(e, e->fetch_idx, room * (sizeof(long long) + sizeof(int))));
+    CHK(ensure_store(e, e->fetch, room));
+    long long *d_idx = e->fetch_idx.as<long long>();
+    int *d_qi = reinterpret_cast<int *>(d_idx + room);
+    e->frame_qi = d_qi;
+    split_pairs_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, d_idx, d_qi);
+    HIPCHK(hipGetLastError());
+    gather_entries_counted_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(d_idx, e->inl_off.as<long long>() + cn, e->tab.view(), e->fetch.view());
+    HIPCHK(hipGetLastError());
+    return SGTD_OK;
+  };
+  if (e->frame_inl_cap == 0) e->frame_inl_cap = 16384;
+  CHK(gather(e->frame_inl_cap));
+  pack_frame_kernel<<<1, 256, 0, e->stream>>>(e->cursors.as<u32>(), e->n_cand.as<int>(), e->q_M.as<u32>(), e->q_pair_base.as<u32>(), e->q_count.as<u32>(),
+                                              e->q_P.as<unsigned long long>(), e->cand_frame.as<int>(), e->cand_votes.as<int>(),
+                                              e->pair_off.as<long long>(), e->v_score.as<double>(), e->v_pose.as<double>(), e->inl_off.as<long long>(),
+                                              cn, e->frame_pack.as<unsigned char>());
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned char> pack(frame_pack_bytes(cn));
+  CHK(d2h(e, pack.data(), e->frame_pack.p, pack.size()));
+  CHK(xfer_sync(e));                                        // ---- wait 1
+  const u32 *w = reinterpret_cast<const u32 *>(pack.data());
+  if (w[10] | w[11]) {
+    // the batch outgrew a work buffer (a first frame, a frame unlike the ones before): sgtd_sync re-runs it, then the
+    // calls this one stands for, one after the other
+    CHK(sync_batch(e));
+    CHK(sgtd_verify(e));
+    CHK(sgtd_result_candidates(e, &io->n_cand, io->cand_frame, io->cand_votes, io->pair_off));
+    CHK(sgtd_result_verify(e, 0, io->score, io->pose));
+    std::vector<int64_t> off((size_t)cn + 1);
+    const int st = sgtd_result_inlier_entries(e, 0, off.data(), io->inlier_q_idx, &io->entries, io->capacity, &io->n_inliers);
+    if (io->inlier_off) std::memcpy(io->inlier_off, off.data(), off.size() * sizeof(int64_t));
+    return st;
+  }
+  // the host-side state every sgtd_result_* call reads, as sync_batch leaves it
+  const int *cf = reinterpret_cast<const int *>(pack.data() + 72), *cv = cf + cn;
+  const long long *po = reinterpret_cast<const long long *>(pack.data() + 72 + (size_t)cn * 8);
+  const double *sc = reinterpret_cast<const double *>(po + cn + 1), *ps = sc + cn;
+  const long long *ioff = reinterpret_cast<const long long *>(ps + (size_t)cn * 12);
+  if (!(e->h_count.resize(1) && e->h_pair_base.resize(2) && e->h_q_M.resize(1) && e->h_q_P.resize(1) && e->h_n_cand.resize(1) &&
+        e->h_cand_frame.resize((size_t)cn) && e->h_cand_votes.resize((size_t)cn) && e->h_pair_off.resize((size_t)cn + 1))) {
+    e->err = "hipHostMalloc of the result tables failed";
+    return SGTD_ERR_HIP;
+  }
+  e->h_count[0] = w[15]; e->h_pair_base[0] = 0; e->h_pair_base[1] = w[14]; e->h_q_M[0] = w[13];
+  std::memcpy(&e->h_q_P[0], pack.data() + 64, 8);
+  e->h_n_cand[0] = (int)w[12];
+  std::memcpy(e->h_cand_frame.data(), cf, (size_t)cn * 4); std::memcpy(e->h_cand_votes.data(), cv, (size_t)cn * 4);
+  std::memcpy(e->h_pair_off.data(), po, ((size_t)cn + 1) * 8);
+  {
+    sgtd_stats &st = e->stats;
+    unsigned long long swept = 0;
+    std::memcpy(&swept, w + 6, 8);
+    st.overflowed = 0; st.last_list_moves = w[9];
+    st.last_queries = 1; st.last_D = w[15]; st.last_P = (int64_t)e->h_q_P[0]; st.last_M = w[13]; st.last_P_swept = (int64_t)swept;
+    st.last_cand_pairs = po[cn];
+  }
+  e->batch_synced = true;
+  e->verified = true;
+  io->n_cand = (int32_t)w[12];
+  if (io->cand_frame) std::memcpy(io->cand_frame, cf, (size_t)cn * 4);
+  if (io->cand_votes) std::memcpy(io->cand_votes, cv, (size_t)cn * 4);
+  if (io->pair_off) std::memcpy(io->pair_off, po, ((size_t)cn + 1) * 8);
+  if (io->score) std::memcpy(io->score, sc, (size_t)cn * 8);
+  if (io->pose) std::memcpy(io->pose, ps, (size_t)cn * 96);
+  if (io->inlier_off) std::memcpy(io->inlier_off, ioff, ((size_t)cn + 1) * 8);
+  const int64_t n_inl = ioff[cn];
+  io->n_inliers = n_inl;
+  if (n_inl > io->capacity) return SGTD_ERR_CAPACITY;       // (everything else is valid; sgtd_result_inlier_entries with more room gives the pairs)
+  if (n_inl == 0) return SGTD_OK;
+  if ((size_t)n_inl > e->frame_inl_cap) {                   // more inlier pairs than the gather had room for: once more, with room
+    e->frame_inl_cap = (size_t)n_inl + (size_t)n_inl / 2;
+    CHK(gather(e->frame_inl_cap));
+  } else if ((size_t)n_inl * 2 > e->frame_inl_cap) {
+    e->frame_inl_cap = (size_t)n_inl * 2;                   // (room for the next frame)
+  }
+  if (io->inlier_q_idx) CHK(d2h(e, io->inlier_q_idx, e->frame_qi, (size_t)n_inl * sizeof(int)));
+  return copy_out(e, e->fetch, 0, (size_t)n_inl, &io->entries, 0);      // ---- wait 2
 }
 
 int sgtd_save_table(sgtd_handle e, const char *path) {

@@ -53,6 +53,8 @@ struct VerifyParams {
   int exact_only;              // test hook (SGTD_VERIFY_EXACT=1): no f32 pre-test, every vertex A test in f64
   const u64 *keep;             // [nq] or NULL: bit c = verify candidate c of the query (sgtd_verify_masked: the candidates that
                                // survived a multi-GPU merge); the others score -1 like a rejected candidate
+  const int *overflow;         // or NULL: the batch's overflow flags — set: the lists are not final (the batch will be re-run), nothing
+                               // is read (sgtd_search_frame enqueues the verification behind the batch without a host round trip)
 };
 
 // One-sided (Hestenes) Jacobi SVD of a 3x3, H = U diag(s) V^T; columns of (near) zero
@@ -176,6 +178,7 @@ __device__ __forceinline__ bool vertex_close(const double *Rt, const double v[3]
 __global__ __launch_bounds__(SGTD_WAVE) void verify_solve_kernel(VerifyParams P) {
   const int tid = threadIdx.x;
   const int q = blockIdx.x / P.cand_num, c = blockIdx.x % P.cand_num;
+  if (P.overflow && (P.overflow[0] | P.overflow[1])) return;
   if (c >= P.n_cand[q] || (P.keep && !((P.keep[q] >> c) & 1ull))) return;
   const long long *po = P.pair_off + (size_t)q * (P.cand_num + 1);
   const u32 base = P.q_pair_base[q] + (u32)po[c];
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
   const int tid = threadIdx.x, lane = lane_id();
   const int q = blockIdx.x / P.cand_num, c = blockIdx.x % P.cand_num;
   double *score = P.score + (size_t)q * P.cand_num + c;
+  if (P.overflow && (P.overflow[0] | P.overflow[1])) return;
   if (c >= P.n_cand[q] || (P.keep && !((P.keep[q] >> c) & 1ull))) { if (tid == 0) *score = -1.0; return; }
   const long long *po = P.pair_off + (size_t)q * (P.cand_num + 1);
   const u32 base = P.q_pair_base[q] + (u32)po[c];
@@ -490,4 +494,75 @@ __global__ __launch_bounds__(SGTD_INLIER_THREADS) void inlier_pairs_kernel(const
     carry += tot;
   }
   if (bound >= 0 && bound >= total) cand_off[tid] = (long long)carry;    // lists that start at the end (empty ones, the closing offset)
+}
+
+// ---- the same compaction by one workgroup per candidate (sgtd_search_frame: the one-frame-per-call path, where the
+// 160 dependent rounds of the single workgroup above were a third of a millisecond): candidate k's inlier flags are
+// counted by workgroup k, then every workgroup places its own list behind the counts of the candidates before it.
+// `overflow` set: the batch's lists are not final, nothing is read.
+#define SGTD_INLIER_CAND_THREADS 256
+__global__ __launch_bounds__(SGTD_INLIER_CAND_THREADS) void inlier_count_kernel(const unsigned char *inlier, const long long *pair_off, const int *n_cand,
+                                                                                const int *overflow, u32 *counts) {
+  __shared__ u32 lds[SGTD_INLIER_CAND_THREADS / SGTD_WAVE + 1];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  if (overflow[0] | overflow[1]) { if (tid == 0) counts[k] = 0; return; }
+  u32 mine = 0;
+  if (k < n_cand[0])
+    for (long long i = pair_off[k] + tid; i < pair_off[k + 1]; i += SGTD_INLIER_CAND_THREADS) mine += inlier[i] ? 1u : 0u;
+  u32 tot;
+  (void)block_excl_scan(mine, lds, tot);
+  if (tid == 0) counts[k] = tot;
+}
+
+__global__ __launch_bounds__(SGTD_INLIER_CAND_THREADS) void inlier_compact_kernel(const u64 *pairs, const unsigned char *inlier, const long long *pair_off,
+                                                                                  const int *n_cand, const int *overflow, const u32 *counts,
+                                                                                  int cand_num, u64 *out, long long *cand_off) {
+  __shared__ u32 lds[SGTD_INLIER_CAND_THREADS / SGTD_WAVE + 1];
+  __shared__ u32 s_base;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  if (overflow[0] | overflow[1]) { if (tid == 0) { cand_off[k] = 0; if (k == 0) cand_off[cand_num] = 0; } return; }
+  if (tid < SGTD_WAVE) {     // inlier pairs of the candidates before k (cand_num <= 64: one wave)
+    const u32 c = tid < cand_num ? counts[tid] : 0u;
+    const u32 before = wave_sum(tid < k ? c : 0u), all = wave_sum(c);
+    if (tid == 0) {
+      s_base = before;
+      cand_off[k] = (long long)before;
+      if (k == 0) cand_off[cand_num] = (long long)all;
+    }
+  }
+  __syncthreads();
+  if (k >= n_cand[0]) return;
+  u32 carry = s_base;
+  const long long lo = pair_off[k], hi = pair_off[k + 1];
+  for (long long i0 = lo; i0 < hi; i0 += SGTD_INLIER_CAND_THREADS) {
+    const long long i = i0 + tid;
+    const u32 f = (i < hi && inlier[i]) ? 1u : 0u;
+    u32 tot;
+    const u32 ex = block_excl_scan(f, lds, tot);
+    if (f) out[carry + ex] = pairs[i];
+    carry += tot;
+  }
+}
+
+// everything of a one-query batch the host needs after sgtd_search_frame's first (and usually only) wait, in one block:
+//   u32 ctr[12] | i32 n_cand, u32 q_M, u32 pairs_total, u32 q_count | u64 q_P | i32 cand_frame[cn] | i32 cand_votes[cn] |
+//   i64 pair_off[cn + 1] | f64 score[cn] | f64 pose[cn * 12] | i64 inl_off[cn + 1]
+__host__ __device__ __forceinline__ size_t frame_pack_bytes(int cn) {
+  return 48 + 16 + 8 + (size_t)cn * 8 + (size_t)(cn + 1) * 8 + (size_t)cn * 8 + (size_t)cn * 96 + (size_t)(cn + 1) * 8;
+}
+__global__ __launch_bounds__(256) void pack_frame_kernel(const u32 *ctr, const int *n_cand, const u32 *q_M, const u32 *q_pair_base, const u32 *q_count,
+                                                         const unsigned long long *q_P, const int *cand_frame, const int *cand_votes,
+                                                         const long long *pair_off, const double *score, const double *pose, const long long *inl_off,
+                                                         int cn, unsigned char *out) {
+  const int t = threadIdx.x;
+  u32 *w = reinterpret_cast<u32 *>(out);
+  if (t < 12) w[t] = ctr[t];
+  if (t == 0) { w[12] = (u32)n_cand[0]; w[13] = q_M[0]; w[14] = q_pair_base[1]; w[15] = q_count[0]; *reinterpret_cast<unsigned long long *>(out + 64) = q_P[0]; }
+  int *cf = reinterpret_cast<int *>(out + 72), *cv = cf + cn;
+  long long *po = reinterpret_cast<long long *>(out + 72 + (size_t)cn * 8);
+  double *sc = reinterpret_cast<double *>(po + cn + 1), *ps = sc + cn;
+  long long *io = reinterpret_cast<long long *>(ps + (size_t)cn * 12);
+  for (int k = t; k < cn; k += 256) { cf[k] = cand_frame[k]; cv[k] = cand_votes[k]; sc[k] = score[k]; }
+  for (int k = t; k <= cn; k += 256) { po[k] = pair_off[k]; io[k] = inl_off[k]; }
+  for (int k = t; k < cn * 12; k += 256) ps[k] = pose[k];
 }

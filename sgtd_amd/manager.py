@@ -389,6 +389,31 @@ class STDescManager:
         self._check(self._L.sgtd_search_loop(self._h, float(icp_threshold), _p(bc), _p(bf), _p(bs)))
         return bc, bf, bs
 
+    def search_frame(self, stds_vec, capacity=16384):
+        """sgtd_search_frame: candidate_selector + candidate_verify + the inlier pairs of every candidate with their table
+        entries for ONE query frame given as descriptors, in one call -> dict(n_cand, cand_frame, cand_votes, pair_off,
+        score, rot, t, inlier_off, inlier_q_idx, entries (Descs), n_inliers, status)"""
+        from ._lib import FrameSearch
+        cn = self.config_setting_["candidate_num"]
+        out = dict(cand_frame=np.zeros(cn, np.int32), cand_votes=np.zeros(cn, np.int32), pair_off=np.zeros(cn + 1, np.int64),
+                   score=np.zeros(cn, np.float64), pose=np.zeros((cn, 12), np.float64), inlier_off=np.zeros(cn + 1, np.int64),
+                   inlier_q_idx=np.zeros(max(capacity, 1), np.int32))
+        ent = Descs(max(capacity, 1))
+        fs = FrameSearch()
+        for k in ("cand_frame", "cand_votes", "pair_off", "score", "pose", "inlier_off", "inlier_q_idx"):
+            setattr(fs, k, out[k].ctypes.data)
+        fs.entries = ent.soa()
+        fs.capacity = int(capacity)
+        s = stds_vec.soa()
+        self._nq = 1
+        st = self._L.sgtd_search_frame(self._h, C.byref(s), stds_vec.n, C.byref(fs))
+        if st not in (0, -4):
+            self._check(st)
+        n = int(fs.n_inliers)
+        out.update(status=st, n_cand=int(fs.n_cand), n_inliers=n, rot=out["pose"][:, :9].reshape(cn, 3, 3).copy(), t=out["pose"][:, 9:].copy(),
+                   inlier_q_idx=out["inlier_q_idx"][:min(n, capacity)].copy(), entries=ent.head(min(n, capacity)))
+        return out
+
     def SearchLoop(self, stds_vec, icp_threshold=None):
         """mirror of STDescManager::SearchLoop (STDesc.cpp:84-147) for one query given as
         descriptors -> (loop_result (frame, score), (t, rot), success pair positions,

@@ -203,6 +203,19 @@ int sgtd_result_inlier_entries(sgtd_handle h, int q, int64_t *cand_off, int32_t 
   return SGTD_OK;
 }
 
+int sgtd_search_frame(sgtd_handle h, const sgtd_desc_soa *q, int64_t nq, sgtd_frame_search *io) {
+  if (!h || !io) return SGTD_ERR_INVALID;
+  int st = sgtd_query_descs(h, q, nq);
+  if (st != SGTD_OK) return st;
+  if ((st = sgtd_verify(h)) != SGTD_OK) return st;
+  if ((st = sgtd_result_candidates(h, &io->n_cand, io->cand_frame, io->cand_votes, io->pair_off)) != SGTD_OK) return st;
+  if ((st = sgtd_result_verify(h, 0, io->score, io->pose)) != SGTD_OK) return st;
+  std::vector<int64_t> off((size_t)h->cfg.candidate_num + 1);
+  st = sgtd_result_inlier_entries(h, 0, off.data(), io->inlier_q_idx, &io->entries, io->capacity, &io->n_inliers);
+  if (io->inlier_off) memcpy(io->inlier_off, off.data(), off.size() * sizeof(int64_t));
+  return st;
+}
+
 // "page-locked" memory: plain heap blocks, so that the sanitizers see every byte of them
 int sgtd_host_alloc(size_t bytes, void **out) {
   if (!out) return SGTD_ERR_INVALID;

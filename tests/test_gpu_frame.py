@@ -1,0 +1,106 @@
+"""The one-frame-per-call path (the reference's call pattern, semantic_graph_localization.cpp:590-603): sgtd_build's
+one-block transfer form and sgtd_search_frame — candidate_selector + candidate_verify + the inlier pairs with their
+table entries in one call — against the calls they stand for, value for value, and against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from oracle import oracle
+    from sgtd_amd import manager, synth
+    oracle.build_library()
+    return oracle, manager, synth
+
+
+def _five_calls(g, d):
+    """sgtd_query_descs + sgtd_result_candidates + sgtd_result_pairs + sgtd_verify + sgtd_result_verify + sgtd_result_inlier_entries"""
+    cands = g.candidate_selector(d)
+    res = g.results()
+    g.verify()
+    score, rot, t = g.result_verify(0)
+    off, qi, ent = g.result_inlier_entries(0, int(res.pair_off[0, -1]))
+    return cands, res, score, rot, t, off, qi, ent
+
+
+def _same(fs, ref, cn):
+    cands, res, score, rot, t, off, qi, ent = ref
+    nc = int(res.n_cand[0])
+    assert fs["n_cand"] == nc
+    assert np.array_equal(fs["cand_frame"], res.cand_frame[0]) and np.array_equal(fs["cand_votes"], res.cand_votes[0])
+    assert np.array_equal(fs["pair_off"], res.pair_off[0])
+    assert np.array_equal(fs["score"], score) and np.array_equal(fs["rot"], rot) and np.array_equal(fs["t"], t)
+    assert np.array_equal(fs["inlier_off"], off) and fs["n_inliers"] == len(qi)
+    if fs["status"] == 0:
+        assert np.array_equal(fs["inlier_q_idx"], qi)
+        for name, _, _ in ent.FIELDS:
+            assert np.array_equal(getattr(fs["entries"], name), getattr(ent, name)), name
+
+
+def test_search_frame_equals_the_calls_it_stands_for(mods, monkeypatch):
+    oracle, manager, synth = mods
+    m = synth.make_map(160, 200, stream=131)
+    qs = synth.make_queries(m, 6, stream=131)
+    g = manager.STDescManager()
+    g.add_frames(m.xyz, m.label)
+    o = oracle.OracleManager()
+    o.add_frames(m.xyz, m.label)
+    cn = g.config_setting_["candidate_num"]
+    for q in range(6):
+        d = g.BuildSingleScanSTD(qs.xyz[q], qs.label[q])
+        od = o.build(qs.xyz[q], qs.label[q])
+        assert d.n == od.n and np.array_equal(d.side, od.side) and np.array_equal(d.vertex, od.vertex) and np.array_equal(d.node_id, od.node_id)
+        ref = _five_calls(g, d)
+        room = int(ref[1].pair_off[0, -1])           # (every pair an inlier: always enough)
+        fs = g.search_frame(d, capacity=room)
+        assert fs["status"] == 0 and fs["n_inliers"] > 0
+        _same(fs, ref, cn)
+        # the handle is left as the five calls leave it: the lists of the same batch can still be read, and are the oracle's
+        r = o.select()
+        qi, de = g.result_pairs(0, g.results())
+        assert np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
+        # too little room for the inlier pairs: everything else is valid, the pairs come from the second call
+        small = g.search_frame(d, capacity=7)
+        assert small["status"] == -4 and small["n_inliers"] == fs["n_inliers"]
+        _same(small, ref, cn)
+        off, qi2, ent2 = g.result_inlier_entries(0, small["n_inliers"])
+        assert np.array_equal(qi2, fs["inlier_q_idx"]) and np.array_equal(ent2.side, fs["entries"].side)
+    # an empty frame, a frame without a candidate
+    none = g.search_frame(g.BuildSingleScanSTD(qs.xyz[0][:5], qs.label[0][:5]))
+    assert none["status"] == 0 and none["n_cand"] == 0 and none["n_inliers"] == 0
+    far = qs.xyz[1] * 3.7
+    fr = g.search_frame(g.BuildSingleScanSTD(far, qs.label[1]))
+    assert fr["status"] == 0 and fr["n_inliers"] == 0 and np.all(fr["score"][:fr["n_cand"]] <= 0)
+    g.close()
+    # a first frame that outgrows its work buffers: the call falls back to the re-run and gives the same
+    monkeypatch.setenv("SGTD_REC_CAP", "4096")
+    h = manager.STDescManager()
+    monkeypatch.delenv("SGTD_REC_CAP")
+    h.add_frames(m.xyz, m.label)
+    d = h.BuildSingleScanSTD(qs.xyz[2], qs.label[2])
+    fs = h.search_frame(d, capacity=1 << 20)
+    assert h.stats()["overflowed"] == 1 and fs["status"] == 0
+    _same(fs, _five_calls(h, d), cn)
+    h.close()
+
+
+def test_build_one_block_form_and_the_general_form_agree(mods):
+    """sgtd_build of one frame takes the one-transfer form up to 4 MB of descriptors and the general form beyond (more
+    than ~850 keypoints: also the global-memory dedup); both against the oracle"""
+    oracle, manager, synth = mods
+    rng = np.random.default_rng(7)
+    g = manager.STDescManager()
+    o = oracle.OracleManager()
+    for n in (9, 10, 57, 200, 400, 900):
+        xyz = (rng.random((n, 3)) * np.array([60.0, 60.0, 3.0])).astype(np.float32)
+        lab = rng.integers(3, 12, n).astype(np.uint32)
+        if synth.has_knn_ties(xyz, 10):
+            continue
+        d = g.BuildSingleScanSTD(xyz, lab)
+        od = o.build(xyz, lab)
+        assert d.n == od.n, n
+        for name in ("side", "angle", "center", "vertex", "label", "frame", "node_id"):
+            assert np.array_equal(getattr(d, name), getattr(od, name)), (n, name)
+    g.close()
