@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel and whole-step traffic of bench.py's default step from the rocprofv3 passes of
-profiles/collect_r04.sh:  python3 profiles/summarize_step.py <out dir> <tag> <commit>
+profiles/collect_r05.sh:  python3 profiles/summarize_step.py <out dir> <tag> <commit>
 
 Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary), <tag>_step.json (per kernel
 and step: launches, median duration in the kernel trace, HBM-side bytes from the FETCH_SIZE and WRITE_SIZE
