@@ -719,15 +719,43 @@ def main():
         d_qxyz, d_qlab = to_dev(queries.xyz[q_lo:q_hi], queries.label[q_lo:q_hi])
         d_rot = [to_dev(r.xyz[q_lo:q_hi], r.label[q_lo:q_hi]) for r in rot_sets]
 
-        def step(i=-1):
-            """the shard's pipeline on the main stream; exchange (all_gather + merge kernel inside the table group) and the
-            gather of the groups' result tables on the side stream: nothing waits on the host"""
-            x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
-            m2.query_async(x, l)
-            with torch.cuda.stream(m2.side):
-                merged["out"] = m2.gather_groups()
+        # `--in-flight` engines per rank over the rank's one table (the others attached to the first: sgtd_attach_table),
+        # each with its own streams and exchange buffers; steps go to them in turn
+        m2s = [m2] + [Map2D(F, rank, world, r_t=r_t, device_id=local_rank, lists=args.lists, attach_to=m2, max_frame_n=max(20000, F + 1))
+                      for _ in range(1, max(1, args.in_flight))]
+        turn = {"k": 0}
 
-    elapsed = timed(step, mgr, info=timed_info)
+        class Engines:
+            def sync(self):
+                for m_ in m2s:
+                    m_.mgr.sync()
+
+            def stats(self):
+                out_ = dict(m2s[0].mgr.stats())
+                for m_ in m2s[1:]:
+                    s_ = m_.mgr.stats()
+                    for k_ in InFlight.SUMMED:
+                        out_[k_] += s_[k_]
+                return out_
+        mgr_all = Engines()
+
+        def step(i=-1):
+            """the shard's pipeline on the engine's main stream; exchange (all_gather + merge kernel inside the table group) and
+            the gather of the groups' result tables on its side stream: nothing waits on the host"""
+            x, l = (d_qxyz, d_qlab) if i < 0 else d_rot[i % n_rot]
+            mm = m2s[0 if turn.get("pin") else turn["k"] % len(m2s)]
+            turn["k"] += 1
+            mm.query_async(x, l)
+            with torch.cuda.stream(mm.side):
+                merged["out"] = mm.gather_groups()
+
+    if m2 is not None:
+        for _ in range(2 * len(m2s)):       # every engine's work buffers reach their size
+            step(-1)
+        mgr_all.sync(); torch.cuda.synchronize()
+    elapsed = timed(step, mgr if m2 is None else mgr_all, info=timed_info)
+    if m2 is not None:
+        timed_info["batches_in_flight"] = len(m2s)
     one_in_flight = None
     if mode == "single" and args.in_flight > 1:
         # The headline: `--in-flight` batches in flight over the one table.  The measurement above (ONE batch in flight,
@@ -747,7 +775,7 @@ def main():
         timed_info["batches_in_flight"] = args.in_flight
     # the same measurement the way rounds 1-3 took it — ONE batch over and over (the room prediction is then exact, no
     # list ever moves) — beside the headline, which rotates fresh batches
-    cur_step, cur_mgr = (fstep_, flight) if flight is not None else (step, mgr)
+    cur_step, cur_mgr = (fstep_, flight) if flight is not None else (step, mgr if m2 is None else mgr_all)
     k_same = max(3, args.steps // 2)
     same_elapsed = timed(lambda i: cur_step(-1), cur_mgr, steps=k_same)
     timed_info.update(same_batch_ms_per_step=1000.0 * same_elapsed / k_same, same_batch_steps=k_same,
@@ -793,6 +821,9 @@ def main():
                              "page-locked arrays) before its handle takes the next batch; a batch that outgrew a work buffer would be re-run inside"}
         if flight is not None:
             flight.sync()
+    if m2 is not None:
+        mgr_all.sync()
+        turn["pin"] = True          # (everything below works on the rank's first engine)
     step(-1); mgr.sync(); torch.cuda.synchronize()          # leave the handle on the warm-up batch: the parity, recall and profile legs read its results
     backend_ran = dist.get_backend() if world > 1 else None
     collective = {"nccl": "RCCL (torch.distributed backend nccl)", "gloo": "gloo (NOT RCCL: test fallback)"}.get(backend_ran, backend_ran)

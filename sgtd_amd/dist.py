@@ -150,7 +150,9 @@ def plan_2d(world, n_frames, queries_per_group, keypoints=200, span_limit=32000,
 class Map2D:
     """one rank of an R_t x R_q grid: rank = g * R_t + t serves query group g with table shard t"""
 
-    def __init__(self, n_frames_total, rank, world, r_t=None, device_id=0, lists="all", **cfg):
+    def __init__(self, n_frames_total, rank, world, r_t=None, device_id=0, lists="all", attach_to=None, **cfg):
+        """attach_to: another Map2D of the same grid on this rank — this one borrows its table (sgtd_attach_table) and keeps
+        work buffers, streams and exchange buffers of its own: steps issued alternately on the two overlap on the device"""
         from . import _lib
         from .manager import STDescManager
         assert lists in ("all", "winners")
@@ -178,8 +180,14 @@ class Map2D:
                 grp = dist.new_group(list(range(t, world, self.r_t))) if 1 < self.r_q < world else None
                 if t == self.t:
                     self.col_group = grp
-        self.main = torch.cuda.current_stream(self.dev)
+        if attach_to is None:
+            self.main = torch.cuda.current_stream(self.dev)
+        else:
+            assert (attach_to.r_t, attach_to.rank, attach_to.world) == (self.r_t, rank, world)
+            self.main = torch.cuda.Stream(self.dev)
         self.mgr.set_stream(self.main.cuda_stream)
+        if attach_to is not None:
+            self.mgr.attach_table(attach_to.mgr)
         self.side = torch.cuda.Stream(self.dev)
         self._nq_buf = -1
         self.merged = None
