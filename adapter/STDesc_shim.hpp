@@ -56,7 +56,7 @@
 #endif
 
 #ifndef SGTD_SHIM_FILL_THREADS
-#define SGTD_SHIM_FILL_THREADS 8u   // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call (2 / 4 / 8 / 12 measured: 6.4 / 5.4 / 4.1 / 3.1 ms for the fill)
+#define SGTD_SHIM_FILL_THREADS 12u  // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call (2 / 4 / 8 / 12 measured: 6.4 / 5.4 / 4.1 / 3.1 ms for the fill; never more than the host has)
 #endif
 
 namespace sgtd_shim {

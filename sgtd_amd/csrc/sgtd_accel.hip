@@ -847,8 +847,19 @@ Views make_views(sgtd_engine *e) {
   {
     const double per_pass = SGTD_PAIR >= 4 ? 3.2 : (SGTD_PAIR >= 2 ? 1.9 : 1.0);
     B.rec_rate = 64;
-    if (e->stats.last_P_swept > 0 && e->stats.last_M > 0)
-      B.rec_rate = (u32)std::min(256.0, std::max(16.0, std::ceil(3.0 * 256.0 * (double)e->stats.last_M / ((double)e->stats.last_P_swept * per_pass))));
+    if (e->stats.last_P_swept > 0 && e->stats.last_M > 0) {
+      // three times the batch before's matches per visited entry and descriptor — but not more than lets the
+      // reservations of a batch like the one before (rate / 256 of every pass's visit list per descriptor, + 256
+      // records each) fit three fifths of the record buffer (slabs strand an eighth, batches differ): on maps whose visit lists match little (skewed label
+      // frequencies: a twelfth of the visits) three times the rate over-reserves the 32-bit record index by itself,
+      // and every batch would pay a re-run.  Never below 1.2 times the measured rate (lists that outgrow their room move).
+      const double meas = 256.0 * (double)e->stats.last_M / ((double)e->stats.last_P_swept * per_pass);
+      const double scale = e->stats.last_queries > 0 ? (double)e->nq / (double)e->stats.last_queries : 1.0;
+      const double fit = 256.0 * (0.6 * (double)e->rec_cap - 256.0 * (double)e->stats.last_D * scale) /
+                         std::max(1.0, (double)e->stats.last_P_swept * scale * per_pass);
+      const double want = std::max(std::min(3.0 * meas, fit), 1.2 * meas);
+      B.rec_rate = (u32)std::min(256.0, std::max(want < 16.0 && fit < 16.0 ? 2.0 : 16.0, std::ceil(want)));
+    }
     B.rec_rate = std::min(B.rec_rate, e->rec_rate_cap);
     if (e->diag) B.rec_rate = 256;
     if (e->rec_rate_hook) B.rec_rate = e->rec_rate_hook;
@@ -1885,7 +1896,7 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
   e->last_kind = 1; e->last_xyz = dx; e->last_label = dl; e->last_max_n = max_n;
   e->last_qframe = e->current_frame_id;
   e->diag = false;   // a new batch runs the product sweep; sgtd_result_rough re-runs it in the diagnostic form
-  e->rec_rate_cap = 256;
+  e->rec_rate_cap = e->stats.overflowed ? e->rec_rate_cap : std::min<u32>(256, e->rec_rate_cap * 2);   // (a cap a re-run needed recovers slowly)
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride * n_queries));
   CHK(ensure(e, e->q_count, (size_t)n_queries * sizeof(u32)));
   if (!e->rec_cap_fixed && e->stats.last_queries == 0) {
@@ -1916,7 +1927,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   e->q_stride = std::max<long long>(nq, 1);
   e->last_kind = 2;
   e->diag = false;
-  e->rec_rate_cap = 256;
+  e->rec_rate_cap = e->stats.overflowed ? e->rec_rate_cap : std::min<u32>(256, e->rec_rate_cap * 2);
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
@@ -2431,7 +2442,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   e->q_stride = std::max<long long>(nq, 1);
   e->last_kind = 2;
   e->diag = false;
-  e->rec_rate_cap = 256;
+  e->rec_rate_cap = e->stats.overflowed ? e->rec_rate_cap : std::min<u32>(256, e->rec_rate_cap * 2);
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q, /*wait=*/false));
