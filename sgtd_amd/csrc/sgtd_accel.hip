@@ -2384,9 +2384,9 @@ int sgtd_result_inlier_entries(sgtd_handle e, int q, int64_t *cand_off, int32_t 
                                                                 e->inl_off.as<long long>());
   HIPCHK(hipGetLastError());
   if (total > 0) {
-    split_pairs_kernel<<<grid_for(total, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, d_idx, d_qi);
+    split_pairs_kernel<<<grid_for(total, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)total, d_idx, d_qi);
     HIPCHK(hipGetLastError());
-    gather_entries_counted_kernel<<<grid_for(total, 256), 256, 0, e->stream>>>(d_idx, e->inl_off.as<long long>() + cn, e->tab.view(), e->fetch.view());
+    gather_entries_counted_kernel<<<grid_for(total, 256), 256, 0, e->stream>>>(d_idx, e->inl_off.as<long long>() + cn, (long long)total, e->tab.view(), e->fetch.view());
     HIPCHK(hipGetLastError());
   }
   std::vector<long long> off((size_t)cn + 1);
@@ -2480,9 +2480,9 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
     long long *d_idx = e->fetch_idx.as<long long>();
     int *d_qi = reinterpret_cast<int *>(d_idx + room);
     e->frame_qi = d_qi;
-    split_pairs_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, d_idx, d_qi);
+    split_pairs_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)room, d_idx, d_qi);
     HIPCHK(hipGetLastError());
-    gather_entries_counted_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(d_idx, e->inl_off.as<long long>() + cn, e->tab.view(), e->fetch.view());
+    gather_entries_counted_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(d_idx, e->inl_off.as<long long>() + cn, (long long)room, e->tab.view(), e->fetch.view());
     HIPCHK(hipGetLastError());
     return SGTD_OK;
   };

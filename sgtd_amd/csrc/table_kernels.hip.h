@@ -438,15 +438,16 @@ __global__ void gather_entries_kernel(const long long *idx, long long n, DescArr
   gather_entry(idx, i, tab, out);
 }
 // the same with the count still on the device (the launch covers an upper bound)
-__global__ void gather_entries_counted_kernel(const long long *idx, const long long *n_p, DescArrays tab, DescArrays out) {
+// (cap: the room of idx / out — the count on the device may exceed it, the caller then gathers again with more room)
+__global__ void gather_entries_counted_kernel(const long long *idx, const long long *n_p, long long cap, DescArrays tab, DescArrays out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= *n_p) return;
+  if (i >= *n_p || i >= cap) return;
   gather_entry(idx, i, tab, out);
 }
 // pairs (q_idx << 32 | g) -> the two index lists
-__global__ void split_pairs_kernel(const u64 *pairs, const long long *n_p, long long *idx, int *q_idx) {
+__global__ void split_pairs_kernel(const u64 *pairs, const long long *n_p, long long cap, long long *idx, int *q_idx) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= *n_p) return;
+  if (i >= *n_p || i >= cap) return;
   const u64 pr = pairs[i];
   idx[i] = (long long)(pr & 0xFFFFFFFFull);
   q_idx[i] = (int)(pr >> 32);

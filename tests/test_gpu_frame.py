@@ -104,3 +104,28 @@ def test_build_one_block_form_and_the_general_form_agree(mods):
         for name in ("side", "angle", "center", "vertex", "label", "frame", "node_id"):
             assert np.array_equal(getattr(d, name), getattr(od, name)), (n, name)
     g.close()
+
+
+def test_search_frame_when_the_inlier_pairs_outgrow_the_gather_room_twice(mods):
+    """found by tools/stress_parity.py (seed 5001, round 1773): frames that are exact copies of each other give tens of
+    thousands of inlier pairs; the first call grows the gather's room to 1.5 x its count — not a multiple of the launch's
+    256 threads — and a later frame with more pairs than that room must not write past it"""
+    oracle, manager, synth = mods
+    cfg = dict(descriptor_near_num=10, std_side_resolution=2.0, rough_dis_threshold=0.03, candidate_num=22)
+    m = synth.make_map(28, 113, stream=78507, sigma=1e-4)
+    q = synth.make_queries(m, 3, stream=78507)
+    g = manager.STDescManager(**cfg)
+    g.add_frames(m.xyz[:14], m.label[:14])
+    counts = []
+    for stage in range(2):
+        if stage == 1:
+            g.add_frames(m.xyz[14:], m.label[14:])
+        for i in range(3):
+            d = g.BuildSingleScanSTD(q.xyz[i], q.label[i])
+            ref = _five_calls(g, d)
+            fs = g.search_frame(d, capacity=int(ref[1].pair_off[0, -1]))
+            assert fs["status"] == 0
+            _same(fs, ref, cfg["candidate_num"])
+            counts.append(fs["n_inliers"])
+    assert max(counts) > 16384 and counts[-1] != counts[0]
+    g.close()

@@ -72,6 +72,40 @@ def one_round(rng, rnd):
                 g.AddSTDescs(d)
 
     def check():
+        # round 5's paths, drawn per check: the batch through a VIEW of the table (sgtd_attach_table: own work buffers and
+        # stream, the owner's table), and one query frame through sgtd_search_frame against the calls it stands for
+        if not multi and rng.random() < 0.35:
+            view = manager.STDescManager(**cfg)
+            view.attach_table(g)
+            rv = view.query_frames(q.xyz, q.label)
+            r0 = g.query_frames(q.xyz, q.label)
+            assert np.array_equal(rv.n_cand, r0.n_cand) and np.array_equal(rv.cand_frame, r0.cand_frame) and np.array_equal(rv.cand_votes, r0.cand_votes), desc + " view"
+            for i in range(3):
+                a, b = view.result_pairs(i, rv), g.result_pairs(i, r0)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), desc + " view lists"
+            view.close()
+            FORMS["view"] = FORMS.get("view", 0) + 1
+        if not multi and rng.random() < 0.35:
+            d0 = g.BuildSingleScanSTD(q.xyz[1], q.label[1])
+            if d0.n > 0:
+                cands = g.candidate_selector(d0)
+                r1 = g.results()
+                g.verify()
+                sc, rot, tt = g.result_verify(0)
+                cap = int(r1.pair_off[0, -1])
+                off, qi1, ent1 = g.result_inlier_entries(0, cap)
+                fs = g.search_frame(d0, capacity=max(cap, 1))
+                assert fs["status"] == 0 and fs["n_cand"] == int(r1.n_cand[0]), desc + " frame"
+                assert np.array_equal(fs["cand_frame"], r1.cand_frame[0]) and np.array_equal(fs["cand_votes"], r1.cand_votes[0]) and np.array_equal(fs["pair_off"], r1.pair_off[0]), desc + " frame tables"
+                assert np.array_equal(fs["score"], sc) and np.array_equal(fs["rot"], rot) and np.array_equal(fs["t"], tt), desc + " frame verify"
+                assert np.array_equal(fs["inlier_off"], off) and np.array_equal(fs["inlier_q_idx"], qi1) and np.array_equal(fs["entries"].side, ent1.side) and np.array_equal(fs["entries"].vertex, ent1.vertex), desc + " frame inliers"
+                # ... and the verification itself against the oracle's (same one-sided Jacobi SVD restated on the CPU)
+                o.build(q.xyz[1], q.label[1], export=False)
+                ow = o.select()
+                for kc in range(min(len(ow["cand_frame"]), 3)):
+                    o_score, o_t, o_rot, o_idx = o.verify(kc, int(ow["cand_off"][kc + 1] - ow["cand_off"][kc]))
+                    assert sc[kc] == o_score and (o_score < 0 or (np.array_equal(tt[kc], o_t) and np.array_equal(rot[kc], o_rot))), desc + " verify vs oracle"
+                FORMS["frame"] = FORMS.get("frame", 0) + 1
         r = g.query_frames(q.xyz, q.label)
         for i in range(3):
             o.build(q.xyz[i], q.label[i], export=False)
@@ -131,7 +165,7 @@ def main():
         except Exception:
             pass
         with open(sys.argv[3], "a") as fh:
-            fh.write(json.dumps({"rounds_without_a_difference": rnd, "rounds_per_query_workgroups": FORMS.get("2", 0), "rounds_block_passes": FORMS.get("1", 0),
+            fh.write(json.dumps({"rounds_without_a_difference": rnd, "rounds_per_query_workgroups": FORMS.get("2", 0), "rounds_block_passes": FORMS.get("1", 0), "checks_through_a_view": FORMS.get("view", 0), "checks_of_search_frame_and_verify": FORMS.get("frame", 0),
                                  "seconds": round(time.time() - t0, 1), "seed": seed, "git_head": head,
                                  "compared": "candidates, votes, ordered match lists, P/M counters, ordered rough list (q, cell, entry, frame, dis) against oracle/sgtd_oracle.cpp",
                                  "last_round": d}) + "\n")
