@@ -129,6 +129,69 @@ def one_round(rng, rnd):
             for key in ("q_idx", "cell", "db_entry", "frame", "dis"):
                 assert np.array_equal(gr[key], orr[key]), desc + " rough " + key
 
+    def exchange_check():
+        """the multi-GPU step's device side in one process: 2-4 frame-range shards, packed export behind the vote pass, the
+        merge kernel, the winners' lists (deferred, masked) — merged candidates, votes and the winners' ordered lists
+        against the oracle's single table"""
+        import torch
+        from sgtd_amd.dist import shard_range
+        W = int(rng.integers(2, 5))
+        cn = cfg["candidate_num"]
+        dev = torch.device("cuda", 0)
+        ints = 2 * 3 * cn + 4
+        shards, packed, base = [], [], [0]
+        for r_ in range(W):
+            lo, hi = shard_range(n_frames, W, r_)
+            sm = manager.STDescManager(first_frame_id=lo, **cfg)
+            if hi > lo:
+                sm.add_frames(m.xyz[lo:hi], m.label[lo:hi])
+            pk = torch.zeros(ints, dtype=torch.int32, device=dev)
+            sm.set_candidate_export(pk)
+            sm.set_deferred_lists(True)
+            sm.query_frames(q.xyz, q.label, fetch=False)
+            shards.append(sm); packed.append(pk)
+            base.append(base[-1] + sm.stats()["n_entries"])
+        torch.cuda.synchronize()
+        gathered = torch.cat(packed).contiguous()
+        outs = []
+        for r_, sm in enumerate(shards):
+            of = torch.empty((3, cn), dtype=torch.int32, device=dev)
+            ov = torch.empty_like(of); osrc = torch.empty_like(of)
+            on = torch.empty(3, dtype=torch.int32, device=dev)
+            keep = torch.empty(3, dtype=torch.int64, device=dev)
+            flags = torch.zeros(4, dtype=torch.int32, device=dev)
+            sm.merge_candidates_dev(0, gathered, W, r_, 3, of, ov, on, osrc, keep, flags)
+            torch.cuda.synchronize()
+            if int(flags[0]) != 0:          # a shard's first batch outgrew a work buffer: re-run, export again, merge again
+                for s2 in shards:
+                    s2.sync()
+                torch.cuda.synchronize()
+                gathered = torch.cat(packed).contiguous()
+                sm.merge_candidates_dev(0, gathered, W, r_, 3, of, ov, on, osrc, keep, flags)
+                torch.cuda.synchronize()
+                assert int(flags[0]) == 0, desc + " exchange flags"
+            sm.finish_lists(keep)
+            outs.append((of, ov, on, osrc, keep))
+        torch.cuda.synchronize()
+        local = [sm.results() for sm in shards]
+        for i in range(3):
+            o.build(q.xyz[i], q.label[i], export=False)
+            want = o.select()
+            nc = len(want["cand_frame"])
+            of, ov, on, osrc, _ = outs[0]
+            assert int(on[i]) == nc and np.array_equal(of[i, :nc].cpu().numpy(), want["cand_frame"]) and np.array_equal(ov[i, :nc].cpu().numpy(), want["cand_votes"]), desc + " exchange merge"
+            lists = [shards[r_].result_pairs(i, local[r_]) for r_ in range(W)]
+            src = osrc[i].cpu().numpy()
+            for kc in range(nc):
+                r_, sl = src[kc] >> 8, src[kc] & 255
+                lo_, hi_ = local[r_].pair_off[i, sl], local[r_].pair_off[i, sl + 1]
+                wl, wh = want["cand_off"][kc], want["cand_off"][kc + 1]
+                assert hi_ - lo_ == wh - wl, desc + " exchange list length"
+                assert np.array_equal(lists[r_][0][lo_:hi_], want["q_idx"][wl:wh]) and np.array_equal(lists[r_][1][lo_:hi_] + base[r_], want["db_entry"][wl:wh]), desc + " exchange lists"
+        for sm in shards:
+            sm.close()
+        FORMS["exchange"] = FORMS.get("exchange", 0) + 1
+
     if pattern == "tail":
         cut = max(1, n_frames // 2)
         add(0, cut, "batch"); check()
@@ -136,6 +199,8 @@ def one_round(rng, rnd):
     else:
         add(0, n_frames, pattern)
         check()
+        if pattern == "batch" and not multi and rng.random() < 0.4:
+            exchange_check()
     g.close()
     return desc
 
@@ -165,7 +230,7 @@ def main():
         except Exception:
             pass
         with open(sys.argv[3], "a") as fh:
-            fh.write(json.dumps({"rounds_without_a_difference": rnd, "rounds_per_query_workgroups": FORMS.get("2", 0), "rounds_block_passes": FORMS.get("1", 0), "checks_through_a_view": FORMS.get("view", 0), "checks_of_search_frame_and_verify": FORMS.get("frame", 0),
+            fh.write(json.dumps({"rounds_without_a_difference": rnd, "rounds_per_query_workgroups": FORMS.get("2", 0), "rounds_block_passes": FORMS.get("1", 0), "checks_through_a_view": FORMS.get("view", 0), "checks_of_search_frame_and_verify": FORMS.get("frame", 0), "checks_of_the_exchange_kernels": FORMS.get("exchange", 0),
                                  "seconds": round(time.time() - t0, 1), "seed": seed, "git_head": head,
                                  "compared": "candidates, votes, ordered match lists, P/M counters, ordered rough list (q, cell, entry, frame, dis) against oracle/sgtd_oracle.cpp",
                                  "last_round": d}) + "\n")
