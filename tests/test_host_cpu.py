@@ -205,3 +205,30 @@ def test_step_summariser_cuts_steps_out_of_a_dispatch_sequence(tmp_path):
     assert pk["radix_scatter_kernel<unsigned int>"] == {"launches_per_step": 2, "per_step": 4.0}
     assert pk["probe_sorted_kernel<false, false, false>"]["per_step"] == 50.0            # median of the last four steps: 30, 40, 50, 60
     assert pk["build_frames_kernel<true, 10>"]["launches_per_step"] == 1
+
+
+def test_plan_2d_prefers_query_groups_and_respects_the_envelope():
+    """sgtd_amd/dist.py::plan_2d: the smallest number of table shards whose shard fits one GPU — everything a rank does
+    per query is repeated on every rank of a table group, so the other factor of N goes to query groups"""
+    from sgtd_amd.dist import plan_2d, shard_range
+    assert plan_2d(8, 10000, 2048) == (1, 8)           # the north-star map fits one GPU: eight replicas' worth of query groups
+    assert plan_2d(1, 10000, 2048) == (1, 1)
+    assert plan_2d(8, 100000, 256) == (4, 2)           # cfg4: a 25 000-frame shard fits the LDS vote histogram, 50 000 do not
+    assert plan_2d(2, 100000, 256) == (2, 1)           # nothing fits: as many shards as there are ranks
+    assert plan_2d(8, 30000, 2048)[0] == 2             # the batch's match records under the 32-bit index
+    assert plan_2d(8, 10000, 2048, r_t=8) == (8, 1) and plan_2d(4, 400, 24, r_t=2) == (2, 2)
+    for world in (1, 2, 3, 8):
+        cover = [shard_range(1001, world, r) for r in range(world)]
+        assert cover[0][0] == 0 and cover[-1][1] == 1001 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+def test_bench_relays_exactly_one_result_line():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    noisy = '[Gloo] Rank 0 is connected to 1 peer ranks\n{"not": "a result"}\n{"metric": "m", "value": 1}\ntrailing chatter\n'
+    assert b.last_result_line(noisy) == '{"metric": "m", "value": 1}'
+    assert b.last_result_line("no json here\n") is None
+    assert b.modelled_all_gather_ms(1 << 20, 1) == 0.0 and b.modelled_all_gather_ms(1 << 20, 8) > b.modelled_all_gather_ms(1 << 20, 2) > 0
