@@ -36,6 +36,8 @@ def main():
     sm.add_shard_frames(smap.xyz[sm.lo:sm.hi], smap.label[sm.lo:sm.hi])
     frames, votes, n_cand, scores, poses, bc, bf, bs = sm.search_loop(qs.xyz, qs.label)
     torch.cuda.synchronize()
+    if os.environ.get("SGTD_TEST_EXPECT_REPAIR") == "1":
+        assert sm.exchanges >= 2 and sm.mgr.stats()["reruns_total"] >= 1, "the batch was expected to overflow and be repaired (%d exchanges)" % sm.exchanges
     # every rank holds the same merged result
     probe = torch.cat([frames.double().flatten(), votes.double().flatten(), scores.flatten(), poses.flatten(), bf.double(), bs]).contiguous()
     ref = probe.clone()

@@ -94,12 +94,12 @@ def test_four_rank_two_by_two_grid():
     assert g["recall"]["top1_pose_within_5m"] > 0.9
 
 
-def _search_loop(n, r_t, lists):
+def _search_loop(n, r_t, lists, extra_env=None):
     import socket
     n_dev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip() or 0)
     backend = "nccl" if n_dev >= n else "gloo"
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGTD_TEST_BACKEND=backend, SGTD_TEST_RT=str(r_t), SGTD_TEST_LISTS=lists)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGTD_TEST_BACKEND=backend, SGTD_TEST_RT=str(r_t), SGTD_TEST_LISTS=lists, **(extra_env or {}))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "tests", "_sharded_search_loop_worker.py")],
                          capture_output=True, text=True, timeout=900, env=env)
@@ -119,3 +119,12 @@ def test_sharded_search_loop_over_the_collective_backend(lists):
 @pytest.mark.gpu
 def test_search_loop_on_a_two_by_two_grid():
     _search_loop(4, 2, "winners")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lists", ["all", "winners"])
+def test_a_shard_whose_batch_outgrows_its_buffers_is_repaired_by_the_whole_group(lists):
+    """every engine starts with a 4096-record buffer: each rank's first batch overflows, the flag travels in the packed
+    tables, every rank of the group learns it from the same all-gather, re-runs and exchanges again (Map2D.query) —
+    and the result is still the single table's"""
+    _search_loop(2, 2, lists, {"SGTD_REC_CAP": "4096", "SGTD_TEST_EXPECT_REPAIR": "1"})
