@@ -893,7 +893,9 @@ int launch_pairs_query(sgtd_engine *e, const Views &v, const u64 *keep = nullptr
   const int cn = e->dc.cand_num;
   const size_t img = (size_t)SGTD_PQ_TILE_RECS * sizeof(u32);
   const size_t tab = (((size_t)v.span + 15) & ~(size_t)15) + 16;     // (+ the bytes that answer for dead records)
-  if (img + tab <= 100 * 1024) {
+  // (up to 100 KB two workgroups share a CU; a span whose byte table only fits alone — 100 000 frames: 132 KB with the
+  // image — still beats the candidates' hash: one workgroup per CU)
+  if (img + tab <= 150 * 1024) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_query_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img + tab)));
     pairs_query_kernel<true><<<e->nq, SGTD_PQ_THREADS, img + tab, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
                                                                                 e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
@@ -995,10 +997,13 @@ int launch_select(sgtd_engine *e) {
   // five-kernel form with one wave per 128-descriptor block.
   const u32 tile_span = span <= 36 * 1024 ? span : 36 * 1024;
   const u32 n_tiles = (span + tile_span - 1) / tile_span;
-  // (automatic choice only where a query's vote histogram fits LDS: with the candidates' hash instead of the frame -> slot
+  // (automatic choice where a query's vote histogram fits LDS: with the candidates' hash instead of the frame -> slot
   // byte table the list pass is slower than the block passes — 100 000-frame map, 256 queries: 6.1 against 2.9 ms)
   const bool votes_fit = votes_topk_lds_bytes(span) <= 150 * 1024;
-  const bool per_query = e->select_mode == 2 || (e->select_mode == 0 && nq >= e->n_cus && votes_fit);
+  // ... or at least its frame -> slot byte table beside a tile's image (one workgroup per CU then; 100 000 frames, 256 queries:
+  // votes by tiles + top-k + this list pass 15.1 ms per step against 16.1 with the block passes, gpurun_out/r05o_*)
+  const bool table_fits = (size_t)SGTD_PQ_TILE_RECS * sizeof(u32) + (((size_t)span + 15) & ~(size_t)15) + 16 <= 150 * 1024;
+  const bool per_query = e->select_mode == 2 || (e->select_mode == 0 && nq >= e->n_cus && (votes_fit || table_fits));
   // (an image word of the list pass is slot(6) | descriptor(9) | rank: with 64 candidates AND ranks of the full width the
   // word of slot 63, descriptor 511, rank 2^17 - 1 would be the pass's "no record" marker — that corner takes the block form)
   const bool fused_pairs = per_query && !e->wide_pairs && (e->id_bits ? e->id_bits : 13) <= SGTD_PQ_RANK_BITS &&
