@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--cpu-protocol", choices=["bounded", "ref_full", "full"], default="ref_full",
                     help="ref_full = BASELINE.md §2 (10 warm-up + 200 queries) at the reference's thread rule, a bounded sample at the "
                          "other settings; full = the protocol at every setting (slow); bounded = a bounded sample everywhere")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="N=1: batches in flight over the one table (handles attached with sgtd_attach_table, one stream each); "
                          "1 = every batch behind the one before (reported beside the headline either way)")
     ap.add_argument("--rotate", type=int, default=4,

@@ -454,10 +454,14 @@ int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64
   }
   *max_n = mx;
   CHK(ensure(e, kp_buf, (size_t)(n_frames + 1) * sizeof(long long)));
-  HIPCHK(hipMemcpyAsync(kp_buf.p, off.data(), (size_t)(n_frames + 1) * sizeof(long long),
-                        hipMemcpyHostToDevice, e->stream));
-  // the staging vector dies at return: make the copy complete first
-  CHK(xfer_sync(e));
+  // through the page-locked staging (the bytes leave `off` here): no wait for the stream — a caller that enqueues batch
+  // after batch keeps the device fed, the next batch's kernels queue up behind the running one's
+  if ((size_t)(n_frames + 1) * sizeof(long long) <= kPinMax) {
+    CHK(h2d(e, kp_buf.p, off.data(), (size_t)(n_frames + 1) * sizeof(long long)));
+  } else {
+    HIPCHK(hipMemcpyAsync(kp_buf.p, off.data(), (size_t)(n_frames + 1) * sizeof(long long), hipMemcpyHostToDevice, e->stream));
+    CHK(xfer_sync(e));      // (the staging vector dies at return)
+  }
   const long long total = off[n_frames] - off[0];
   if (device_ptrs) {
     *d_xyz = xyz;
@@ -468,8 +472,7 @@ int stage_inputs(sgtd_engine *e, const float *xyz, const u32 *label, const int64
     if (total > 0) {
       CHK(h2d(e, xyz_buf.as<float>() + off[0] * 3, xyz + off[0] * 3,
                             (size_t)total * 3 * sizeof(float)));
-      HIPCHK(hipMemcpyAsync(label_buf.as<u32>() + off[0], label + off[0], (size_t)total * sizeof(u32),
-                            hipMemcpyHostToDevice, e->stream));
+      CHK(h2d(e, label_buf.as<u32>() + off[0], label + off[0], (size_t)total * sizeof(u32)));
     }
     *d_xyz = xyz_buf.as<float>();
     *d_label = label_buf.as<u32>();
