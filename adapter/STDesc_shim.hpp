@@ -46,6 +46,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <thread>
 #include <utility>
@@ -265,6 +266,18 @@ void deal_lists(int n, const int64_t *off, F &&fill) {
   for (auto &th : team) th.join();
 }
 
+// Which candidates' LOOP_RESULT::loop_std_pair SearchLoop builds.  0 (default): every candidate's, as the reference does
+// (STDesc.cpp:105-131) — 155 000 pair<STDesc, STDesc> per frame on a 10 000-frame map, 3-4.5 ms of host time, which is
+// most of the call.  1 (SGTD_SHIM_FILL=best in the environment, or fill_policy() = 1): only the best candidate's, which
+// is what SearchLoop hands back as loop_std_pair; the other candidates keep match_id, match_fitness and loop_transform
+// and an EMPTY list.  A deviation: the node copies the list of whichever candidate its GICP step prefers
+// (semantic_graph_localization.cpp:709,718) and only draws it (:787-788, :858) — with policy 1 that drawing is empty
+// unless GICP prefers the best-scored candidate.  The maintainer's choice; never the default.
+inline int &fill_policy() {
+  static int p = [] { const char *o = std::getenv("SGTD_SHIM_FILL"); return (o && o[0] == 'b') ? 1 : 0; }();
+  return p;
+}
+
 struct Selection {
   int32_t n_cand = 0;
   std::vector<int32_t> frame, votes, q_idx;
@@ -437,9 +450,10 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   // Every pair is CONSTRUCTED in place (reserve + emplace_back: the query descriptor copied, the table
   // descriptor built and moved), not value-initialised by a resize and then assigned: a resize
   // zeroes the 832 bytes of every pair first — 129 MB per frame, on the calling thread.
+  const int only = fill_policy() == 1 ? best : -2;
   deal_lists(s.n_cand, ioff.data(), [&](int k0, int k1) {
     for (int k = k0; k < k1; k++) {
-      if (!(score[k] >= 0)) continue;
+      if (!(score[k] >= 0) || (only != -2 && k != only)) continue;
       std::vector<std::pair<Desc, Desc>> &lp = match_result_list[first + (size_t)k].loop_std_pair;
       lp.reserve((size_t)(ioff[(size_t)k + 1] - ioff[(size_t)k]));
       for (int64_t j = ioff[(size_t)k]; j < ioff[(size_t)k + 1]; j++)

@@ -225,8 +225,11 @@ def cpp_adapter_leg(smap, queries, n_frames):
         by_part = {"select": v[0], "verify": v[1], "inlier_pairs_and_entries": v[2], "host_fill_of_loop_std_pair": v[3],
                    "device_and_transfers": round(sum(v[:3]), 3)}
     sel = re.search(r"candidate_selector alone: ([0-9.]+) ms per frame for ([0-9.]+) pairs", out.stdout)
+    bo = re.search(r"with only the best candidate's loop_std_pair built \(SGTD_SHIM_FILL=best\): ([0-9.]+) ms per frame; (\d+)/(\d+)", out.stdout)
     return {"cpp_adapter_ms_per_frame": float(m.group(2)), "cpp_adapter_search_loop_by_part_ms": by_part,
             "cpp_adapter_ms_candidate_selector_alone": float(sel.group(1)) if sel else None,
+            "cpp_adapter_ms_per_frame_best_candidates_list_only": float(bo.group(1)) if bo else None,
+            "cpp_adapter_best_only_same_choice_and_list": "%s/%s" % (bo.group(2), bo.group(3)) if bo else None,
             "cpp_adapter_pairs_in_match_lists": float(sel.group(2)) if sel else None, "cpp_adapter_ms_build": float(m.group(3)),
             "cpp_adapter_ms_search_loop": float(m.group(4)), "cpp_adapter_frames": int(m.group(1)),
             "cpp_adapter_agree_with_batched": "%s/%s" % (m.group(5), m.group(6)), "cpp_adapter_inlier_pairs_per_loop": float(m.group(7)),

@@ -218,8 +218,8 @@ int main(int argc, char **argv) {
     OK(sgtd_add_frames(mgr.handle(), map.xyz, map.label, map.off, map.n, 0));   // the map, batched (the per-frame form is tests/cpp/test_manager.cpp)
     OK(sgtd_current_frame_id(mgr.handle(), &mgr.current_frame_id_));
     OK(sgtd_finalize(mgr.handle()));
-    double ms_build = 0, ms_search = 0, ms_selector = 0;
-    long same = 0, pairs = 0, list_pairs = 0;
+    double ms_build = 0, ms_search = 0, ms_selector = 0, ms_best_only = 0;
+    long same = 0, pairs = 0, list_pairs = 0, same_best = 0;
     std::vector<int32_t> bf(1);
     for (int i = 0; i < n_pf; i++) {
       std::vector<sgtd::PointXYZL> cloud;
@@ -253,11 +253,33 @@ int main(int argc, char **argv) {
       OK(mgr.last_status());
       ms_selector += std::chrono::duration<double, std::milli>(d1 - d0).count();
       for (const auto &ml : candidate_matcher_vec) list_pairs += (long)ml.match_list_.size();
+      // ... and SearchLoop with only the best candidate's loop_std_pair built (sgtd_shim::fill_policy() = 1: an opt-in
+      // deviation, adapter/STDesc_shim.hpp): same choice, same list for the chosen frame
+      {
+        const sgtd_shim::SearchTiming keep = sgtd_shim::search_timing();     // (the by-part report below is the default policy's)
+        sgtd_shim::fill_policy() = 1;
+        auto e0 = std::chrono::steady_clock::now();
+        std::vector<sgtd::STDesc> stds2;
+        mgr.BuildSingleScanSTD(cloud, stds2);
+        std::pair<int, double> r2(-1, 0);
+        std::pair<sgtd::Vec3, sgtd::Mat3> t2;
+        std::vector<std::pair<sgtd::STDesc, sgtd::STDesc>> lp2;
+        std::vector<sgtd::LOOP_RESULT> mr2;
+        mgr.SearchLoop(stds2, r2, t2, lp2, mr2);
+        auto e1 = std::chrono::steady_clock::now();
+        sgtd_shim::fill_policy() = 0;
+        sgtd_shim::search_timing() = keep;
+        OK(mgr.last_status());
+        ms_best_only += std::chrono::duration<double, std::milli>(e1 - e0).count();
+        same_best += r2.first == search_result.first && lp2.size() == loop_std_pair.size() && mr2.size() == match_result_list.size();
+      }
     }
     std::printf("per-frame calls through STDescManager (%d frames): %.3f ms per frame = BuildSingleScanSTD %.3f + SearchLoop %.3f; "
                 "%ld/%d agree with the batched run, %.1f inlier pairs per loop\n",
                 n_pf, (ms_build + ms_search) / n_pf, ms_build / n_pf, ms_search / n_pf, same, n_pf, (double)pairs / n_pf);
     std::printf("candidate_selector alone: %.3f ms per frame for %.0f pairs in the match lists\n", ms_selector / n_pf, (double)list_pairs / n_pf);
+    std::printf("with only the best candidate's loop_std_pair built (SGTD_SHIM_FILL=best): %.3f ms per frame; %ld/%d the same choice and list\n",
+                ms_best_only / n_pf, same_best, n_pf);
     const sgtd_shim::SearchTiming &tm = sgtd_shim::search_timing();
     if (tm.calls)
       std::printf("SearchLoop by part (ms per frame): select %.3f, verify %.3f, inlier pairs and their entries %.3f, host fill of loop_std_pair %.3f\n",

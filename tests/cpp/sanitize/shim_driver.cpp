@@ -45,7 +45,10 @@ static int run(int seed, int frames, int calls) {
       pairs += (long)r.loop_std_pair.size();
       for (const auto &p : r.loop_std_pair)
         if (p.first.node_id.size() != 3 || p.second.node_id.size() != 3) return 13;
-      if (r.match_fitness >= 0 && (long)r.loop_std_pair.size() != r.match_fitness) return 14;    // (the stub's score = its inlier count)
+      // (the stub's score = its inlier count; with SGTD_SHIM_FILL=best only the winner's list is built)
+      const bool built = sgtd_shim::fill_policy() == 0 || (loop_result.first >= 0 && r.match_id == loop_result.first && r.match_fitness == (int)loop_result.second);
+      if (r.match_fitness >= 0 && built && (long)r.loop_std_pair.size() != r.match_fitness) return 14;
+      if (sgtd_shim::fill_policy() == 1 && !built && !r.loop_std_pair.empty()) return 18;
     }
     if (loop_result.first >= 0) {
       loops++;

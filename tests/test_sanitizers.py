@@ -29,6 +29,9 @@ def _run(exe, args, token, timeout=600):
 def test_adapter_under_asan_and_ubsan(tmp_path):
     exe = _build(tmp_path, "shim_asan", [os.path.join(SAN, "shim_driver.cpp"), os.path.join(SAN, "stub_abi.cpp")], ASAN)
     _run(exe, ["24"], "shim under the sanitizers: ok")
+    # the opt-in policy that builds only the best candidate's loop_std_pair
+    out = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=600, env=dict(ENV, SGTD_SHIM_FILL="best"))
+    assert out.returncode == 0 and "shim under the sanitizers: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 def test_adapter_fill_team_under_tsan(tmp_path):
