@@ -192,6 +192,14 @@ class Map2D:
         self._nq_buf = -1
         self.merged = None
         self.exchanges = 0
+        # defer = True: for transports whose all-gather of device tensors BLOCKS THE HOST (gloo copies through host memory,
+        # so the call returns only once the packed table exists — a whole sweep after the step was enqueued — and the
+        # host cannot feed the device meanwhile).  The all-gather is then issued asynchronously from a copy of the packed
+        # table and its merge is enqueued at the start of the NEXT exchange (or by flush()): the merged tables lag one
+        # step.  Measurement aid for one-GPU boxes (bench.py `exchange_exposed_ms_host_not_blocked`); RCCL collectives are
+        # stream-ordered and never need it.
+        self.defer = False
+        self._pending = None
         if lists == "winners":
             self.mgr.set_deferred_lists(True)
 
@@ -209,6 +217,7 @@ class Map2D:
         ints = int(self._L.sgtd_candidate_export_ints(nq, cn))
         self.packed = torch.empty(ints, dtype=torch.int32, device=dev)
         self.gathered = torch.empty(rt * ints, dtype=torch.int32, device=dev)
+        self.staged = torch.empty(ints, dtype=torch.int32, device=dev)
         self.m_frame = torch.empty((nq, cn), dtype=torch.int32, device=dev)
         self.m_votes = torch.empty((nq, cn), dtype=torch.int32, device=dev)
         self.m_src = torch.empty((nq, cn), dtype=torch.int32, device=dev)
@@ -227,9 +236,30 @@ class Map2D:
         return self.r_t > 1 and dist.is_initialized()
 
     # ---- the step ---------------------------------------------------------------------------
+    def flush(self):
+        """finish a deferred exchange (defer = True): wait for its all-gather, enqueue its merge"""
+        if self._pending is None:
+            return
+        work, nq = self._pending
+        self._pending = None
+        work.wait()
+        self.mgr.merge_candidates_dev(self.side.cuda_stream, self.gathered, self.r_t, self.t, nq, self.m_frame, self.m_votes, self.m_n,
+                                      self.m_src, self.m_keep, self.m_flags)
+
     def _exchange(self):
         """side stream: wait for the packed local table, all-gather it inside the table group, merge"""
         nq = self.mgr._nq
+        if self.defer and self._table_collective() and self.lists == "all":
+            self.flush()
+            self.mgr.export_wait(self.side.cuda_stream)
+            with torch.cuda.stream(self.side):
+                self.staged.copy_(self.packed, non_blocking=True)      # the engine's buffer is free again at once
+            self.mgr.export_release(self.side.cuda_stream)
+            with torch.cuda.stream(self.side):
+                work = dist.all_gather_into_tensor(self.gathered, self.staged, group=self.table_group, async_op=True)
+            self._pending = (work, nq)
+            self.exchanges += 1
+            return
         self.mgr.export_wait(self.side.cuda_stream)
         with torch.cuda.stream(self.side):
             if self._table_collective():
@@ -259,6 +289,7 @@ class Map2D:
         """all ranks of a table group pass the same query batch; returns the group's merged candidate list
         (frames, votes, n_cand) as device tensors, identical on every rank of the group"""
         self.query_async(xyz, label, kp_off)
+        self.flush()
         for _ in range(4):
             self.side.synchronize()
             if int(self.m_flags[0].item()) == 0:
