@@ -222,3 +222,23 @@ def test_batch_insert_equals_frame_by_frame():
         rb = (b.build(q.xyz[i], q.label[i], export=False), b.select())[1]
         for k in ra:
             assert np.array_equal(ra[k], rb[k]), k
+
+
+def test_parity_audit_counts_no_flipped_decision_on_small_workloads(tmp_path):
+    """tools/parity_audit.py --quick: the oracle's loops with the inferred third-party arithmetic in its alternatives side
+    by side (right association, FMA contraction, +-1 ulp on the threshold) — no decision differs, and the audit's own
+    counters are alive (gate tests, visits, triplets, sides that do differ in the last bit under the right association)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "audit.json")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "parity_audit.py"), "--quick", "--out", out, "--threads", "2"],
+                          stdout=subprocess.DEVNULL)
+    t = json.load(open(out))["totals"]
+    assert t["visits"] > 1e6 and t["gate_tests"] > 1e5 and t["triplets"] > 1e5 and t["knn_points"] > 1e3
+    assert t["match_flips"] == [0, 0, 0] and t["gate_flips"] == [0, 0, 0] and t["build_flips"] == [0, 0, 0]
+    assert t["thr_ulp_flips_plus_minus"] == [0, 0] and t["near_calls"] == 0 and t["knn_tied_points"] == 0
+    assert t["side_value_diffs"][0] > 0 and t["side_value_diffs"][1] == 0        # squares of f32 differences are exact: contraction alone changes nothing
+    assert t["min_margin_ulps"] > 1e3
