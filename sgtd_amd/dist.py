@@ -147,6 +147,30 @@ def plan_2d(world, n_frames, queries_per_group, keypoints=200, span_limit=32000,
     return world, 1
 
 
+def grid_groups(world, r_t):
+    """the rank lists of an R_t x R_q grid (rank = g * R_t + t): the R_q table groups (ranks that share query group g and
+    hold the shards of one table copy) and the R_t column groups (ranks that hold the same shard t, one per query group)"""
+    assert r_t >= 1 and world % r_t == 0
+    r_q = world // r_t
+    return [list(range(g * r_t, (g + 1) * r_t)) for g in range(r_q)], [list(range(t, world, r_t)) for t in range(r_t)]
+
+
+def make_grid_groups(world, r_t, rank):
+    """the process groups of `rank` in the grid, created by EVERY rank in the same order (torch.distributed's rule);
+    None stands for the default group (a grid side as long as the world) or for a side of one (no collective)"""
+    tables, cols = grid_groups(world, r_t)
+    table_group = col_group = None
+    for ranks in tables:
+        grp = dist.new_group(ranks) if 1 < len(ranks) < world else None
+        if rank in ranks:
+            table_group = grp
+    for ranks in cols:
+        grp = dist.new_group(ranks) if 1 < len(ranks) < world else None
+        if rank in ranks:
+            col_group = grp
+    return table_group, col_group
+
+
 class Map2D:
     """one rank of an R_t x R_q grid: rank = g * R_t + t serves query group g with table shard t"""
 
@@ -172,14 +196,7 @@ class Map2D:
         self.table_group, self.col_group = None, None
         if dist.is_initialized() and world > 1:
             assert dist.get_world_size() == world and dist.get_rank() == rank
-            for g in range(self.r_q):
-                grp = dist.new_group(list(range(g * self.r_t, (g + 1) * self.r_t))) if 1 < self.r_t < world else None
-                if g == self.g:
-                    self.table_group = grp
-            for t in range(self.r_t):
-                grp = dist.new_group(list(range(t, world, self.r_t))) if 1 < self.r_q < world else None
-                if t == self.t:
-                    self.col_group = grp
+            self.table_group, self.col_group = make_grid_groups(world, self.r_t, rank)
         if attach_to is None:
             self.main = torch.cuda.current_stream(self.dev)
         else:

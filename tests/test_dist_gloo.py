@@ -164,3 +164,52 @@ def test_topk_from_votes_is_the_reference_rule():
         assert (f[q, len(want_f):] == -1).all() and (v[q, len(want_f):] == 0).all()
     own = key_owner(rng.integers(0, 4096, 1000), rng.integers(0, 200, 1000), rng.integers(0, 200, 1000), rng.integers(0, 200, 1000), 8)
     assert own.min() >= 0 and own.max() < 8 and len(np.unique(own)) == 8
+
+
+def _grid_worker(rank, world, port, r_t):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgtd_amd.dist import grid_groups, make_grid_groups, merge_candidates
+        tables, cols = grid_groups(world, r_t)
+        tg, cg = make_grid_groups(world, r_t, rank)
+        t, g = rank % r_t, rank // r_t
+        # the table group's exchange: every rank contributes its shard's local table, the merge is identical inside the group
+        lf = torch.full((2, CAND), -1, dtype=torch.int32)
+        lv = torch.zeros((2, CAND), dtype=torch.int32)
+        lf[:, 0] = 100 * t + g                      # one candidate per shard: frame ids disjoint inside a group
+        lv[:, 0] = 5 + t
+        packed = torch.stack([lf, lv]).contiguous()
+        n_t = len(tables[g])
+        out = torch.empty((n_t * 2, 2, CAND), dtype=torch.int32)
+        if n_t > 1:
+            dist.all_gather_into_tensor(out, packed, group=tg)
+        else:
+            out.copy_(packed)
+        out = out.view(n_t, 2, 2, CAND)
+        mf, mv, n = merge_candidates(out[:, 0], out[:, 1], CAND)
+        want = sorted([(5 + tt, 100 * tt + g) for tt in range(r_t)], key=lambda kv: (-kv[0], kv[1]))
+        assert n.tolist() == [r_t, r_t] and mf[0, :r_t].tolist() == [f for _, f in want] and mv[0, :r_t].tolist() == [v for v, _ in want]
+        # the column group's gather of the groups' result tables: group-major on every rank
+        res = torch.full((1, 3), g, dtype=torch.int32)
+        n_c = len(cols[t])
+        allr = torch.empty((n_c, 3), dtype=torch.int32)
+        if n_c > 1:
+            dist.all_gather_into_tensor(allr, res, group=cg)
+        else:
+            allr.copy_(res)
+        assert allr[:, 0].tolist() == list(range(world // r_t))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("r_t", [1, 2, 4])
+def test_grid_groups_exchange_inside_table_groups_and_across_query_groups(r_t):
+    """the R_t x R_q grid of sgtd_amd/dist.py on four gloo ranks: the process groups every rank creates, the all-gather
+    inside a table group (+ the reference's merge rule) and the gather of the groups' results across the column group"""
+    from sgtd_amd.dist import grid_groups
+    assert grid_groups(8, 4) == ([[0, 1, 2, 3], [4, 5, 6, 7]], [[0, 4], [1, 5], [2, 6], [3, 7]])
+    assert grid_groups(4, 1) == ([[0], [1], [2], [3]], [[0, 1, 2, 3]])
+    mp.spawn(_grid_worker, args=(4, _free_port(), r_t), nprocs=4, join=True)
