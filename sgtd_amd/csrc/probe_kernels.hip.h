@@ -1688,8 +1688,13 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
   __shared__ u32 s_M;
   __shared__ unsigned long long s_P;
   const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-  const int q = blockIdx.x;
-  const u32 tile_lo = blockIdx.y * tile_span;
+  // workgroup b = query b / n_tiles, tile b % n_tiles: the tiles of a query are dispatched next to each other and read the
+  // query's records at about the same time — from the Infinity Cache after the first of them (with the tile in blockIdx.y
+  // a query's tiles ran a whole grid row apart: 100 000 frames, 768 queries: 7.1 ms for three full reads from HBM)
+  const u32 n_tiles = (frame_span + tile_span - 1u) / tile_span;
+  const int q = (int)(blockIdx.x / n_tiles);
+  const u32 tile_id = blockIdx.x % n_tiles;
+  const u32 tile_lo = tile_id * tile_span;
   const u32 n_bins = min(tile_span, frame_span - tile_lo);
   const bool dead = B.overflow()[0] != 0;     // the batch is re-run: leave zeros
   for (u32 f = tid; f < n_bins; f += SGTD_VOTES_Q_THREADS) s_hist[f] = 0;
@@ -1703,7 +1708,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
       if (d_first >= cnt) break;
       votes_of_block<true>(Q, B, q, d_first, cnt, tile_lo, n_bins, s_hist, nullptr, s_pre[wid], s_ptr[wid], s_cnt[wid], visits, total);
     }
-    if (lane == 0 && blockIdx.y == 0) {
+    if (lane == 0 && tile_id == 0) {
       atomicAdd(&s_M, total);
       atomicAdd(&s_P, (unsigned long long)visits);
     }
@@ -1711,7 +1716,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
   __syncthreads();
   u32 *votes = B.votes + (size_t)q * frame_span + tile_lo;
   for (u32 f = tid; f < n_bins; f += SGTD_VOTES_Q_THREADS) votes[f] = s_hist[f];
-  if (tid == 0 && blockIdx.y == 0) {      // resolve_undecided_kernel has already subtracted the records it killed
+  if (tid == 0 && tile_id == 0) {      // resolve_undecided_kernel has already subtracted the records it killed
     atomicAdd(&q_M[q], s_M);
     atomicAdd(&q_P[q], s_P);
   }

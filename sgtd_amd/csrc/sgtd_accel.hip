@@ -1188,7 +1188,7 @@ int launch_select(sgtd_engine *e) {
       const size_t tile_bytes = (size_t)tile_span * sizeof(u32);
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_query_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
-      votes_query_kernel<<<dim3(nq, n_tiles), SGTD_VOTES_Q_THREADS, tile_bytes, e->stream>>>(
+      votes_query_kernel<<<nq * (int)n_tiles, SGTD_VOTES_Q_THREADS, tile_bytes, e->stream>>>(
           v.Q, v.B, span, v.T.frame_lo, tile_span, blocks, e->q_M.as<u32>(), e->q_P.as<unsigned long long>());
     } else if (lds_votes) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&votes_kernel<true>),
