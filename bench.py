@@ -78,6 +78,10 @@ def parse():
                     help="N=1: ranks of the job whose rank 0 is measured part by part for `scaling_prediction` (0 = off)")
     ap.add_argument("--skew", choices=["on", "off"], default="on", help="N=1: also measure the skewed, reference-shaped workload (workload_skew)")
     ap.add_argument("--cfg1", choices=["on", "off"], default="on", help="N=1: also run BASELINE configs[0] (graph JSON in, 100-frame map) with its CPU timing")
+    ap.add_argument("--rccl-one", choices=["on", "off"], default="on",
+                    help="N=1: also run the multi-GPU step of ONE rank with its collectives issued through RCCL all the same (a group of one: "
+                         "what a one-GPU box can put on hardware of the exchange), in a child process")
+    ap.add_argument("--rccl-one-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--multi-handle", choices=["auto", "on", "off"], default="auto",
                     help="N>1: also drive all N devices from ONE process through sgtd_create_multi (auto: when N real devices exist)")
     ap.add_argument("--cfg4", choices=["auto", "on", "off"], default="auto",
@@ -482,8 +486,121 @@ def cfg1_leg(args, dev, stream, local_rank):
             "identical_candidates_votes_matchlists": "%d/%d" % (ident, NQ - 10)}
 
 
+def rccl_one_child(args):
+    """the child process of rccl_one_leg: ONE rank, backend nccl (= RCCL), a Map2D whose collectives are issued although its
+    table group and its column have one member (Map2D.force_collective) — communicator set-up, all_gather_into_tensor of the
+    packed candidate table on the side stream behind the engine's export event, the merge kernel behind it, the gather of the
+    groups' result tables: everything of the exchange but the bytes on the links"""
+    result_out = claim_stdout()
+    import torch
+    import torch.distributed as dist
+    from sgtd_amd import synth
+    from sgtd_amd.dist import Map2D
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    F, N, Q = args.frames, args.keypoints, args.queries
+    smap = synth.make_map(F, N, stream=1)
+    sets = [synth.make_queries(smap, Q, stream=1000 + b) for b in range(2)]
+
+    def to_dev(xyz, label):
+        return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
+                torch.from_numpy(np.ascontiguousarray(label).astype(np.int64)).to(dev).to(torch.int32).contiguous())
+    d_map = to_dev(smap.xyz, smap.label)
+    d_sets = [to_dev(q.xyz, q.label) for q in sets]
+    k = max(4, args.steps // 2)
+    out = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "queries_per_step": Q, "map_frames": F, "steps": k,
+           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "forms": {}}
+    for lists in ("all", "winners"):
+        m = Map2D(F, 0, 1, r_t=1, device_id=0, lists=lists, max_frame_n=max(20000, F + 1))
+        m.force_collective = True
+        m.add_shard_frames(*d_map)
+        mg = m.mgr
+
+        def with_x(i):
+            m.query_async(*d_sets[i % 2])
+            with torch.cuda.stream(m.side):
+                m.gather_groups()
+
+        def without_x(i):
+            mg.query_frames(*d_sets[i % 2], fetch=False)
+            if lists == "winners":
+                mg.finish_lists(None)
+
+        def clock(step):
+            for i in range(2):
+                step(i)
+            mg.sync(); torch.cuda.synchronize()
+            s0 = mg.stats()
+            t0 = time.perf_counter()
+            for i in range(k):
+                step(i)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            mg.sync()
+            return 1000.0 * el / k, int(mg.stats()["overflow_launches_total"] - s0["overflow_launches_total"])
+        for i in range(4):          # work buffers and the communicator reach their state
+            with_x(i); mg.sync()
+        torch.cuda.synchronize()
+        # alternately, three times each: the smallest of each form (a shared box's noise is one-sided)
+        t_w, t_o, ovf = [], [], 0
+        for _ in range(3):
+            a, o1 = clock(with_x)
+            b, o2 = clock(without_x)
+            t_w.append(a); t_o.append(b); ovf += o1 + o2
+        # the exchange alone, on its stream (the packed table of the last batch is still there)
+        with_x(0); mg.sync(); torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        with torch.cuda.stream(m.side):
+            ev[0].record()
+        for _ in range(10):
+            m._exchange()
+            with torch.cuda.stream(m.side):
+                m.gather_groups()
+        with torch.cuda.stream(m.side):
+            ev[1].record()
+        m.side.synchronize()
+        # the merged table of a group of one is the engine's own candidate table
+        with_x(0); mg.sync(); torch.cuda.synchronize()
+        r = mg.results()
+        live = np.arange(m.cand_num)[None, :] < np.asarray(r.n_cand)[:, None]
+        same = bool(np.array_equal(m.m_n.cpu().numpy(), r.n_cand) and int(m.m_flags[0].item()) == 0
+                    and np.array_equal(m.m_frame.cpu().numpy()[live], np.asarray(r.cand_frame)[live])
+                    and np.array_equal(m.m_votes.cpu().numpy()[live], np.asarray(r.cand_votes)[live]))
+        out["forms"][lists] = {"ms_per_step_with_exchange": min(t_w), "ms_per_step_without_exchange": min(t_o),
+                               "exchange_exposed_ms": max(0.0, min(t_w) - min(t_o)), "all_measurements_ms": {"with": t_w, "without": t_o},
+                               "exchange_alone_ms_on_its_stream": ev[0].elapsed_time(ev[1]) / 10,
+                               "launches_that_overflowed": ovf, "merged_table_equals_the_engines_own": same,
+                               "packed_table_bytes": int(m.packed.numel() * 4)}
+        mg.close()
+        del m, mg
+    out["note"] = ("one rank over RCCL with every collective of the step issued (group of one: the all-gather copies one table): stream-ordered, "
+                   "nothing blocks the host — what the gloo runs on a one-GPU box cannot show; the bytes on the links are not in it "
+                   "(modelled under scaling_prediction)")
+    dist.destroy_process_group()
+    result_out.write(json.dumps({"metric": "rccl_group_of_one", "result": out}) + "\n")
+    result_out.flush()
+
+
+def rccl_one_leg(args):
+    """runs rccl_one_child in a process of its own (a hung communicator set-up must not cost the measured line): a rendezvous
+    on 127.0.0.1, WORLD_SIZE = 1"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))      # (as the ranks of an N > 1 run set it: main())
+    cmd = [sys.executable, os.path.abspath(__file__), "--rccl-one-child", "--frames", str(args.frames), "--keypoints", str(args.keypoints),
+           "--queries", str(args.queries), "--steps", str(args.steps)]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    line = last_result_line(p.stdout)
+    if p.returncode != 0 or line is None:
+        return {"error": "child exited with %d: %s" % (p.returncode, p.stderr[-600:])}
+    return json.loads(line)["result"]
+
+
 def main():
     args = parse()
+    if args.rccl_one_child:
+        return rccl_one_child(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         # start the ranks BEFORE anything touches a GPU (no exec after GPU init on this pool):
@@ -499,6 +616,11 @@ def main():
             sys.stderr.write(p.stdout)
         sys.exit(p.returncode if (p.returncode or line is not None) else 1)
     world = int(env_world or "1")
+    if world > 1:
+        # main stream, side stream and RCCL's own stream of every engine in flight: with the runtime's default of four
+        # hardware queues some of them share one and the exchange queues up behind the list pass (measured with a group of
+        # one: 0.13 ms of the step exposed at 4 queues, 0.04 at 8 — DESIGN.md §4); read by the HIP runtime when it starts
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     result_out = claim_stdout()
@@ -1390,6 +1512,14 @@ def main():
         except Exception as exc:
             incremental = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
+    # ---- the exchange through RCCL itself, as far as one GPU goes (a child process: one rank, a group of one)
+    rccl_one = None
+    if mode == "single" and args.rccl_one == "on" and args.sweep != "none":
+        try:
+            rccl_one = rccl_one_leg(args)
+        except Exception as exc:
+            rccl_one = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     ranks_seen = 1
     entries_per_rank = [int(st["n_entries"])]
     if world > 1:
@@ -1454,6 +1584,8 @@ def main():
             out["boundary"] = boundary
         if incremental is not None:
             out["incremental_insert"] = incremental
+        if rccl_one is not None:
+            out["rccl_group_of_one"] = rccl_one
         if table_sharded is not None:
             out["table_sharded"] = table_sharded
         if fixed_total is not None:

@@ -23,6 +23,8 @@ writes the lists of the winners only (`lists="winners"`).  Either way sgtd_verif
 only the candidates that survived the merge.
 """
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -217,6 +219,10 @@ class Map2D:
         # stream-ordered and never need it.
         self.defer = False
         self._pending = None
+        # force_collective: issue the collectives even along a grid side of ONE rank (the all-gather of a single table is a
+        # copy).  A one-GPU box can put the RCCL calls, their stream ordering against the engine's export events and the
+        # merge behind them on hardware this way (tests/test_dist_gpu.py); never set in production.
+        self.force_collective = os.environ.get("SGTD_FORCE_COLLECTIVE") == "1"
         if lists == "winners":
             self.mgr.set_deferred_lists(True)
 
@@ -250,7 +256,7 @@ class Map2D:
         self._nq_buf = nq
 
     def _table_collective(self):
-        return self.r_t > 1 and dist.is_initialized()
+        return (self.r_t > 1 or self.force_collective) and dist.is_initialized()
 
     # ---- the step ---------------------------------------------------------------------------
     def flush(self):
@@ -327,7 +333,7 @@ class Map2D:
 
     def gather_groups(self):
         """the merged tables of ALL query groups (group-major): (frames, votes) [R_q * nq, cn] on every rank"""
-        if self.r_q == 1 or not dist.is_initialized():
+        if (self.r_q == 1 and not self.force_collective) or not dist.is_initialized():
             return self.m_frame, self.m_votes
         packed = torch.stack([self.m_frame, self.m_votes]).contiguous()
         out = torch.empty((self.r_q * 2,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)

@@ -71,6 +71,21 @@ def main():
             traceback.print_exc()
         if single is not None:
             single.close()
+    if os.environ.get("SGTD_FORCE_COLLECTIVE") == "1" and backend == "nccl":
+        # what one call of the step's all-gather costs inside RCCL when nothing has to travel (a group of one): the packed
+        # table of a 2048-query batch, event-timed on the side stream
+        ints = 2 * 2048 * sm.cand_num + 4
+        a, b = torch.zeros(ints, dtype=torch.int32, device=dev), torch.empty(world * ints, dtype=torch.int32, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        with torch.cuda.stream(sm.side):
+            for _ in range(5):
+                dist.all_gather_into_tensor(b, a)
+            ev[0].record()
+            for _ in range(50):
+                dist.all_gather_into_tensor(b, a)
+            ev[1].record()
+        sm.side.synchronize()
+        print("rccl all_gather_into_tensor, group of %d, %d KB: %.1f us per call on the stream" % (world, ints * 4 // 1024, ev[0].elapsed_time(ev[1]) * 1000 / 50))
     flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
     dist.broadcast(flag, src=0)
     dist.barrier()

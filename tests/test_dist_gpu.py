@@ -97,10 +97,10 @@ def test_four_rank_two_by_two_grid():
     assert g["recall"]["top1_pose_within_5m"] > 0.9
 
 
-def _search_loop(n, r_t, lists, extra_env=None):
+def _search_loop(n, r_t, lists, extra_env=None, backend=None):
     import socket
     n_dev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip() or 0)
-    backend = "nccl" if n_dev >= n else "gloo"
+    backend = backend or ("nccl" if n_dev >= n else "gloo")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGTD_TEST_BACKEND=backend, SGTD_TEST_RT=str(r_t), SGTD_TEST_LISTS=lists, **(extra_env or {}))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
@@ -131,3 +131,13 @@ def test_a_shard_whose_batch_outgrows_its_buffers_is_repaired_by_the_whole_group
     tables, every rank of the group learns it from the same all-gather, re-runs and exchanges again (Map2D.query) —
     and the result is still the single table's"""
     _search_loop(2, 2, lists, {"SGTD_REC_CAP": "4096", "SGTD_TEST_EXPECT_REPAIR": "1"})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lists", ["all", "winners"])
+def test_rccl_calls_on_hardware_with_a_group_of_one(lists):
+    """What a one-GPU box can put through RCCL itself: ONE rank, backend nccl, every collective of the step issued all the
+    same (SGTD_FORCE_COLLECTIVE: the all-gather of a single table is a copy inside RCCL) — the communicator, the dtypes
+    and shapes handed to all_gather_into_tensor, its stream ordering against the engine's export events on the side
+    stream, the merge kernel and the verification gather behind it; the result must be the single table's."""
+    _search_loop(1, 1, lists, {"SGTD_FORCE_COLLECTIVE": "1"}, backend="nccl")
