@@ -68,6 +68,21 @@ class OrcAudit(C.Structure):
         return out
 
 
+class OrcVerifyAudit(C.Structure):
+    """orc_verify_audit of sgtd_oracle.h (tools/parity_audit.py --verify)"""
+    _fields_ = [("candidates", C.c_int64), ("hypotheses", C.c_int64), ("pair_tests", C.c_int64), ("vertex_tests", C.c_int64),
+                ("vertex_flips", C.c_int64), ("pair_flips", C.c_int64), ("vote_list_diffs", C.c_int64),
+                ("best_index_diffs", C.c_int64), ("score_diffs", C.c_int64), ("inlier_set_diffs", C.c_int64), ("near_calls", C.c_int64),
+                ("min_margin", C.c_double), ("max_norm_diff", C.c_double), ("max_rot_diff", C.c_double), ("max_t_diff", C.c_double)]
+
+    def __init__(self):
+        super().__init__()
+        self.min_margin = float("inf")
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 def build_library(force=False):
     """compile oracle/libsgtd_oracle.so with the committed Makefile"""
     if force or not os.path.exists(_LIB_PATH) or (
@@ -226,6 +241,39 @@ class OracleManager:
         L.orc_audit_select.argtypes = [C.c_void_p, C.POINTER(OrcAudit)]
         L.orc_audit_select.restype = None
         L.orc_audit_select(self._h, C.byref(acc))
+
+    def verify_hyp_inputs(self, cand):
+        """per hypothesis of candidate `cand` of the last select: covariance matrix (:558), query centre, table centre"""
+        L = lib()
+        L.orc_verify_hyp_inputs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_verify_hyp_inputs.restype = C.c_int
+        n = L.orc_verify_hyp_inputs(self._h, cand, None, None, None)
+        cov, qc, ec = np.zeros((n, 3, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+        if n:
+            L.orc_verify_hyp_inputs(self._h, cand, _p(cov), _p(qc), _p(ec))
+        return cov, qc, ec
+
+    def verify_hyp_solutions(self, cand):
+        """the restatement's own hypotheses of candidate `cand`: [use_size, 12] (R row-major, t)"""
+        L = lib()
+        L.orc_verify_hyp_inputs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_verify_hyp_inputs.restype = C.c_int
+        n = L.orc_verify_hyp_inputs(self._h, cand, None, None, None)
+        rt = np.zeros((n, 12))
+        L.orc_verify_hyp_solutions.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_verify_hyp_solutions.restype = None
+        if n:
+            L.orc_verify_hyp_solutions(self._h, cand, _p(rt))
+        return rt
+
+    def audit_verify(self, cand, other_rt, acc):
+        """candidate_verify of candidate `cand` with this restatement's hypotheses AND `other_rt` ([n_hyp, 12]: R row-major, t)
+        side by side (accumulates into the OrcVerifyAudit `acc`)"""
+        other_rt = np.ascontiguousarray(other_rt, dtype=np.float64).reshape(-1, 12)
+        L = lib()
+        L.orc_audit_verify.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(OrcVerifyAudit)]
+        L.orc_audit_verify.restype = None
+        L.orc_audit_verify(self._h, cand, _p(other_rt), other_rt.shape[0], C.byref(acc))
 
     def add_frames(self, xyz, label):
         """xyz (F, N, 3), label (F, N): what F build + add_last pairs give (builds on all host threads)"""

@@ -31,6 +31,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <array>
 #include <bitset>
 #include <chrono>
 #include <cmath>
@@ -933,3 +934,139 @@ void orc_audit_select(orc_manager *mg, orc_audit *A) {
 }
 
 }  // extern "C"
+
+// ---- candidate_verify with two solutions of every hypothesis side by side (sgtd_oracle.h: orc_verify_audit)
+namespace {
+struct CandPairs {
+  std::vector<std::pair<const Desc *, const Desc *>> ml;
+  int skip_len = 1, use_size = 0;
+};
+CandPairs pairs_of(orc_manager *m, int cand) {
+  CandPairs c;
+  const int64_t lo = m->cand_off[cand], hi = m->cand_off[cand + 1];
+  const int64_t n = hi - lo;
+  c.ml.resize(n);
+  for (int64_t k = 0; k < n; k++) {
+    const auto &loc = m->entry_loc[m->cm_e[lo + k]];
+    c.ml[k] = {&m->last_query[m->cm_q[lo + k]], &m->data_base_.at(loc.first)[loc.second]};
+  }
+  c.skip_len = (int)(n / 50) + 1;
+  c.use_size = (int)(n / c.skip_len);
+  return c;
+}
+// the three vertex distances of a pair under (rot, t), as pair_inlier computes them (no early exit)
+inline void vertex_dists(const Desc &qa, const Desc &db, const double t[3], const M3 &rot, double d[3]) {
+  const V3 *qs[3] = {&qa.vertex_A_, &qa.vertex_B_, &qa.vertex_C_};
+  const V3 *ds[3] = {&db.vertex_A_, &db.vertex_B_, &db.vertex_C_};
+  for (int v = 0; v < 3; v++) {
+    V3 p;
+    for (int r = 0; r < 3; r++)
+      p[r] = (rot.m[r][0] * (*qs[v])[0] + rot.m[r][1] * (*qs[v])[1] + rot.m[r][2] * (*qs[v])[2]) + t[r];
+    d[v] = norm3(sub(p, *ds[v]));
+  }
+}
+}  // namespace
+
+int orc_verify_hyp_inputs(orc_manager *m, int cand, double *cov_out, double *qc, double *ec) {
+  const CandPairs c = pairs_of(m, cand);
+  if (!cov_out) return c.use_size;
+  for (int i = 0; i < c.use_size; i++) {
+    const Desc &qa = *c.ml[(size_t)i * c.skip_len].first, &db = *c.ml[(size_t)i * c.skip_len].second;
+    M3 src{}, ref{};
+    const V3 *qs[3] = {&qa.vertex_A_, &qa.vertex_B_, &qa.vertex_C_};
+    const V3 *ds[3] = {&db.vertex_A_, &db.vertex_B_, &db.vertex_C_};
+    for (int cc = 0; cc < 3; cc++)
+      for (int r = 0; r < 3; r++) {
+        src.m[r][cc] = (*qs[cc])[r] - qa.center_[r];
+        ref.m[r][cc] = (*ds[cc])[r] - db.center_[r];
+      }
+    const M3 cov = mul(src, transpose(ref));
+    for (int r = 0; r < 3; r++) {
+      for (int cc = 0; cc < 3; cc++) cov_out[(size_t)i * 9 + r * 3 + cc] = cov.m[r][cc];
+      qc[(size_t)i * 3 + r] = qa.center_[r];
+      ec[(size_t)i * 3 + r] = db.center_[r];
+    }
+  }
+  return c.use_size;
+}
+
+void orc_verify_hyp_solutions(orc_manager *m, int cand, double *rt) {
+  const CandPairs c = pairs_of(m, cand);
+  for (int i = 0; i < c.use_size; i++) {
+    double t[3];
+    M3 rot;
+    solve_triangle(*c.ml[(size_t)i * c.skip_len].first, *c.ml[(size_t)i * c.skip_len].second, t, rot);
+    for (int r = 0; r < 3; r++) {
+      for (int cc = 0; cc < 3; cc++) rt[(size_t)i * 12 + r * 3 + cc] = rot.m[r][cc];
+      rt[(size_t)i * 12 + 9 + r] = t[r];
+    }
+  }
+}
+
+void orc_audit_verify(orc_manager *m, int cand, const double *other_rt, int n_hyp, orc_verify_audit *A) {
+  const CandPairs c = pairs_of(m, cand);
+  if (n_hyp != c.use_size) return;
+  const int64_t n = (int64_t)c.ml.size();
+  const double thr = 3.0;
+  A->candidates++;
+  std::vector<int> votes_a(c.use_size, 0), votes_b(c.use_size, 0);
+  std::vector<M3> ra(c.use_size), rb(c.use_size);
+  std::vector<std::array<double, 3>> ta(c.use_size), tb(c.use_size);
+  for (int i = 0; i < c.use_size; i++) {
+    solve_triangle(*c.ml[(size_t)i * c.skip_len].first, *c.ml[(size_t)i * c.skip_len].second, ta[i].data(), ra[i]);
+    for (int r = 0; r < 3; r++) {
+      for (int cc = 0; cc < 3; cc++) {
+        rb[i].m[r][cc] = other_rt[(size_t)i * 12 + r * 3 + cc];
+        A->max_rot_diff = std::max(A->max_rot_diff, std::fabs(rb[i].m[r][cc] - ra[i].m[r][cc]));
+      }
+      tb[i][r] = other_rt[(size_t)i * 12 + 9 + r];
+      A->max_t_diff = std::max(A->max_t_diff, std::fabs(tb[i][r] - ta[i][r]));
+    }
+    A->hypotheses++;
+    for (int64_t j = 0; j < n; j++) {
+      double da[3], db_[3];
+      vertex_dists(*c.ml[j].first, *c.ml[j].second, ta[i].data(), ra[i], da);
+      vertex_dists(*c.ml[j].first, *c.ml[j].second, tb[i].data(), rb[i], db_);
+      bool in_a = true, in_b = true;
+      for (int v = 0; v < 3; v++) {
+        const bool a = da[v] < thr, b = db_[v] < thr;
+        in_a = in_a && a; in_b = in_b && b;
+        A->vertex_tests++;
+        if (a != b) A->vertex_flips++;
+        const double mg = std::fabs(da[v] - thr);
+        if (mg <= 1e-9) A->near_calls++;
+        if (mg < A->min_margin) A->min_margin = mg;
+        A->max_norm_diff = std::max(A->max_norm_diff, std::fabs(da[v] - db_[v]));
+      }
+      A->pair_tests++;
+      if (in_a != in_b) A->pair_flips++;
+      votes_a[i] += in_a ? 1 : 0;
+      votes_b[i] += in_b ? 1 : 0;
+    }
+    if (votes_a[i] != votes_b[i]) A->vote_list_diffs++;
+  }
+  auto best_of = [&](const std::vector<int> &vl, int &idx, int &mx) {
+    idx = 0; mx = 0;
+    for (int i = 0; i < c.use_size; i++)
+      if (mx < vl[i]) { idx = i; mx = vl[i]; }
+  };
+  int ia, ma, ib, mb;
+  best_of(votes_a, ia, ma);
+  best_of(votes_b, ib, mb);
+  if (ia != ib) A->best_index_diffs++;
+  // the score (:539) and the set of kept pairs (:516-539) under each solution's own best hypothesis
+  auto kept = [&](int idx, int mx, const M3 &rot, const double *t, std::vector<char> &flags) {
+    flags.assign((size_t)n, 0);
+    if (mx < 4) return -1;
+    int ns = 0;
+    for (int64_t j = 0; j < n; j++)
+      if (pair_inlier(*c.ml[j].first, *c.ml[j].second, t, rot, thr)) { flags[(size_t)j] = 1; ns++; }
+    (void)idx;
+    return ns;
+  };
+  std::vector<char> fa, fb;
+  const int sa = c.use_size ? kept(ia, ma, ra[ia], ta[ia].data(), fa) : -1;
+  const int sb = c.use_size ? kept(ib, mb, rb[ib], tb[ib].data(), fb) : -1;
+  if (sa != sb) A->score_diffs++;
+  if (fa != fb) A->inlier_set_diffs++;
+}

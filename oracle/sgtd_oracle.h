@@ -167,6 +167,28 @@ void orc_audit_build(orc_manager *m, const float *xyz, const uint32_t *label, in
 /* audits candidate_selector's loop for the last built frame against the table (results are not kept) */
 void orc_audit_select(orc_manager *m, orc_audit *acc);
 
+/* ---- the same for candidate_verify (STDesc.cpp:462-547): Eigen::JacobiSVD is the third inferred piece (this restatement
+ * solves the 3x3 problem with a one-sided Jacobi SVD).  The caller hands in the hypotheses (R row-major, t: 12 doubles each)
+ * another SVD gives for the same covariance matrices — tools/parity_audit.py --verify uses LAPACK's through numpy — and
+ * every decision of the candidate's verification is evaluated with both. */
+typedef struct orc_verify_audit {
+  int64_t candidates, hypotheses, pair_tests;   /* pair_tests = (pair, hypothesis) combinations (:488-505)              */
+  int64_t vertex_tests;                         /* vertex distance tests evaluated (all three of every combination)     */
+  int64_t vertex_flips, pair_flips;             /* ... whose outcome differs with the other SVD's (R, t)                */
+  int64_t vote_list_diffs;                      /* hypotheses whose vote count differs                                  */
+  int64_t best_index_diffs, score_diffs, inlier_set_diffs;   /* candidates whose :507-514 choice / :539 score / :516-539 set differs */
+  int64_t near_calls;                           /* vertex tests with | ||d|| - 3 | <= 1e-9                              */
+  double min_margin;                            /* min | ||d|| - 3 | over all vertex tests                             */
+  double max_norm_diff;                         /* max | ||d||_this - ||d||_other |                                    */
+  double max_rot_diff, max_t_diff;              /* largest entry difference between the two solutions                  */
+} orc_verify_audit;
+/* use_size of candidate `cand` of the last select (0: none) and, if cov != NULL, per hypothesis the covariance matrix
+ * (:558, row-major), the query centre and the table centre */
+int orc_verify_hyp_inputs(orc_manager *m, int cand, double *cov, double *qc, double *ec);
+/* the restatement's own hypotheses of the candidate, [use_size][12] (R row-major, t) */
+void orc_verify_hyp_solutions(orc_manager *m, int cand, double *rt);
+void orc_audit_verify(orc_manager *m, int cand, const double *other_rt, int n_hyp, orc_verify_audit *acc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,3 +242,41 @@ def test_parity_audit_counts_no_flipped_decision_on_small_workloads(tmp_path):
     assert t["thr_ulp_flips_plus_minus"] == [0, 0] and t["near_calls"] == 0 and t["knn_tied_points"] == 0
     assert t["side_value_diffs"][0] > 0 and t["side_value_diffs"][1] == 0        # squares of f32 differences are exact: contraction alone changes nothing
     assert t["min_margin_ulps"] > 1e3
+
+
+def test_verify_audit_counts_what_it_should():
+    """orc_audit_verify (tools/parity_audit.py --verify): candidate_verify with two solutions of every hypothesis side by
+    side.  With the restatement's own hypotheses as the "other" ones nothing differs and its score is orc_verify's; with
+    LAPACK's SVD no decision differs either (the hypotheses do, in their last bits); with a hypothesis pushed 5 cm every
+    counter moves."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from parity_audit import other_svd_hypotheses
+    from oracle.oracle import OrcVerifyAudit
+    from sgtd_amd import synth
+    m = synth.make_map(120, 200, stream=2)
+    q = synth.make_queries(m, 1, stream=2)
+    o = OracleManager(num_threads=2)
+    o.add_frames(m.xyz, m.label)
+    o.build(q.xyz[0], q.label[0], export=False)
+    sel = o.select()
+    assert len(sel["cand_frame"]) >= 3
+    same, lapack, pushed = OrcVerifyAudit(), OrcVerifyAudit(), OrcVerifyAudit()
+    for c in range(3):
+        own = o.verify_hyp_solutions(c)
+        cov, qc, ec = o.verify_hyp_inputs(c)
+        assert own.shape[0] == cov.shape[0] > 0
+        o.audit_verify(c, own, same)
+        rt, ratio = other_svd_hypotheses(cov, qc, ec)
+        assert np.abs(rt - own).max() < 1e-8 and (ratio > 0).all()
+        o.audit_verify(c, rt, lapack)
+        far = own.copy()
+        far[:, 9:] += 0.05
+        o.audit_verify(c, far, pushed)
+    for a in (same, lapack):
+        assert a.candidates == 3 and a.pair_tests > 1e4 and a.vertex_tests == 3 * a.pair_tests
+        assert a.vertex_flips == a.pair_flips == a.vote_list_diffs == a.best_index_diffs == a.score_diffs == a.inlier_set_diffs == 0
+    assert same.max_norm_diff == 0.0 and same.max_rot_diff == 0.0 and 0 < lapack.max_rot_diff < 1e-8
+    assert pushed.vertex_flips > 0 and pushed.pair_flips > 0 and pushed.vote_list_diffs > 0 and pushed.max_t_diff > 0.049

@@ -70,6 +70,91 @@ def audit_skewed(name, n_frames, n_queries, build_frames, threads=8):
     return d
 
 
+def other_svd_hypotheses(cov, qc, ec):
+    """triangle_solver (STDesc.cpp:549-571) with ANOTHER SVD of the same covariance matrices: LAPACK's (numpy.linalg.svd,
+    gesdd) instead of the restatement's one-sided Jacobi.  Returns [n, 12] (R row-major, t) and sigma_2 / sigma_1."""
+    n = cov.shape[0]
+    out = np.zeros((n, 12))
+    ratio = np.ones(n)
+    for i in range(n):
+        U, S, Vt = np.linalg.svd(cov[i])
+        V = Vt.T
+        R = V @ U.T
+        if np.linalg.det(R) < 0:
+            R = V @ np.diag([1.0, 1.0, -1.0]) @ U.T
+        out[i, :9] = R.reshape(9)
+        out[i, 9:] = -(R @ qc[i]) + ec[i]
+        ratio[i] = S[1] / S[0] if S[0] > 0 else 0.0
+    return out, ratio
+
+
+def audit_verify(name, n_frames, n_kp, n_queries, stream, threads=8, skewed=False):
+    """candidate_verify of every candidate of n_queries query frames with both SVDs' hypotheses (orc_audit_verify)"""
+    from oracle.oracle import OracleManager, OrcVerifyAudit
+    from sgtd_amd import synth
+    t0 = time.time()
+    o = OracleManager(num_threads=threads, max_frame_n=max(20000, n_frames + 1))
+    if skewed:
+        smap, world = synth.make_skewed_map(n_frames, stream=31)
+        qs = synth.make_skewed_queries(world, n_queries, stream=3100)
+        for f in range(n_frames):
+            x, l = smap.frame(f)
+            o.build(x, l, export=False)
+            o.add_last()
+        frames = [qs.frame(q) for q in range(n_queries)]
+    else:
+        smap = synth.make_map(n_frames, n_kp, stream=stream)
+        qs = synth.make_queries(smap, n_queries, stream=stream)
+        for f0 in range(0, n_frames, 500):
+            o.add_frames(smap.xyz[f0:min(n_frames, f0 + 500)], smap.label[f0:min(n_frames, f0 + 500)])
+        frames = [(qs.xyz[q], qs.label[q]) for q in range(n_queries)]
+    o.set_current_frame_id(n_frames)
+    acc = OrcVerifyAudit()
+    flattest = 1.0
+    for x, l in frames:
+        o.build(x, l, export=False)
+        sel = o.select()
+        for c in range(len(sel["cand_frame"])):
+            cov, qc, ec = o.verify_hyp_inputs(c)
+            if cov.shape[0] == 0:
+                continue
+            rt, ratio = other_svd_hypotheses(cov, qc, ec)
+            flattest = min(flattest, float(ratio.min()))
+            o.audit_verify(c, rt, acc)
+    d = acc.as_dict()
+    d.update(workload=name, map_frames=n_frames, queries=n_queries, flattest_triangle_sigma2_over_sigma1=flattest,
+             seconds=round(time.time() - t0, 1))
+    return d
+
+
+def main_verify(args):
+    T = args.threads
+    if args.quick:
+        plan = [("cfg2-like (quick)", lambda n: audit_verify(n, 120, 200, 4, 2, threads=T))]
+    else:
+        plan = [("cfg2: 1k-frame map", lambda n: audit_verify(n, 1000, 200, 48, 2, threads=T)),
+                ("north star: 10k-frame map", lambda n: audit_verify(n, 10000, 200, 48, 1, threads=T)),
+                ("skewed workload, 2 500 frames", lambda n: audit_verify(n, 2500, 0, 24, 0, threads=T, skewed=True))]
+    runs = []
+    for name, fn in plan:
+        runs.append(fn(name))
+        print("done:", name, runs[-1]["seconds"], "s", flush=True)
+    tot = {k: sum(r[k] for r in runs) for k in ("candidates", "hypotheses", "pair_tests", "vertex_tests", "vertex_flips", "pair_flips",
+                                                "vote_list_diffs", "best_index_diffs", "score_diffs", "inlier_set_diffs", "near_calls")}
+    tot["min_margin"] = min(r["min_margin"] for r in runs)
+    for k in ("max_norm_diff", "max_rot_diff", "max_t_diff"):
+        tot[k] = max(r[k] for r in runs)
+    tot["flattest_triangle_sigma2_over_sigma1"] = min(r["flattest_triangle_sigma2_over_sigma1"] for r in runs)
+    out = {"what": "candidate_verify (STDesc.cpp:462-547) of every candidate with the hypotheses of two SVDs side by side: the restatement's "
+                   "one-sided Jacobi (what the GPU path computes, bit for bit) and LAPACK's (numpy.linalg.svd) — a stand-in for the "
+                   "Eigen::JacobiSVD of the real binary, which is not in this image; decisions = vertex tests ||R v + t - w|| < 3 (:488-505), "
+                   "vote counts, the first maximum (:507-514), the score (:539), the kept pairs (:516-539)",
+           "totals": tot, "runs": runs}
+    with open(args.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(tot, indent=1))
+
+
 def tie_rate(n_frames, n_kp, sigma):
     """how often the generator's tie filter fires: frames of raw draws (no regeneration) with an exact f32 tie among the
     squared distances of some point's K + 1 nearest"""
@@ -88,7 +173,12 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity_audit.json"))
     ap.add_argument("--quick", action="store_true", help="small sizes (the CPU test)")
     ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
+    ap.add_argument("--verify", action="store_true", help="audit candidate_verify against another SVD instead (default --out: ..._verify.json)")
     args = ap.parse_args()
+    if args.verify:
+        if args.out.endswith("r05_parity_audit.json"):
+            args.out = args.out.replace("r05_parity_audit.json", "r05_parity_audit_verify.json")
+        return main_verify(args)
     T = args.threads
     if args.quick:
         plan = [("cfg2-like (quick)", lambda n: audit_uniform(n, 120, 200, 6, 40, 2, threads=T)),
