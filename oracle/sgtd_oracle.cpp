@@ -1055,18 +1055,17 @@ void orc_audit_verify(orc_manager *m, int cand, const double *other_rt, int n_hy
   best_of(votes_b, ib, mb);
   if (ia != ib) A->best_index_diffs++;
   // the score (:539) and the set of kept pairs (:516-539) under each solution's own best hypothesis
-  auto kept = [&](int idx, int mx, const M3 &rot, const double *t, std::vector<char> &flags) {
+  auto kept = [&](int mx, const M3 &rot, const double *t, std::vector<char> &flags) {
     flags.assign((size_t)n, 0);
-    if (mx < 4) return -1;
+    if (mx < 4) return -1;  // :515
     int ns = 0;
     for (int64_t j = 0; j < n; j++)
       if (pair_inlier(*c.ml[j].first, *c.ml[j].second, t, rot, thr)) { flags[(size_t)j] = 1; ns++; }
-    (void)idx;
     return ns;
   };
   std::vector<char> fa, fb;
-  const int sa = c.use_size ? kept(ia, ma, ra[ia], ta[ia].data(), fa) : -1;
-  const int sb = c.use_size ? kept(ib, mb, rb[ib], tb[ib].data(), fb) : -1;
+  const int sa = c.use_size ? kept(ma, ra[ia], ta[ia].data(), fa) : -1;
+  const int sb = c.use_size ? kept(mb, rb[ib], tb[ib].data(), fb) : -1;
   if (sa != sb) A->score_diffs++;
   if (fa != fb) A->inlier_set_diffs++;
 }
