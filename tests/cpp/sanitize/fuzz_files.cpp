@@ -141,7 +141,7 @@ int main(int argc, char **argv) {
   const int n_bin = argc > 2 ? atoi(argv[2]) : 3000;
   std::string dir = argc > 3 ? argv[3] : "/tmp/sgtd_fuzz_files";
   mkdir(dir.c_str(), 0755);
-  Rng r{0x1234567ull};
+  Rng r{argc > 4 ? strtoull(argv[4], nullptr, 0) : 0x1234567ull};      // (a fourth argument: another stream of mutations)
   double sink = 0;
   if (hand_cases()) return 1;
 
