@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Every query frame of ONE full benchmark batch against the CPU restatement (diagnostic; uses the oracle: test
+infrastructure): the north-star map (F frames, 200 keypoints), Q query frames through sgtd_query_frames in one call, then
+per query the oracle's candidate_selector — candidate frames, votes, and every candidate's ordered match list
+(query descriptor index, table entry id).  bench.py's cpu_baseline leg does this for 200 queries per run; this is the
+whole batch.      python tools/full_batch_parity.py [F] [Q] [out.json]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from oracle.oracle import OracleManager
+    from sgtd_amd import synth
+    from sgtd_amd.manager import STDescManager
+    from sgtd_amd.synth import effective_cpus
+    F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    Q = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+    out_path = sys.argv[3] if len(sys.argv) > 3 else None
+    stream = int(os.environ.get("FULL_PARITY_STREAM", "1000"))       # bench.py's first rotating batch
+    smap = synth.make_map(F, 200, stream=1)
+    qs = synth.make_queries(smap, Q, stream=stream)
+    dev = torch.device("cuda", 0)
+    g = STDescManager(device_id=0, max_frame_n=max(20000, F + 1))
+    g.add_frames(torch.from_numpy(smap.xyz).to(dev), torch.from_numpy(smap.label.astype(np.int64)).to(dev).to(torch.int32))
+    g.finalize()
+    res = g.query_frames(qs.xyz, qs.label)
+    st = g.stats()
+    o = OracleManager(num_threads=effective_cpus(), max_frame_n=max(20000, F + 1))
+    t0 = time.time()
+    for f0 in range(0, F, 500):
+        o.add_frames(smap.xyz[f0:min(F, f0 + 500)], smap.label[f0:min(F, f0 + 500)])
+    t_map = time.time() - t0
+    same_c = same_l = 0
+    pairs = P = M = 0
+    bad = []
+    t0 = time.time()
+    for q in range(Q):
+        o.build(qs.xyz[q], qs.label[q], export=False)
+        r = o.select()
+        c = o.counters()
+        P += c["P"]; M += c["M"]
+        nc = int(res.n_cand[q])
+        ok_c = nc == len(r["cand_frame"]) and np.array_equal(res.cand_frame[q, :nc], r["cand_frame"]) and np.array_equal(res.cand_votes[q, :nc], r["cand_votes"])
+        ok_l = False
+        if ok_c:
+            qi, de = g.result_pairs(q, res)
+            ok_l = np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
+            pairs += len(qi)
+        same_c += int(ok_c); same_l += int(ok_l)
+        if not (ok_c and ok_l) and len(bad) < 10:
+            bad.append(q)
+        if (q + 1) % 256 == 0:
+            print("%d / %d compared, %d identical, %.0f s" % (q + 1, Q, same_l, time.time() - t0), flush=True)
+    out = {"map_frames": F, "queries_in_the_batch": Q, "query_stream": stream,
+           "identical_candidates_and_votes": same_c, "identical_ordered_match_lists": same_l, "first_differing_queries": bad,
+           "match_list_pairs_compared": int(pairs), "P_visits_oracle": int(P), "M_matches_oracle": int(M),
+           "P_visits_gpu_counter": int(st["last_P"]), "M_matches_gpu_counter": int(st["last_M"]),
+           "oracle_threads": effective_cpus(), "oracle_map_build_s": round(t_map, 1), "oracle_seconds": round(time.time() - t0, 1),
+           "select_form": int(st["select_form"])}
+    print(json.dumps(out))
+    if out_path:
+        with open(out_path, "w") as fh:
+            json.dump(out, fh, indent=1)
+    g.close()
+    sys.exit(0 if same_l == Q and int(st["last_P"]) == P and int(st["last_M"]) == M else 1)
+
+
+if __name__ == "__main__":
+    main()
