@@ -25,25 +25,42 @@ def main():
     Q = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
     stream = int(os.environ.get("FULL_PARITY_STREAM", "1000"))       # bench.py's first rotating batch
-    smap = synth.make_map(F, 200, stream=1)
-    qs = synth.make_queries(smap, Q, stream=stream)
+    skew = os.environ.get("FULL_PARITY_SKEW") == "1"       # bench.py's workload_skew leg: Zipf labels, 50-400 keypoints, clusters
     dev = torch.device("cuda", 0)
     g = STDescManager(device_id=0, max_frame_n=max(20000, F + 1))
-    g.add_frames(torch.from_numpy(smap.xyz).to(dev), torch.from_numpy(smap.label.astype(np.int64)).to(dev).to(torch.int32))
-    g.finalize()
-    res = g.query_frames(qs.xyz, qs.label)
-    st = g.stats()
     o = OracleManager(num_threads=effective_cpus(), max_frame_n=max(20000, F + 1))
-    t0 = time.time()
-    for f0 in range(0, F, 500):
-        o.add_frames(smap.xyz[f0:min(F, f0 + 500)], smap.label[f0:min(F, f0 + 500)])
+    if skew:
+        smap, world = synth.make_skewed_map(F, stream=31)
+        qs = synth.make_skewed_queries(world, Q, stream=3100)
+        g.add_frames(smap.xyz, smap.label, kp_off=smap.kp_off)
+        g.finalize()
+        res = g.query_frames(qs.xyz, qs.label, kp_off=qs.kp_off)
+        t0 = time.time()
+        for f in range(F):
+            x, l = smap.frame(f)
+            o.build(x, l, export=False)
+            o.add_last()
+        frame_of = qs.frame
+    else:
+        smap = synth.make_map(F, 200, stream=1)
+        qs = synth.make_queries(smap, Q, stream=stream)
+        g.add_frames(torch.from_numpy(smap.xyz).to(dev), torch.from_numpy(smap.label.astype(np.int64)).to(dev).to(torch.int32))
+        g.finalize()
+        res = g.query_frames(qs.xyz, qs.label)
+        t0 = time.time()
+        for f0 in range(0, F, 500):
+            o.add_frames(smap.xyz[f0:min(F, f0 + 500)], smap.label[f0:min(F, f0 + 500)])
+
+        def frame_of(q):
+            return qs.xyz[q], qs.label[q]
     t_map = time.time() - t0
+    st = g.stats()
     same_c = same_l = 0
     pairs = P = M = 0
     bad = []
     t0 = time.time()
     for q in range(Q):
-        o.build(qs.xyz[q], qs.label[q], export=False)
+        o.build(*frame_of(q), export=False)
         r = o.select()
         c = o.counters()
         P += c["P"]; M += c["M"]
@@ -57,9 +74,10 @@ def main():
         same_c += int(ok_c); same_l += int(ok_l)
         if not (ok_c and ok_l) and len(bad) < 10:
             bad.append(q)
-        if (q + 1) % 256 == 0:
+        if (q + 1) % (32 if skew else 256) == 0:
             print("%d / %d compared, %d identical, %.0f s" % (q + 1, Q, same_l, time.time() - t0), flush=True)
-    out = {"map_frames": F, "queries_in_the_batch": Q, "query_stream": stream,
+    out = {"workload": "skewed (Zipf labels, 50-400 keypoints, clusters)" if skew else "uniform, 200 keypoints per frame",
+           "map_frames": F, "queries_in_the_batch": Q, "query_stream": 3100 if skew else stream,
            "identical_candidates_and_votes": same_c, "identical_ordered_match_lists": same_l, "first_differing_queries": bad,
            "match_list_pairs_compared": int(pairs), "P_visits_oracle": int(P), "M_matches_oracle": int(M),
            "P_visits_gpu_counter": int(st["last_P"]), "M_matches_gpu_counter": int(st["last_M"]),
