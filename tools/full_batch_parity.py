@@ -55,6 +55,11 @@ def main():
             return qs.xyz[q], qs.label[q]
     t_map = time.time() - t0
     st = g.stats()
+    verify = os.environ.get("FULL_PARITY_VERIFY") == "1"   # also candidate_verify + SearchLoop's choice of every query (STDesc.cpp:462-571, :105-146)
+    v_cands = v_same = v_accepted = v_inliers = choice_same = 0
+    if verify:
+        g.verify()
+        bc, bf, bs = g.search_loop()
     same_c = same_l = 0
     pairs = P = M = 0
     bad = []
@@ -72,6 +77,25 @@ def main():
             ok_l = np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
             pairs += len(qi)
         same_c += int(ok_c); same_l += int(ok_l)
+        if verify and ok_c and ok_l:
+            score, rot, t = g.result_verify(q)
+            best_s, best_k = 0.0, -1
+            for k in range(nc):
+                n_pairs = int(res.pair_off[q, k + 1] - res.pair_off[q, k])
+                o_score, o_t, o_rot, o_idx = o.verify(k, n_pairs)
+                ok = score[k] == o_score
+                if ok and o_score >= 0:
+                    ok = np.array_equal(t[k], o_t) and np.array_equal(rot[k], o_rot) and np.array_equal(g.result_inliers(q, k, n_pairs), o_idx)
+                    v_accepted += 1
+                    v_inliers += len(o_idx)
+                v_cands += 1
+                v_same += int(bool(ok))
+                if o_score > best_s:
+                    best_s, best_k = o_score, k
+            thr = g.icp_threshold_
+            want = (best_k, int(r["cand_frame"][best_k]), best_s) if best_s > thr else (-1, -1, 0.0)
+            choice_same += int((int(bc[q]), int(bf[q]), float(bs[q])) == want)
+            ok_l = ok_l and v_same == v_cands
         if not (ok_c and ok_l) and len(bad) < 10:
             bad.append(q)
         if (q + 1) % (32 if skew else 256) == 0:
@@ -83,12 +107,15 @@ def main():
            "P_visits_gpu_counter": int(st["last_P"]), "M_matches_gpu_counter": int(st["last_M"]),
            "oracle_threads": effective_cpus(), "oracle_map_build_s": round(t_map, 1), "oracle_seconds": round(time.time() - t0, 1),
            "select_form": int(st["select_form"])}
+    if verify:
+        out.update(candidates_verified=v_cands, identical_score_pose_and_inlier_set=v_same, candidates_accepted=v_accepted,
+                   inlier_pairs_compared=int(v_inliers), identical_search_loop_choice=choice_same)
     print(json.dumps(out))
     if out_path:
         with open(out_path, "w") as fh:
             json.dump(out, fh, indent=1)
     g.close()
-    sys.exit(0 if same_l == Q and int(st["last_P"]) == P and int(st["last_M"]) == M else 1)
+    sys.exit(0 if same_l == Q and int(st["last_P"]) == P and int(st["last_M"]) == M and v_same == v_cands and (not verify or choice_same == Q) else 1)
 
 
 if __name__ == "__main__":
