@@ -616,10 +616,12 @@ def main():
             sys.stderr.write(p.stdout)
         sys.exit(p.returncode if (p.returncode or line is not None) else 1)
     world = int(env_world or "1")
-    if world > 1:
+    if world > 1 and os.environ.get("SGTD_BENCH_SHARE_GPU") != "1":
         # main stream, side stream and RCCL's own stream of every engine in flight: with the runtime's default of four
         # hardware queues some of them share one and the exchange queues up behind the list pass (measured with a group of
-        # one: 0.13 ms of the step exposed at 4 queues, 0.04 at 8 — DESIGN.md §4); read by the HIP runtime when it starts
+        # one: 0.13 ms of the step exposed at 4 queues, 0.04 at 8 — DESIGN.md §4); read by the HIP runtime when it starts.
+        # One process per GPU only: two processes with eight queues each on ONE device (the gloo test mode) are
+        # time-sliced against each other and run at half the rate (165 k -> 85 k frames/s, gpurun_out/r05an_*).
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
