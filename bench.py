@@ -1390,10 +1390,16 @@ def main():
                     entries_r = int(mm.stats()["n_entries"])
                 # the merge kernel over rt packed tables of Q queries, timed alone on this GPU
                 ints = 2 * Q * cn + 4
+                # (tables as full as real ones: cn qualifying candidates per query and table, distinct frames, interleaved vote
+                # counts — the kernel's rounds are what it costs; round 5's first figures were taken on empty tables: no rounds)
                 fake = torch.zeros(rt * ints, dtype=torch.int32, device=dev)
+                kk = torch.arange(cn, dtype=torch.int32, device=dev)
                 for t_ in range(rt):
-                    fake[t_ * ints + 2 * Q * cn + 1] = Q
-                    fake[t_ * ints + 2 * Q * cn + 2] = cn
+                    b_ = t_ * ints
+                    fake[b_:b_ + Q * cn] = (kk + t_ * 100000).repeat(Q)
+                    fake[b_ + Q * cn:b_ + 2 * Q * cn] = (5 + (cn - kk) * rt + t_).repeat(Q)
+                    fake[b_ + 2 * Q * cn + 1] = Q
+                    fake[b_ + 2 * Q * cn + 2] = cn
                 outs = [torch.empty((Q, cn), dtype=torch.int32, device=dev) for _ in range(3)] + \
                        [torch.empty(Q, dtype=torch.int32, device=dev), torch.empty(Q, dtype=torch.int64, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)]
                 torch.cuda.synchronize()
@@ -1402,6 +1408,7 @@ def main():
                     mgr.merge_candidates_dev(stream.cuda_stream, fake, rt, 0, Q, outs[0], outs[1], outs[3], outs[2], outs[4], outs[5])
                 torch.cuda.synchronize()
                 merge_ms = 1000.0 * (time.perf_counter() - t0) / 20
+                assert int(outs[3].min().item()) == cn, "the timed merge must pick candidate_num candidates per query"
                 ag_ms = modelled_all_gather_ms(ints * 4, rt) + modelled_all_gather_ms(2 * Q * cn * 4, rq)
                 one_gpu_ms = rq * (pre1 + shard1)
                 # the exchange runs beside the list pass (lists "all"): only what outlasts that pass would be waited for

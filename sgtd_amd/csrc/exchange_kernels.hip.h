@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void export_candidates_kernel(const int *cand_
 //                    sgtd_verify_masked only run for them)
 // Frames of different tables must be disjoint (they are: frame-range shards); equal keys collapse into one candidate.
 #define SGTD_MERGE_PER_LANE 16      // n_tables * cn <= 1024
+
+// largest value over the 64 lanes, in every lane (the DPP steps of wave_incl_scan with max for +; 0 is the identity)
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+  int x = (int)v;
+#define SGTD_MAX_STEP(ctrl, rows) { const u32 o = (u32)__builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xf, false); x = (int)((u32)x > o ? (u32)x : o); }
+  SGTD_MAX_STEP(0x111, 0xf) SGTD_MAX_STEP(0x112, 0xf) SGTD_MAX_STEP(0x114, 0xf) SGTD_MAX_STEP(0x118, 0xf)
+  SGTD_MAX_STEP(0x142, 0xa) SGTD_MAX_STEP(0x143, 0xc)
+#undef SGTD_MAX_STEP
+  return (u32)__builtin_amdgcn_readlane(x, SGTD_WAVE - 1);
+}
+
+// PER: key registers per lane (the host picks the smallest of 1, 4, 8, 16 that holds n_tables * cn keys — a round costs
+// PER compares to find the lane's best and PER to clear it: with 16 registers for the 50 keys of ONE table the kernel took
+// 85 us for 2048 queries).  The largest 64-bit key of the wave: the largest high word (votes) by one DPP reduction, then
+// the largest low word among its holders by another — two short chains instead of twelve ds_bpermute round trips.
+template <int PER>
 __global__ __launch_bounds__(256) void merge_candidates_kernel(const int *gathered, long long table_stride, int n_tables, int my_table,
                                                                int nq, int cn, int min_votes, int *out_frame, int *out_votes,
                                                                int *out_n, int *out_src, u64 *out_keep, int *out_flags) {
@@ -56,9 +72,9 @@ __global__ __launch_bounds__(256) void merge_candidates_kernel(const int *gather
   }
   if (q >= nq) return;
   const int n_items = n_tables * cn;
-  u64 a[SGTD_MERGE_PER_LANE];
+  u64 a[PER];
 #pragma unroll
-  for (int j = 0; j < SGTD_MERGE_PER_LANE; j++) {
+  for (int j = 0; j < PER; j++) {
     const int i = j * SGTD_WAVE + lane;
     a[j] = 0;
     if (i < n_items) {
@@ -66,7 +82,7 @@ __global__ __launch_bounds__(256) void merge_candidates_kernel(const int *gather
       const int *base = gathered + (long long)t * table_stride;
       const int f = base[(long long)q * cn + s];
       const int v = base[(long long)nq * cn + (long long)q * cn + s];
-      if (f >= 0 && v >= min_votes) a[j] = ((u64)(u32)v << 32) | (u64)(0xFFFFFFFFu - (u32)f);
+      if (f >= 0 && v >= min_votes && v > 0) a[j] = ((u64)(u32)v << 32) | (u64)(0xFFFFFFFFu - (u32)f);
     }
   }
   int picked = 0;
@@ -75,24 +91,21 @@ __global__ __launch_bounds__(256) void merge_candidates_kernel(const int *gather
     u64 best = 0;
     int bj = 0;
 #pragma unroll
-    for (int j = 0; j < SGTD_MERGE_PER_LANE; j++)
+    for (int j = 0; j < PER; j++)
       if (a[j] > best) { best = a[j]; bj = j; }
-    u64 wbest = best;
-#pragma unroll
-    for (int d = SGTD_WAVE / 2; d > 0; d >>= 1) {
-      const u64 o = __shfl_xor(wbest, d);
-      wbest = o > wbest ? o : wbest;
-    }
-    if (wbest == 0) break;                                   // nothing with >= min_votes votes is left (:427,433)
+    const u32 whi = wave_max_u32((u32)(best >> 32));
+    if (whi == 0u) break;                                    // nothing with >= min_votes votes is left (:427,433)
+    const u32 wlo = wave_max_u32((u32)(best >> 32) == whi ? (u32)best : 0u);
+    const u64 wbest = ((u64)whi << 32) | (u64)wlo;
     const u64 holders = __ballot(best == wbest);
     const int L = __builtin_ctzll(holders);                  // (equal keys: the lowest item index names the source)
-    const int item = __shfl(bj * SGTD_WAVE + lane, L);
+    const int item = __builtin_amdgcn_readlane(bj * SGTD_WAVE + lane, L);
 #pragma unroll
-    for (int j = 0; j < SGTD_MERGE_PER_LANE; j++) a[j] = (a[j] == wbest) ? 0ull : a[j];
+    for (int j = 0; j < PER; j++) a[j] = (a[j] == wbest) ? 0ull : a[j];
     const int t = item / cn, s = item - t * cn;
     if (lane == 0) {
-      out_frame[(long long)q * cn + picked] = (int)(0xFFFFFFFFu - (u32)(wbest & 0xFFFFFFFFull));
-      out_votes[(long long)q * cn + picked] = (int)(u32)(wbest >> 32);
+      out_frame[(long long)q * cn + picked] = (int)(0xFFFFFFFFu - wlo);
+      out_votes[(long long)q * cn + picked] = (int)whi;
       out_src[(long long)q * cn + picked] = (t << 8) | s;
     }
     if (t == my_table) keep |= 1ull << s;

@@ -2055,9 +2055,15 @@ int sgtd_merge_candidates_dev(sgtd_handle e, void *stream, const int32_t *d_gath
   if ((long long)n_tables * cn > (long long)SGTD_MERGE_PER_LANE * SGTD_WAVE || n_tables > 0x7FFFFF) return SGTD_ERR_UNSUPPORTED;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   // (min_votes 5: max_vote >= 5, STDesc.cpp:433)
-  merge_candidates_kernel<<<std::max(1, grid_for(n_queries, 4)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
-      d_gathered, (long long)xchg_packed_ints(n_queries, cn), n_tables, my_table, n_queries, cn, 5, d_frame, d_votes, d_n_cand, d_src,
-      reinterpret_cast<u64 *>(d_keep), d_flags);
+  const int n_keys = n_tables * cn;
+#define SGTD_MERGE(PER) merge_candidates_kernel<PER><<<std::max(1, grid_for(n_queries, 4)), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>( \
+      d_gathered, (long long)xchg_packed_ints(n_queries, cn), n_tables, my_table, n_queries, cn, 5, d_frame, d_votes, d_n_cand, d_src,             \
+      reinterpret_cast<u64 *>(d_keep), d_flags)
+  if (n_keys <= SGTD_WAVE) SGTD_MERGE(1);
+  else if (n_keys <= 4 * SGTD_WAVE) SGTD_MERGE(4);
+  else if (n_keys <= 8 * SGTD_WAVE) SGTD_MERGE(8);
+  else SGTD_MERGE(SGTD_MERGE_PER_LANE);
+#undef SGTD_MERGE
   HIPCHK(hipGetLastError());
   return SGTD_OK;
 }
