@@ -88,7 +88,7 @@ def other_svd_hypotheses(cov, qc, ec):
     return out, ratio
 
 
-def audit_verify(name, n_frames, n_kp, n_queries, stream, threads=8, skewed=False):
+def audit_verify(name, n_frames, n_kp, n_queries, stream, threads=8, skewed=False, label_lo=3, label_hi=11):
     """candidate_verify of every candidate of n_queries query frames with both SVDs' hypotheses (orc_audit_verify)"""
     from oracle.oracle import OracleManager, OrcVerifyAudit
     from sgtd_amd import synth
@@ -103,7 +103,7 @@ def audit_verify(name, n_frames, n_kp, n_queries, stream, threads=8, skewed=Fals
             o.add_last()
         frames = [qs.frame(q) for q in range(n_queries)]
     else:
-        smap = synth.make_map(n_frames, n_kp, stream=stream)
+        smap = synth.make_map(n_frames, n_kp, stream=stream, label_lo=label_lo, label_hi=label_hi)
         qs = synth.make_queries(smap, n_queries, stream=stream)
         for f0 in range(0, n_frames, 500):
             o.add_frames(smap.xyz[f0:min(n_frames, f0 + 500)], smap.label[f0:min(n_frames, f0 + 500)])
@@ -133,7 +133,9 @@ def main_verify(args):
         plan = [("cfg2-like (quick)", lambda n: audit_verify(n, 120, 200, 4, 2, threads=T))]
     else:
         plan = [("cfg2: 1k-frame map", lambda n: audit_verify(n, 1000, 200, 48, 2, threads=T)),
+                ("cfg3: 4 541-frame map (KITTI-00 length)", lambda n: audit_verify(n, 4541, 200, 32, 3, threads=T)),
                 ("north star: 10k-frame map", lambda n: audit_verify(n, 10000, 200, 48, 1, threads=T)),
+                ("cfg5 labels: 13 wild classes, 5k-frame map", lambda n: audit_verify(n, 5000, 200, 32, 5, threads=T, label_lo=0, label_hi=12)),
                 ("skewed workload, 2 500 frames", lambda n: audit_verify(n, 2500, 0, 24, 0, threads=T, skewed=True))]
     runs = []
     for name, fn in plan:
