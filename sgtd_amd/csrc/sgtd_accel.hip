@@ -2261,8 +2261,8 @@ int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
     unsigned long long st[8];
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_vstat), sizeof(st)));
-    fprintf(stderr, "[vstat] steps %llu anyA %llu | combos %llu passA %llu passAB %llu passABC %llu | pairs %llu pairs-anyA %llu\n",
-            st[0], st[1], st[7], st[2], st[3], st[4], st[5], st[6]);
+    fprintf(stderr, "[vstat] steps %llu  steps with a pair left by vertex A %llu  with eight or more %llu | (pair, hypothesis) tests %llu  left by A %llu  of them in steps "
+            "with eight or more %llu  not far on all three %llu  certain votes %llu\n", st[0], st[1], st[3], st[7], st[2], st[5], st[6], st[4]);
     unsigned long long z[8] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vstat), z, sizeof(z)));
   }

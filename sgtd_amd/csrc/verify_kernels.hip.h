@@ -221,9 +221,9 @@ __global__ __launch_bounds__(SGTD_WAVE) void verify_solve_kernel(VerifyParams P)
 #define SGTD_VERIFY_WAVES __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 #ifdef SGTD_EXP_VSTAT
-// experiment build: how the (pair, hypothesis) tests fall out.  0 steps (128 pairs x hypothesis), 1 steps where some
-// pair passes A, 2 / 3 / 4 (pair, hypothesis) combinations that pass A / A,B / A,B,C, 5 pairs, 6 pairs that pass A
-// for some hypothesis, 7 valid (pair, hypothesis) combinations
+// experiment build: how the (pair, hypothesis) tests fall out.  0 steps (128 pairs x one hypothesis), 1 steps where vertex A
+// leaves some pair, 3 steps where it leaves eight or more, 7 valid (pair, hypothesis) combinations, 2 of them left by A,
+// 5 of those in steps with eight or more, 6 combinations not far on all three vertices, 4 certain votes
 __device__ unsigned long long g_vstat[8];
 #define VSTAT(i, x) do { if (lane == 0) atomicAdd(&g_vstat[i], (unsigned long long)(x)); } while (0)
 #else
@@ -377,6 +377,11 @@ __global__ __launch_bounds__(SGTD_VERIFY_THREADS) SGTD_VERIFY_WAVES void verify_
         VSTAT(0, 1); VSTAT(7, __builtin_popcountll(valid0) + __builtin_popcountll(valid1)); VSTAT(4, __builtin_popcountll(yes0) + __builtin_popcountll(yes1));
 #ifdef SGTD_EXP_VSTAT
         any0 |= in0; any1 |= in1;
+        {   // vertex A alone: how many of the wave's pairs it leaves, and in how many steps it leaves any / eight or more
+          const u64 a0 = valid0 & ~__builtin_amdgcn_ballot_w64(d2[0].x > hi2.x), a1 = valid1 & ~__builtin_amdgcn_ballot_w64(d2[0].y > hi2.y);
+          const int na = __builtin_popcountll(a0) + __builtin_popcountll(a1);
+          VSTAT(2, na); VSTAT(1, na > 0 ? 1 : 0); VSTAT(3, na >= 8 ? 1 : 0); VSTAT(5, na >= 8 ? na : 0); VSTAT(6, __builtin_popcountll(in0) + __builtin_popcountll(in1));
+        }
 #endif
         // the pair's bit of the hypothesis: the lane mask selects it (one v_cndmask and one v_or per pair)
         const u32 hb = 1u << (h & 31);
