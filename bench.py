@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="N=1: batches in flight over the one table (handles attached with sgtd_attach_table, one stream each); "
                          "1 = every batch behind the one before (reported beside the headline either way)")
+    ap.add_argument("--repeat-region", type=int, default=5, help="how many times the headline's timed region is measured (median, min, max reported; value = the first)")
     ap.add_argument("--rotate", type=int, default=4,
                     help="distinct query batches the timed region rotates through (all different from the warm-up batch)")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps timed per kernel for the roofline")
@@ -302,6 +303,54 @@ def load_traffic(F, N, Q, world):
         except Exception:
             pass
     return None
+
+
+FLAT_CONFIG_KEYS = ("delivered_frames_per_s", "one_in_flight_ms_per_step", "overflowed_launches_in_timed_region", "parity_identical_of_200",
+                    "verify_ms_per_batch", "skew_frames_per_s", "region_ms_per_step_median", "region_ms_per_step_min", "region_ms_per_step_max",
+                    "regions_timed", "cfg1_identical_of_200", "cpp_adapter_ms_per_frame", "R_t", "R_q")
+FLAT_CONFIG_KEYS_MULTI = ("table_sharded_frames_per_s", "table_sharded_equals_single_table", "cfg4_frames_per_s", "exchange_exposed_ms")
+FLAT_ROOFLINE_KEYS = ("useful_frac", "step_compulsory_frac")
+
+
+def flatten_evidence(out):
+    """The driver's record keeps scalars only (and of nested objects only `config` and `roofline`'s scalar members): what
+    the line's nested objects say is repeated here as scalar keys under `config` and `roofline` (VERDICT r5 item 4;
+    tests/test_host_cpu.py checks the names)."""
+    def get(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d or d[k] is None:
+                return None
+            d = d[k]
+        return d
+    c, r = out["config"], out["roofline"]
+    tr = out.get("timed_region") or {}
+    c["delivered_frames_per_s"] = get(out, "delivered", "frames_per_s")
+    c["one_in_flight_ms_per_step"] = get(out, "one_batch_in_flight", "ms_per_step")
+    c["overflowed_launches_in_timed_region"] = tr.get("launches_that_overflowed_a_work_buffer")
+    for k in ("region_ms_per_step_median", "region_ms_per_step_min", "region_ms_per_step_max", "regions_timed"):
+        c[k] = tr.get(k)
+    c["parity_identical_of_200"] = get(out, "parity", "identical_candidates_votes_matchlists")
+    c["verify_ms_per_batch"] = get(out, "verify", "ms_per_batch")
+    c["skew_frames_per_s"] = get(out, "workload_skew", "frames_per_s")
+    cfg1 = get(out, "map_size_sweep", "100_cfg1_json_in", "identical_candidates_votes_matchlists")
+    c["cfg1_identical_of_200"] = int(str(cfg1).split("/")[0]) if cfg1 else None
+    c["cpp_adapter_ms_per_frame"] = get(out, "boundary", "cpp_adapter_ms_per_frame")
+    c["R_t"], c["R_q"] = c.get("table_shards_R_t"), c.get("query_groups_R_q")
+    if out.get("n_gpus", 1) > 1:
+        c["table_sharded_frames_per_s"] = get(out, "table_sharded", "value")
+        c["table_sharded_equals_single_table"] = out.get("merged_list_equals_single_table")
+        c["cfg4_frames_per_s"] = get(out, "cfg4", "value")
+        c["exchange_exposed_ms"] = get(out, "scaling_parts", "exchange_exposed_ms")
+    # the sweep's USEFUL fraction of the HBM roof: the probe layout once + every 4-byte match record once, over the sweep's
+    # live time; and the whole step's compulsory I/O over the step's time
+    comp = r.get("compulsory") or {}
+    t_probe = (get(r, "kernel_ms", "ms_probe") or 0.0) * 1e-3
+    if t_probe > 0 and comp.get("probe_layout_once") is not None and comp.get("match_records_once") is not None:
+        r["useful_frac"] = (comp["probe_layout_once"] + comp["match_records_once"]) / t_probe / 1e9 / r["peak"]
+    else:
+        r["useful_frac"] = None
+    r["step_compulsory_frac"] = comp.get("frac")
+    return out
 
 
 def run_steps(step, sync, steps):
@@ -900,9 +949,16 @@ def main():
         timed_info = {}
         elapsed = timed(fstep_, flight, info=timed_info)
         timed_info["batches_in_flight"] = args.in_flight
+    cur_step, cur_mgr = (fstep_, flight) if flight is not None else (step, mgr if m2 is None else mgr_all)
+    # the headline region four more times (each with its own warm-up, barrier and overflow check): `value` stays the FIRST
+    # region's — the contract's K steps — the spread of the five is reported beside it
+    region_ms = [1000.0 * elapsed / args.steps]
+    for _ in range(max(0, args.repeat_region - 1)):
+        region_ms.append(1000.0 * timed(cur_step, cur_mgr) / args.steps)
+    timed_info.update(regions_timed=len(region_ms), region_ms_per_step_all=region_ms, region_ms_per_step_median=float(np.median(region_ms)),
+                      region_ms_per_step_min=float(min(region_ms)), region_ms_per_step_max=float(max(region_ms)))
     # the same measurement the way rounds 1-3 took it — ONE batch over and over (the room prediction is then exact, no
     # list ever moves) — beside the headline, which rotates fresh batches
-    cur_step, cur_mgr = (fstep_, flight) if flight is not None else (step, mgr if m2 is None else mgr_all)
     k_same = max(3, args.steps // 2)
     same_elapsed = timed(lambda i: cur_step(-1), cur_mgr, steps=k_same)
     timed_info.update(same_batch_ms_per_step=1000.0 * same_elapsed / k_same, same_batch_steps=k_same,
@@ -1622,6 +1678,8 @@ def main():
                 out["cpu_baseline_error"] = "%s: %s" % (type(exc).__name__, exc)
         else:
             out["cpu_baseline"] = None
+    if rank == 0:
+        flatten_evidence(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -198,8 +198,10 @@ int sgtd_finalize(sgtd_handle h);
  * its own work buffers, results and stream.  Batches enqueued alternately on the two handles' streams overlap on the
  * device: the descriptor build, home-cell sort and plan of one run beside the passes over the other's match records.
  * The owner must outlive its views (sgtd_destroy of an owner with views is SGTD_ERR_STATE); after anything that changes
- * the owner's table (sgtd_add*, sgtd_load_table, a finalize that merges a tail) a view's next query returns
- * SGTD_ERR_STATE until it is attached again.  A view cannot add, load or rebuild (SGTD_ERR_STATE).  Neither handle
+ * the owner's table (sgtd_add*, sgtd_load_table, a finalize that merges a tail — the owner's own fifth batch on a tail
+ * does) every call of a view that would touch the table again returns SGTD_ERR_STATE until it is attached again: the next
+ * query, and for a batch still pending sgtd_sync / sgtd_verify* / sgtd_search_loop / the result calls that gather entries
+ * (the view's batch is dropped; nothing reads the owner's freed buffers).  A view cannot add, load or rebuild (SGTD_ERR_STATE).  Neither handle
  * is thread safe; the table itself is only read by queries, so one host thread per handle is fine. */
 int sgtd_attach_table(sgtd_handle view, sgtd_handle owner);
 

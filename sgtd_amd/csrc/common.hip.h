@@ -268,6 +268,16 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
   return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(v), SGTD_WAVE - 1);
 }
 
+// largest value over the 64 lanes, in every lane (the DPP steps of wave_incl_scan with max for +; 0 is the identity)
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+  int x = (int)v;
+#define SGTD_MAX_STEP(ctrl, rows) { const u32 o = (u32)__builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xf, false); x = (int)((u32)x > o ? (u32)x : o); }
+  SGTD_MAX_STEP(0x111, 0xf) SGTD_MAX_STEP(0x112, 0xf) SGTD_MAX_STEP(0x114, 0xf) SGTD_MAX_STEP(0x118, 0xf)
+  SGTD_MAX_STEP(0x142, 0xa) SGTD_MAX_STEP(0x143, 0xc)
+#undef SGTD_MAX_STEP
+  return (u32)__builtin_amdgcn_readlane(x, SGTD_WAVE - 1);
+}
+
 // Stable multi-split rank inside one wave: lanes with equal `digit` (BITS wide)
 // among the `valid` lanes form a group; returns the lane's rank inside its
 // group (in lane order) and the group size.  BITS ballots, no LDS.

@@ -41,16 +41,6 @@ __global__ __launch_bounds__(256) void export_candidates_kernel(const int *cand_
 // Frames of different tables must be disjoint (they are: frame-range shards); equal keys collapse into one candidate.
 #define SGTD_MERGE_PER_LANE 16      // n_tables * cn <= 1024
 
-// largest value over the 64 lanes, in every lane (the DPP steps of wave_incl_scan with max for +; 0 is the identity)
-__device__ __forceinline__ u32 wave_max_u32(u32 v) {
-  int x = (int)v;
-#define SGTD_MAX_STEP(ctrl, rows) { const u32 o = (u32)__builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xf, false); x = (int)((u32)x > o ? (u32)x : o); }
-  SGTD_MAX_STEP(0x111, 0xf) SGTD_MAX_STEP(0x112, 0xf) SGTD_MAX_STEP(0x114, 0xf) SGTD_MAX_STEP(0x118, 0xf)
-  SGTD_MAX_STEP(0x142, 0xa) SGTD_MAX_STEP(0x143, 0xc)
-#undef SGTD_MAX_STEP
-  return (u32)__builtin_amdgcn_readlane(x, SGTD_WAVE - 1);
-}
-
 // PER: key registers per lane (the host picks the smallest of 1, 4, 8, 16 that holds n_tables * cn keys — a round costs
 // PER compares to find the lane's best and PER to clear it: with 16 registers for the 50 keys of ONE table the kernel took
 // 85 us for 2048 queries).  The largest 64-bit key of the wave: the largest high word (votes) by one DPP reduction, then

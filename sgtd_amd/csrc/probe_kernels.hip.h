@@ -75,17 +75,24 @@ struct QueryView {
   int n_queries;
 };
 
+// A match list starts on a GRANULE of four records (16 bytes) and is named by its granule: 32-bit list starts, slab
+// cursors and capacities then address 2^34 records (64 GB of them) — a batch's records outgrow a 32-bit RECORD index
+// exactly where large batches pay (2048 query frames on a 100 000-frame map: 1.5e10).  The list passes read records four
+// at a time anyway (a quad is a granule: aligned 16-byte loads), and a list wastes at most three records at its end.
+#define SGTD_REC_SHIFT 2
 struct ProbeBuffers {
-  u32 *rec;             // [rec_cap] match records: the entry's id (frame and entry in one word, common.hip.h IdMap)
-  unsigned char *rec_cell;  // [rec_cap] voxel_round index (diagnostic build only)
-  double *rec_dis;      // [rec_cap] distance (diagnostic build only)
-  u32 rec_cap;
-  u32 rec_slab;         // smallest slab a wave takes from the global cursor (SGTD_REC_SLAB; less for small record buffers:
+  u32 *rec;             // [4 rec_cap] match records: the entry's id (frame and entry in one word, common.hip.h IdMap)
+  unsigned char *rec_cell;  // [4 rec_cap] voxel_round index (diagnostic build only)
+  double *rec_dis;      // [4 rec_cap] distance (diagnostic build only)
+  u32 rec_cap;          // in granules
+  u32 rec_slab;         // smallest slab (in granules) a wave takes from the global cursor (SGTD_REC_SLAB records; less for small record buffers:
                         // every stream of every wave holds one, and together they must stay a fraction of the buffer)
+  __host__ __device__ __forceinline__ size_t rec_index(u32 granule) const { return (size_t)granule << SGTD_REC_SHIFT; }
+  __host__ __device__ __forceinline__ u32 *rec_at(u32 granule) const { return rec + ((size_t)granule << SGTD_REC_SHIFT); }
   u32 rec_rate;         // room a descriptor's list is given when its pass starts: rec_rate / 256 of the visit list (+ 256 records),
                         // at most the whole list; a list that outgrows what its slab has left moves to a new one
   // the batch's counters live in ONE buffer (a single base address in the kernels' scalar
-  // registers): words 0-1 the global slab cursor of the match records (64-bit: requests can
+  // registers): words 0-1 the global slab cursor of the match records in granules (64-bit: requests can
   // add up beyond 2^32), 2 the undecided-record queue's fill, 3 the compact lists' cursor,
   // 4-5 matches that found no room (sizes the regrown buffer), 6-7 table entries the sweep
   // really loaded (after slice pruning), 8 the pass pool's cursor, 9 match lists that moved to a fresh
@@ -102,7 +109,7 @@ struct ProbeBuffers {
   __host__ __device__ __forceinline__ int *overflow() const { return reinterpret_cast<int *>(ctr + 10); }
   __host__ __device__ __forceinline__ u32 *xcd_heads() const { return ctr + 1024; }
   // per descriptor slot d:
-  uint2 *list;          // {first record of the descriptor's list, its matches}
+  uint2 *list;          // {granule of the first record of the descriptor's list, its matches}
   u32 *n_visit;         // entries the reference's loop visits for the descriptor (STDesc.cpp:372)
   u32 *votes;           // [n_queries * frame_span]
   u32 id_bits;          // a record's local frame (frame - table frame_lo) is rec >> id_bits
@@ -148,8 +155,8 @@ static_assert(SGTD_PAIR == 1 || SGTD_PAIR == 2 || SGTD_PAIR == 4, "the sweep com
 struct WaveSlab {
   // this wave's private ranges of match records: one bump stream per descriptor column of a pass, so
   // that every descriptor's list stays contiguous.  The streams' state is parked in the lanes of ONE
-  // vector register between passes (lane k: next free record of stream k, lane 4 + k: end of its slab;
-  // during a pass lane 8 + k: the room the pass's list has in the slab)
+  // vector register between passes (lane k: next free GRANULE of stream k, lane 4 + k: end of its slab, a granule too;
+  // during a pass lane 8 + k: the room, in records, the pass's list has in the slab)
   // — scalar registers are what the sweep runs out of.
   u32 state;
   u64 swept;                             // entries this wave loaded
@@ -859,11 +866,14 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
   // does outgrow what its slab has left is moved to a fresh slab (relocate below, rare).
   bool fits = true;
   bool tight = false;   // some column's room is below the worst case: the groups check it
-  u32 next0[K];         // first record of the column's list
+  u32 next0[K];         // granule of the first record of the column's list
 #pragma unroll
   for (int k = 0; k < K; k++) next0[k] = 0;
   const u32 want = DIAG ? total : min(total, (total >> 8) * B.rec_rate + (((total & 255u) * B.rec_rate) >> 8) + 256u);
-  // a slab of `take` records from the global cursor (0, 0: the buffer is exhausted)
+  auto granules = [](u32 records) { return (records >> SGTD_REC_SHIFT) + ((records & 3u) ? 1u : 0u); };
+  auto room_of = [](u32 nxt, u32 end) { const u32 g = end - nxt; return g > (0xFFFFFFFFu >> SGTD_REC_SHIFT) ? 0xFFFFFFFFu : g << SGTD_REC_SHIFT; };   // records
+  const u32 want_g = granules(want);
+  // a slab of `take` GRANULES from the global cursor (0, 0: the buffer is exhausted)
   auto new_slab = [&](u32 take, u32 &nxt, u32 &end) {
     u64 got = 0;
     if (lane == 0) got = atomicAdd(B.rec_cursor(), (unsigned long long)take);
@@ -875,16 +885,16 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     constexpr int k = decltype(kc)::value;
     if ((u32)k >= pv.k_real) return;      // (the fourth column of a pass of three has no list)
     u32 nxt = (u32)__builtin_amdgcn_readlane((int)slab.state, k), end = (u32)__builtin_amdgcn_readlane((int)slab.state, 4 + k);
-    if (total && (u64)nxt + want > (u64)end) {
+    if (total && (u64)nxt + want_g > (u64)end) {
       // only the matches stay in a slab: slabs of 8 expected lists keep the space abandoned at a
       // slab's end to about an eighth however long the visit lists are
-      new_slab(want > (1u << 28) ? want : max(B.rec_slab, 8u * want), nxt, end);
+      new_slab(want_g > (1u << 28) ? want_g : max(B.rec_slab, 8u * want_g), nxt, end);
       slab.state = write_lane<k>(slab.state, nxt);
       slab.state = write_lane<4 + k>(slab.state, end);
     }
-    fits = fits && ((u64)nxt + want <= (u64)end);
-    tight = tight || (end - nxt < total);
-    slab.state = write_lane<8 + k>(slab.state, end - nxt);
+    fits = fits && ((u64)nxt + want_g <= (u64)end);
+    tight = tight || (room_of(nxt, end) < total);
+    slab.state = write_lane<8 + k>(slab.state, room_of(nxt, end));
     next0[k] = nxt;
   });
   if (!fits && lane == 0) B.overflow()[0] = 1;
@@ -895,7 +905,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
 #pragma unroll
   for (int k = 0; k < K; k++) {
     matches[k] = 0;
-    list_base[k] = reinterpret_cast<char *>(B.rec + next0[k]);
+    list_base[k] = reinterpret_cast<char *>(B.rec_at(next0[k]));
   }
   // wave-uniform constants of the columns in vector registers
   u32 qfv[K];
@@ -1024,7 +1034,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
 #endif
         if (hit && fits) *reinterpret_cast<u32 *>(list_base[k] + (at << 2)) = id;
         if constexpr (DIAG) {
-          if (hit && fits) { B.rec_cell[(size_t)next0[k] + at] = (unsigned char)cellv[u]; B.rec_dis[(size_t)next0[k] + at] = dis; }
+          if (hit && fits) { B.rec_cell[B.rec_index(next0[k]) + at] = (unsigned char)cellv[u]; B.rec_dis[B.rec_index(next0[k]) + at] = dis; }
         }
         // amb_any |= m & ballot(!(d2 < lo2)) — as one unit, so that no hit mask outlives its test
         // (left to the scheduler, the masks of a whole group wait in scalar registers for this)
@@ -1093,18 +1103,18 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         if (room - matches[k] < 256u) {
           const u32 rest = total - min(total, w0 << 6);          // visits still to come
           const u32 more = min(rest, (rest >> 8) * B.rec_rate + (((rest & 255u) * B.rec_rate) >> 8) + 512u);
-          const u32 need = matches[k] + more;
+          const u32 need = matches[k] + more, need_g = granules(need);
           u32 nxt, end;
-          new_slab(max(B.rec_slab, need > (1u << 28) ? need : 4u * need), nxt, end);
-          if (end - nxt < need) { fits = false; if (lane == 0) B.overflow()[0] = 1; return; }
-          u32 *from = B.rec + next0[k], *to = B.rec + nxt;
+          new_slab(max(B.rec_slab, need_g > (1u << 28) ? need_g : 4u * need_g), nxt, end);
+          if (end - nxt < need_g) { fits = false; if (lane == 0) B.overflow()[0] = 1; return; }
+          u32 *from = B.rec_at(next0[k]), *to = B.rec_at(nxt);
           __builtin_amdgcn_s_waitcnt(0x0F70);   // the list's records so far are in L2 ...
           for (u32 i = (u32)lane; i < matches[k]; i += SGTD_WAVE)
             to[i] = __hip_atomic_load(from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and are read from there
           next0[k] = nxt;
           list_base[k] = reinterpret_cast<char *>(to);
           if (lane == 0) atomicAdd(B.list_moves(), 1u);
-          room = end - nxt;
+          room = room_of(nxt, end);
           slab.state = write_lane<4 + k>(slab.state, end);
           slab.state = write_lane<8 + k>(slab.state, room);
         }
@@ -1159,7 +1169,7 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
     constexpr int k = decltype(kc)::value;
     if ((u32)k >= pv.k_real) return;
     if (!fits && lane == 0) atomicAdd(B.rec_need(), (unsigned long long)matches[k]);
-    if (fits) slab.state = write_lane<k>(slab.state, next0[k] + matches[k]);
+    if (fits) slab.state = write_lane<k>(slab.state, next0[k] + granules(matches[k]));
   });
   __builtin_amdgcn_wave_barrier();
   PH_ADD(4);
@@ -1313,7 +1323,7 @@ __global__ void resolve_undecided_kernel(TableView T, QueryView Q, ProbeBuffers 
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint2 it = B.amb_queue[i];
     const QueryRec &r = Q.qrec[it.y];
-    u32 *rec = B.rec + (size_t)B.list[it.y].x + it.x;      // (index in the list: a list may have moved during its pass)
+    u32 *rec = B.rec_at(B.list[it.y].x) + it.x;      // (index in the list: a list may have moved during its pass)
     const double *sp = T.cold_side + (size_t)id_entry(T.map, *rec) * 3;
     const double dx = r.q0 - sp[0], dy = r.q1 - sp[1], dz = r.q2 - sp[2];
     const double d2 = (dx * dx + dy * dy) + dz * dz;   // Eigen norm() association
@@ -1481,39 +1491,6 @@ __device__ __forceinline__ BlockId assemble_block(int n_queries, int blocks_per_
   return id;
 }
 
-// the 32-descriptor sub-block [d0, d0+32) of query q: prefix of n_match and list
-// pointers into LDS; returns the number of records
-__device__ __forceinline__ u32 sub_open(const QueryView &Q, const ProbeBuffers &B, int q, u32 d0, u32 cnt,
-                                        u32 *s_pre /*[32]*/, u32 *s_ptr /*[32]*/, u32 &visits) {
-  const int lane = lane_id();
-  u32 n = 0, p = 0, v = 0;
-  if (lane < SGTD_SUB_DESCS && d0 + lane < cnt) {
-    const long long d = (long long)q * Q.stride + d0 + lane;
-    const uint2 lp = B.list[d];
-    n = lp.y; p = lp.x; v = B.n_visit[d];
-  }
-  const u32 inc = wave_incl_scan(n);
-  const u32 R = __shfl(inc, SGTD_WAVE - 1);
-  visits += wave_sum(v);
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 32) { s_pre[lane] = inc - n; s_ptr[lane] = p; }
-  __builtin_amdgcn_wave_barrier();
-  return R;
-}
-
-// record r of the sub-block -> (descriptor index inside it, record address)
-__device__ __forceinline__ void sub_locate(const u32 *s_pre, const u32 *s_ptr, u32 r, u32 &dd, u32 &addr) {
-  // last dd with pre[dd] <= r (descriptors without matches share offsets and are skipped)
-  u32 c = 0;
-  if (s_pre[16] <= r) c = 16;
-  if (s_pre[c + 8] <= r) c += 8;
-  if (s_pre[c + 4] <= r) c += 4;
-  if (s_pre[c + 2] <= r) c += 2;
-  if (s_pre[c + 1] <= r) c += 1;
-  dd = c;
-  addr = s_ptr[c] + (r - s_pre[c]);
-}
-
 // The same sub-block as a stream of QUADS — four consecutive records of one list, the last quad
 // of a list possibly short: one list search serves four records (the record buffer has room
 // for the reads past a list's end).  s_pre: exclusive quad offsets, s_ptr: list starts, s_cnt:
@@ -1539,7 +1516,7 @@ __device__ __forceinline__ u32 sub_open_quads(const QueryView &Q, const ProbeBuf
   return RQ;
 }
 
-// quad r of the sub-block -> (descriptor index inside it, address of its first record, records in it)
+// quad r of the sub-block -> (descriptor index inside it, granule of its first record, records in it)
 __device__ __forceinline__ void sub_locate_quad(const u32 *s_pre, const u32 *s_ptr, const u32 *s_cnt, u32 r, u32 &dd,
                                                 u32 &addr, u32 &k) {
   u32 c = 0;
@@ -1549,9 +1526,9 @@ __device__ __forceinline__ void sub_locate_quad(const u32 *s_pre, const u32 *s_p
   if (s_pre[c + 2] <= r) c += 2;
   if (s_pre[c + 1] <= r) c += 1;
   dd = c;
-  const u32 first = (r - s_pre[c]) << 2;      // record index of the quad inside its list
-  addr = s_ptr[c] + first;
-  k = min(4u, s_cnt[c] - first);
+  const u32 quad = r - s_pre[c];              // the quad inside its list
+  addr = s_ptr[c] + quad;                     // a quad is a granule: the address stays one too
+  k = min(4u, s_cnt[c] - (quad << 2));
 }
 
 // frame -> candidate slot of one query as an LDS open-addressing table (cand_num <= 64
@@ -1605,8 +1582,7 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
         u32 dd, addr, k;
         sub_locate_quad(s_pre, s_ptr, s_cnt, r < RQ ? r : 0u, dd, addr, k);
         nk[u] = r < RQ ? k : 0u;
-        const u32 *src = B.rec + addr;      // 4-byte aligned
-        nrec[u] = make_uint4(src[0], src[1], src[2], src[3]);
+        nrec[u] = *reinterpret_cast<const uint4 *>(B.rec_at(addr));      // (a granule: 16-byte aligned)
       }
     };
     if (RQ) load2(0);
@@ -1807,7 +1783,7 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
     const u32 jdst = (n != 0u ? __builtin_amdgcn_mbcnt_hi((u32)(hm >> 32), __builtin_amdgcn_mbcnt_lo((u32)hm, 0u)) : 63u) << 2;   // (lane 63 is nobody's range)
     const u32 pre = inc - n;
     const u32 offj = (u32)__builtin_amdgcn_ds_permute((int)jdst, (int)pre);
-    const u32 delc = (u32)__builtin_amdgcn_ds_permute((int)jdst, (int)(p - pre));     // record address = stream position + delta
+    const u32 grac = (u32)__builtin_amdgcn_ds_permute((int)jdst, (int)p);             // the range's list: its first granule (its stream offset: offj)
     const u32 ddc = (u32)__builtin_amdgcn_ds_permute((int)jdst, lane);
     const u32 offc = (u32)lane < nr ? offj : ((u32)lane == nr ? R : 0xFFFFFFFFu);
     const bool marks = (u32)lane <= nr && offc != 0u;
@@ -1828,10 +1804,10 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
         const u64 bm = bits[(w0 + u) & 63u];
         const u32 before = (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(offc <= w_lo)) - 1u;
         const u32 j4 = __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, before)) << 2;
-        const u32 dsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)delc);
+        const u32 gsel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)grac), osel = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)offj);
         ndd[u] = (u32)__builtin_amdgcn_ds_bpermute((int)j4, (int)ddc);
         const u32 r = w_lo + lane;
-        nid[u] = B.rec[r < R ? r + dsel : 0u];
+        nid[u] = r < R ? B.rec_at(gsel)[r - osel] : B.rec[0];     // record = the list's first + the position inside the list
       }
     };
     if (R) load4(0);
@@ -2096,10 +2072,11 @@ __global__ __launch_bounds__(256) void rough_gather_kernel(QueryView Q, ProbeBuf
       long long last = -1;    // key of the last record put out: cell << 32 | entry id
       for (u32 k = 0; k < n; k++) {
         long long best = 0x7FFFFFFFFFFFFFFFll;
-        u32 at = 0;
+        size_t at = 0;
         {
           const uint2 lp = B.list[d];
-          const u32 p0 = lp.x, m = lp.y;
+          const size_t p0 = B.rec_index(lp.x);
+          const u32 m = lp.y;
           for (u32 j = 0; j < m; j++) {
             const long long key = ((long long)B.rec_cell[p0 + j] << 32) | (long long)id_entry(map, B.rec[p0 + j]);
             if (key > last && key < best) { best = key; at = p0 + j; }

@@ -238,7 +238,7 @@ static_assert(SGTD_PQ_WAVE_RECS * 4 >= 4 * 64 * 8 && (SGTD_PQ_WAVES & (SGTD_PQ_W
 
 // One non-empty list of the super-block as the tiles see it: its first quad in the super-block's stream of
 // quads, its first record, its records, its descriptor (index inside the super-block).
-struct __attribute__((aligned(16))) PqList { u32 pre, first, n, desc; };
+struct __attribute__((aligned(16))) PqList { u32 pre, first, n, desc; };     // (pre: quads before the list, first: its first granule)
 
 // dynamic LDS: u32 image[SGTD_PQ_TILE_RECS] | slot table u8[span rounded to 16, + 16] (SLOT_TABLE)
 template <bool SLOT_TABLE>
@@ -352,11 +352,10 @@ __global__ __launch_bounds__(SGTD_PQ_THREADS) __attribute__((amdgpu_waves_per_eu
         const u32 r = r0 + (u32)u * SGTD_WAVE + (u32)lane;
         const PqList L = s_ne[min(kl[u], K - 1u)];
         const bool ok = r < RQ;
-        const u32 firstrec = (r - L.pre) << 2;       // record index of the quad inside its list
-        nk[u] = ok ? min(4u, L.n - firstrec) : 0u;
+        const u32 quad = r - L.pre;                  // the quad inside its list (a quad is a granule of the record buffer)
+        nk[u] = ok ? min(4u, L.n - (quad << 2)) : 0u;
         ndd[u] = L.desc << SGTD_PQ_RANK_BITS;
-        const u32 *src = B.rec + (ok ? L.first + firstrec : 0u);      // 4-byte aligned; the buffer has room for the reads past a list's end
-        nrec[u] = make_uint4(src[0], src[1], src[2], src[3]);
+        nrec[u] = *reinterpret_cast<const uint4 *>(B.rec_at(ok ? L.first + quad : 0u));      // 16-byte aligned; the buffer has room for the reads past a list's end
       }
     };
     fetch(0);

@@ -18,6 +18,7 @@
 #include "probe_kernels.hip.h"
 #include "select_kernels.hip.h"
 #include "verify_kernels.hip.h"
+#include "verify_mfma.hip.h"
 #include "exchange_kernels.hip.h"
 #include "graph_ingest.hip.h"
 #include "table_file.h"
@@ -175,6 +176,8 @@ struct sgtd_engine {
   char *pin_build = nullptr;                  // ... and in page-locked host memory
   size_t pin_build_cap = 0;
   DevBuf v_hyp64, v_hyp32, v_bound;           // hypotheses between the two passes of sgtd_verify
+  DevBuf v_hypB, v_tau, v_words;              // the matrix-core vote pass: hypothesis features, |t|^2, vote words
+  DevBuf v_okey[2], v_oval[2];                // its dispatch order: (candidate frame, candidate index) sorted
   bool verified = false;
   // ---- multi-GPU step (exchange_kernels.hip.h): the batch's local candidate tables are written, packed, into a caller
   // device buffer as soon as they are final (behind votes_topk_kernel / topk_kernel) and ev_cand is recorded; a side
@@ -358,6 +361,17 @@ int h2d(sgtd_engine *e, void *dst_dev, const void *src, size_t bytes) {
 }
 
 int grid_for(long long n, int threads) { return (int)((n + threads - 1) / threads); }
+// what 32-bit indices can name: candidate pairs one by one, match records by granules of four (probe_kernels.hip.h)
+constexpr size_t kIndexLimit = 0xFFFFFFF0ull;
+constexpr size_t kRecLimit = kIndexLimit << SGTD_REC_SHIFT;
+// dynamic LDS a kernel may ask for: gfx950 gives a workgroup 160 KB, the kernel's static __shared__ arrays included (the
+// policy bound of 150 KB alone let a launch of a kernel with 12.6 KB of static LDS fail for spans that need 147.5 .. 150 KB)
+template <class K>
+size_t lds_room(K *kernel) {
+  hipFuncAttributes a;
+  const size_t fixed = hipFuncGetAttributes(&a, reinterpret_cast<const void *>(kernel)) == hipSuccess ? a.sharedSizeBytes : 16384;
+  return std::min<size_t>(150 * 1024, 160 * 1024 - std::min<size_t>(fixed, 160 * 1024));
+}
 
 // device-wide exclusive scan (u32), in place allowed
 int device_scan(sgtd_engine *e, const u32 *in, u32 *out, long long n, size_t lvl = 0) {
@@ -788,10 +802,10 @@ int do_finalize(sgtd_engine *e, bool force_merge = false) {
 // the query pipeline on descriptors already in e->qd (strided)
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e, bool compact_lists) {
-  CHK(ensure(e, e->rec, (e->rec_cap + 4) * sizeof(u32)));      // + a quad: the vote pass reads four records at the last list's tail
+  CHK(ensure(e, e->rec, (e->rec_cap + 16) * sizeof(u32)));     // + a few quads: the list passes read four records at the last list's tail
   // (the compact candidate lists between block_count and block_write: every block reserves room for all of its records —
   // twice the record buffer; the per-query list pass needs none)
-  if (compact_lists) CHK(ensure(e, e->c_pair, e->rec_cap * sizeof(u64)));
+  if (compact_lists) CHK(ensure(e, e->c_pair, std::min(e->rec_cap, kIndexLimit) * sizeof(u64)));
   if (e->diag) {
     CHK(ensure(e, e->rec_cell, e->rec_cap));
     CHK(ensure(e, e->rec_dis, e->rec_cap * sizeof(double)));
@@ -830,7 +844,7 @@ Views make_views(sgtd_engine *e) {
   Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq;
   ProbeBuffers &B = v.B;
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
-  B.rec_cap = (u32)std::min<size_t>(e->rec_cap, 0xFFFFFFF0u);
+  B.rec_cap = (u32)std::min<size_t>(e->rec_cap >> SGTD_REC_SHIFT, kIndexLimit);      // granules
   B.rec = e->rec.as<u32>(); B.id_bits = e->id_bits ? e->id_bits : 13;
   B.ctr = e->cursors.as<u32>();
   // the smallest slab: the streams of all resident waves hold one each (8192 waves x SGTD_PAIR streams) — together
@@ -843,7 +857,7 @@ Views make_views(sgtd_engine *e) {
     u32 slab = SGTD_REC_SLAB;
     while (slab > 512u && (size_t)slab * streams * 4 > e->rec_cap) slab >>= 1;
     if (const char *o = getenv("SGTD_REC_SLAB")) slab = (u32)std::max(512, atoi(o));   // experiment knob
-    B.rec_slab = slab;
+    B.rec_slab = slab >> SGTD_REC_SHIFT;      // granules
   }
   // room a list gets when its pass starts (ProbeBuffers::rec_rate): three times the matches per visited entry
   // and descriptor of the batch before; a quarter of the visit list for the first batch
@@ -898,7 +912,8 @@ int launch_pairs_query(sgtd_engine *e, const Views &v, const u64 *keep = nullptr
   const size_t tab = (((size_t)v.span + 15) & ~(size_t)15) + 16;     // (+ the bytes that answer for dead records)
   // (up to 100 KB two workgroups share a CU; a span whose byte table only fits alone — 100 000 frames: 132 KB with the
   // image — still beats the candidates' hash: one workgroup per CU)
-  if (img + tab <= 150 * 1024) {
+  static const size_t room = lds_room(&pairs_query_kernel<true>);
+  if (img + tab <= room) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_query_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(img + tab)));
     pairs_query_kernel<true><<<e->nq, SGTD_PQ_THREADS, img + tab, e->stream>>>(v.Q, v.B, e->n_cand.as<int>(), e->cand_frame.as<int>(), cn,
                                                                                 e->pair_off.as<long long>(), e->q_pair_base.as<u32>(),
@@ -1002,10 +1017,11 @@ int launch_select(sgtd_engine *e) {
   const u32 n_tiles = (span + tile_span - 1) / tile_span;
   // (automatic choice where a query's vote histogram fits LDS: with the candidates' hash instead of the frame -> slot
   // byte table the list pass is slower than the block passes — 100 000-frame map, 256 queries: 6.1 against 2.9 ms)
-  const bool votes_fit = votes_topk_lds_bytes(span) <= 150 * 1024;
+  static const size_t votes_room = lds_room(&votes_topk_kernel), list_room = lds_room(&pairs_query_kernel<true>);
+  const bool votes_fit = votes_topk_lds_bytes(span) <= votes_room;
   // ... or at least its frame -> slot byte table beside a tile's image (one workgroup per CU then; 100 000 frames, 256 queries:
   // votes by tiles + top-k + this list pass 15.1 ms per step against 16.1 with the block passes, gpurun_out/r05o_*)
-  const bool table_fits = (size_t)SGTD_PQ_TILE_RECS * sizeof(u32) + (((size_t)span + 15) & ~(size_t)15) + 16 <= 150 * 1024;
+  const bool table_fits = (size_t)SGTD_PQ_TILE_RECS * sizeof(u32) + (((size_t)span + 15) & ~(size_t)15) + 16 <= list_room;
   const bool per_query = e->select_mode == 2 || (e->select_mode == 0 && nq >= e->n_cus && (votes_fit || table_fits));
   // (an image word of the list pass is slot(6) | descriptor(9) | rank: with 64 candidates AND ranks of the full width the
   // word of slot 63, descriptor 511, rank 2^17 - 1 would be the pass's "no record" marker — that corner takes the block form)
@@ -1320,9 +1336,37 @@ int rerun_write(sgtd_engine *e) {
   return SGTD_OK;
 }
 
+// A handle attached to another one's table (sgtd_attach_table) holds that table's device pointers.  Whatever changes the
+// owner's table — an add, a load, a finalize that rebuilds or merges a segment (its own fifth batch on a tail does) — may
+// have freed them: every call of the view that would touch the table again (a batch's re-run, the verification, gathers of
+// entries) asks here first.  (Work the view had already enqueued is safe: hipFree waits for the device.)
+int view_current(sgtd_engine *e) {
+  if (!e->attached_to) return SGTD_OK;
+  if (e->attached_to->table_version != e->attached_version || !e->attached_to->finalized) {
+    e->err = "the owner's table changed since sgtd_attach_table: attach again";
+    e->batch_valid = false;
+    return SGTD_ERR_STATE;
+  }
+  return SGTD_OK;
+}
+
+// the batch's stage times from its events (the batch has been waited for)
+void stage_times(sgtd_engine *e) {
+  if (!e->timing) return;
+  sgtd_stats &s = e->stats;
+  auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[b]); return ms; };
+  if (e->last_kind == 1) { s.ms_build = el(EV_START, EV_BUILD); s.ms_sort = el(EV_BUILD, EV_SORT); }
+  else { s.ms_build = 0; s.ms_sort = el(EV_START, EV_SORT); }
+  s.ms_probe = el(EV_SORT, EV_PROBE); s.ms_votes = el(EV_PROBE, EV_VOTES);
+  s.ms_topk = el(EV_VOTES, EV_TOPK); s.ms_count = el(EV_TOPK, EV_COUNT_T);
+  s.ms_scan = el(EV_COUNT_T, EV_SCAN); s.ms_write = el(EV_SCAN, EV_WRITE);
+  s.ms_total = el(EV_START, EV_WRITE);
+}
+
 int sync_batch(sgtd_engine *e) {
   PinScope pin_scope(e);
   if (!e->batch_valid) return SGTD_ERR_STATE;
+  CHK(view_current(e));
   if (e->batch_synced) return SGTD_OK;
   e->stats.overflowed = 0;
   unsigned long long swept = 0;
@@ -1342,13 +1386,14 @@ int sync_batch(sgtd_engine *e) {
     CHK(d2h(e, &total, e->q_pair_base.as<u32>() + e->nq, sizeof(u32)));
     CHK(xfer_sync(e));
     std::memcpy(&cursor, ctr, 8); std::memcpy(&need, ctr + 4, 8); std::memcpy(&swept, ctr + 6, 8);
+    cursor <<= SGTD_REC_SHIFT;          // (the device counts granules of four records)
     pool_used = ctr[8]; ovf[0] = (int)ctr[10]; ovf[1] = (int)ctr[11];
     e->stats.last_list_moves = ctr[9];
     e->stats.batches_total = (int64_t)tot[0]; e->stats.overflow_launches_total = (int64_t)tot[1]; e->stats.list_moves_total = (int64_t)tot[2];
     if (!ovf[0] && !ovf[1]) {
       // slab use varies a little from run to run (which wave sweeps what): when a batch comes within
       // a tenth of the capacity, make room for half as much again (reallocated at the next launch)
-      const size_t lim0 = 0xFFFFFFF0ull;
+      const size_t lim0 = kRecLimit;
       if ((double)cursor * 1.1 > (double)e->rec_cap) e->rec_cap = std::min<size_t>(lim0, (size_t)((double)cursor * 1.5));
       break;
     }
@@ -1358,8 +1403,8 @@ int sync_batch(sgtd_engine *e) {
       fprintf(stderr, "sgtd: batch re-run (attempt %d): flags %d %d, records %llu of %zu (+%llu wanted), pass pool %u of %zu units, home cells %u of %zu rows, pairs %u of %zu\n",
               attempt, ovf[0], ovf[1], cursor, e->rec_cap, need, pool_used, e->pool_units, n_groups, e->group_cap, total, e->pair_cap);
     if (attempt == 11) return SGTD_ERR_CAPACITY;
-    // grow towards the u32 index limit; a batch that does not fit even there must be split
-    const size_t lim = 0xFFFFFFF0ull;
+    // grow towards the index limits; a batch that does not fit even there must be split
+    const size_t lim = kRecLimit, pair_lim = kIndexLimit;
     if (ovf[0] && (size_t)n_groups > e->group_cap) {
       // more distinct home cells than GroupRows were reserved
       e->group_cap = (size_t)n_groups + (size_t)n_groups / 4 + 1024;
@@ -1383,8 +1428,8 @@ int sync_batch(sgtd_engine *e) {
       const size_t want = (size_t)((double)(e->rec_cap + need) * 1.4) + (size_t)e->n_cus * 32 * SGTD_PAIR * 512;
       e->rec_cap = std::min<size_t>(lim, std::max<size_t>(reservations ? e->rec_cap : e->rec_cap * 2, want));
     } else if (ovf[1]) {
-      if (e->pair_cap >= lim) return SGTD_ERR_CAPACITY;
-      e->pair_cap = std::min<size_t>(lim, std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536));
+      if (e->pair_cap >= pair_lim) return SGTD_ERR_CAPACITY;
+      e->pair_cap = std::min<size_t>(pair_lim, std::max<size_t>(e->pair_cap * 2, (size_t)total + (total >> 3) + 65536));
       CHK(rerun_write(e));
       continue;
     }
@@ -1418,15 +1463,7 @@ int sync_batch(sgtd_engine *e) {
     s.last_M += e->h_q_M[q];
     s.last_cand_pairs += e->h_pair_off[(size_t)q * (cn + 1) + cn];
   }
-  if (e->timing) {
-    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[b]); return ms; };
-    if (e->last_kind == 1) { s.ms_build = el(EV_START, EV_BUILD); s.ms_sort = el(EV_BUILD, EV_SORT); }
-    else { s.ms_build = 0; s.ms_sort = el(EV_START, EV_SORT); }
-    s.ms_probe = el(EV_SORT, EV_PROBE); s.ms_votes = el(EV_PROBE, EV_VOTES);
-    s.ms_topk = el(EV_VOTES, EV_TOPK); s.ms_count = el(EV_TOPK, EV_COUNT_T);
-    s.ms_scan = el(EV_COUNT_T, EV_SCAN); s.ms_write = el(EV_SCAN, EV_WRITE);
-    s.ms_total = el(EV_START, EV_WRITE);
-  }
+  stage_times(e);
   e->batch_synced = true;
   return SGTD_OK;
 }
@@ -1465,13 +1502,7 @@ int settle_pending(sgtd_engine *e) {
 // (one full build, ~0.25 ms per million entries).
 #define SGTD_TAIL_BATCHES 4
 int settle_tail(sgtd_engine *e) {
-  if (e->attached_to) {
-    if (e->attached_to->table_version != e->attached_version || !e->attached_to->finalized) {
-      e->err = "the owner's table changed since sgtd_attach_table: attach again";
-      return SGTD_ERR_STATE;
-    }
-    return SGTD_OK;
-  }
+  if (e->attached_to) return view_current(e);
   if (e->finalized && e->n_seg == 2) {
     if (e->tail_batches >= SGTD_TAIL_BATCHES) { e->tail_batches = 0; return do_finalize(e, /*force_merge=*/true); }
     e->tail_batches++;
@@ -1638,7 +1669,7 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->seg[1].hot, &e->seg[1].perm, &e->seg[1].hash, &e->seg[1].bucket_start, &e->seg[1].bucket_key, &e->seg[1].dir, &e->slice_of, &e->sq_sum,
                     &e->keyA, &e->keyB, &e->valA, &e->valB, &e->hist, &e->digit_tot, &e->flags, &e->bad_flag,
                     &e->kp_off_dev, &e->xyz_dev, &e->label_dev, &e->b_kp_off_dev, &e->b_xyz_dev, &e->b_label_dev, &e->ws_keys, &e->ws_slots, &e->cnt_scan,
-                    &e->tmp_count, &e->q_count, &e->n_valid, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->pos_of_slot, &e->rec_off, &e->pass_pool, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->inl_pairs, &e->inl_off, &e->v_hyp64, &e->v_hyp32, &e->v_bound, &e->cursors, &e->list, &e->n_visit,
+                    &e->tmp_count, &e->q_count, &e->n_valid, &e->cell_rows, &e->gid, &e->q_prefix, &e->group_first, &e->n_groups, &e->pos_of_slot, &e->rec_off, &e->pass_pool, &e->v_score, &e->v_pose, &e->v_inlier, &e->v_best, &e->inl_pairs, &e->inl_off, &e->v_hyp64, &e->v_hyp32, &e->v_bound, &e->v_hypB, &e->v_tau, &e->v_words, &e->v_okey[0], &e->v_okey[1], &e->v_oval[0], &e->v_oval[1], &e->cursors, &e->list, &e->n_visit,
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
@@ -1919,9 +1950,9 @@ int sgtd_query_frames(sgtd_handle e, const float *xyz, const uint32_t *label, co
     const double margin = e->n_entries > 100000000 ? 1.75 : 1.3;    // (long buckets: the estimate runs low at 100 000 frames)
     const double want = margin * per_query * (double)n_queries + std::min(slab_slack, margin * per_query * (double)n_queries);
     const double cap_mem = (double)free_b / 4.0 / 16.0;    // records + compact list + pairs, a quarter of what is free
-    const size_t cap = (size_t)std::min(std::min(want, cap_mem), (double)0xFFFFFFF0ull);
+    const size_t cap = (size_t)std::min(std::min(want, cap_mem), (double)kRecLimit);
     if (cap > e->rec_cap) e->rec_cap = cap;
-    if (cap / 2 > e->pair_cap) e->pair_cap = cap / 2;   // candidate pairs: 0.2 .. 0.5 of the matches
+    if (std::min(cap / 2, kIndexLimit) > e->pair_cap) e->pair_cap = std::min(cap / 2, kIndexLimit);   // candidate pairs: 0.2 .. 0.5 of the matches
   }
   return enqueue_frames(e);
 }
@@ -1961,7 +1992,9 @@ int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
   (void)hipMemGetInfo(&free_b, &total_b);
   // 16 B per record (records 4, compact list 8, candidate pairs ~4) on top of what the buffers already hold
   const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->pairs.bytes) / 16.0;
-  const double lim = std::min((double)0xFFFFFFF0ull, mem_records);
+  // records are named by granules (6.9e10 of them), a batch's candidate pairs one by one: 0.2 .. 0.5 of the matches, four
+  // tenths here (per_query carries a factor of two already)
+  const double lim = std::min(std::min((double)kRecLimit, mem_records), (double)kIndexLimit / 0.4 * 2.0);
   *max_queries = (int64_t)std::max(1.0, std::floor(lim / per_query));
   return SGTD_OK;
 }
@@ -2240,21 +2273,51 @@ int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
   P.q_vertex = e->qd.vertex.as<float>(); P.q_center = e->qd.center.as<double>();
   P.t_vertex = e->tab.vertex.as<float>(); P.t_center = e->tab.center.as<double>();
   P.score = e->v_score.as<double>(); P.pose = e->v_pose.as<double>(); P.inlier = e->v_inlier.as<unsigned char>();
-  // per-pair vote masks between the kernel's two passes: the compact candidate lists of the assemble
-  // passes are dead once the pairs are final (sync_batch above), and hold a word per record
-  CHK(ensure(e, e->c_pair, (size_t)std::max<int64_t>(total, 1) * sizeof(u64)));
-  P.passed = e->c_pair.as<u64>();
   P.thr2 = 9.0;   // sqrt_rn(y) < 3.0 <=> y < 9.0 (sqrt(9) = 3, sqrt(pred(9)) rounds to pred(3)); dis_threshold :469
   { const char *o = getenv("SGTD_VERIFY_EXACT"); P.exact_only = (o && atoi(o)) ? 1 : 0; }
+  // the vote pass: on the matrix cores (verify_mfma.hip.h) unless SGTD_VERIFY_FORM=valu asks for the packed-f32 form
+  bool mfma = true;
+  { const char *o = getenv("SGTD_VERIFY_FORM"); if (o && !strcmp(o, "valu")) mfma = false; }
   CHK(ensure(e, e->v_hyp64, (size_t)nq * cn * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F64 * sizeof(double)));
-  CHK(ensure(e, e->v_hyp32, (size_t)nq * cn * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F32 * sizeof(float)));
   CHK(ensure(e, e->v_bound, (size_t)nq * cn * 2 * sizeof(u32)));
-  P.hyp64 = e->v_hyp64.as<double>(); P.hyp32 = e->v_hyp32.as<float>(); P.bound = e->v_bound.as<u32>();
+  P.hyp64 = e->v_hyp64.as<double>(); P.bound = e->v_bound.as<u32>();
+  P.passed = nullptr; P.hyp32 = nullptr; P.words = nullptr; P.hypB = nullptr; P.tau = nullptr;
+  if (mfma) {
+    // a row of 64 vote words per 32 pairs; candidate k of the batch starts at row (first pair / 32 + k)
+    CHK(ensure(e, e->v_words, ((size_t)std::max<int64_t>(total, 1) / 32 + (size_t)nq * cn + 2) * 64 * sizeof(u32)));
+    CHK(ensure(e, e->v_hypB, (size_t)nq * cn * 6 * 64 * sizeof(uint4)));
+    CHK(ensure(e, e->v_tau, (size_t)nq * cn * 2 * SGTD_VERIFY_MAX_HYP * sizeof(float)));
+    P.words = e->v_words.as<u32>(); P.hypB = e->v_hypB.as<uint4>(); P.tau = e->v_tau.as<float>();
+  } else {
+    // per-pair vote masks between the kernel's two passes (a buffer of their own: the compact candidate lists in c_pair may
+    // still be needed by a re-run of the batch's list pass when this is enqueued behind an unfinished batch)
+    CHK(ensure(e, e->v_words, (size_t)std::max<int64_t>(total, 1) * sizeof(u64)));
+    CHK(ensure(e, e->v_hyp32, (size_t)nq * cn * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F32 * sizeof(float)));
+    P.passed = e->v_words.as<u64>(); P.hyp32 = e->v_hyp32.as<float>();
+  }
   P.keep = e->verify_keep;
   P.overflow = guard ? reinterpret_cast<const int *>(e->cursors.as<u32>() + 10) : nullptr;
+  P.order = nullptr; P.n_blocks = (u32)(nq * cn);
+  int grid = nq * cn;
+  // a batch of many candidates is dispatched in the order of the candidates' frames (SGTD_VERIFY_ORDER=0: as they stand)
+  static const bool order_on = [] { const char *o = getenv("SGTD_VERIFY_ORDER"); return !(o && !atoi(o)); }();
+  if (mfma && order_on && !guard && nq * cn >= 4096 && e->have_frames) {
+    const u32 nb = (u32)(nq * cn);
+    for (int k = 0; k < 2; k++) { CHK(ensure(e, e->v_okey[k], (size_t)nb * sizeof(u32))); CHK(ensure(e, e->v_oval[k], (size_t)nb * sizeof(u32))); }
+    u32 *kin = e->v_okey[0].as<u32>(), *kout = e->v_okey[1].as<u32>(), *vin = e->v_oval[0].as<u32>(), *vout = e->v_oval[1].as<u32>();
+    const u32 last = e->frame_hi + 1u;          // key of a candidate slot that is empty
+    verify_order_keys_kernel<<<grid_for(nb, 256), 256, 0, e->stream>>>(e->cand_frame.as<int>(), e->n_cand.as<int>(), cn, nb, last, kin, vin);
+    HIPCHK(hipGetLastError());
+    int bits = 1;
+    while (bits < 32 && (last >> bits)) bits++;
+    CHK(radix_sort_pairs<u32>(e, kin, kout, vin, vout, (long long)nb, bits, false));
+    P.order = vin;
+    grid = 8 * (int)((nb + 7) / 8);
+  }
   verify_solve_kernel<<<nq * cn, SGTD_WAVE, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
-  verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
+  if (mfma) verify_mfma_kernel<<<grid, SGTD_VM_THREADS, 0, e->stream>>>(P);
+  else verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
 #ifdef SGTD_EXP_VSTAT
   {
@@ -2265,6 +2328,10 @@ int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
             "with eight or more %llu  not far on all three %llu  certain votes %llu\n", st[0], st[1], st[3], st[7], st[2], st[5], st[6], st[4]);
     unsigned long long z[8] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vstat), z, sizeof(z)));
+    HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_vmstat), sizeof(st)));
+    fprintf(stderr, "[vmstat] (32 pairs x 32 hypotheses) steps %llu  with something left open %llu | combinations queued for the exact test %llu  of them votes %llu  "
+            "queue drains %llu  certain votes %llu\n", st[0], st[1], st[2], st[3], st[4], st[5]);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vmstat), z, sizeof(z)));
   }
 #endif
   return SGTD_OK;
@@ -2382,6 +2449,7 @@ int sgtd_result_inlier_entries(sgtd_handle e, int q, int64_t *cand_off, int32_t 
     return entries ? sgtd_fetch_entries(e, ent.data(), *n_pairs, entries) : SGTD_OK;
   }
   HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(view_current(e));
   if (!e->verified || !e->batch_valid || q < 0 || q >= e->nq) return SGTD_ERR_INVALID;
   const int cn = e->dc.cand_num;
   const int64_t total = e->h_pair_off[(size_t)q * (cn + 1) + cn];
@@ -2508,7 +2576,9 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
                                               cn, e->frame_pack.as<unsigned char>());
   HIPCHK(hipGetLastError());
   std::vector<unsigned char> pack(frame_pack_bytes(cn));
+  unsigned long long tot[3] = {0, 0, 0};                    // the handle's running totals, as sync_batch reads them
   CHK(d2h(e, pack.data(), e->frame_pack.p, pack.size()));
+  if (e->totals.p) CHK(d2h(e, tot, e->totals.p, sizeof(tot)));
   CHK(xfer_sync(e));                                        // ---- wait 1
   const u32 *w = reinterpret_cast<const u32 *>(pack.data());
   if (w[10] | w[11]) {
@@ -2545,7 +2615,9 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
     st.overflowed = 0; st.last_list_moves = w[9];
     st.last_queries = 1; st.last_D = w[15]; st.last_P = (int64_t)e->h_q_P[0]; st.last_M = w[13]; st.last_P_swept = (int64_t)swept;
     st.last_cand_pairs = po[cn];
+    if (e->totals.p) { st.batches_total = (int64_t)tot[0]; st.overflow_launches_total = (int64_t)tot[1]; st.list_moves_total = (int64_t)tot[2]; }
   }
+  stage_times(e);
   e->batch_synced = true;
   e->verified = true;
   io->n_cand = (int32_t)w[12];
@@ -2649,6 +2721,7 @@ int sgtd_fetch_entries(sgtd_handle e, const int64_t *db_entry, int64_t n, sgtd_d
   if (e && e->grp) return multi::fetch_entries(e, db_entry, n, out);
   if (!e || n < 0 || (n > 0 && (!db_entry || !out))) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
+  CHK(view_current(e));
   if (n == 0) return SGTD_OK;
   bool contiguous = true;
   for (int64_t i = 0; i < n; i++) {

@@ -53,6 +53,12 @@ struct VerifyParams {
   int exact_only;              // test hook (SGTD_VERIFY_EXACT=1): no f32 pre-test, every vertex A test in f64
   const u64 *keep;             // [nq] or NULL: bit c = verify candidate c of the query (sgtd_verify_masked: the candidates that
                                // survived a multi-GPU merge); the others score -1 like a rejected candidate
+  // the matrix-core vote pass (verify_mfma.hip.h)
+  u32 *words;                  // vote words: u32 [rows of 32 pairs][64], a candidate's rows start at (first pair / 32 + its index in the batch)
+  uint4 *hypB;                 // [nq * cand_num][2][3][64] hypothesis features as the MFMAs' B operands
+  float *tau;                  // [nq * cand_num][2][SGTD_VERIFY_MAX_HYP] |t|^2 (NaN: exact test only) and |t|_1 of the hypotheses
+  const u32 *order;            // or NULL: the (query, candidate) indices in dispatch order (by candidate frame), n_blocks of them
+  u32 n_blocks;
   const int *overflow;         // or NULL: the batch's overflow flags — set: the lists are not final (the batch will be re-run), nothing
                                // is read (sgtd_search_frame enqueues the verification behind the batch without a host round trip)
 };
@@ -168,6 +174,70 @@ __device__ __forceinline__ bool vertex_close(const double *Rt, const double v[3]
   return ((dx * dx + dy * dy) + dz * dz) < thr2;
 }
 
+#define SGTD_VM_BLIMIT 2.5e4        // largest hypothesis feature the matrix pass accepts
+// ---- the hypothesis side, written by verify_solve_kernel's thread h for hypothesis h (NaN tau: exact test only) -----------
+// Layout = the B operand of the four MFMAs as the lanes read it: block (T, mi), T = h / 32, mi = 2 u + part; lane
+// (h % 32) + 32 hh holds for k = 0..3 the feature of term 8 hh + 4 u + k, its high part (part 0) or low part (part 1), twice.
+__device__ __forceinline__ void vm_split(float x, _Float16 &hi, _Float16 &lo) {
+  const float h = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);   // the top 11 significant bits
+  hi = (_Float16)h;
+  lo = (_Float16)(x - h);
+}
+__device__ inline void vm_write_hypothesis(const double out[12], bool solved, uint4 *hypB /* of the candidate */, float *tau /* of the candidate */, int h) {
+  // b[4 i + j] = M_ij of  s (d^2 - 9) = sum_ij M_ij (w0, w1, w2, 1)_i s (v0, v1, v2, 1)_j + s (|v|^2 + |w|^2 - 9):
+  // M = [ -2 R, -2 t ; 2 (R^T t)^T, |t|^2 ]
+  double b[16];
+  const double tt = (out[9] * out[9] + out[10] * out[10]) + out[11] * out[11];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) b[4 * i + j] = -2.0 * out[i * 3 + j];
+    b[4 * i + 3] = -2.0 * out[9 + i];
+  }
+  for (int j = 0; j < 3; j++) b[12 + j] = 2.0 * (out[0 * 3 + j] * out[9] + out[1 * 3 + j] * out[10] + out[2 * 3 + j] * out[11]);
+  b[15] = tt;
+  bool ok = solved;
+  double gmax = 0;      // |R^T R - I|_max
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double g = out[0 * 3 + i] * out[0 * 3 + j] + out[1 * 3 + i] * out[1 * 3 + j] + out[2 * 3 + i] * out[2 * 3 + j] - (i == j ? 1.0 : 0.0);
+      gmax = fmax(gmax, fabs(g));
+      if (!(g == g)) ok = false;
+    }
+  if (!(gmax <= 1e-6)) ok = false;
+  for (int k = 0; k < 16; k++) if (!(fabs(b[k]) < SGTD_VM_BLIMIT)) ok = false;
+  _Float16 hi[16], lo[16];
+  for (int k = 0; k < 16; k++) {
+    if (ok) vm_split((float)b[k], hi[k], lo[k]);
+    else { hi[k] = (_Float16)0.0f; lo[k] = (_Float16)0.0f; }
+  }
+  tau[h] = ok ? (float)tt : __builtin_nanf("");
+  {   // |t|_1, rounded up
+    const double a1 = (fabs(out[9]) + fabs(out[10])) + fabs(out[11]);
+    tau[SGTD_VERIFY_MAX_HYP + h] = ok ? (float)(a1 * 1.000001) : 0.0f;
+  }
+  // block (T, 0) and (T, 1): the high parts of the features of terms 8 hh + 0..3 and 8 hh + 4..7, each twice (against a product's
+  // high and low part); block (T, 2): the low parts of terms 8 hh + 0..7, two to a word (against the products' high parts)
+  const int T = h >> 5, c = h & 31;
+  auto bits_of = [](_Float16 x) { unsigned short b16; __builtin_memcpy(&b16, &x, 2); return (u32)b16; };
+  for (int hh = 0; hh < 2; hh++) {
+    u32 wd[3][4];
+    for (int k = 0; k < 4; k++) {
+      wd[0][k] = bits_of(hi[8 * hh + k]) * 0x10001u;
+      wd[1][k] = bits_of(hi[8 * hh + 4 + k]) * 0x10001u;
+      wd[2][k] = bits_of(lo[8 * hh + 2 * k]) | (bits_of(lo[8 * hh + 2 * k + 1]) << 16);
+    }
+    for (int mi = 0; mi < 3; mi++) hypB[(size_t)(T * 3 + mi) * 64 + (size_t)(c + 32 * hh)] = make_uint4(wd[mi][0], wd[mi][1], wd[mi][2], wd[mi][3]);
+  }
+}
+
+// keys of the dispatch order: the candidate's frame (candidates that do not exist last)
+__global__ void verify_order_keys_kernel(const int *cand_frame, const int *n_cand, int cand_num, u32 n, u32 last, u32 *key, u32 *val) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int q = (int)(i / (u32)cand_num), c = (int)(i % (u32)cand_num);
+  key[i] = c < n_cand[q] ? min((u32)cand_frame[i], last) : last;
+  val[i] = i;
+}
+
 // ---- pass 1: the hypotheses (:467-468,481-487).  One 64-thread workgroup per (query, candidate): thread h
 // solves the 3x3 Kabsch problem of pair h * skip_len.  Out: per hypothesis (R, t) in f64 (12 doubles) and
 // the same rounded to f32 with every value TWICE (24 floats: the operands of the vote pass's packed f32
@@ -187,16 +257,20 @@ __global__ __launch_bounds__(SGTD_WAVE) void verify_solve_kernel(VerifyParams P)
   const int use_size = (int)(n / skip_len);        // :468
   const size_t qslot0 = (size_t)q * (size_t)P.q_stride;
   u32 rm_bits = P.exact_only ? 0x7FC00000u : 0u, tm_bits = 0u;
+  double out[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (tid < use_size) {
-    double qv[9], ev[9], qc[3], ec[3], out[12];
+    double qv[9], ev[9], qc[3], ec[3];
     const u64 pr = P.pairs[base + (long long)tid * skip_len];
     const size_t qd = qslot0 + (size_t)(pr >> 32), g = (size_t)(pr & 0xFFFFFFFFull);
     for (int k = 0; k < 9; k++) { qv[k] = (double)P.q_vertex[qd * 9 + k]; ev[k] = (double)P.t_vertex[g * 9 + k]; }
     for (int k = 0; k < 3; k++) { qc[k] = P.q_center[qd * 3 + k]; ec[k] = P.t_center[g * 3 + k]; }
     solve_triangle_dev(qv, qc, ev, ec, out);
     double *h64 = P.hyp64 + ((size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP + tid) * SGTD_HYP_F64;
-    float *h32 = P.hyp32 + ((size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP + tid) * SGTD_HYP_F32;
-    for (int k = 0; k < 12; k++) { h64[k] = out[k]; const float f = (float)out[k]; h32[2 * k] = f; h32[2 * k + 1] = f; }
+    for (int k = 0; k < 12; k++) h64[k] = out[k];
+    if (P.hyp32) {
+      float *h32 = P.hyp32 + ((size_t)blockIdx.x * SGTD_VERIFY_MAX_HYP + tid) * SGTD_HYP_F32;
+      for (int k = 0; k < 12; k++) { const float f = (float)out[k]; h32[2 * k] = f; h32[2 * k + 1] = f; }
+    }
     // largest |rot entry| and |t|_1, rounded up, as float bit patterns (non-negative floats order like
     // their bits; a NaN beats everything)
     double rm = 0, tm = fabs(out[9]) + fabs(out[10]) + fabs(out[11]);
@@ -205,6 +279,7 @@ __global__ __launch_bounds__(SGTD_WAVE) void verify_solve_kernel(VerifyParams P)
     rm_bits = max(rm_bits, __float_as_uint((float)(rm * 1.000001)));
     tm_bits = __float_as_uint((float)(tm * 1.000001));
   }
+  if (P.hypB) vm_write_hypothesis(out, tid < use_size, P.hypB + (size_t)blockIdx.x * 6 * 64, P.tau + (size_t)blockIdx.x * 2 * SGTD_VERIFY_MAX_HYP, tid);
 #pragma unroll
   for (int d = SGTD_WAVE / 2; d > 0; d >>= 1) {
     rm_bits = max(rm_bits, (u32)__shfl_xor((int)rm_bits, d));

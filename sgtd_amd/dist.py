@@ -223,6 +223,9 @@ class Map2D:
         # copy).  A one-GPU box can put the RCCL calls, their stream ordering against the engine's export events and the
         # merge behind them on hardware this way (tests/test_dist_gpu.py); never set in production.
         self.force_collective = os.environ.get("SGTD_FORCE_COLLECTIVE") == "1"
+        # (a grid side of ONE rank has no process group of its own — None means WORLD to torch.distributed — so the switch only
+        # makes sense in a job of one rank)
+        assert not self.force_collective or world == 1, "SGTD_FORCE_COLLECTIVE=1 is for one-rank jobs"
         if lists == "winners":
             self.mgr.set_deferred_lists(True)
 
@@ -265,7 +268,8 @@ class Map2D:
             return
         work, nq = self._pending
         self._pending = None
-        work.wait()
+        with torch.cuda.stream(self.side):      # wait() orders the CURRENT stream behind the collective: the merge runs on the side stream
+            work.wait()
         self.mgr.merge_candidates_dev(self.side.cuda_stream, self.gathered, self.r_t, self.t, nq, self.m_frame, self.m_votes, self.m_n,
                                       self.m_src, self.m_keep, self.m_flags)
 
@@ -329,17 +333,28 @@ class Map2D:
         else:
             raise RuntimeError("sgtd_amd.dist: a batch kept outgrowing its work buffers")
         self.main.wait_stream(self.side)
+        # the merged tables are ordered against self.main — for a map with a stream of its own (attach_to) that is not the
+        # caller's: whatever the caller enqueues next on ITS stream comes behind them
+        self._caller_waits()
         return self.m_frame, self.m_votes, self.m_n
+
+    def _caller_waits(self):
+        cur = torch.cuda.current_stream(self.dev)
+        if cur.cuda_stream != self.main.cuda_stream:
+            cur.wait_stream(self.main)
 
     def gather_groups(self):
         """the merged tables of ALL query groups (group-major): (frames, votes) [R_q * nq, cn] on every rank"""
         if (self.r_q == 1 and not self.force_collective) or not dist.is_initialized():
             return self.m_frame, self.m_votes
-        packed = torch.stack([self.m_frame, self.m_votes]).contiguous()
-        out = torch.empty((self.r_q * 2,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(out, packed, group=self.col_group)
-        out = out.view((self.r_q, 2) + tuple(packed.shape[1:]))
-        return out[:, 0].reshape(-1, self.cand_num), out[:, 1].reshape(-1, self.cand_num)
+        with torch.cuda.stream(self.main):       # torch ops and the collective behind the engine's work on self.main
+            packed = torch.stack([self.m_frame, self.m_votes]).contiguous()
+            out = torch.empty((self.r_q * 2,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+            dist.all_gather_into_tensor(out, packed, group=self.col_group)
+            out = out.view((self.r_q, 2) + tuple(packed.shape[1:]))
+            res = out[:, 0].reshape(-1, self.cand_num), out[:, 1].reshape(-1, self.cand_num)
+        self._caller_waits()
+        return res
 
     def search_loop(self, xyz, label, kp_off=None, icp_threshold=None, group=None):
         """SearchLoop over the sharded map: query + merge, candidate_verify of this rank's WINNERS only
@@ -348,16 +363,21 @@ class Map2D:
         Returns (frames, votes, n_cand, scores, poses, best_cand, best_frame, best_score), identical on every rank."""
         frames, votes, n_cand = self.query(xyz, label, kp_off)
         nq, cn = frames.shape
-        self.mgr.verify_masked(self.m_keep)
-        self.mgr.export_verify(self.v_local[:nq * cn], self.v_local[nq * cn:])
-        if self._table_collective():
-            dist.all_gather_into_tensor(self.v_gathered, self.v_local, group=self.table_group)
-            src = self.v_gathered
-        else:
-            src = self.v_local
-        self.mgr.gather_verified_dev(self.main.cuda_stream, src, self.r_t, self.m_src, nq, self.v_score, self.v_pose)
-        thr = self.mgr.icp_threshold_ if icp_threshold is None else icp_threshold
-        bc, bf, bs = search_loop_choice(frames, n_cand, self.v_score, thr)
+        # everything below on self.main: the verification, its export copies, the all-gather of the results, the gather kernel and
+        # the choice are one chain on the engine's stream (a map with a stream of its own — attach_to — would otherwise start the
+        # all-gather on the caller's stream before the verification had written v_local)
+        with torch.cuda.stream(self.main):
+            self.mgr.verify_masked(self.m_keep)
+            self.mgr.export_verify(self.v_local[:nq * cn], self.v_local[nq * cn:])
+            if self._table_collective():
+                dist.all_gather_into_tensor(self.v_gathered, self.v_local, group=self.table_group)
+                src = self.v_gathered
+            else:
+                src = self.v_local
+            self.mgr.gather_verified_dev(self.main.cuda_stream, src, self.r_t, self.m_src, nq, self.v_score, self.v_pose)
+            thr = self.mgr.icp_threshold_ if icp_threshold is None else icp_threshold
+            bc, bf, bs = search_loop_choice(frames, n_cand, self.v_score, thr)
+        self._caller_waits()
         return frames, votes, n_cand, self.v_score, self.v_pose, bc, bf, bs
 
 

@@ -34,6 +34,13 @@ def main():
     # handed the same queries here, so all ranks must end with the same result
     sm = Map2D(F, rank, world, r_t=int(os.environ.get("SGTD_TEST_RT", world)), device_id=local, lists=os.environ.get("SGTD_TEST_LISTS", "all"))
     sm.add_shard_frames(smap.xyz[sm.lo:sm.hi], smap.label[sm.lo:sm.hi])
+    if os.environ.get("SGTD_TEST_ATTACHED") == "1":
+        # a second map of the grid on this rank, borrowing the first one's table: it has a stream of ITS OWN, so the step's
+        # collectives and torch ops must be ordered against that stream, not against the caller's current one
+        owner = sm
+        owner.mgr.query_frames(qs.xyz, qs.label)            # (the owner has a batch of its own in flight meanwhile)
+        sm = Map2D(F, rank, world, r_t=owner.r_t, device_id=local, lists=owner.lists, attach_to=owner)
+        assert sm.main.cuda_stream != torch.cuda.current_stream(dev).cuda_stream
     frames, votes, n_cand, scores, poses, bc, bf, bs = sm.search_loop(qs.xyz, qs.label)
     torch.cuda.synchronize()
     if os.environ.get("SGTD_TEST_EXPECT_REPAIR") == "1":

@@ -120,6 +120,15 @@ def test_sharded_search_loop_over_the_collective_backend(lists):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lists", ["all", "winners"])
+def test_search_loop_on_a_map_attached_to_another(lists):
+    """the same through a second Map2D of the rank that borrows the first one's table (attach_to): its engine runs on a stream
+    of its own, and verification, export copies, the all-gather of the results and the choice must all be ordered against
+    THAT stream (they once ran on the caller's current stream: the all-gather could start before the scores were written)"""
+    _search_loop(2, 2, lists, {"SGTD_TEST_ATTACHED": "1"})
+
+
+@pytest.mark.gpu
 def test_search_loop_on_a_two_by_two_grid():
     _search_loop(4, 2, "winners")
 

@@ -224,5 +224,17 @@ def test_attached_view_queries_the_owners_table(mods):
     r2 = view.query_frames(qa.xyz, qa.label)
     r3 = own.query_frames(qa.xyz, qa.label)
     assert np.array_equal(r2.cand_frame, r3.cand_frame) and np.array_equal(r2.cand_votes, r3.cand_votes)
+    # a view's PENDING batch after the owner's table changed (the owner reallocates and frees what the view borrowed): the
+    # verification, SearchLoop's choice and the gathers of entries refuse instead of reading freed memory
+    view.query_frames(qa.xyz, qa.label, fetch=False)
+    own.add_frames(smap.xyz[3:6], smap.label[3:6])
+    own.finalize()
+    for call in (view.verify, view.sync, lambda: view.fetch_entries(np.arange(4, dtype=np.int64))):
+        with pytest.raises(SgtdError):
+            call()
+    view.attach_table(own)
+    r4, r5 = view.query_frames(qb.xyz, qb.label), own.query_frames(qb.xyz, qb.label)
+    view.verify(); own.verify()
+    assert np.array_equal(r4.cand_frame, r5.cand_frame) and all(np.array_equal(x, y) for x, y in zip(view.result_verify(0), own.result_verify(0)))
     view.close()
     own.close()

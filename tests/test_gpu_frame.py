@@ -54,9 +54,13 @@ def test_search_frame_equals_the_calls_it_stands_for(mods, monkeypatch):
         assert d.n == od.n and np.array_equal(d.side, od.side) and np.array_equal(d.vertex, od.vertex) and np.array_equal(d.node_id, od.node_id)
         ref = _five_calls(g, d)
         room = int(ref[1].pair_off[0, -1])           # (every pair an inlier: always enough)
+        before = g.stats()["batches_total"]
         fs = g.search_frame(d, capacity=room)
         assert fs["status"] == 0 and fs["n_inliers"] > 0
         _same(fs, ref, cn)
+        # the one-wait path leaves the handle's running totals and stage times as a waited batch does
+        st = g.stats()
+        assert st["batches_total"] == before + 1 and st["last_queries"] == 1 and st["ms_total"] >= 0
         # the handle is left as the five calls leave it: the lists of the same batch can still be read, and are the oracle's
         r = o.select()
         qi, de = g.result_pairs(0, g.results())

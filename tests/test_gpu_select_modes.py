@@ -160,10 +160,13 @@ def test_frame_span_that_nearly_fills_lds(mods):
         np.testing.assert_array_equal(v.astype(np.float64), o.votes()[lo:lo + len(v)])
 
 
-def test_frame_spans_beyond_lds_take_the_tiled_votes_and_the_candidates_hash(mods):
+@pytest.mark.parametrize("stride", [6521, 5200], ids=["span150k", "span120k"])
+def test_frame_spans_beyond_lds_take_the_tiled_votes_and_the_candidates_hash(mods, stride):
     """frame ids spread over 150 000 (caller-stamped): the vote histogram of a query does not fit LDS — votes in frame
     tiles by votes_query_kernel, top-k by topk_kernel, the lists' offsets by cand_prefix_kernel — and neither does the
-    frame -> slot byte table of pairs_query_kernel, which looks the candidates up in their 256-entry hash instead"""
+    frame -> slot byte table of pairs_query_kernel, which looks the candidates up in their 256-entry hash instead.
+    span120k: 119 611 frames — the byte table and the tile image together are within the 150 KB the launch code allowed but,
+    with the kernel's 12.6 KB of static LDS, beyond the 160 KB a workgroup has (the launch used to fail there)"""
     oracle, manager, synth = mods
     g = manager.STDescManager(max_frame_n=200000)
     o = oracle.OracleManager(max_frame_n=200000)
@@ -171,7 +174,7 @@ def test_frame_spans_beyond_lds_take_the_tiled_votes_and_the_candidates_hash(mod
     for f in range(24):
         d = g.BuildSingleScanSTD(m.xyz[f], m.label[f])
         od = o.build(m.xyz[f], m.label[f])
-        fid = 11 + f * 6521                      # ascending, up to 149 994
+        fid = 11 + f * stride                    # ascending, up to 149 994 / 119 611
         d.frame[:] = fid; od.frame[:] = fid
         g.AddSTDescs(d); o.add(od)
     qs = synth.make_queries(m, 4, stream=144)

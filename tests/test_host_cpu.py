@@ -232,3 +232,34 @@ def test_bench_relays_exactly_one_result_line():
     assert b.last_result_line(noisy) == '{"metric": "m", "value": 1}'
     assert b.last_result_line("no json here\n") is None
     assert b.modelled_all_gather_ms(1 << 20, 1) == 0.0 and b.modelled_all_gather_ms(1 << 20, 8) > b.modelled_all_gather_ms(1 << 20, 2) > 0
+
+
+def test_bench_line_repeats_its_evidence_as_scalar_keys():
+    """the driver's record of a bench line keeps scalars (and the scalar members of `config` / `roofline`) only: what the nested
+    objects say — delivered rate, one batch in flight, overflowed launches, parity count, verification time, skewed workload,
+    the spread of the repeated timed region, for N > 1 the table-sharded and cfg4 figures, the sweep's useful fraction of the
+    HBM roof — must also be there as scalar keys (bench.flatten_evidence)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    line = {"n_gpus": 8, "config": {"table_shards_R_t": 4, "query_groups_R_q": 2},
+            "roofline": {"peak": 8000.0, "kernel_ms": {"ms_probe": 5.0},
+                         "compulsory": {"probe_layout_once": 711000000, "match_records_once": 6090000000, "frac": 0.107}},
+            "timed_region": {"launches_that_overflowed_a_work_buffer": 0, "region_ms_per_step_median": 11.0, "region_ms_per_step_min": 10.9,
+                             "region_ms_per_step_max": 11.2, "regions_timed": 5},
+            "delivered": {"frames_per_s": 184600.0}, "one_batch_in_flight": {"ms_per_step": 11.87},
+            "parity": {"identical_candidates_votes_matchlists": 200}, "verify": {"ms_per_batch": 9.5},
+            "workload_skew": {"frames_per_s": 18800.0}, "boundary": {"cpp_adapter_ms_per_frame": 6.5},
+            "map_size_sweep": {"100_cfg1_json_in": {"identical_candidates_votes_matchlists": "200/200"}},
+            "table_sharded": {"value": 60000.0}, "merged_list_equals_single_table": True, "cfg4": {"value": 150000.0},
+            "scaling_parts": {"exchange_exposed_ms": 0.05}}
+    out = bench.flatten_evidence(line)
+    for k in bench.FLAT_CONFIG_KEYS + bench.FLAT_CONFIG_KEYS_MULTI:
+        assert k in out["config"] and out["config"][k] is not None and not isinstance(out["config"][k], (dict, list)), k
+    for k in bench.FLAT_ROOFLINE_KEYS:
+        assert isinstance(out["roofline"][k], float), k
+    assert abs(out["roofline"]["useful_frac"] - (0.711 + 6.09) / 5.0e-3 / 8000.0) < 1e-9 and out["config"]["cfg1_identical_of_200"] == 200
+    # a line without the optional legs still gets the keys (null), and never fails
+    bare = bench.flatten_evidence({"n_gpus": 1, "config": {}, "roofline": {"peak": 8000.0}})
+    assert all(k in bare["config"] for k in bench.FLAT_CONFIG_KEYS) and bare["roofline"]["useful_frac"] is None
