@@ -1990,11 +1990,15 @@ int sgtd_max_batch(sgtd_handle e, int n_keypoints, int64_t *max_queries) {
   const double per_query = std::max(1.0, est_matches_per_query(e, n_keypoints)) * 2.0;   // margin: slab slack, variation
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  // 16 B per record (records 4, compact list 8, candidate pairs ~4) on top of what the buffers already hold
-  const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->pairs.bytes) / 16.0;
-  // records are named by granules (6.9e10 of them), a batch's candidate pairs one by one: 0.2 .. 0.5 of the matches, four
-  // tenths here (per_query carries a factor of two already)
-  const double lim = std::min(std::min((double)kRecLimit, mem_records), (double)kIndexLimit / 0.4 * 2.0);
+  // records are named by granules (6.9e10 of them), a batch's candidate pairs one by one: 0.2 .. 0.5 of the matches on the
+  // uniform maps (four tenths before anything was measured; per_query carries a factor of two already)
+  double pair_share = 0.4;
+  if (e->stats.last_M > 0 && e->stats.last_cand_pairs > 0)      // measured on the batch before, half as much again
+    pair_share = std::min(1.0, std::max(0.05, 1.5 * (double)e->stats.last_cand_pairs / (double)e->stats.last_M));
+  // memory: 4 B per record and 8 B per candidate pair on top of what the buffers already hold (a batch this large takes the
+  // per-query passes: no compact lists between the block passes, which would be 8 B per record more)
+  const double mem_records = ((double)free_b * 0.8 + (double)e->rec.bytes + (double)e->c_pair.bytes + (double)e->pairs.bytes) / (4.0 + 8.0 * pair_share);
+  const double lim = std::min(std::min((double)kRecLimit, mem_records), (double)kIndexLimit / pair_share * 2.0);
   *max_queries = (int64_t)std::max(1.0, std::floor(lim / per_query));
   return SGTD_OK;
 }

@@ -229,9 +229,15 @@ def test_attached_view_queries_the_owners_table(mods):
     view.query_frames(qa.xyz, qa.label, fetch=False)
     own.add_frames(smap.xyz[3:6], smap.label[3:6])
     own.finalize()
-    for call in (view.verify, view.sync, lambda: view.fetch_entries(np.arange(4, dtype=np.int64))):
+    for call in (view.verify, lambda: view.fetch_entries(np.arange(4, dtype=np.int64))):
         with pytest.raises(SgtdError):
             call()
+    view.sync()                                            # (the refused batch is dropped: nothing is pending any more)
+    view.attach_table(own)
+    view.query_frames(qa.xyz, qa.label, fetch=False)
+    own.add_frames(smap.xyz[6:8], smap.label[6:8])
+    with pytest.raises(SgtdError):
+        view.sync()                                        # the wait for a pending batch is where a re-run would touch the table
     view.attach_table(own)
     r4, r5 = view.query_frames(qb.xyz, qb.label), own.query_frames(qb.xyz, qb.label)
     view.verify(); own.verify()
