@@ -48,6 +48,63 @@ def _same_as_oracle(g, o, res, q, xyz, label):
     return r
 
 
+def test_cfg1_one_scan_per_call_against_a_100_frame_map_graph_json_in(mods, tmp_path):
+    """BASELINE configs[0] at its own size: a 100-frame map and 200 scans, every one a graph-JSON file in the producer's format
+    (get_json.cpp:332-341; synthetic stand-in: KITTI-00 is not in the tree) read by the ingest, one scan per call with host
+    pointers in (the reference's call pattern, semantic_graph_localization.cpp:590-603) and the same scans as one batch —
+    candidates, votes, ordered match lists, the verification's score / pose and SearchLoop's choice of all 200 against the oracle"""
+    oracle, manager, synth = mods
+    from sgtd_amd import evaluate as ev, ingest
+    F, N, NQ = 100, 200, 200
+    smap = synth.make_map(F, N, stream=0)
+    qs = synth.make_queries(smap, NQ, stream=0)
+    mp, qp = [], []
+    for f in range(F):
+        mp.append(str(tmp_path / ("map_%04d.json" % f)))
+        ingest.write_graph_json(mp[-1], smap.xyz[f], smap.label[f], ev.pose_row(*smap.pose[f]))
+    for q in range(NQ):
+        qp.append(str(tmp_path / ("scan_%04d.json" % q)))
+        ingest.write_graph_json(qp[-1], qs.xyz[q], qs.label[q], ev.pose_row(*qs.pose[q]))
+    gm, gq = ingest.load_graphs(mp), ingest.load_graphs(qp)
+    assert gm.n_frames == F and gq.n_frames == NQ and np.array_equal(gm.xyz.reshape(F, N, 3), smap.xyz) and np.array_equal(gq.xyz.reshape(NQ, N, 3), qs.xyz)
+    g = manager.STDescManager()
+    g.add_frames(gm.xyz, gm.label, kp_off=gm.kp_off)
+    o = _oracle_map(oracle, [smap])
+    qx, ql = gq.xyz.reshape(NQ, N, 3), gq.label.reshape(NQ, N)
+    batch = g.query_frames(qx, ql)
+    g.verify()
+    b_choice = g.search_loop()
+    b_pairs = [g.result_pairs(q, batch) for q in range(NQ)]
+    b_ver = [g.result_verify(q) for q in range(NQ)]
+    loops = 0
+    for q in range(NQ):
+        one = g.query_frames(qx[q:q + 1], ql[q:q + 1])          # one scan per call
+        r = _same_as_oracle(g, o, one, 0, qx[q], ql[q])
+        nc = int(one.n_cand[0])
+        assert int(batch.n_cand[q]) == nc and np.array_equal(batch.cand_frame[q, :nc], r["cand_frame"]) and np.array_equal(batch.cand_votes[q, :nc], r["cand_votes"])
+        assert np.array_equal(b_pairs[q][0], r["q_idx"]) and np.array_equal(b_pairs[q][1], r["db_entry"])
+        g.verify()
+        score, rot, t = g.result_verify(0)
+        best_s, best_k = 0.0, -1
+        for k in range(nc):
+            o_score, o_t, o_rot, _ = o.verify(k, int(one.pair_off[0, k + 1] - one.pair_off[0, k]))
+            assert score[k] == o_score, (q, k)
+            if o_score >= 0:
+                assert np.array_equal(t[k], o_t) and np.array_equal(rot[k], o_rot), (q, k)
+            if o_score > best_s:
+                best_s, best_k = o_score, k
+        assert all(np.array_equal(a[:nc], b[:nc]) for a, b in zip(b_ver[q], (score, rot, t)))
+        bc, bf, bs = g.search_loop()
+        assert (int(bc[0]), int(bf[0]), float(bs[0])) == (int(b_choice[0][q]), int(b_choice[1][q]), float(b_choice[2][q]))
+        if best_s > g.icp_threshold_:          # SearchLoop's choice (STDesc.cpp:105-146): the first candidate with the largest score
+            assert int(bc[0]) == best_k and float(bs[0]) == best_s and int(bf[0]) == int(r["cand_frame"][best_k])
+        else:
+            assert int(bf[0]) == -1
+        loops += int(bf[0] >= 0)
+    assert loops >= NQ * 9 // 10
+    g.close()
+
+
 def _list_properties(g, res, q):
     """what every candidate_selector result satisfies whatever the size: votes descending with
     ties by ascending frame, at least 5 votes, list lengths == votes, q_idx ascending per list"""
