@@ -1673,7 +1673,10 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
-                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals, &e->inl_counts, &e->frame_pack, &e->b_in, &e->b_out};
+                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals, &e->inl_counts, &e->frame_pack, &e->b_in, &e->b_out,
+                    // (the entry-id map: missing from this list until the engine's host code ran under the sanitizers — every destroyed
+                    // handle kept them, 8 bytes per map frame and, with frame ids out of insertion order, 8 bytes per entry)
+                    &e->frame_first, &e->by_frame, &e->id_of_g, &e->longest};
   for (DevBuf *b : bufs) free_buf(*b);
   for (auto &b : e->scan_lvl) free_buf(b);
   if (e->pin) (void)hipHostFree(e->pin);
