@@ -5,12 +5,13 @@
 # Separate passes for timing and each counter; the program itself after `--`.
 set -u
 TAG=$1; COMMIT=$2; ARGS=$3
+PROG=${4:-bench.py}          # the program under the profiler (default bench.py; tools/skew_step.py for the skewed step alone)
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/bench_under_stats.json 2> $OUT/stats.err
-timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_under_fetch.json 2> $OUT/fetch.err
-timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_under_write.json 2> $OUT/write.err
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $PROG $ARGS > $OUT/bench_under_stats.json 2> $OUT/stats.err
+timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $PROG $ARGS > $OUT/bench_under_fetch.json 2> $OUT/fetch.err
+timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $PROG $ARGS > $OUT/bench_under_write.json 2> $OUT/write.err
 python3 - "$OUT" "$TAG" "$COMMIT" "$ARGS" <<'PY'
 import sys, glob, csv, json, collections, os
 src, tag, commit, args = sys.argv[1:5]
@@ -35,9 +36,9 @@ try:
     line = json.loads(open(os.path.join(src, "bench_under_stats.json")).read().strip().splitlines()[-1])
 except Exception as exc:
     line = {"error": str(exc)}
-out = {"tag": tag, "commit": commit, "bench_args": args, "kernels": rows,
+out = {"tag": tag, "commit": commit, "args": args, "kernels": rows,
        "correction": "read bytes = 2 x FETCH_SIZE KiB (gfx950 wide-load undercount), write bytes = WRITE_SIZE KiB, medians per launch; both count Infinity-Cache hits",
-       "bench_line_under_the_kernel_trace": {k: line.get(k) for k in ("value", "ms_per_step", "config", "workload_skew") if isinstance(line, dict) and k in line}}
+       "line_under_the_kernel_trace": {k: v for k, v in line.items() if k in ("value", "ms_per_step", "config", "workload", "queries_per_step", "frames_per_s_each_step_waited_for", "reruns", "kernel_ms_last_step", "M_matches_per_query", "P_swept_per_query", "candidate_pairs")} if isinstance(line, dict) else None}
 if isinstance(line, dict) and isinstance(line.get("roofline"), dict):
     out["kernel_ms_live"] = line["roofline"].get("kernel_ms")
 json.dump(out, open(os.path.join(src, "%s_profile.json" % tag), "w"), indent=1, sort_keys=True)

@@ -55,7 +55,7 @@ if "FETCH_SIZE" in vk:
     out["verify_kernel_hbm_bytes"] = {"fetch_as_counted": vk["FETCH_SIZE"] * 1024, "fetch_times_2": vk["FETCH_SIZE"] * 2048, "write": vk.get("WRITE_SIZE", 0) * 1024}
 vs = os.path.join(src, "vstat.err")
 if os.path.exists(vs):
-    out["vstat"] = [l.strip() for l in open(vs) if l.startswith("[vstat]")]
+    out["vstat"] = [l.strip() for l in open(vs) if l.startswith("[vstat]") or l.startswith("[vmstat]")]
 json.dump(out, open(os.path.join(src, "%s_verify_profile.json" % tag), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True)[:6000])
 PY
