@@ -82,8 +82,11 @@ def parse():
                     help="N=1: also run the multi-GPU step of ONE rank with its collectives issued through RCCL all the same (a group of one: "
                          "what a one-GPU box can put on hardware of the exchange), in a child process")
     ap.add_argument("--rccl-one-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rccl-one-shape", choices=["headline", "cfg4"], default="headline",
+                    help="N=1: the one-rank RCCL leg also at cfg4's shape (one of four 25 000-frame shards, lists = winners)")
     ap.add_argument("--multi-handle", choices=["auto", "on", "off"], default="auto",
                     help="N>1: also drive all N devices from ONE process through sgtd_create_multi (auto: when N real devices exist)")
+    ap.add_argument("--cfg4-queries", type=int, default=None, help="query frames per query group of the cfg4 leg (default: --queries)")
     ap.add_argument("--cfg4", choices=["auto", "on", "off"], default="auto",
                     help="N>1: also measure BASELINE configs[3] (100 000-frame map, table-sharded); auto = at N == 8")
     ap.add_argument("--sweep", default="1000,4541",
@@ -340,6 +343,7 @@ def flatten_evidence(out):
         c["table_sharded_frames_per_s"] = get(out, "table_sharded", "value")
         c["table_sharded_equals_single_table"] = out.get("merged_list_equals_single_table")
         c["cfg4_frames_per_s"] = get(out, "cfg4", "value")
+        c["cfg4_leg_wall_s"] = get(out, "cfg4", "leg_wall_s")
         c["exchange_exposed_ms"] = get(out, "scaling_parts", "exchange_exposed_ms")
     # the sweep's USEFUL fraction of the HBM roof: the probe layout once + every 4-byte match record once, over the sweep's
     # live time; and the whole step's compulsory I/O over the step's time
@@ -623,12 +627,120 @@ def rccl_one_child(args):
                                "packed_table_bytes": int(m.packed.numel() * 4)}
         mg.close()
         del m, mg
+    if args.rccl_one_shape == "cfg4":
+        out["cfg4_shape"] = rccl_one_cfg4_shape(args, dev, N)
     out["note"] = ("one rank over RCCL with every collective of the step issued (group of one: the all-gather copies one table): stream-ordered, "
                    "nothing blocks the host — what the gloo runs on a one-GPU box cannot show; the bytes on the links are not in it "
                    "(modelled under scaling_prediction)")
     dist.destroy_process_group()
     result_out.write(json.dumps({"metric": "rccl_group_of_one", "result": out}) + "\n")
     result_out.flush()
+
+
+def rccl_one_cfg4_shape(args, dev, N):
+    """One rank of cfg4's grid as far as one GPU and one process can stand for it: a quarter of the 100 000-frame
+    map (frames 0 .. 24 999: one of R_t = 4 frame-range shards), the whole query group's batch, lists = "winners" — the shard's
+    sweep and vote pass, the packed local table out behind votes_topk_kernel, the all-gather through RCCL (group of one: ITS table;
+    the three others' arrive as device copies of it here, which costs the local copy engine what three link transfers cost the
+    links' DMA — not the links' time), the merge kernel over FOUR tables, the winners' mask, the masked list pass; and the
+    verification of the winners with its all-gather.  Times by HIP events on the streams the work runs on."""
+    import torch
+    import torch.distributed as dist
+    from sgtd_amd import synth
+    from sgtd_amd.dist import Map2D
+    F4, RT, Q = 100000, 4, args.queries
+    t0 = time.perf_counter()
+    m4 = synth.make_map(F4 // RT, N, stream=4)          # (the shard's frames of a world of its own: the same density and table statistics)
+    t_map = time.perf_counter() - t0
+    q4 = synth.make_queries(m4, Q, stream=4)
+
+    def to_dev(xyz, label):
+        return (torch.from_numpy(np.ascontiguousarray(xyz)).to(dev).contiguous(),
+                torch.from_numpy(np.ascontiguousarray(label).astype(np.int64)).to(dev).to(torch.int32).contiguous())
+
+    class OneOfFour(Map2D):
+        """a Map2D of a one-rank job that merges FOUR tables: its own through the RCCL all-gather, three copies of it beside"""
+        def _buffers(self, nq):
+            fresh = nq != self._nq_buf
+            super()._buffers(nq)
+            if fresh:
+                ints = self.packed.numel()
+                self.gathered = torch.empty(RT * ints, dtype=torch.int32, device=self.dev)
+                self.v_gathered = torch.empty(RT * self.v_local.numel(), dtype=torch.float64, device=self.dev)
+
+        def _exchange(self):
+            nq = self.mgr._nq
+            ints = self.packed.numel()
+            self.mgr.export_wait(self.side.cuda_stream)
+            with torch.cuda.stream(self.side):
+                dist.all_gather_into_tensor(self.gathered[:ints], self.packed)
+                for t in range(1, RT):
+                    self.gathered[t * ints:(t + 1) * ints].copy_(self.gathered[:ints], non_blocking=True)
+            self.mgr.merge_candidates_dev(self.side.cuda_stream, self.gathered, RT, 0, nq, self.m_frame, self.m_votes, self.m_n,
+                                          self.m_src, self.m_keep, self.m_flags)
+            self.mgr.export_release(self.side.cuda_stream)
+            self.exchanges += 1
+    m = OneOfFour(F4 // RT, 0, 1, r_t=1, device_id=0, lists="winners", max_frame_n=F4 + 1)
+    m.force_collective = True
+    t0 = time.perf_counter()
+    m.add_shard_frames(*to_dev(m4.xyz, m4.label))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    x, l = to_dev(q4.xyz, q4.label)
+    mg = m.mgr
+    for _ in range(3):
+        m.query_async(x, l); mg.sync()
+    torch.cuda.synchronize()
+    k = max(3, args.steps // 2)
+
+    def clock(step):
+        step(); mg.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        mg.sync()
+        return 1000.0 * el / k
+
+    def without_x():
+        mg.query_frames(x, l, fetch=False)
+        mg.finish_lists(None)
+    t_w = min(clock(lambda: m.query_async(x, l)) for _ in range(2))
+    t_o = min(clock(without_x) for _ in range(2))
+    # the exchange alone on its stream
+    m.query_async(x, l); mg.sync(); torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    with torch.cuda.stream(m.side):
+        ev[0].record()
+    for _ in range(10):
+        m._exchange()
+    with torch.cuda.stream(m.side):
+        ev[1].record()
+    m.side.synchronize()
+    # the verification of the winners and its all-gather (search_loop's second half), on the engine's stream
+    m.query_async(x, l); mg.sync(); torch.cuda.synchronize()
+    nq, cn = m.m_frame.shape
+    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    with torch.cuda.stream(m.main):
+        ev2[0].record()
+        mg.verify_masked(m.m_keep)
+        ev2[1].record()
+        mg.export_verify(m.v_local[:nq * cn], m.v_local[nq * cn:])
+        dist.all_gather_into_tensor(m.v_gathered[:m.v_local.numel()], m.v_local)
+        ev2[2].record()
+    torch.cuda.synchronize()
+    st = mg.stats()
+    kept = int(torch.sum(torch.tensor([bin(int(v) & ((1 << 64) - 1)).count("1") for v in m.m_keep.cpu().tolist()])))
+    out = {"what": "one rank of R_t = 4 over RCCL (group of one): 25 000 of 100 000 frames, %d query frames per step, lists = winners" % Q,
+           "ms_per_step_with_exchange": t_w, "ms_per_step_without_exchange": t_o, "exchange_exposed_ms": max(0.0, t_w - t_o),
+           "exchange_alone_ms_on_its_stream": ev[0].elapsed_time(ev[1]) / 10, "packed_table_bytes": int(m.packed.numel() * 4),
+           "tables_merged": RT, "winners_kept_of_local_candidates": kept, "verify_masked_ms": ev2[0].elapsed_time(ev2[1]),
+           "verify_export_and_all_gather_ms": ev2[1].elapsed_time(ev2[2]), "verified_results_bytes_per_rank": int(m.v_local.numel() * 8),
+           "shard_entries": int(st["n_entries"]), "M_matches_per_query_on_the_shard": st["last_M"] / Q,
+           "synthetic_map_25000_frames_s": t_map, "shard_build_s": t_build, "frames_per_s_of_the_group_at_this_step": Q / t_w * 1000.0}
+    mg.close()
+    return out
 
 
 def rccl_one_leg(args):
@@ -638,12 +750,15 @@ def rccl_one_leg(args):
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))      # (as the ranks of an N > 1 run set it: main())
     cmd = [sys.executable, os.path.abspath(__file__), "--rccl-one-child", "--frames", str(args.frames), "--keypoints", str(args.keypoints),
-           "--queries", str(args.queries), "--steps", str(args.steps)]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+           "--queries", str(args.queries), "--steps", str(args.steps), "--rccl-one-shape", args.rccl_one_shape]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     line = last_result_line(p.stdout)
     if p.returncode != 0 or line is None:
         return {"error": "child exited with %d: %s" % (p.returncode, p.stderr[-600:])}
     return json.loads(line)["result"]
+
+
+T_PROCESS_START = time.perf_counter()
 
 
 def main():
@@ -1325,14 +1440,18 @@ def main():
         # Only rank-local work sits under try/except; the ranks agree on its success (host-side) before every stage
         # that contains a collective, so that one rank's failure (an allocation, a damaged cache file) skips the leg
         # on EVERY rank instead of leaving the others inside an all_gather.
-        F4, Q4 = 100000, 256
+        # (2048 query frames per group: with the match lists named by granules a step's records may pass 2^32 — on a 100 000-frame
+        # map that is where batches pay, 29.0 k against 22.9 k frames/s at 768 on one GPU)
+        F4, Q4 = 100000, (args.queries if args.cfg4_queries is None else args.cfg4_queries)
         rt4, rq4 = plan_2d(world, F4, Q4, N)
         m4 = q4 = s4 = x4 = l4 = None
         err4 = None
+        t_leg4 = time.perf_counter()
         try:
             m4 = make_map_once(F4, N, 4)                  # every rank holds the world, keeps its frames (its barrier is always reached)
         except Exception as exc:
             err4 = exc
+        t_map4 = time.perf_counter() - t_leg4
         if all_ok(err4 is None):
             try:
                 q4 = synth.make_queries(m4, Q4 * rq4, stream=4)
@@ -1357,7 +1476,8 @@ def main():
                     "value": Q4 * rq4 * args.steps / e4, "unit": "frames/s", "ms_per_step": 1000.0 * e4 / args.steps,
                     "queries_per_step": Q4 * rq4, "table_shards_R_t": rt4, "query_groups_R_q": rq4,
                     "table_entries_per_rank": entries_of(s4.mgr), "collective": collective,
-                    "recall": recall(m4, q4, top1)}
+                    "recall": recall(m4, q4, top1),
+                    "map_generation_s_rank0_then_cache": t_map4, "leg_wall_s": time.perf_counter() - t_leg4}
         else:
             cfg4 = {"error": "skipped on every rank: %s" % ("%s: %s" % (type(err4).__name__, err4) if err4 is not None else "another rank failed")}
         del s4, m4, q4, x4, l4
@@ -1679,6 +1799,7 @@ def main():
         else:
             out["cpu_baseline"] = None
     if rank == 0:
+        out["config"]["wall_s_of_this_rank_until_the_line"] = time.perf_counter() - T_PROCESS_START
         flatten_evidence(out)
     if world > 1:
         dist.barrier()

@@ -406,6 +406,106 @@ __global__ void pass_slots_kernel(const u32 *gid, const u32 *group_first, const 
   if ((((u32)p - f) % SGTD_PAIR) == 0u) pos_of_slot[g + (f + SGTD_PAIR - 1u) / SGTD_PAIR + ((u32)p - f) / SGTD_PAIR] = (u32)p;
 }
 
+// ---- ONE frame per call (nq = 1, at most 8192 descriptor slots, 32-bit home keys): everything between the descriptors and
+// the GroupRows — the batch's counters and result tables cleared, query_prefix, home_keys, the four radix passes, group_heads, the
+// scan, group_first, pos_of_slot's reset and pass_slots: twenty-seven launches of about 5 us each on the device's timeline —
+// by ONE workgroup in LDS.  The order is a bitonic sort of (home key << 13 | slot): the slot in the low bits makes equal
+// keys keep their insertion order, which is all the stable radix sort gives.
+#define SGTD_SMALL_SLOTS 8192
+#define SGTD_SMALL_THREADS 1024
+struct SmallOrder {
+  u32 *ctr; u32 ctr_words;                  // ProbeBuffers::ctr, cleared
+  u32 *q_M; unsigned long long *q_P;        // [1], cleared
+  u32 *votes; u32 *slot_of_words; u32 span; // block passes: the vote histogram (zero) and the frame -> slot bytes (0xFF), span frames
+  int *cand_frame, *cand_votes; int cand_num;
+  u32 *q_prefix, *n_valid, *order, *gid, *group_first, *n_groups, *pos_of_slot;
+  u32 n_slots, max_pass_slots;
+  int cbits, sub_bits, pair;
+};
+__global__ __launch_bounds__(SGTD_SMALL_THREADS) void small_order_kernel(QueryView Q, SmallOrder S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  u64 *s_key = reinterpret_cast<u64 *>(s_raw);                                 // [8192] home key << 13 | slot
+  u32 *s_gid = reinterpret_cast<u32 *>(s_raw + SGTD_SMALL_SLOTS * 8);          // [8192]
+  u32 *s_first = s_gid + SGTD_SMALL_SLOTS;                                     // [8192]
+  __shared__ u32 s_sum[SGTD_SMALL_THREADS / SGTD_WAVE + 1];
+  const u32 tid = threadIdx.x;
+  // ---- what the memsets did
+  for (u32 i = tid; i < S.ctr_words; i += SGTD_SMALL_THREADS) S.ctr[i] = 0u;
+  if (tid == 0) { S.q_M[0] = 0u; S.q_P[0] = 0ull; S.q_prefix[0] = 0u; }
+  if (S.votes) for (u32 i = tid; i < S.span; i += SGTD_SMALL_THREADS) S.votes[i] = 0u;
+  if (S.slot_of_words) for (u32 i = tid; i < (S.span + 3u) / 4u; i += SGTD_SMALL_THREADS) S.slot_of_words[i] = 0xFFFFFFFFu;
+  if (S.cand_frame) for (u32 i = tid; i < (u32)S.cand_num; i += SGTD_SMALL_THREADS) { S.cand_frame[i] = -1; S.cand_votes[i] = 0; }
+  for (u32 i = tid; i < S.max_pass_slots; i += SGTD_SMALL_THREADS) S.pos_of_slot[i] = SGTD_NO_PASS;
+  // ---- home keys (home_keys_kernel<u32>)
+  const u32 nv = min(Q.count[0], S.n_slots);
+  u32 P = 64;
+  while (P < nv) P <<= 1;
+  const u64 cmask = (1ull << S.cbits) - 1ull;
+  const int ny = 1 << (S.sub_bits >> 1), nz = 1 << (S.sub_bits - (S.sub_bits >> 1));
+  for (u32 d = tid; d < P; d += SGTD_SMALL_THREADS) {
+    u64 k = ~0ull;
+    if (d < nv) {
+      const u64 code = label_code(Q.label[d * 3 + 0], Q.label[d * 3 + 1], Q.label[d * 3 + 2]);
+      const u64 x = min((u64)(u32)(int)Q.side[d * 3 + 0], cmask), y = min((u64)(u32)(int)Q.side[d * 3 + 1], cmask),
+                z = min((u64)(u32)(int)Q.side[d * 3 + 2], cmask);
+      const double f1 = Q.side[d * 3 + 1] - (double)(int)Q.side[d * 3 + 1], f2 = Q.side[d * 3 + 2] - (double)(int)Q.side[d * 3 + 2];
+      const u64 sub = (u64)min(max((int)(f1 * ny), 0), ny - 1) * nz + (u64)min(max((int)(f2 * nz), 0), nz - 1);
+      const u32 key = (u32)(((((code << S.cbits | x) << S.cbits | y) << S.cbits) | z) << S.sub_bits | sub);
+      k = ((u64)key << 13) | (u64)d;
+    }
+    s_key[d] = k;
+  }
+  __syncthreads();
+  // ---- bitonic sort of the P keys
+  for (u32 size = 2; size <= P; size <<= 1)
+    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+      for (u32 t = tid; t < (P >> 1); t += SGTD_SMALL_THREADS) {
+        const u32 lo = 2u * t - (t & (stride - 1u)), hi = lo + stride;
+        const bool up = (lo & size) == 0u;
+        const u64 a = s_key[lo], b = s_key[hi];
+        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  // ---- group ids: flags[p] = position p + 1 starts a new group (group_heads_kernel), gid = their exclusive scan
+  constexpr u32 PER = SGTD_SMALL_SLOTS / SGTD_SMALL_THREADS;      // 8 consecutive positions per thread
+  u32 fl[PER], mine = 0;
+#pragma unroll
+  for (u32 j = 0; j < PER; j++) {
+    const u32 p = tid * PER + j;
+    u32 head = 0;
+    if (p + 1 < nv) {
+      const u64 a = (s_key[p + 1] >> 13) >> S.sub_bits, b = (s_key[p] >> 13) >> S.sub_bits;
+      head = (a != b) || ((a & cmask) == cmask) || (((a >> S.cbits) & cmask) == cmask) || (((a >> (2 * S.cbits)) & cmask) == cmask);
+    }
+    fl[j] = head;
+    mine += head;
+  }
+  u32 tot;
+  u32 ex = block_excl_scan(mine, s_sum, tot);
+#pragma unroll
+  for (u32 j = 0; j < PER; j++) {
+    const u32 p = tid * PER + j;
+    s_gid[p] = ex;
+    if (p < S.n_slots) { S.gid[p] = ex; if (p < nv) S.order[p] = (u32)(s_key[p] & 8191ull); }
+    ex += fl[j];
+  }
+  __syncthreads();
+  // ---- first position of every group, the number of groups
+  for (u32 p = tid; p < nv; p += SGTD_SMALL_THREADS) {
+    const u32 g = s_gid[p];
+    if (p == 0 || s_gid[p - 1] != g) { s_first[g] = p; S.group_first[g] = p; }
+  }
+  if (tid == 0) { *S.n_valid = nv; *S.n_groups = nv ? s_gid[nv - 1] + 1u : 0u; }
+  __syncthreads();
+  // ---- pass slots (pass_slots_kernel)
+  for (u32 p = tid; p < nv; p += SGTD_SMALL_THREADS) {
+    if (!S.pair) { S.pos_of_slot[p] = p; continue; }
+    const u32 g = s_gid[p], f = s_first[g];
+    if (((p - f) % SGTD_PAIR) == 0u) S.pos_of_slot[g + (f + SGTD_PAIR - 1u) / SGTD_PAIR + (p - f) / SGTD_PAIR] = p;
+  }
+}
+
 __device__ __forceinline__ void reached_slices(float dq, float t_up, int n, int &lo, int &hi) {
   // slices of the cell interval reached by [q - t, q + t]; slice s holds the entries with
   // (side + 0.5 - cell) * n in [s, s + 1).  q - cell is below 2.5 in magnitude for every gated

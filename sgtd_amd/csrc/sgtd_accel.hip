@@ -997,7 +997,7 @@ int launch_select(sgtd_engine *e) {
   CHK(ensure(e, e->list, (size_t)std::max<long long>(n_slots, 1) * sizeof(uint2)));
   CHK(ensure(e, e->n_visit, (size_t)std::max<long long>(n_slots, 1) * sizeof(u32)));
   CHK(ensure(e, e->votes, (size_t)nq * span * sizeof(u32)));
-  CHK(ensure(e, e->slot_of, (size_t)nq * span));
+  CHK(ensure(e, e->slot_of, (size_t)nq * span + 4));      // (+ a word: small_order_kernel clears it by words)
   CHK(ensure(e, e->q_M, (size_t)nq * sizeof(u32)));
   CHK(ensure(e, e->q_P, (size_t)nq * sizeof(unsigned long long)));
   CHK(ensure(e, e->q_pairs, (size_t)nq * sizeof(u32)));
@@ -1030,15 +1030,30 @@ int launch_select(sgtd_engine *e) {
   const bool fused_votes = fused_pairs && votes_fit;     // (block_count_kernel wants topk_kernel's slot table)
   CHK(rec_alloc(e, !fused_pairs));
   const bool votes_per_query = n_tiles == 1 ? nq >= e->n_cus : ((long long)nq * n_tiles >= e->n_cus / 4 && n_tiles <= 8);
-  HIPCHK(hipMemsetAsync(e->cursors.p, 0, kCtrWords * sizeof(u32), e->stream));
-  if (!fused_votes) {
-    if (!votes_per_query) HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));   // (global vote atomics)
-    HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
-    HIPCHK(hipMemsetAsync(e->cand_frame.p, 0xFF, (size_t)nq * cn * sizeof(int), e->stream));
-    HIPCHK(hipMemsetAsync(e->cand_votes.p, 0, (size_t)nq * cn * sizeof(int), e->stream));
+  // bits per cell coordinate of the sort key: the largest cell a built descriptor can have
+  int cbits = 1;
+  while ((1ll << cbits) < (long long)(e->dc.max_len * e->dc.scale) + 3 && cbits < 16) cbits++;
+  // (+ the position inside the cell, home_keys_kernel: the bits that are free below the next multiple of a sort
+  // digit, or four bits and one more pass)
+  const int spare = (8 - (12 + 3 * cbits) % 8) % 8;
+  int sub_bits = spare >= 2 ? std::min(spare, 6) : 4;
+  if (const char *o = getenv("SGTD_HOME_SUB_BITS")) sub_bits = std::min(6, std::max(0, atoi(o)));   // experiment knob
+  const int key_bits = 12 + 3 * cbits + sub_bits;
+  // one frame per call: the clearing of the batch's counters and tables and the whole ordering of its descriptors in ONE
+  // launch (small_order_kernel; SGTD_SMALL_ORDER=0: the general form)
+  const bool small_on = [] { const char *o = getenv("SGTD_SMALL_ORDER"); return !(o && !atoi(o)); }();
+  const bool small = small_on && nq == 1 && n_slots <= SGTD_SMALL_SLOTS && key_bits <= 32 && !fused_votes && span <= (1u << 20);
+  if (!small) {
+    HIPCHK(hipMemsetAsync(e->cursors.p, 0, kCtrWords * sizeof(u32), e->stream));
+    if (!fused_votes) {
+      if (!votes_per_query) HIPCHK(hipMemsetAsync(e->votes.p, 0, (size_t)nq * span * sizeof(u32), e->stream));   // (global vote atomics)
+      HIPCHK(hipMemsetAsync(e->slot_of.p, 0xFF, (size_t)nq * span, e->stream));
+      HIPCHK(hipMemsetAsync(e->cand_frame.p, 0xFF, (size_t)nq * cn * sizeof(int), e->stream));
+      HIPCHK(hipMemsetAsync(e->cand_votes.p, 0, (size_t)nq * cn * sizeof(int), e->stream));
+    }
+    HIPCHK(hipMemsetAsync(e->q_M.p, 0, (size_t)nq * sizeof(u32), e->stream));
+    HIPCHK(hipMemsetAsync(e->q_P.p, 0, (size_t)nq * sizeof(unsigned long long), e->stream));
   }
-  HIPCHK(hipMemsetAsync(e->q_M.p, 0, (size_t)nq * sizeof(u32), e->stream));
-  HIPCHK(hipMemsetAsync(e->q_P.p, 0, (size_t)nq * sizeof(unsigned long long), e->stream));
 
   Views v = make_views(e);
   const size_t hist_bytes = (size_t)span * sizeof(u32);
@@ -1073,15 +1088,6 @@ int launch_select(sgtd_engine *e) {
     CHK(ensure(e, e->n_valid, sizeof(u32)));
     u64 *kin = e->keyA.as<u64>(), *kout = e->keyB.as<u64>();
     u32 *vin = e->valA.as<u32>(), *vout = e->valB.as<u32>();
-    // bits per cell coordinate of the sort key: the largest cell a built descriptor can have
-    int cbits = 1;
-    while ((1ll << cbits) < (long long)(e->dc.max_len * e->dc.scale) + 3 && cbits < 16) cbits++;
-    // (+ the position inside the cell, home_keys_kernel: the bits that are free below the next multiple of a sort
-    // digit, or four bits and one more pass)
-    const int spare = (8 - (12 + 3 * cbits) % 8) % 8;
-    int sub_bits = spare >= 2 ? std::min(spare, 6) : 4;
-    if (const char *o = getenv("SGTD_HOME_SUB_BITS")) sub_bits = std::min(6, std::max(0, atoi(o)));   // experiment knob
-    const int key_bits = 12 + 3 * cbits + sub_bits;
     CHK(ensure(e, e->q_prefix, (size_t)nq * sizeof(u32)));
     CHK(ensure(e, e->group_first, (size_t)n_slots * sizeof(u32)));
     CHK(ensure(e, e->n_groups, sizeof(u32)));
@@ -1095,6 +1101,21 @@ int launch_select(sgtd_engine *e) {
     if (e->pool_units == 0) e->pool_units = std::max<size_t>(65536, (size_t)n_slots * (e->n_entries > 100000000 ? 16 : 10));
     CHK(ensure(e, e->pass_pool, (e->pool_units + SGTD_PASS_SLACK_UNITS) * sizeof(uint4)));
     const u32 *nv = e->n_valid.as<u32>();
+    if (small) {
+      SmallOrder SO;
+      SO.ctr = e->cursors.as<u32>(); SO.ctr_words = (u32)kCtrWords;
+      SO.q_M = e->q_M.as<u32>(); SO.q_P = e->q_P.as<unsigned long long>();
+      SO.votes = votes_per_query ? nullptr : e->votes.as<u32>(); SO.slot_of_words = e->slot_of.as<u32>(); SO.span = span;
+      SO.cand_frame = e->cand_frame.as<int>(); SO.cand_votes = e->cand_votes.as<int>(); SO.cand_num = cn;
+      SO.q_prefix = e->q_prefix.as<u32>(); SO.n_valid = e->n_valid.as<u32>(); SO.order = vin; SO.gid = e->gid.as<u32>();
+      SO.group_first = e->group_first.as<u32>(); SO.n_groups = e->n_groups.as<u32>(); SO.pos_of_slot = e->pos_of_slot.as<u32>();
+      SO.n_slots = (u32)n_slots; SO.max_pass_slots = (u32)max_pass_slots; SO.cbits = cbits; SO.sub_bits = sub_bits; SO.pair = pair ? 1 : 0;
+      const size_t lds = (size_t)SGTD_SMALL_SLOTS * 16;
+      static const bool lds_set = [&] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&small_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; }();
+      if (!lds_set) return SGTD_ERR_HIP;
+      small_order_kernel<<<1, SGTD_SMALL_THREADS, lds, e->stream>>>(v.Q, SO);
+      HIPCHK(hipGetLastError());
+    } else {
     query_prefix_kernel<<<1, 256, 0, e->stream>>>(e->q_count.as<u32>(), e->q_prefix.as<u32>(), nq, e->n_valid.as<u32>());
     HIPCHK(hipGetLastError());
     if (key_bits <= 32) {      // 32-bit keys: a third less traffic in every sort pass
@@ -1118,6 +1139,7 @@ int launch_select(sgtd_engine *e) {
     pass_slots_kernel<<<grid_for(n_slots, 256), 256, 0, e->stream>>>(e->gid.as<u32>(), e->group_first.as<u32>(), nv,
                                                                        e->pos_of_slot.as<u32>(), n_slots, pair ? 1 : 0);
     HIPCHK(hipGetLastError());
+    }
     // pass slots per wave ticket: about 1.5k entry visits (neighbouring home cells then go to different waves of one XCD at
     // about the same time and find each other's buckets in its L2: at six waves per SIMD tickets of 4 / 3 / 2 pass slots
     // fetch 8.0 / 6.0 / 4.2 GB per sweep of the default batch in the same 4.8-5.0 ms; 1: 3.1 GB in 6.0 ms), from the visits per descriptor the

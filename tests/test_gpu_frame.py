@@ -133,3 +133,37 @@ def test_search_frame_when_the_inlier_pairs_outgrow_the_gather_room_twice(mods):
             counts.append(fs["n_inliers"])
     assert max(counts) > 16384 and counts[-1] != counts[0]
     g.close()
+
+
+def test_one_frame_ordering_in_one_launch_equals_the_general_form(mods, monkeypatch):
+    """a one-frame batch orders its descriptors by home key in ONE launch (small_order_kernel: counters cleared, keys, a bitonic
+    sort in LDS, group ids, pass slots) where the general form takes twenty-seven; both against the oracle and against each
+    other — candidates, votes, ordered match lists, the ordered rough list (the sweep's order shows there) and the counters"""
+    oracle, manager, synth = mods
+    m = synth.make_map(120, 200, stream=141)
+    qs = synth.make_queries(m, 5, stream=141)
+    o = oracle.OracleManager()
+    o.add_frames(m.xyz, m.label)
+    got = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("SGTD_SMALL_ORDER", form)
+        g = manager.STDescManager()
+        g.add_frames(m.xyz, m.label)
+        rows = []
+        for q in range(5):
+            res = g.query_frames(qs.xyz[q:q + 1], qs.label[q:q + 1])
+            st = g.stats()
+            o.build(qs.xyz[q], qs.label[q], export=False)
+            r = o.select()
+            nc = int(res.n_cand[0])
+            assert nc == len(r["cand_frame"]) and np.array_equal(res.cand_frame[0, :nc], r["cand_frame"]) and np.array_equal(res.cand_votes[0, :nc], r["cand_votes"])
+            qi, de = g.result_pairs(0, res)
+            assert np.array_equal(qi, r["q_idx"]) and np.array_equal(de, r["db_entry"])
+            rows.append((res.cand_frame.copy(), res.cand_votes.copy(), qi, de, st["last_P"], st["last_M"], st["last_D"]))
+        # a frame with very few descriptors and an empty one
+        few = g.query_frames(qs.xyz[0:1, :12], qs.label[0:1, :12])
+        rows.append((few.cand_frame.copy(), few.n_cand.copy()))
+        got[form] = rows
+        g.close()
+    for a, b in zip(got["1"], got["0"]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
