@@ -409,8 +409,7 @@ __global__ void pass_slots_kernel(const u32 *gid, const u32 *group_first, const 
 // ---- ONE frame per call (nq = 1, at most 8192 descriptor slots, 32-bit home keys): everything between the descriptors and
 // the GroupRows — the batch's counters and result tables cleared, query_prefix, home_keys, the four radix passes, group_heads, the
 // scan, group_first, pos_of_slot's reset and pass_slots: twenty-seven launches of about 5 us each on the device's timeline —
-// by ONE workgroup in LDS.  The order is a bitonic sort of (home key << 13 | slot): the slot in the low bits makes equal
-// keys keep their insertion order, which is all the stable radix sort gives.
+// by ONE workgroup in LDS (a stable radix sort of (home key << 13 | slot) by the key's digits).
 #define SGTD_SMALL_SLOTS 8192
 #define SGTD_SMALL_THREADS 1024
 struct SmallOrder {
@@ -420,7 +419,8 @@ struct SmallOrder {
   int *cand_frame, *cand_votes; int cand_num;
   u32 *q_prefix, *n_valid, *order, *gid, *group_first, *n_groups, *pos_of_slot;
   u32 n_slots, max_pass_slots;
-  int cbits, sub_bits, pair;
+  int cbits, sub_bits, pair, key_bits;
+  QueryRec *qrec; u32 n_qrec; double rough;  // descriptors handed in by the caller: their sweep records are written here too (thr2_kernel)
 };
 __global__ __launch_bounds__(SGTD_SMALL_THREADS) void small_order_kernel(QueryView Q, SmallOrder S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(SGTD_SMALL_THREADS) void small_order_kernel(QueryVi
   u32 *s_gid = reinterpret_cast<u32 *>(s_raw + SGTD_SMALL_SLOTS * 8);          // [8192]
   u32 *s_first = s_gid + SGTD_SMALL_SLOTS;                                     // [8192]
   __shared__ u32 s_sum[SGTD_SMALL_THREADS / SGTD_WAVE + 1];
+  __shared__ u32 s_cnt[4096];                                                  // the sort's counts per (digit, wave)
   const u32 tid = threadIdx.x;
   // ---- what the memsets did
   for (u32 i = tid; i < S.ctr_words; i += SGTD_SMALL_THREADS) S.ctr[i] = 0u;
@@ -436,9 +437,11 @@ __global__ __launch_bounds__(SGTD_SMALL_THREADS) void small_order_kernel(QueryVi
   if (S.slot_of_words) for (u32 i = tid; i < (S.span + 3u) / 4u; i += SGTD_SMALL_THREADS) S.slot_of_words[i] = 0xFFFFFFFFu;
   if (S.cand_frame) for (u32 i = tid; i < (u32)S.cand_num; i += SGTD_SMALL_THREADS) { S.cand_frame[i] = -1; S.cand_votes[i] = 0; }
   for (u32 i = tid; i < S.max_pass_slots; i += SGTD_SMALL_THREADS) S.pos_of_slot[i] = SGTD_NO_PASS;
+  if (S.qrec)
+    for (u32 i = tid; i < S.n_qrec; i += SGTD_SMALL_THREADS) write_query_rec(S.qrec + i, Q.side[i * 3], Q.side[i * 3 + 1], Q.side[i * 3 + 2], S.rough, Q.frame[i]);
   // ---- home keys (home_keys_kernel<u32>)
   const u32 nv = min(Q.count[0], S.n_slots);
-  u32 P = 64;
+  u32 P = SGTD_SMALL_THREADS;                    // (a multiple of 64 positions for every wave)
   while (P < nv) P <<= 1;
   const u64 cmask = (1ull << S.cbits) - 1ull;
   const int ny = 1 << (S.sub_bits >> 1), nz = 1 << (S.sub_bits - (S.sub_bits >> 1));
@@ -456,17 +459,49 @@ __global__ __launch_bounds__(SGTD_SMALL_THREADS) void small_order_kernel(QueryVi
     s_key[d] = k;
   }
   __syncthreads();
-  // ---- bitonic sort of the P keys
-  for (u32 size = 2; size <= P; size <<= 1)
-    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-      for (u32 t = tid; t < (P >> 1); t += SGTD_SMALL_THREADS) {
-        const u32 lo = 2u * t - (t & (stride - 1u)), hi = lo + stride;
-        const bool up = (lo & size) == 0u;
-        const u64 a = s_key[lo], b = s_key[hi];
-        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+  // ---- stable LSD radix sort of the P keys by their home key (8-bit digits, the passes the key has bits for): wave w owns the
+  // P / 16 consecutive positions [w P / 16, (w + 1) P / 16); counts per (digit, wave) in LDS, one scan over them in (digit, wave)
+  // order, then every wave places its positions chunk by chunk (rank inside a chunk: eight ballots, wave_group_rank)
+  {
+    u64 *src = s_key, *dst = reinterpret_cast<u64 *>(s_raw + SGTD_SMALL_SLOTS * 8);
+    const u32 wid = tid >> 6, lane = tid & 63u, per_wave = P / (SGTD_SMALL_THREADS / SGTD_WAVE);
+    for (int sh = 0; sh < S.key_bits; sh += 8) {
+      for (u32 i = tid; i < 4096u; i += SGTD_SMALL_THREADS) s_cnt[i] = 0u;
+      __syncthreads();
+      for (u32 c = 0; c < per_wave; c += SGTD_WAVE) {
+        const u32 d = (u32)((src[wid * per_wave + c + lane] >> (13 + sh)) & 255ull);
+        atomicAdd(&s_cnt[d * 16u + wid], 1u);
       }
       __syncthreads();
+      {
+        u32 v[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[j] = s_cnt[tid * 4 + j]; sum += v[j]; }
+        u32 tot;
+        u32 ex = block_excl_scan(sum, s_sum, tot);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s_cnt[tid * 4 + j] = ex; ex += v[j]; }
+      }
+      __syncthreads();
+      for (u32 c = 0; c < per_wave; c += SGTD_WAVE) {
+        const u64 k = src[wid * per_wave + c + lane];
+        const u32 d = (u32)((k >> (13 + sh)) & 255ull);
+        u32 rank, count;
+        wave_group_rank<8>(d, true, rank, count);
+        const u32 at = s_cnt[d * 16u + wid];
+        __builtin_amdgcn_wave_barrier();
+        if (rank == 0) s_cnt[d * 16u + wid] = at + count;
+        dst[at + rank] = k;
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
+      u64 *t = src; src = dst; dst = t;
     }
+    if (src != s_key) {
+      for (u32 i = tid; i < P; i += SGTD_SMALL_THREADS) s_key[i] = src[i];
+      __syncthreads();
+    }
+  }
   // ---- group ids: flags[p] = position p + 1 starts a new group (group_heads_kernel), gid = their exclusive scan
   constexpr u32 PER = SGTD_SMALL_SLOTS / SGTD_SMALL_THREADS;      // 8 consecutive positions per thread
   u32 fl[PER], mine = 0;

@@ -126,6 +126,7 @@ struct sgtd_engine {
   int64_t tail_max = 0;                  // SGTD_TAIL_MAX: entries the tail may hold before a merge (0 = an eighth of the main segment)
   float ms_finalize = 0.f;               // wall time of the last probe-layout build
   u32 coarse_at = 62, whole_at = 62;     // SGTD_COARSE_AT, SGTD_WHOLE_AT: see TableView
+  long long thr2_pending = 0;            // descriptors handed in by the caller whose QueryRec is still to be written (launch_select)
   u32 rec_rate_hook = 0;                 // SGTD_REC_RATE (test hook): ProbeBuffers::rec_rate, 1..256
   u32 rec_rate_cap = 256;                // upper bound on rec_rate for the pending batch: quartered by every re-run whose RESERVATIONS
                                          // (not its matches) outgrew the record buffer — long visit lists with few matches, skewed maps
@@ -245,8 +246,21 @@ int ensure(sgtd_engine *e, DevBuf &b, size_t bytes, bool keep = false) {
   // (a buffer that grows again gets a quarter more than asked for: the one-frame-per-call pattern would
   // otherwise free and allocate a dozen work buffers on every frame that is a little larger than the last)
   size_t want = keep ? std::max(bytes, b.bytes + b.bytes / 2) : (b.p ? bytes + bytes / 4 : bytes);
+  // nothing to keep: the old buffer goes first (a record buffer that grows from 30 to 45 GB must not need 75 for a moment)
+  if (!keep && b.p) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+  }
   void *np = nullptr;
-  HIPCHK(hipMalloc(&np, want));
+  {
+    const hipError_t st_ = hipMalloc(&np, want);
+    if (st_ != hipSuccess) {
+      (void)hipGetLastError();      // (the runtime's "last error" is the caller's too — torch raises on it at its next call — this one is reported here)
+      e->err = "hipMalloc of " + std::to_string(want) + " bytes: " + hipGetErrorString(st_);
+      return SGTD_ERR_HIP;
+    }
+  }
   e->stats.device_allocs_total++;
   if (keep && b.p && b.bytes) {
     HIPCHK(hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, e->stream));
@@ -1043,6 +1057,11 @@ int launch_select(sgtd_engine *e) {
   // launch (small_order_kernel; SGTD_SMALL_ORDER=0: the general form)
   const bool small_on = [] { const char *o = getenv("SGTD_SMALL_ORDER"); return !(o && !atoi(o)); }();
   const bool small = small_on && nq == 1 && n_slots <= SGTD_SMALL_SLOTS && key_bits <= 32 && !fused_votes && span <= (1u << 20);
+  if (e->thr2_pending > 0) {      // (not inside small_order_kernel: the thresholds and gate masks of 7 000 descriptors are 50 us of ONE workgroup's time, 5 us of eighteen's)
+    thr2_kernel<<<grid_for(e->thr2_pending, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.frame.as<u32>(), e->qd.qrec.as<QueryRec>(), e->thr2_pending,
+                                                                        e->dc.rough);
+    HIPCHK(hipGetLastError());
+  }
   if (!small) {
     HIPCHK(hipMemsetAsync(e->cursors.p, 0, kCtrWords * sizeof(u32), e->stream));
     if (!fused_votes) {
@@ -1109,7 +1128,8 @@ int launch_select(sgtd_engine *e) {
       SO.cand_frame = e->cand_frame.as<int>(); SO.cand_votes = e->cand_votes.as<int>(); SO.cand_num = cn;
       SO.q_prefix = e->q_prefix.as<u32>(); SO.n_valid = e->n_valid.as<u32>(); SO.order = vin; SO.gid = e->gid.as<u32>();
       SO.group_first = e->group_first.as<u32>(); SO.n_groups = e->n_groups.as<u32>(); SO.pos_of_slot = e->pos_of_slot.as<u32>();
-      SO.n_slots = (u32)n_slots; SO.max_pass_slots = (u32)max_pass_slots; SO.cbits = cbits; SO.sub_bits = sub_bits; SO.pair = pair ? 1 : 0;
+      SO.n_slots = (u32)n_slots; SO.max_pass_slots = (u32)max_pass_slots; SO.cbits = cbits; SO.sub_bits = sub_bits; SO.pair = pair ? 1 : 0; SO.key_bits = key_bits;
+      SO.qrec = nullptr; SO.n_qrec = 0; SO.rough = e->dc.rough;
       const size_t lds = (size_t)SGTD_SMALL_SLOTS * 16;
       static const bool lds_set = [&] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&small_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; }();
       if (!lds_set) return SGTD_ERR_HIP;
@@ -1140,6 +1160,7 @@ int launch_select(sgtd_engine *e) {
                                                                        e->pos_of_slot.as<u32>(), n_slots, pair ? 1 : 0);
     HIPCHK(hipGetLastError());
     }
+    e->thr2_pending = 0;
     // pass slots per wave ticket: about 1.5k entry visits (neighbouring home cells then go to different waves of one XCD at
     // about the same time and find each other's buckets in its L2: at six waves per SIMD tickets of 4 / 3 / 2 pass slots
     // fetch 8.0 / 6.0 / 4.2 GB per sweep of the default batch in the same 4.8-5.0 ms; 1: 3.1 GB in 6.0 ms), from the visits per descriptor the
@@ -1995,11 +2016,7 @@ int sgtd_query_descs(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq) {
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q));
-  if (nq > 0) {
-    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.frame.as<u32>(), e->qd.qrec.as<QueryRec>(), nq,
-                                                           e->dc.rough);
-    HIPCHK(hipGetLastError());
-  }
+  e->thr2_pending = nq;      // the descriptors' sweep records (thresholds, gate masks): launch_select writes them — one frame per call in its one launch
   u32 cnt = (u32)nq;
   CHK(h2d(e, e->q_count.p, &cnt, sizeof(u32)));
   CHK(xfer_sync(e));
@@ -2295,7 +2312,6 @@ int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
   CHK(ensure(e, e->v_score, (size_t)nq * cn * sizeof(double)));
   CHK(ensure(e, e->v_pose, (size_t)nq * cn * 12 * sizeof(double)));
   CHK(ensure(e, e->v_inlier, (size_t)std::max<int64_t>(total, 1)));
-  HIPCHK(hipMemsetAsync(e->v_pose.p, 0, (size_t)nq * cn * 12 * sizeof(double), e->stream));
   VerifyParams P;
   P.pairs = e->pairs.as<u64>(); P.pair_off = e->pair_off.as<long long>(); P.q_pair_base = e->q_pair_base.as<u32>();
   P.n_cand = e->n_cand.as<int>(); P.cand_num = cn; P.q_stride = e->q_stride;
@@ -2323,6 +2339,7 @@ int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
     CHK(ensure(e, e->v_words, (size_t)std::max<int64_t>(total, 1) * sizeof(u64)));
     CHK(ensure(e, e->v_hyp32, (size_t)nq * cn * SGTD_VERIFY_MAX_HYP * SGTD_HYP_F32 * sizeof(float)));
     P.passed = e->v_words.as<u64>(); P.hyp32 = e->v_hyp32.as<float>();
+    HIPCHK(hipMemsetAsync(e->v_pose.p, 0, (size_t)nq * cn * 12 * sizeof(double), e->stream));     // (the matrix-core kernel writes every pose itself)
   }
   P.keep = e->verify_keep;
   P.overflow = guard ? reinterpret_cast<const int *>(e->cursors.as<u32>() + 10) : nullptr;
@@ -2557,11 +2574,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q, /*wait=*/false));
-  if (nq > 0) {
-    thr2_kernel<<<grid_for(nq, 256), 256, 0, e->stream>>>(e->qd.side.as<double>(), e->qd.frame.as<u32>(), e->qd.qrec.as<QueryRec>(), nq,
-                                                           e->dc.rough);
-    HIPCHK(hipGetLastError());
-  }
+  e->thr2_pending = nq;      // the descriptors' sweep records (thresholds, gate masks): launch_select writes them — one frame per call in its one launch
   const u32 cnt = (u32)nq;
   CHK(h2d(e, e->q_count.p, &cnt, sizeof(u32)));      // (staged: the bytes are copied out of `cnt` here)
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_START], e->stream));

@@ -136,7 +136,7 @@ def test_search_frame_when_the_inlier_pairs_outgrow_the_gather_room_twice(mods):
 
 
 def test_one_frame_ordering_in_one_launch_equals_the_general_form(mods, monkeypatch):
-    """a one-frame batch orders its descriptors by home key in ONE launch (small_order_kernel: counters cleared, keys, a bitonic
+    """a one-frame batch orders its descriptors by home key in ONE launch (small_order_kernel: counters cleared, keys, a radix
     sort in LDS, group ids, pass slots) where the general form takes twenty-seven; both against the oracle and against each
     other — candidates, votes, ordered match lists, the ordered rough list (the sweep's order shows there) and the counters"""
     oracle, manager, synth = mods
