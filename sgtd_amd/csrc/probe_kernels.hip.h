@@ -468,9 +468,14 @@ __global__ __launch_bounds__(SGTD_SMALL_THREADS) void small_order_kernel(QueryVi
     for (int sh = 0; sh < S.key_bits; sh += 8) {
       for (u32 i = tid; i < 4096u; i += SGTD_SMALL_THREADS) s_cnt[i] = 0u;
       __syncthreads();
-      for (u32 c = 0; c < per_wave; c += SGTD_WAVE) {
-        const u32 d = (u32)((src[wid * per_wave + c + lane] >> (13 + sh)) & 255ull);
-        atomicAdd(&s_cnt[d * 16u + wid], 1u);
+      for (u32 c = 0; c < per_wave; c += SGTD_WAVE) {      // (a chunk's equal digits as ONE add by their first lane: sixty-four atomic adds to a
+        const u32 d = (u32)((src[wid * per_wave + c + lane] >> (13 + sh)) & 255ull);      // word that most of the chunk shares take each other's turn)
+        u32 rank, count;
+        wave_group_rank<8>(d, true, rank, count);
+        const u32 have = s_cnt[d * 16u + wid];
+        __builtin_amdgcn_wave_barrier();
+        if (rank == 0) s_cnt[d * 16u + wid] = have + count;
+        __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
       {

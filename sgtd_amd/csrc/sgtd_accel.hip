@@ -2604,9 +2604,8 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
     long long *d_idx = e->fetch_idx.as<long long>();
     int *d_qi = reinterpret_cast<int *>(d_idx + room);
     e->frame_qi = d_qi;
-    split_pairs_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)room, d_idx, d_qi);
-    HIPCHK(hipGetLastError());
-    gather_entries_counted_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(d_idx, e->inl_off.as<long long>() + cn, (long long)room, e->tab.view(), e->fetch.view());
+    gather_pair_entries_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)room, d_qi,
+                                                                                        e->tab.view(), e->fetch.view());
     HIPCHK(hipGetLastError());
     return SGTD_OK;
   };

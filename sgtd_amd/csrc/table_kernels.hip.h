@@ -431,7 +431,7 @@ __global__ void bucket_sq_kernel(const u32 *bucket_start, u32 n_buckets, u32 n_e
 
 // sgtd_fetch_entries: table entries idx[0..n) gathered into contiguous staging arrays (one
 // device-to-host copy per field afterwards instead of one per entry)
-__device__ __forceinline__ void gather_entry(const long long *idx, long long i, const DescArrays &tab, const DescArrays &out);
+__device__ __forceinline__ void gather_entry(const long long *idx, long long i, const DescArrays &tab, const DescArrays &out, long long at = -1);
 __global__ void gather_entries_kernel(const long long *idx, long long n, DescArrays tab, DescArrays out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -444,6 +444,15 @@ __global__ void gather_entries_counted_kernel(const long long *idx, const long l
   if (i >= *n_p || i >= cap) return;
   gather_entry(idx, i, tab, out);
 }
+// the two in one launch (one frame per call): inlier pair i (q_idx << 32 | g) -> its query index and its table entry
+__global__ void gather_pair_entries_kernel(const u64 *pairs, const long long *n_p, long long cap, int *q_idx, DescArrays tab, DescArrays out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_p || i >= cap) return;
+  const u64 pr = pairs[i];
+  q_idx[i] = (int)(pr >> 32);
+  const long long g = (long long)(pr & 0xFFFFFFFFull);
+  gather_entry(&g, 0, tab, out, i);
+}
 // pairs (q_idx << 32 | g) -> the two index lists
 __global__ void split_pairs_kernel(const u64 *pairs, const long long *n_p, long long cap, long long *idx, int *q_idx) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,8 +461,9 @@ __global__ void split_pairs_kernel(const u64 *pairs, const long long *n_p, long 
   idx[i] = (long long)(pr & 0xFFFFFFFFull);
   q_idx[i] = (int)(pr >> 32);
 }
-__device__ __forceinline__ void gather_entry(const long long *idx, long long i, const DescArrays &tab, const DescArrays &out) {
+__device__ __forceinline__ void gather_entry(const long long *idx, long long i, const DescArrays &tab, const DescArrays &out, long long at) {
   const size_t g = (size_t)idx[i];
+  if (at >= 0) i = at;          // (entry idx[i] goes to slot `at` of the output)
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     out.side[i * 3 + k] = tab.side[g * 3 + k];

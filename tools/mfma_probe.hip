@@ -19,7 +19,46 @@ __global__ void k(const _Float16 *A /*[32][16]*/, const _Float16 *B /*[16][32]*/
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   for (int g = 0; g < 16; g++) D[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r] = c[g];
 }
+// ---- how the 16 products and C are summed: one lane-0 experiment per case, A row 0 x B column 0 + C[0][0]
+__global__ void k_round(const _Float16 *A16 /*[n][16]*/, const _Float16 *B16 /*[n][16]*/, const float *C0 /*[n]*/, float *D0 /*[n]*/, int n) {
+  const int l = threadIdx.x, r = l & 31, h = l >> 5;
+  for (int t = 0; t < n; t++) {
+    h8 a, b;
+    for (int j = 0; j < 8; j++) { a[j] = r == 0 ? A16[t * 16 + 8 * h + j] : (_Float16)0.0f; b[j] = r == 0 ? B16[t * 16 + 8 * h + j] : (_Float16)0.0f; }
+    f16v c = {0};
+    if (l == 0) c[0] = C0[t];
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    if (l == 0) D0[t] = c[0];
+  }
+}
+static void rounding_cases() {
+  // case: C, products p_k = a_k b_k.  ulp(1.0) = 2^-23; half ulp = 2^-24
+  struct Case { const char *what; float C; int np; float a[16], b[16]; };
+  Case cs[8] = {};
+  int n = 0;
+  auto two = [](int e) { return ldexpf(1.0f, e); };
+  { Case &c = cs[n++]; c.what = "C = 1, one product 2^-24 (1 + 2^-6): above half an ulp of C          -> RNE 1 + 2^-23, truncation 1"; c.C = 1.0f; c.np = 1; c.a[0] = two(-12); c.b[0] = two(-12) * (1 + two(-6)); }
+  { Case &c = cs[n++]; c.what = "C = 1, one product 2^-24 exactly (a tie)                              -> RNE (to even) 1, round-half-up 1 + 2^-23"; c.C = 1.0f; c.np = 1; c.a[0] = two(-12); c.b[0] = two(-12); }
+  { Case &c = cs[n++]; c.what = "C = 1, three products of 2^-26 + one of 2^-25 (together 2^-24 (1 + 1/4)) -> summed exactly first: 1 + 2^-23; added one by one (RNE): 1";
+    c.C = 1.0f; c.np = 4; for (int k = 0; k < 3; k++) { c.a[k] = two(-13); c.b[k] = two(-13); } c.a[3] = two(-13); c.b[3] = two(-12); }
+  { Case &c = cs[n++]; c.what = "C = 1, sixteen products of 2^-27 (together 2^-23)                      -> summed exactly first: 1 + 2^-23; one by one: 1";
+    c.C = 1.0f; c.np = 16; for (int k = 0; k < 16; k++) { c.a[k] = two(-14); c.b[k] = two(-13); } }
+  { Case &c = cs[n++]; c.what = "C = 0, products 1 and 2^-24 (1 + 2^-6) and -1                          -> exact sum 2^-24 (1 + 2^-6) = 6.05e-08; left to right with rounding: 0 or 1.19e-07";
+    c.C = 0.0f; c.np = 3; c.a[0] = 1.0f; c.b[0] = 1.0f; c.a[1] = two(-12); c.b[1] = two(-12) * (1 + two(-6)); c.a[2] = -1.0f; c.b[2] = 1.0f; }
+  { Case &c = cs[n++]; c.what = "C = -1, products 1 (k = 0) and 2^-24 (1 + 2^-6) (k = 8: the other lane half) -> exact 6.05e-08";
+    c.C = -1.0f; c.np = 9; c.a[0] = 1.0f; c.b[0] = 1.0f; c.a[8] = two(-12); c.b[8] = two(-12) * (1 + two(-6)); }
+  _Float16 hA[8 * 16], hB[8 * 16]; float hC[8], hD[8];
+  for (int t = 0; t < n; t++) { hC[t] = cs[t].C; for (int k = 0; k < 16; k++) { hA[t * 16 + k] = (_Float16)cs[t].a[k]; hB[t * 16 + k] = (_Float16)cs[t].b[k]; } }
+  _Float16 *dA, *dB; float *dC, *dD;
+  hipMalloc(&dA, sizeof(hA)); hipMalloc(&dB, sizeof(hB)); hipMalloc(&dC, sizeof(hC)); hipMalloc(&dD, sizeof(hD));
+  hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice); hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice); hipMemcpy(dC, hC, sizeof(hC), hipMemcpyHostToDevice);
+  k_round<<<1, 64>>>(dA, dB, dC, dD, n);
+  hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost);
+  for (int t = 0; t < n; t++) printf("rounding: %s\n          got %.9g (C + %.3g ulp of 1)\n", cs[t].what, hD[t], (hD[t] - cs[t].C) / ldexp(1.0, -23));
+}
+
 int main() {
+  rounding_cases();
   _Float16 hA[32 * 16], hB[16 * 32];
   srand(7);
   for (int i = 0; i < 32 * 16; i++) hA[i] = (_Float16)((rand() % 2001 - 1000) / 64.0f);
