@@ -47,11 +47,15 @@ typedef float sgtd_f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SGTD_VM_WAVES
 #define SGTD_VM_WAVES 2
 #endif
-#ifndef SGTD_VM_BOTH
-#define SGTD_VM_BOTH 1
+// SGTD_VM_PIPE (experiment switch): 1 / 2 = a software pipeline across tiles — the next tile prepared between the current tile's
+// MFMAs (one hypothesis tile's / both tiles', the order forced with sched_group_barrier).  Measured and not the default: 13.8 / 13.1
+// against 12.7 ms per batch on the same box — the kernel is bound by the NUMBER of vector instructions (4 cycles each on a SIMD
+// whichever wave they come from), not by where the MFMAs sit among them.
+#ifndef SGTD_VM_PIPE
+#define SGTD_VM_PIPE 0
 #endif
-#ifndef SGTD_VM_PREFETCH
-#define SGTD_VM_PREFETCH 1
+#ifndef SGTD_VM_VALU_PER_MFMA
+#define SGTD_VM_VALU_PER_MFMA 18
 #endif
 
 #ifdef SGTD_EXP_VSTAT
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu
   __shared__ u32 s_votes[SGTD_VERIFY_MAX_HYP];
   __shared__ u32 s_best, s_count;
   __shared__ u64 s_queue[SGTD_VM_THREADS / SGTD_WAVE][SGTD_VM_QCAP];
-  __shared__ __attribute__((aligned(16))) float s_kap[SGTD_VM_THREADS / SGTD_WAVE][3][32];
+  __shared__ __attribute__((aligned(16))) float s_kap[SGTD_VM_THREADS / SGTD_WAVE][2][96];      // per wave: kap of two tiles x three vertices x 32 pairs
   const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the wave's number in a scalar register)
   const u32 r = (u32)lane & 31u, hh = (u32)lane >> 5;
   if (P.overflow && (P.overflow[0] | P.overflow[1])) return;
@@ -198,20 +202,12 @@ __global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu
   // instead of waiting for all of them)
   const u32 n_tiles = (n + 31u) >> 5;
   const u32 last_tile = n_tiles > (u32)wave ? (u32)wave + ((n_tiles - 1u - (u32)wave) / STEP) * STEP : (u32)wave;
-  Tile cur;
-  vertices_of(pair_of((u32)wave), cur);
-  u64 pr_next = pair_of(min((u32)wave + STEP, last_tile));
-
-  for (u32 tile = (u32)wave; tile < n_tiles; tile += STEP) {
-#if SGTD_VM_PREFETCH
-    Tile nxt;
-    vertices_of(pr_next, nxt);
-    const u64 pr_after = pair_of(min(tile + 2 * STEP, last_tile));
-#else
-    if (tile != (u32)wave) vertices_of(pair_of(tile), cur);
-#endif
+  // what a tile's pairs become before the matrix pipe sees them: the tile's scale and masks, and per vertex the two-part products
+  // (the MFMAs' A operands) and kap (through LDS: a lane needs it for its sixteen ROWS)
+  struct Prep { float Umax, s, se; u32 off16, wild16; sgtd_h8 Aop[3][3]; };
+  auto prepare = [&](const Tile &t, u32 tile, float *kap_buf, Prep &p) {
     const bool valid = tile * 32u + r < n;
-    float (&v)[3][3] = cur.v, (&w)[3][3] = cur.w;
+    const float (&v)[3][3] = t.v, (&w)[3][3] = t.w;
     // V = max_m |v_m|_1, W = max_m |w_m|_1 (one v_add with |.| on both inputs and one more per vertex); the sum of all of them
     // catches what a maximum drops: a NaN
     float s1[3], s2[3];
@@ -227,27 +223,27 @@ __global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu
     // a pair the matrix pass cannot take (not a number, or beyond every sensible coordinate): exact test for all its hypotheses.
     // Its features may be anything: a row of the A operand only ever reaches its own row of the result, which is masked out
     const bool wild = valid && !(all < 1e6f);
-    const float U = (valid && !wild) ? __builtin_fmaf(rho, V, W) : 0.0f;       // rho V + W: with a hypothesis's |t|_1 the bound B of the error analysis
-    const float Umax = __uint_as_float(wave_max_u32(__float_as_uint(U)));     // (non-negative floats order like their bit patterns)
+    // rho V + W: with a hypothesis's |t|_1 the bound B of the error analysis (masked, not selected by a branch: the block must stay ONE
+    // scheduling region for the interleaving below)
+    const float U = __uint_as_float(__float_as_uint(__builtin_fmaf(rho, V, W)) & ((valid && !wild) ? 0xFFFFFFFFu : 0u));
+    p.Umax = __uint_as_float(wave_max_u32(__float_as_uint(U)));               // (non-negative floats order like their bit patterns)
     // s = a power of two <= 3 / (EPS B) for the candidate's largest |t|_1 (scaling by it is exact; rcp's last bits are covered by
-    // the 2.9): no feature exceeds s V W <= 3 / (4 EPS) = 60 000
-    const float bmax = (Umax + tmaxf) * (Umax + tmaxf) + 16.0f;
+    // the 2.9): no feature exceeds s V W <= 3 / (4 EPS) = 57 700
+    const float bmax = (p.Umax + tmaxf) * (p.Umax + tmaxf) + 16.0f;
     const float s = __uint_as_float(__float_as_uint(2.9f * __builtin_amdgcn_rcpf(SGTD_VM_EPS * 1.0001f * bmax)) & 0x7F800000u);
-    const float se = s * (SGTD_VM_EPS * 1.0001f);
+    p.s = s;
+    p.se = s * (SGTD_VM_EPS * 1.0001f);
     const u32 off_rows = (u32)__builtin_amdgcn_ballot_w64(!valid || wild);           // rows without a matrix result (low 32 bits: lanes 0..31)
     const u32 wild_rows = (u32)__builtin_amdgcn_ballot_w64(wild);
-    const u32 off16 = vm_rows16(off_rows, hh), wild16 = vm_rows16(wild_rows, hh);
-
-    // ---- pair features of the three vertices: the products (w0, w1, w2, 1)_i x s (v0, v1, v2, 1)_j, rows i = 2 hh, 2 hh + 1 in
-    // this lane, each as a (high part, low part) pair of f16 = the A operands of two MFMA pairs; and per vertex
-    // kap = s (|v|^2 + |w|^2 - 9), which enters through the accumulators' initial value (from LDS: a lane needs it for its 16 rows)
-    sgtd_h8 Aop[3][3];
+    p.off16 = vm_rows16(off_rows, hh); p.wild16 = vm_rows16(wild_rows, hh);
+    // the products (w0, w1, w2, 1)_i x s (v0, v1, v2, 1)_j, rows i = 2 hh, 2 hh + 1 in this lane, each as a (high part, low part)
+    // pair of f16; kap = s (|v|^2 + |w|^2 - 9) enters through the accumulators' initial value
 #pragma unroll
     for (int m = 0; m < 3; m++) {
       const f32x2 sv01 = (f32x2){v[m][0], v[m][1]} * (f32x2){s, s}, sv2s = (f32x2){v[m][2], 1.0f} * (f32x2){s, s};
       const float kap = __builtin_fmaf(v[m][0], sv01.x, __builtin_fmaf(v[m][1], sv01.y, __builtin_fmaf(v[m][2], sv2s.x,
                         s * __builtin_fmaf(w[m][0], w[m][0], __builtin_fmaf(w[m][1], w[m][1], __builtin_fmaf(w[m][2], w[m][2], -9.0f))))));
-      kap_w[m * 32 + (int)r] = kap;      // (both lanes of the pair: the same value to the same word)
+      kap_buf[m * 32 + (int)r] = kap;      // (both lanes of the pair: the same value to the same word)
       const float wa = hh ? w[m][2] : w[m][0], wb = hh ? 1.0f : w[m][1];
       const f32x2 x[4] = {(f32x2){wa, wa} * sv01, (f32x2){wa, wa} * sv2s, (f32x2){wb, wb} * sv01, (f32x2){wb, wb} * sv2s};
       u32 wd[8], hw[4];
@@ -262,88 +258,63 @@ __global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu
         __builtin_memcpy(&wd[2 * k + 1], &p1, 4);
         __builtin_memcpy(&hw[k], &p2, 4);
       }
-      __builtin_memcpy(&Aop[m][0], &wd[0], 16);
-      __builtin_memcpy(&Aop[m][1], &wd[4], 16);
-      __builtin_memcpy(&Aop[m][2], &hw[0], 16);
+      __builtin_memcpy(&p.Aop[m][0], &wd[0], 16);
+      __builtin_memcpy(&p.Aop[m][1], &wd[4], 16);
+      __builtin_memcpy(&p.Aop[m][2], &hw[0], 16);
     }
-
-    // ---- the matrix products of a hypothesis tile (four MFMAs per vertex, the accumulators start from kap) and the look at
-    // their results.  SGTD_VM_BOTH: both tiles' MFMAs first — the second tile's run on the matrix pipe while the vector unit
-    // looks at the first tile's results (96 accumulator registers instead of 48)
-    u32 word = 0;             // this lane's vote word of the tile
-    u32 open = 0;             // bit g + 16 T: row g of this lane's half with the lane's hypothesis of tile T goes to the exact test
-    auto products = [&](int T, sgtd_f32x16 (&acc)[3]) {
+  };
+  // the matrix products of a hypothesis tile (three MFMAs per vertex, the accumulators start from kap) ...
+  auto products = [&](int T, const Prep &p, const float *kap_buf, sgtd_f32x16 (&acc)[3]) {
 #pragma unroll
-      for (int m = 0; m < 3; m++) {
-        sgtd_f32x16 a;
+    for (int m = 0; m < 3; m++) {
+      sgtd_f32x16 a;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {        // kap of rows 8 k + 4 hh + (0..3) = registers 4 k + (0..3)
-          const float4 kk = *reinterpret_cast<const float4 *>(kap_w + m * 32 + 8 * k + 4 * (int)hh);
-          a[4 * k] = kk.x; a[4 * k + 1] = kk.y; a[4 * k + 2] = kk.z; a[4 * k + 3] = kk.w;
-        }
+      for (int k = 0; k < 4; k++) {        // kap of rows 8 k + 4 hh + (0..3) = registers 4 k + (0..3)
+        const float4 kk = *reinterpret_cast<const float4 *>(kap_buf + m * 32 + 8 * k + 4 * (int)hh);
+        a[4 * k] = kk.x; a[4 * k + 1] = kk.y; a[4 * k + 2] = kk.z; a[4 * k + 3] = kk.w;
+      }
 #ifdef SGTD_EXP_VM_NOMFMA
-        a[0] += (float)Aop[m][0][0] + (float)Aop[m][1][7] + (float)Bop[T][0][0];     // (experiment: timing without the matrix pipe)
+      a[0] += (float)p.Aop[m][0][0] + (float)p.Aop[m][1][7] + (float)Bop[T][0][0];     // (experiment: timing without the matrix pipe)
 #else
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[m][0], Bop[T][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[m][1], Bop[T][1], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[m][2], Bop[T][2], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(p.Aop[m][0], Bop[T][0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(p.Aop[m][1], Bop[T][1], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(p.Aop[m][2], Bop[T][2], a, 0, 0, 0);
 #endif
-        acc[m] = a;
-      }
-    };
-    auto look = [&](int T, const sgtd_f32x16 (&acc)[3]) {
-      // z = s (d^2 - 9) + e of the worst vertex, e = the bound of its error: z < 0 is a certain vote, z > 2 e certainly none —
-      // the signs of z and of z - 2 e, two registers per packed addition
-      const float bh = (Umax + t1[T]) * (Umax + t1[T]) + 16.0f;
-      const float eh = __builtin_fmaf(se, bh, 0.12f);
-      const f32x2 c1 = {eh, eh}, c2 = {-eh * 1.000001f, -eh * 1.000001f};
-      u32 sure = 0u, und = 0u;
+      acc[m] = a;
+    }
+  };
+  // ... and the look at their results: this lane's vote bits and open bits of the hypothesis tile
+  auto look = [&](int T, const Prep &p, const sgtd_f32x16 (&acc)[3], u32 &word, u32 &open) {
+    // z = s (d^2 - 9) + e of the worst vertex, e = the bound of its error: z < 0 is a certain vote, z > 2 e certainly none —
+    // the signs of z and of z - 2 e, two registers per packed addition
+    const float bh = (p.Umax + t1[T]) * (p.Umax + t1[T]) + 16.0f;
+    const float eh = __builtin_fmaf(p.se, bh, 0.12f);
+    const f32x2 c1 = {eh, eh}, c2 = {-eh * 1.000001f, -eh * 1.000001f};
+    u32 sure = 0u, und = 0u;
 #pragma unroll
-      for (int g = 14; g >= 0; g -= 2) {
-        const f32x2 mx = {__builtin_fmaxf(__builtin_fmaxf(acc[0][g], acc[1][g]), acc[2][g]),
-                          __builtin_fmaxf(__builtin_fmaxf(acc[0][g + 1], acc[1][g + 1]), acc[2][g + 1])};
-        const f32x2 z1 = mx + c1, z2 = mx + c2;
-        sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(z1.y), 31);            // (sure << 1) | sign(z)
-        sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(z1.x), 31);
-        und = __builtin_amdgcn_alignbit(und, __float_as_uint(z2.y), 31);              // (und << 1) | sign(z - 2 e)
-        und = __builtin_amdgcn_alignbit(und, __float_as_uint(z2.x), 31);
-      }
-      VMSTAT(0, 1);
-      // rows without a matrix result: beyond the list's end — nothing —, or a wild pair — exact test; a hypothesis the matrix
-      // pass could not take: exact test for every pair; a lane without a hypothesis: nothing
-      sure &= ~off16 & 0xFFFFu;
-      und = ((und & ~sure & ~off16) | wild16) & 0xFFFFu;
-      if (hyp_exact[T]) { sure = 0u; und = 0xFFFFu & ~(off16 & ~wild16); }
-      if (!hyp_ok[T]) { sure = 0u; und = 0u; }
-      cnt[T] += (u32)__builtin_popcount(sure);
-      word |= sure << (16 * T);
-      open |= und << (16 * T);
-    };
-#if SGTD_VM_BOTH
-    {
-      sgtd_f32x16 acc0[3], acc1[3];
-      products(0, acc0);
-      products(1, acc1);
-      look(0, acc0);
-      look(1, acc1);
+    for (int g = 14; g >= 0; g -= 2) {
+      const f32x2 mx = {__builtin_fmaxf(__builtin_fmaxf(acc[0][g], acc[1][g]), acc[2][g]),
+                        __builtin_fmaxf(__builtin_fmaxf(acc[0][g + 1], acc[1][g + 1]), acc[2][g + 1])};
+      const f32x2 z1 = mx + c1, z2 = mx + c2;
+      sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(z1.y), 31);            // (sure << 1) | sign(z)
+      sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(z1.x), 31);
+      und = __builtin_amdgcn_alignbit(und, __float_as_uint(z2.y), 31);              // (und << 1) | sign(z - 2 e)
+      und = __builtin_amdgcn_alignbit(und, __float_as_uint(z2.x), 31);
     }
-#else
-    {
-      sgtd_f32x16 acc0[3];
-      products(0, acc0);
-      look(0, acc0);
-      if (n_ht > 1) {
-        products(1, acc0);
-        look(1, acc0);
-      }
-    }
-#endif
-    words[(size_t)tile * 64 + lane] = word;
-    // ---- queue what the matrix pass left open, densely: a prefix sum of the lanes' counts places every lane's combinations
-    // (at most 64 x 16 per hypothesis tile: the queue always has room for one tile's after it has been worked off)
-#ifdef SGTD_EXP_VM_NOQUEUE
-    open = 0;
-#endif
+    VMSTAT(0, 1);
+    // rows without a matrix result: beyond the list's end — nothing —, or a wild pair — exact test; a hypothesis the matrix
+    // pass could not take: exact test for every pair; a lane without a hypothesis: nothing
+    sure &= ~p.off16 & 0xFFFFu;
+    und = ((und & ~sure & ~p.off16) | p.wild16) & 0xFFFFu;
+    if (hyp_exact[T]) { sure = 0u; und = 0xFFFFu & ~(p.off16 & ~p.wild16); }
+    if (!hyp_ok[T]) { sure = 0u; und = 0u; }
+    cnt[T] += (u32)__builtin_popcount(sure);
+    word |= sure << (16 * T);
+    open |= und << (16 * T);
+  };
+  // queue what the matrix pass left open, densely: a prefix sum of the lanes' counts places every lane's combinations
+  // (at most 64 x 16 per hypothesis tile: the queue always has room for one tile's after it has been worked off)
+  auto enqueue = [&](u32 tile, u32 open) {
     if (__builtin_amdgcn_ballot_w64(open != 0u)) {
       VMSTAT(1, 1);
 #pragma unroll 1
@@ -361,11 +332,95 @@ __global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu
         qn += total;
       }
     }
-#if SGTD_VM_PREFETCH
+  };
+
+#if SGTD_VM_PIPE
+  // Software pipeline: while tile i's MFMAs run, the vector unit prepares tile i + 1 (its products are independent of them), then
+  // looks at tile i's results.  kap alternates between two LDS buffers (tile i's is read while tile i + 1's is written).
+  Tile raw;                                    // the vertices of the tile that is prepared next
+  vertices_of(pair_of((u32)wave), raw);
+  u64 pr_next = pair_of(min((u32)wave + STEP, last_tile));
+  Prep cur;
+  prepare(raw, (u32)wave, kap_w, cur);
+  vertices_of(pr_next, raw);                   // tile wave + STEP (clamped)
+  pr_next = pair_of(min((u32)wave + 2 * STEP, last_tile));
+  u32 flip = 0;
+  for (u32 tile = (u32)wave; tile < n_tiles; tile += STEP) {
+    float *kap_cur = kap_w + flip * 96, *kap_nxt = kap_w + (flip ^ 1u) * 96;
+    Prep nxt;
+    u32 word = 0, open = 0;
+#if SGTD_VM_PIPE == 2
+    // both hypothesis tiles' eighteen MFMAs with the whole preparation of the next tile between them
+    sgtd_f32x16 acc[3], acc1[3];
+    __builtin_amdgcn_sched_barrier(0);
+    products(0, cur, kap_cur, acc);
+    products(1, cur, kap_cur, acc1);
+    prepare(raw, tile + STEP, kap_nxt, nxt);
+    vertices_of(pr_next, raw);
+    pr_next = pair_of(min(tile + 3 * STEP, last_tile));
+#pragma unroll
+    for (int i = 0; i < 18; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, SGTD_VM_VALU_PER_MFMA / 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    look(0, cur, acc, word, open);
+    look(1, cur, acc1, word, open);
+    words[(size_t)tile * 64 + lane] = word;
+    enqueue(tile, open);
     cur = nxt;
-    pr_next = pr_after;
+    flip ^= 1u;
+    continue;
+#else
+    sgtd_f32x16 acc[3];
+    __builtin_amdgcn_sched_barrier(0);
+    products(0, cur, kap_cur, acc);
+    prepare(raw, tile + STEP, kap_nxt, nxt);                       // (under tile i's first MFMAs)
+    vertices_of(pr_next, raw);                                     // tile i + 2 STEP's vertices, i + 3 STEP's pair word
+    pr_next = pair_of(min(tile + 3 * STEP, last_tile));
+    // (the order the scheduler is asked for: a matrix instruction, then its share of the preparation's vector instructions — left
+    // to itself it issues the nine MFMAs in a row and the wave stands at the matrix pipe while its vector work waits)
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, SGTD_VM_VALU_PER_MFMA, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);       // (the look's vector instructions, which wait for the MFMAs, stay behind this line)
+    look(0, cur, acc, word, open);
+    if (n_ht > 1) {
+      products(1, cur, kap_cur, acc);
+      look(1, cur, acc, word, open);
+    }
+    words[(size_t)tile * 64 + lane] = word;
+    enqueue(tile, open);
+    cur = nxt;
+    flip ^= 1u;
 #endif
   }
+#else
+  Tile cur;
+  vertices_of(pair_of((u32)wave), cur);
+  u64 pr_next = pair_of(min((u32)wave + STEP, last_tile));
+  for (u32 tile = (u32)wave; tile < n_tiles; tile += STEP) {
+    Tile nxt;
+    vertices_of(pr_next, nxt);
+    const u64 pr_after = pair_of(min(tile + 2 * STEP, last_tile));
+    Prep p;
+    prepare(cur, tile, kap_w, p);
+    u32 word = 0, open = 0;
+    // both tiles' MFMAs first — the second tile's run on the matrix pipe while the vector unit looks at the first tile's
+    // results (96 accumulator registers instead of 48)
+    sgtd_f32x16 acc0[3], acc1[3];
+    products(0, p, kap_w, acc0);
+    products(1, p, kap_w, acc1);
+    look(0, p, acc0, word, open);
+    look(1, p, acc1, word, open);
+    words[(size_t)tile * 64 + lane] = word;
+    enqueue(tile, open);
+    cur = nxt;
+    pr_next = pr_after;
+  }
+#endif
   if (qn) { vm_drain(P, bid, queue, qn, base, qslot0, words, s_votes); VMSTAT(4, 1); }
 #pragma unroll
   for (int T = 0; T < 2; T++)
