@@ -73,6 +73,8 @@ struct QueryView {
   const u32 *count;     // [n_queries] descriptors per query
   long long stride;     // descriptor slots per query
   int n_queries;
+  u32 chunk;            // query descriptors per block of the block passes (votes, count, write): SGTD_PROBE_CHUNK, or a fraction of it
+                        // where a batch has too few blocks to fill the chip (one frame per call: 57 blocks of 128 are 57 WAVES)
 };
 
 // A match list starts on a GRANULE of four records (16 bytes) and is named by its granule: 32-bit list starts, slab
@@ -1488,10 +1490,11 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
 // at the threshold than the pool holds, the rounds run over all frames.
 #define SGTD_TOPK_BINS 8192
 #define SGTD_TOPK_POOL 1024
-__global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 frame_span, u32 frame_lo,
+#define SGTD_TOPK_THREADS 1024     // (the two walks over a query's vote array are chains of loads: a thread of 1 024 walks a quarter of what one of 256 did)
+__global__ __launch_bounds__(SGTD_TOPK_THREADS) void topk_kernel(const u32 *votes_all, u32 frame_span, u32 frame_lo,
                                                    int cand_num, int *n_cand, int *cand_frame,
                                                    int *cand_votes, unsigned char *slot_of_all) {
-  __shared__ u64 red[256 / SGTD_WAVE];
+  __shared__ u64 red[SGTD_TOPK_THREADS / SGTD_WAVE];
   __shared__ int n_picked;
   __shared__ u32 s_hist[SGTD_TOPK_BINS];
   __shared__ u64 s_pool[SGTD_TOPK_POOL];
@@ -1500,10 +1503,10 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
   const int tid = threadIdx.x, lane = lane_id();
   const u32 *votes = votes_all + (size_t)q * frame_span;
   unsigned char *slot_of = slot_of_all + (size_t)q * frame_span;
-  for (int b = tid; b < SGTD_TOPK_BINS; b += 256) s_hist[b] = 0;
+  for (int b = tid; b < SGTD_TOPK_BINS; b += SGTD_TOPK_THREADS) s_hist[b] = 0;
   if (tid == 0) { n_picked = 0; s_npool = 0; }
   __syncthreads();
-  for (u32 f = tid; f < frame_span; f += 256) {
+  for (u32 f = tid; f < frame_span; f += SGTD_TOPK_THREADS) {
     const u32 v = votes[f];
     if (v >= 5) atomicAdd(&s_hist[min(v, (u32)SGTD_TOPK_BINS - 1u)], 1u);
   }
@@ -1534,7 +1537,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
   __syncthreads();
   const u32 thr = s_thr;
   if (s_n_ge <= (u32)SGTD_TOPK_POOL) {
-    for (u32 f = tid; f < frame_span; f += 256) {
+    for (u32 f = tid; f < frame_span; f += SGTD_TOPK_THREADS) {
       const u32 v = votes[f];
       if (v >= thr) s_pool[atomicAdd(&s_npool, 1u)] = ((u64)v << 32) | (u64)(0xFFFFFFFFu - f);
     }
@@ -1550,10 +1553,11 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
         u64 best = 0;
 #pragma unroll
         for (int k = 0; k < PER; k++) best = a[k] > best ? a[k] : best;
-#pragma unroll
-        for (int dlt = SGTD_WAVE / 2; dlt > 0; dlt >>= 1) {
-          const u64 o = __shfl_xor(best, dlt);
-          best = o > best ? o : best;
+        {   // the wave's largest key: the largest high word by one DPP reduction, then the largest low word among the lanes that hold
+            // it (two reductions of six DPP steps: the twelve ds_bpermute of a 64-bit butterfly were most of a round's time)
+          const u32 whi = wave_max_u32((u32)(best >> 32));
+          const u32 wlo = wave_max_u32((u32)(best >> 32) == whi ? (u32)best : 0u);
+          best = ((u64)whi << 32) | (u64)wlo;
         }
         if ((u32)(best >> 32) < 5u) break;   // max_vote > 1 && max_vote >= 5 (:427,433)
 #pragma unroll
@@ -1574,7 +1578,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
   for (int round = 0; round < cand_num; round++) {
     // key = votes << 32 | ~local frame : max key = most votes, then lowest frame
     u64 best = 0;
-    for (u32 f = threadIdx.x; f < frame_span; f += 256) {
+    for (u32 f = threadIdx.x; f < frame_span; f += SGTD_TOPK_THREADS) {
       if (slot_of[f] != 0xFF) continue;   // already taken (its match_array entry was zeroed, :435)
       u64 key = ((u64)votes[f] << 32) | (u64)(0xFFFFFFFFu - f);
       best = key > best ? key : best;
@@ -1588,7 +1592,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const u32 *votes_all, u32 fra
     __syncthreads();
     if (threadIdx.x == 0) {
       u64 b = red[0];
-      for (int w = 1; w < 256 / SGTD_WAVE; w++) b = red[w] > b ? red[w] : b;
+      for (int w = 1; w < SGTD_TOPK_THREADS / SGTD_WAVE; w++) b = red[w] > b ? red[w] : b;
       const u32 v = (u32)(b >> 32);
       if (v >= 5) {   // max_vote > 1 && max_vote >= 5 (:427,433)
         const u32 f = 0xFFFFFFFFu - (u32)(b & 0xFFFFFFFFu);
@@ -1708,7 +1712,7 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
                                                u32 frame_lo, u32 limit, u32 *s_hist, u32 *votes, u32 *s_pre, u32 *s_ptr,
                                                u32 *s_cnt, u32 &visits, u32 &total) {
   const int lane = lane_id();
-  for (u32 d0 = d_first; d0 < min(d_first + SGTD_PROBE_CHUNK, cnt); d0 += SGTD_SUB_DESCS) {
+  for (u32 d0 = d_first; d0 < min(d_first + Q.chunk, cnt); d0 += SGTD_SUB_DESCS) {
     u32 records;
     const u32 RQ = sub_open_quads(Q, B, q, d0, cnt, s_pre, s_ptr, s_cnt, visits, records);
     total += records;
@@ -1767,7 +1771,7 @@ __global__ __launch_bounds__(256) void votes_kernel(QueryView Q, ProbeBuffers B,
   }
   u32 *votes = B.votes + (size_t)q * frame_span;
   const u32 cnt = Q.count[q];
-  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
+  const u32 d_first = (u32)id.blk * Q.chunk;
   if (id.valid && d_first < cnt) {
     u32 visits = 0, total = 0;
     votes_of_block<LDS_VOTES>(Q, B, q, d_first, cnt, 0u, frame_span, s_hist, votes, s_pre[wid], s_ptr[wid], s_cnt[wid], visits, total);
@@ -1820,7 +1824,7 @@ __global__ __launch_bounds__(SGTD_VOTES_Q_THREADS) void votes_query_kernel(Query
   if (!dead) {
     u32 visits = 0, total = 0;
     for (int blk = wid; blk < blocks_per_query; blk += NW) {
-      const u32 d_first = (u32)blk * SGTD_PROBE_CHUNK;
+      const u32 d_first = (u32)blk * Q.chunk;
       if (d_first >= cnt) break;
       votes_of_block<true>(Q, B, q, d_first, cnt, tile_lo, n_bins, s_hist, nullptr, s_pre[wid], s_ptr[wid], s_cnt[wid], visits, total);
     }
@@ -1884,11 +1888,11 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
   }
   if (!id.valid) return;
   const u32 cnt = Q.count[q];
-  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
+  const u32 d_first = (u32)id.blk * Q.chunk;
   const size_t bslot = (size_t)q * blocks_per_query + id.blk;
   u32 *out = blk_count + bslot * 64;
   if (d_first >= cnt) { out[lane] = 0; if (lane == 0) { L.blk_start[bslot] = 0; L.blk_n[bslot] = 0; } return; }
-  const u32 d_last = min(d_first + SGTD_PROBE_CHUNK, cnt);
+  const u32 d_last = min(d_first + Q.chunk, cnt);
   // room for the block's compact list: at most every record of the block
   u32 nm = 0;
     for (u32 dd = d_first + lane; dd < d_last; dd += SGTD_WAVE) nm += B.list[(long long)q * Q.stride + dd].y;
@@ -2081,7 +2085,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(QueryView Q, ProbeBuff
   if (nv == 0) return;
   using Word = std::conditional_t<NARROW, u32, u64>;
   const Word *cp = reinterpret_cast<const Word *>(L.pair) + L.blk_start[bslot];
-  const u32 d_first = (u32)id.blk * SGTD_PROBE_CHUNK;
+  const u32 d_first = (u32)id.blk * Q.chunk;
   // lane s carries, for candidate slot s, the output position of its first staged
   // pair (`running`) and the number of staged pairs (`fill`) — and, NARROW, the position of its
   // frame's first entry in the id map (a compact word names the frame by its slot)

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(SGTD_VT_THREADS) void votes_topk_kernel(QueryView Q
   if (!dead) {
     u32 visits = 0, total = 0;
     for (int blk = wid; blk < blocks_per_query; blk += NW) {
-      const u32 d_first = (u32)blk * SGTD_PROBE_CHUNK;
+      const u32 d_first = (u32)blk * Q.chunk;
       if (d_first >= cnt) break;
       votes_of_block<true>(Q, B, q, d_first, cnt, 0u, frame_span, s_hist, nullptr, s_pre[wid], s_ptr[wid], s_cnt[wid], visits, total);
     }

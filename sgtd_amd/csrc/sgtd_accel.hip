@@ -829,6 +829,15 @@ int rec_alloc(sgtd_engine *e, bool compact_lists) {
   return SGTD_OK;
 }
 
+// descriptors per block of the block passes over the match records (one wave per block): 128 — or 64 / 32 where the batch would
+// otherwise have fewer than a thousand blocks (a one-frame batch: 57 blocks = 57 waves on 1 024 SIMDs; SGTD_BLOCK_CHUNK overrides)
+u32 block_chunk(const sgtd_engine *e) {
+  if (const char *o = getenv("SGTD_BLOCK_CHUNK")) { const int c = atoi(o); if (c == 32 || c == 64 || c == 128) return (u32)c; }
+  u32 c = SGTD_PROBE_CHUNK;
+  while (c > SGTD_SUB_DESCS && (long long)e->nq * ((e->q_stride + c - 1) / c) < 1024) c >>= 1;
+  return c;
+}
+
 struct Views {
   TableView T;
   QueryView Q;
@@ -855,7 +864,7 @@ Views make_views(sgtd_engine *e) {
   QueryView &Q = v.Q;
   Q.side = e->qd.side.as<double>(); Q.qrec = e->qd.qrec.as<QueryRec>();
   Q.label = e->qd.label.as<int>(); Q.frame = e->qd.frame.as<u32>();
-  Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq;
+  Q.count = e->q_count.as<u32>(); Q.stride = e->q_stride; Q.n_queries = e->nq; Q.chunk = block_chunk(e);
   ProbeBuffers &B = v.B;
   B.rec_cell = e->rec_cell.as<unsigned char>(); B.rec_dis = e->rec_dis.as<double>();
   B.rec_cap = (u32)std::min<size_t>(e->rec_cap >> SGTD_REC_SHIFT, kIndexLimit);      // granules
@@ -899,7 +908,7 @@ Views make_views(sgtd_engine *e) {
   B.amb_cap = (u32)std::min<size_t>(e->amb_queue.bytes / sizeof(uint2), 0xFFFFFFF0u);
   B.list = e->list.as<uint2>(); B.n_visit = e->n_visit.as<u32>();
   B.votes = e->votes.as<u32>();
-  v.blocks_per_query = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
+  v.blocks_per_query = (int)((e->q_stride + block_chunk(e) - 1) / block_chunk(e));
   return v;
 }
 
@@ -1002,7 +1011,7 @@ int launch_select(sgtd_engine *e) {
   const long long n_slots = (long long)nq * e->q_stride;
   const int cn = e->dc.cand_num;
   const u32 span = e->have_frames ? (e->frame_hi - e->frame_lo + 1) : 1;
-  const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
+  const int blocks = (int)((e->q_stride + block_chunk(e) - 1) / block_chunk(e));
   CHK(ensure(e, e->cursors, kCtrWords * sizeof(u32)));
   if (!e->totals.p) {
     CHK(ensure(e, e->totals, 4 * sizeof(unsigned long long)));
@@ -1262,7 +1271,7 @@ int launch_select(sgtd_engine *e) {
     if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_VOTES], e->stream));
   }
   if (!fused_votes) {
-    topk_kernel<<<nq, 256, 0, e->stream>>>(e->votes.as<u32>(), span, v.T.frame_lo, cn, e->n_cand.as<int>(),
+    topk_kernel<<<nq, SGTD_TOPK_THREADS, 0, e->stream>>>(e->votes.as<u32>(), span, v.T.frame_lo, cn, e->n_cand.as<int>(),
                                             e->cand_frame.as<int>(), e->cand_votes.as<int>(),
                                             e->slot_of.as<unsigned char>());
     HIPCHK(hipGetLastError());
@@ -1361,7 +1370,7 @@ int rerun(sgtd_engine *e) {
 // only the output offsets and the write pass run again
 int rerun_write(sgtd_engine *e) {
   const int nq = e->nq;
-  const int blocks = (int)((e->q_stride + SGTD_PROBE_CHUNK - 1) / SGTD_PROBE_CHUNK);
+  const int blocks = (int)((e->q_stride + block_chunk(e) - 1) / block_chunk(e));
   const int groups = (blocks + 3) / 4;
   const int agrid = ((nq + 7) / 8) * groups * 8;
   CHK(ensure(e, e->pairs, e->pair_cap * sizeof(u64)));
@@ -2362,7 +2371,8 @@ int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
   }
   verify_solve_kernel<<<nq * cn, SGTD_WAVE, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
-  if (mfma) verify_mfma_kernel<<<grid, SGTD_VM_THREADS, 0, e->stream>>>(P);
+  if (mfma && nq * cn >= 1024) verify_mfma_kernel<4><<<grid, 4 * SGTD_WAVE, 0, e->stream>>>(P);
+  else if (mfma) verify_mfma_kernel<8><<<grid, 8 * SGTD_WAVE, 0, e->stream>>>(P);
   else verify_kernel<<<nq * cn, SGTD_VERIFY_THREADS, 0, e->stream>>>(P);
   HIPCHK(hipGetLastError());
 #ifdef SGTD_EXP_VSTAT

@@ -119,11 +119,15 @@ __device__ __forceinline__ void vm_drain(const VerifyParams &P, u32 bid, const u
 // in bit g + 16 (h / 32) the vote of pair 32 tile + vm_row(g, hh) for hypothesis h.
 // (at least two waves per SIMD: within 256 registers the compiler keeps the MFMA results in VGPRs — with AGPR results every
 // register of them costs a v_accvgpr_read before the vector unit can look at it)
-__global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu(SGTD_VM_WAVES, 4))) void verify_mfma_kernel(VerifyParams P) {
+// NW waves per workgroup: four for a batch (hundreds of candidates per CU), eight for a frame's fifty candidates (fifty workgroups on
+// 256 CUs: twice the waves halve the tiles each walks)
+template <int NW>
+__global__ __launch_bounds__(NW * SGTD_WAVE) __attribute__((amdgpu_waves_per_eu(SGTD_VM_WAVES, 4))) void verify_mfma_kernel(VerifyParams P) {
+  constexpr u32 THREADS = NW * SGTD_WAVE;
   __shared__ u32 s_votes[SGTD_VERIFY_MAX_HYP];
   __shared__ u32 s_best, s_count;
-  __shared__ u64 s_queue[SGTD_VM_THREADS / SGTD_WAVE][SGTD_VM_QCAP];
-  __shared__ __attribute__((aligned(16))) float s_kap[SGTD_VM_THREADS / SGTD_WAVE][2][96];      // per wave: kap of two tiles x three vertices x 32 pairs
+  __shared__ u64 s_queue[NW][SGTD_VM_QCAP];
+  __shared__ __attribute__((aligned(16))) float s_kap[NW][2][96];      // per wave: kap of two tiles x three vertices x 32 pairs
   const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the wave's number in a scalar register)
   const u32 r = (u32)lane & 31u, hh = (u32)lane >> 5;
   if (P.overflow && (P.overflow[0] | P.overflow[1])) return;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu
   u32 cnt[2] = {0u, 0u};     // certain votes of this lane's hypotheses (one per tile T) among the rows of its half
   u32 qn = 0;                // entries in the wave's queue
   float *kap_w = s_kap[wave][0];
-  constexpr u32 STEP = SGTD_VM_THREADS / SGTD_WAVE;
+  constexpr u32 STEP = NW;
 
   // the tile's 32 pairs: lanes r and r + 32 both hold pair r (they feed different products of it).  Loaded one tile ahead
   // (the vertices) and two ahead (the pair words): the gather's two dependent round trips never stand in the loop
@@ -440,13 +444,13 @@ __global__ __launch_bounds__(SGTD_VM_THREADS) __attribute__((amdgpu_waves_per_eu
   if (best == 0xFFFFFFFFu) {
     if (tid == 0) *score = -1.0;                    // :541
     if (tid < 12) pose[tid] = 0.0;
-    for (u32 jj = tid; jj < n; jj += SGTD_VM_THREADS) P.inlier[base + jj] = 0;
+    for (u32 jj = tid; jj < n; jj += THREADS) P.inlier[base + jj] = 0;
     return;
   }
   // ---- inliers of the best hypothesis (:516-539): the pairs that voted for it (the words were written by other lanes, some
   // bits by atomics: read past the vector cache)
   u32 mine = 0;
-  for (u32 jj = tid; jj < n; jj += SGTD_VM_THREADS) {
+  for (u32 jj = tid; jj < n; jj += THREADS) {
     const u32 row = jj & 31u, h2 = (row >> 2) & 1u, g = ((row >> 3) << 2) | (row & 3u);
     const u32 wv = __hip_atomic_load(&words[(size_t)(jj >> 5) * 64 + (best & 31u) + 32u * h2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool in = (wv >> (g + 16u * (best >> 5))) & 1u;

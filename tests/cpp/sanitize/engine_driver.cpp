@@ -40,7 +40,8 @@ size_t sgtd_stub_block_size(const void *p);
 }
 
 #define REQUIRE(x) do { if (!(x)) { fprintf(stderr, "engine_driver: %s failed at line %d\n", #x, __LINE__); exit(1); } } while (0)
-#define OK(call) do { const int st_ = (call); if (st_ != SGTD_OK) { fprintf(stderr, "engine_driver: %s = %d at line %d\n", #call, st_, __LINE__); exit(1); } } while (0)
+static sgtd_handle g_last = nullptr;     // (whose error text a failed call reports)
+#define OK(call) do { const int st_ = (call); if (st_ != SGTD_OK) { fprintf(stderr, "engine_driver: %s = %d at line %d (%s)\n", #call, st_, __LINE__, g_last ? sgtd_last_error(g_last) : ""); exit(1); } } while (0)
 
 namespace {
 struct Scenario {
@@ -72,6 +73,14 @@ void hook(const char *name, void **args, void *user) {
     } else {
       *B.rec_cursor() = B.rec_cap / 2;
     }
+  } else if (strstr(name, "small_order_kernel")) {
+    // a one-frame batch clears its counters inside this kernel (the general form: a memset, which the stand-in performs)
+    const kernels_of_the_engine::SmallOrder &O = *static_cast<const kernels_of_the_engine::SmallOrder *>(args[1]);
+    REQUIRE(sgtd_stub_block_size(O.ctr) >= (size_t)O.ctr_words * sizeof(u32) && sgtd_stub_block_size(O.pos_of_slot) >= (size_t)O.max_pass_slots * sizeof(u32));
+    REQUIRE(!O.votes || sgtd_stub_block_size(O.votes) >= (size_t)O.span * sizeof(u32));
+    REQUIRE(sgtd_stub_block_size(O.slot_of_words) >= (size_t)((O.span + 3u) / 4u) * sizeof(u32));
+    REQUIRE(sgtd_stub_block_size(O.gid) >= (size_t)O.n_slots * sizeof(u32) && sgtd_stub_block_size(O.order) >= (size_t)O.n_slots * sizeof(u32));
+    memset(O.ctr, 0, (size_t)O.ctr_words * sizeof(u32));
   } else if (strstr(name, "head_flags_kernel")) {
     // the bucket count of a segment = (head flag of the last entry) + (exclusive scan at the last entry): with no scan running both
     // reads see this word — half the buckets the table is to "have"
@@ -143,6 +152,7 @@ int main(int argc, char **argv) {
   // ---- a table from host descriptors, frame by frame; finalize; appends into a tail; more appends until the tail is merged
   sgtd_handle h = nullptr;
   OK(sgtd_create(&cfg, &h));
+  g_last = h;
   for (int f = 0; f < frames; f++) {
     Descs d = random_descs(rng, 300 + rng() % 500, (uint32_t)f);
     sgtd_desc_soa s = d.soa();
