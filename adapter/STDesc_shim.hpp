@@ -85,11 +85,14 @@ struct SoaBuf {
 };
 
 // The same arrays in page-locked memory (sgtd_host_alloc), kept by the calling thread from call to call
-// and grown when a call needs more: the entries SearchLoop fetches (20 MB per frame) arrive by one DMA
-// transfer per field instead of through the runtime's pageable staging.  Falls back to ordinary memory
-// if the allocation fails.
+// and grown when a call needs more: the entries SearchLoop fetches (20 MB per frame) are written in place by the
+// device (sgtd_search_frame: every array it is handed page-locked -> no copy, one wait) instead of arriving through
+// the runtime's pageable staging.  q_idx: the query side of the fetched pairs, kept like the entries.  Falls back
+// to ordinary memory if the allocation fails.
 struct PinnedSoa {
   sgtd_desc_soa v{};
+  int32_t *q_idx = nullptr;
+  std::vector<int32_t> plain_q;
   size_t cap = 0;
   bool pinned = false;
   std::vector<void *> owned;
@@ -98,20 +101,23 @@ struct PinnedSoa {
     if (n <= cap) return true;
     release();
     const size_t want = n + n / 4 + 1024;
-    void *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const size_t bytes[7] = {want * 3 * sizeof(double), want * 3 * sizeof(double), want * 3 * sizeof(double), want * 9 * sizeof(float),
-                             want * 3 * sizeof(int32_t), want * sizeof(uint32_t), want * 3 * sizeof(int32_t)};
+    void *p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[8] = {want * 3 * sizeof(double), want * 3 * sizeof(double), want * 3 * sizeof(double), want * 9 * sizeof(float),
+                             want * 3 * sizeof(int32_t), want * sizeof(uint32_t), want * 3 * sizeof(int32_t), want * sizeof(int32_t)};
     bool ok = true;
-    for (int i = 0; i < 7 && ok; i++) ok = sgtd_host_alloc(bytes[i], &p[i]) == SGTD_OK && p[i];
+    for (int i = 0; i < 8 && ok; i++) ok = sgtd_host_alloc(bytes[i], &p[i]) == SGTD_OK && p[i];
     if (ok) {
-      owned.assign(p, p + 7);
+      owned.assign(p, p + 8);
       v.side = (double *)p[0]; v.angle = (double *)p[1]; v.center = (double *)p[2]; v.vertex = (float *)p[3];
       v.label = (int32_t *)p[4]; v.frame = (uint32_t *)p[5]; v.node_id = (int32_t *)p[6];
+      q_idx = (int32_t *)p[7];
       pinned = true;
     } else {
       for (void *q : p) if (q) sgtd_host_free(q);
       plain = new SoaBuf(want);
       v = plain->v;
+      plain_q.resize(want);
+      q_idx = plain_q.data();
       pinned = false;
     }
     cap = want;
@@ -121,7 +127,7 @@ struct PinnedSoa {
     for (void *q : owned) sgtd_host_free(q);
     owned.clear();
     delete plain; plain = nullptr;
-    cap = 0; v = sgtd_desc_soa{};
+    cap = 0; v = sgtd_desc_soa{}; q_idx = nullptr;
   }
   PinnedSoa() = default;
   PinnedSoa(const PinnedSoa &) = delete;
@@ -132,7 +138,7 @@ struct PinnedSoa {
 };
 inline PinnedSoa &fetched_entries() { static thread_local PinnedSoa p; return p; }
 // Gives the calling thread's page-locked buffers back.  MANDATORY before a thread that has called SearchLoop or
-// candidate_selector ends (its thread_local destructor no longer calls into the HIP runtime: the seven blocks, some
+// candidate_selector ends (its thread_local destructor no longer calls into the HIP runtime: the eight blocks, some
 // 130 B per fetched entry, would stay page-locked until the process exits); ~STDescManager calls it for the thread
 // that destroys the manager.  The reference calls every method from its main thread (not re-entrant).
 inline void release_thread_buffers() { fetched_entries().release(); }
@@ -373,7 +379,6 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   std::vector<int64_t> ioff((size_t)cn + 1, 0);
   int64_t n_inl = 0;
   PinnedSoa &pe = fetched_entries();      // page-locked, reused from frame to frame
-  static thread_local std::vector<int32_t> iq;            // query side of the inlier pairs, kept like the entries
   // ONE call for candidate_selector (:98), candidate_verify of every candidate (:105-118) and the inlier pairs of every
   // candidate (sucess_match_vec, :516-539) with the table entries they name: two waits for the device instead of eight
   // (sgtd_search_frame).  Room for the inlier pairs: what the frames before needed, with slack; a frame that needs more
@@ -384,18 +389,16 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
     to_soa(stds_vec, qb);
     s.frame.assign(cn, -1); s.votes.assign(cn, 0); s.off.assign((size_t)cn + 1, 0);
     pe.reserve(16384);
-    if (iq.size() < pe.cap) iq.resize(pe.cap);
     sgtd_frame_search fs{};
     fs.cand_frame = s.frame.data(); fs.cand_votes = s.votes.data(); fs.pair_off = s.off.data();
     fs.score = score.data(); fs.pose = pose.data(); fs.inlier_off = ioff.data();
-    fs.inlier_q_idx = iq.data(); fs.entries = pe.v; fs.capacity = (int64_t)pe.cap;
+    fs.inlier_q_idx = pe.q_idx; fs.entries = pe.v; fs.capacity = (int64_t)pe.cap;
     st = sgtd_search_frame(h, &qb.v, (int64_t)stds_vec.size(), &fs);
     s.n_cand = fs.n_cand;
     n_inl = fs.n_inliers;
     if (st == SGTD_ERR_CAPACITY) {         // more inlier pairs than there was room for: everything else is there
       pe.reserve((size_t)n_inl + (size_t)n_inl / 2);
-      iq.resize(pe.cap);
-      st = sgtd_result_inlier_entries(h, 0, ioff.data(), iq.data(), &pe.v, (int64_t)pe.cap, &n_inl);
+      st = sgtd_result_inlier_entries(h, 0, ioff.data(), pe.q_idx, &pe.v, (int64_t)pe.cap, &n_inl);
     }
   }
   if (st == SGTD_ERR_UNSUPPORTED) {        // (a handle over several devices: the calls one after the other)
@@ -410,8 +413,7 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
     SGTD_LAP(verify);
     const int64_t most = s.off[s.n_cand];   // every pair of every candidate's list
     pe.reserve((size_t)most);
-    if (iq.size() < pe.cap) iq.resize(pe.cap);
-    st = sgtd_result_inlier_entries(h, 0, ioff.data(), iq.data(), &pe.v, most, &n_inl);
+    st = sgtd_result_inlier_entries(h, 0, ioff.data(), pe.q_idx, &pe.v, most, &n_inl);
     if (st != SGTD_OK) return st;
     SGTD_LAP(inliers);
   } else {
@@ -420,7 +422,7 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
     SGTD_LAP(select);                        // (the whole device side of the call)
   }
   const sgtd_desc_soa &ent = pe.v;
-  const int32_t *const iqp = iq.data();      // (a thread_local: the fill threads below must see THIS thread's)
+  const int32_t *const iqp = pe.q_idx;       // (a thread_local's: the fill threads below must see THIS thread's)
 #ifdef SGTD_SHIM_TIMING
   std::fprintf(stderr, "  [shim] %lld inlier pairs over %d candidates\n", (long long)n_inl, s.n_cand);
 #endif

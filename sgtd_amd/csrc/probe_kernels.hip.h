@@ -1999,12 +1999,22 @@ __global__ __launch_bounds__(256) void block_count_kernel(QueryView Q, ProbeBuff
 
 // per query: exclusive scan of blk_count over blocks (in place) per slot, then
 // over slots: pair_off[q][k] (relative to the query's first pair), q_pairs[q]
+__device__ __forceinline__ void batch_totals(const u32 *ctr, unsigned long long *tot) {
+  tot[0] += 1ull;
+  tot[1] += (ctr[10] | ctr[11]) ? 1ull : 0ull;
+  tot[2] += (unsigned long long)ctr[9];
+}
+// (one query: its base in the pair buffer is 0 and the batch's total is its own — query_base_kernel's work, done here: one launch less)
 __global__ __launch_bounds__(64) void block_scan_kernel(u32 *blk_count, int blocks_per_query, int cand_num,
                                                         const int *n_cand, long long *pair_off, u32 *q_pairs,
-                                                        const int *overflow) {
+                                                        int *overflow, u32 *q_pair_base_of_one, u32 pair_cap,
+                                                        unsigned long long *totals_of_one) {
   __shared__ u32 tot[64];
-  if (overflow[0]) return;
   const int q = blockIdx.x, s = threadIdx.x;
+  if (overflow[0]) {
+    if (totals_of_one && s == 0) batch_totals(reinterpret_cast<const u32 *>(overflow) - 10, totals_of_one);
+    return;
+  }
   u32 *tc = blk_count + (size_t)q * blocks_per_query * 64;
   u32 run = 0;
   int t = 0;
@@ -2026,16 +2036,18 @@ __global__ __launch_bounds__(64) void block_scan_kernel(u32 *blk_count, int bloc
       if (k < nc) acc += tot[k];
     }
     q_pairs[q] = acc;
+    if (q_pair_base_of_one) {
+      q_pair_base_of_one[0] = 0u; q_pair_base_of_one[1] = acc;
+      if (acc > pair_cap) overflow[1] = 1;
+    }
+    // (and the handle's running totals: every flag and count they read is final here — the list pass behind this kernel sets none)
+    if (totals_of_one) batch_totals(reinterpret_cast<const u32 *>(overflow) - 10, totals_of_one);
   }
 }
 
 // behind a batch's last kernel: the handle's running totals (never reset: they also see the batches a caller enqueues
 // one after the other without synchronising) — launches, launches that raised an overflow flag, match lists that moved
-__global__ void batch_totals_kernel(const u32 *ctr, unsigned long long *tot) {
-  tot[0] += 1ull;
-  tot[1] += (ctr[10] | ctr[11]) ? 1ull : 0ull;
-  tot[2] += (unsigned long long)ctr[9];
-}
+__global__ void batch_totals_kernel(const u32 *ctr, unsigned long long *tot) { batch_totals(ctr, tot); }
 
 // exclusive scan of q_pairs over queries: q_pair_base[q], [n] = total
 __global__ __launch_bounds__(256) void query_base_kernel(const u32 *q_pairs, u32 *q_pair_base, int n_queries,

@@ -170,9 +170,11 @@ struct sgtd_engine {
   DevBuf n_cand, cand_frame, cand_votes, pair_off, pairs;
   DevBuf v_score, v_pose, v_inlier, v_best;   // sgtd_verify results of the batch
   DevBuf inl_pairs, inl_off;                  // sgtd_result_inlier_pairs staging
-  DevBuf inl_counts, frame_pack;              // sgtd_search_frame: inlier pairs per candidate, the packed small results
+  bool verify_counted = false;                // the last verify_enqueue left the inlier counts in inl_counts
+  DevBuf inl_counts;                          // sgtd_search_frame: inlier pairs per candidate
   size_t frame_inl_cap = 0;                   // ... entries its gather has room for (grown when a frame has more inlier pairs)
-  const int *frame_qi = nullptr;              // ... the query-descriptor indices of the gathered inlier pairs (inside fetch_idx)
+  char *frame_host = nullptr;                 // ... page-locked host memory the call's last kernels write straight into: the packed small results,
+  size_t frame_host_bytes = 0;                //     then the inlier pairs' entries field by field and their query indices (no copy, no second wait)
   DevBuf b_in, b_out;                         // sgtd_build's one-block staging on the device: inputs / all descriptor fields
   char *pin_build = nullptr;                  // ... and in page-locked host memory
   size_t pin_build_cap = 0;
@@ -1333,17 +1335,22 @@ int launch_select(sgtd_engine *e) {
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_COUNT_T], e->stream));
   block_scan_kernel<<<nq, 64, 0, e->stream>>>(e->blk_count.as<u32>(), blocks, cn, e->n_cand.as<int>(),
                                                e->pair_off.as<long long>(), e->q_pairs.as<u32>(),
-                                               v.B.overflow());
+                                               v.B.overflow(), nq == 1 ? e->q_pair_base.as<u32>() : nullptr, (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u),
+                                               nq == 1 ? e->totals.as<unsigned long long>() : nullptr);
   HIPCHK(hipGetLastError());
-  query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
-                                               (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
-  HIPCHK(hipGetLastError());
+  if (nq != 1) {
+    query_base_kernel<<<1, 256, 0, e->stream>>>(e->q_pairs.as<u32>(), e->q_pair_base.as<u32>(), nq,
+                                                 (u32)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), v.B.overflow());
+    HIPCHK(hipGetLastError());
+  }
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_SCAN], e->stream));
   CHK(launch_block_write(e, v, CL, agrid, blocks));
   HIPCHK(hipGetLastError());
   if (e->timing) HIPCHK(hipEventRecord(e->ev[EV_WRITE], e->stream));
-  batch_totals_kernel<<<1, 1, 0, e->stream>>>(v.B.ctr, e->totals.as<unsigned long long>());
-  HIPCHK(hipGetLastError());
+  if (nq != 1) {
+    batch_totals_kernel<<<1, 1, 0, e->stream>>>(v.B.ctr, e->totals.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
+  }
   e->batch_valid = true;
   e->verified = false;
   e->batch_synced = false;
@@ -1725,13 +1732,14 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
-                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals, &e->inl_counts, &e->frame_pack, &e->b_in, &e->b_out,
+                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals, &e->inl_counts, &e->b_in, &e->b_out,
                     // (the entry-id map: missing from this list until the engine's host code ran under the sanitizers — every destroyed
                     // handle kept them, 8 bytes per map frame and, with frame ids out of insertion order, 8 bytes per entry)
                     &e->frame_first, &e->by_frame, &e->id_of_g, &e->longest};
   for (DevBuf *b : bufs) free_buf(*b);
   for (auto &b : e->scan_lvl) free_buf(b);
   if (e->pin) (void)hipHostFree(e->pin);
+  if (e->frame_host) (void)hipHostFree(e->frame_host);
   if (e->pin_build) (void)hipHostFree(e->pin_build);
   for (int i = 0; i < EV_COUNT; i++)
     if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
@@ -2351,6 +2359,12 @@ int verify_enqueue(sgtd_engine *e, int64_t total, bool guard) {
     HIPCHK(hipMemsetAsync(e->v_pose.p, 0, (size_t)nq * cn * 12 * sizeof(double), e->stream));     // (the matrix-core kernel writes every pose itself)
   }
   P.keep = e->verify_keep;
+  P.inl_count = nullptr;
+  if (guard && mfma) {        // (sgtd_search_frame: the kernel leaves the candidates' inlier counts behind)
+    CHK(ensure(e, e->inl_counts, (size_t)std::max(nq * cn, SGTD_MAX_CAND) * sizeof(u32)));
+    P.inl_count = e->inl_counts.as<u32>();
+  }
+  e->verify_counted = P.inl_count != nullptr;
   P.overflow = guard ? reinterpret_cast<const int *>(e->cursors.as<u32>() + 10) : nullptr;
   P.order = nullptr; P.n_blocks = (u32)(nq * cn);
   int grid = nq * cn;
@@ -2561,6 +2575,18 @@ int sgtd_search_loop(sgtd_handle e, double icp_threshold, int32_t *best_cand, in
   return SGTD_OK;
 }
 
+// [p, p + bytes) is page-locked host memory a kernel can write through the same address (hipHostMalloc / sgtd_host_alloc)
+static bool device_can_write(const void *p, size_t bytes) {
+  if (!p) return true;        // (a member the caller does not want)
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (a.type != hipMemoryTypeHost || a.devicePointer != p) return false;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return static_cast<const char *>(p) + bytes <= static_cast<const char *>(base) + size;
+}
+
 // One query frame through candidate_selector, candidate_verify and the inlier pairs with their table entries in ONE call
 // and (normally) two waits: the reference's per-frame call pattern (semantic_graph_localization.cpp:590-603 ->
 // STDesc.cpp:84-147) as sgtd_query_descs + sgtd_verify + sgtd_result_candidates + sgtd_result_verify +
@@ -2574,6 +2600,17 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   HIPCHK(hipSetDevice(e->cfg.device_id));
   const int cn = e->dc.cand_num;
   io->n_cand = 0; io->n_inliers = 0;
+#ifdef SGTD_EXP_FRAME_LAPS      // host time of the call by part, to stderr (an experiment build)
+  struct Laps {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t = t0;
+    std::string s;
+    void lap(const char *what) { const auto n = std::chrono::steady_clock::now(); char b[64]; snprintf(b, sizeof b, " %s %.0f", what, std::chrono::duration<double, std::micro>(n - t).count()); s += b; t = n; }
+    ~Laps() { fprintf(stderr, "[frame laps us]%s | all %.0f\n", s.c_str(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+  } laps;
+#define LAP(x) laps.lap(x)
+#else
+#define LAP(x) do { } while (0)
+#endif
   CHK(settle_tail(e));
   // ---- sgtd_query_descs without its waits
   e->nq = 1;
@@ -2584,6 +2621,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   CHK(ensure_store(e, e->qd, (size_t)e->q_stride));
   CHK(ensure(e, e->q_count, sizeof(u32)));
   CHK(copy_in(e, e->qd, 0, (size_t)nq, q, /*wait=*/false));
+  LAP("descriptors_in");
   e->thr2_pending = nq;      // the descriptors' sweep records (thresholds, gate masks): launch_select writes them — one frame per call in its one launch
   const u32 cnt = (u32)nq;
   CHK(h2d(e, e->q_count.p, &cnt, sizeof(u32)));      // (staged: the bytes are copied out of `cnt` here)
@@ -2593,6 +2631,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   const int ls = launch_select(e);
   e->defer_lists = deferred;
   CHK(ls);
+  LAP("select_launches");
   // ---- candidate_verify behind it, sized by what the pair buffer holds
   CHK(verify_enqueue(e, (int64_t)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), /*guard=*/true));
   // ---- the inlier pairs of every candidate, compacted by one workgroup per candidate, and the entries they name
@@ -2600,37 +2639,74 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   CHK(ensure(e, e->inl_counts, (size_t)SGTD_MAX_CAND * sizeof(u32)));
   CHK(ensure(e, e->inl_off, (size_t)(cn + 1) * sizeof(long long)));
   CHK(ensure(e, e->inl_pairs, std::min<size_t>(e->pair_cap, 0xFFFFFFF0u) * sizeof(u64)));
-  CHK(ensure(e, e->frame_pack, frame_pack_bytes(cn)));
-  inlier_count_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(), e->n_cand.as<int>(), ovf,
-                                                                       e->inl_counts.as<u32>());
-  HIPCHK(hipGetLastError());
+  if (!e->verify_counted) {     // (the packed-f32 form of the vote pass does not count)
+    inlier_count_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(), e->n_cand.as<int>(), ovf,
+                                                                         e->inl_counts.as<u32>());
+    HIPCHK(hipGetLastError());
+  }
   inlier_compact_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->pairs.as<u64>(), e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(),
                                                                          e->n_cand.as<int>(), ovf, e->inl_counts.as<u32>(), cn, e->inl_pairs.as<u64>(),
                                                                          e->inl_off.as<long long>());
   HIPCHK(hipGetLastError());
-  auto gather = [&](size_t room) -> int {      // index lists + entries of the first `room` inlier pairs (the count is on the device)
-    CHK(ensure(e, e->fetch_idx, room * (sizeof(long long) + sizeof(int))));
-    CHK(ensure_store(e, e->fetch, room));
-    long long *d_idx = e->fetch_idx.as<long long>();
-    int *d_qi = reinterpret_cast<int *>(d_idx + room);
-    e->frame_qi = d_qi;
-    gather_pair_entries_kernel<<<grid_for((long long)room, 256), 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)room, d_qi,
-                                                                                        e->tab.view(), e->fetch.view());
+  // the results go where the host reads them: page-locked memory the kernels write over the link — the packed block first (the
+  // handle's), then the inlier pairs' entries and query indices: straight into the CALLER's arrays when those are page-locked
+  // (sgtd_host_alloc: the 23 MB of a frame's 160 000 pairs on a 10 000-frame map cross the link once, at its rate, and the call
+  // has ONE wait), else into the handle's own block, room for `room` pairs, and from there with memcpy.  (Copies device ->
+  // host cost 0.15 ms each on this runtime and ran at 16 GB/s: eight of them for the entries were 1.4 ms of the call.)
+  const size_t pack_bytes = (frame_pack_bytes(cn) + 24 + 255) & ~(size_t)255;
+  const size_t ucap = (size_t)io->capacity;
+  const sgtd_desc_soa &o = io->entries;
+  static const bool direct_on = [] { const char *v = getenv("SGTD_FRAME_DIRECT"); return !(v && !atoi(v)); }();
+  const bool direct = direct_on && ucap > 0 && device_can_write(io->inlier_q_idx, ucap * 4) && device_can_write(o.side, ucap * 24) && device_can_write(o.angle, ucap * 24) &&
+                      device_can_write(o.center, ucap * 24) && device_can_write(o.vertex, ucap * 36) && device_can_write(o.label, ucap * 12) &&
+                      device_can_write(o.node_id, ucap * 12) && device_can_write(o.frame, ucap * 4);
+  DescArrays host_out{};
+  int *host_qi = nullptr;
+  auto gather = [&](size_t room) -> int {      // entries of the first `room` inlier pairs (the count is on the device)
+    const size_t need = pack_bytes + (direct ? 0 : room * 144);
+    if (need > e->frame_host_bytes) {
+      HIPCHK(hipStreamSynchronize(e->stream));          // (nothing may still be writing the block that is given back)
+      if (e->frame_host) (void)hipHostFree(e->frame_host);
+      e->frame_host = nullptr; e->frame_host_bytes = 0;
+      void *hp = nullptr;
+      if (hipHostMalloc(&hp, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->err = "hipHostMalloc of the frame results failed"; return SGTD_ERR_HIP; }
+      e->frame_host = static_cast<char *>(hp); e->frame_host_bytes = need;
+    }
+    if (direct) {
+      DescArrays user{};
+      user.side = o.side; user.angle = o.angle; user.center = o.center; user.vertex = o.vertex; user.label = o.label; user.frame = o.frame; user.node_id = o.node_id;
+      gather_pair_entries_kernel<<<1024, 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)ucap, io->inlier_q_idx, e->tab.view(), user);
+      HIPCHK(hipGetLastError());
+      return SGTD_OK;
+    }
+    char *at = e->frame_host + pack_bytes;               // (doubles first: every array stays aligned to its element)
+    host_out.side = reinterpret_cast<double *>(at); at += room * 24;
+    host_out.angle = reinterpret_cast<double *>(at); at += room * 24;
+    host_out.center = reinterpret_cast<double *>(at); at += room * 24;
+    host_out.vertex = reinterpret_cast<float *>(at); at += room * 36;
+    host_out.label = reinterpret_cast<int *>(at); at += room * 12;
+    host_out.node_id = reinterpret_cast<int *>(at); at += room * 12;
+    host_out.frame = reinterpret_cast<u32 *>(at); at += room * 4;
+    host_qi = reinterpret_cast<int *>(at);
+    host_out.qrec = nullptr;
+    gather_pair_entries_kernel<<<(unsigned)std::min<long long>(grid_for((long long)room * 8, 256), 1024), 256, 0, e->stream>>>(
+        e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)room, host_qi, e->tab.view(), host_out);
     HIPCHK(hipGetLastError());
     return SGTD_OK;
   };
   if (e->frame_inl_cap == 0) e->frame_inl_cap = 16384;
-  CHK(gather(e->frame_inl_cap));
+  CHK(gather(direct ? ucap : e->frame_inl_cap));
   pack_frame_kernel<<<1, 256, 0, e->stream>>>(e->cursors.as<u32>(), e->n_cand.as<int>(), e->q_M.as<u32>(), e->q_pair_base.as<u32>(), e->q_count.as<u32>(),
                                               e->q_P.as<unsigned long long>(), e->cand_frame.as<int>(), e->cand_votes.as<int>(),
                                               e->pair_off.as<long long>(), e->v_score.as<double>(), e->v_pose.as<double>(), e->inl_off.as<long long>(),
-                                              cn, e->frame_pack.as<unsigned char>());
+                                              cn, reinterpret_cast<unsigned char *>(e->frame_host), e->totals.as<unsigned long long>());
   HIPCHK(hipGetLastError());
-  std::vector<unsigned char> pack(frame_pack_bytes(cn));
-  unsigned long long tot[3] = {0, 0, 0};                    // the handle's running totals, as sync_batch reads them
-  CHK(d2h(e, pack.data(), e->frame_pack.p, pack.size()));
-  if (e->totals.p) CHK(d2h(e, tot, e->totals.p, sizeof(tot)));
-  CHK(xfer_sync(e));                                        // ---- wait 1
+  LAP("verify_and_result_launches");
+  HIPCHK(hipStreamSynchronize(e->stream));                  // ---- the call's one wait
+  struct { const unsigned char *p; const unsigned char *data() const { return p; } } pack{reinterpret_cast<const unsigned char *>(e->frame_host)};
+  unsigned long long tot[3];                                // the handle's running totals, as sync_batch reads them
+  std::memcpy(tot, pack.data() + frame_pack_bytes(cn), sizeof(tot));
+  LAP("wait_1");
   const u32 *w = reinterpret_cast<const u32 *>(pack.data());
   if (w[10] | w[11]) {
     // the batch outgrew a work buffer (a first frame, a frame unlike the ones before): sgtd_sync re-runs it, then the
@@ -2682,15 +2758,28 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   io->n_inliers = n_inl;
   if (n_inl > io->capacity) return SGTD_ERR_CAPACITY;       // (everything else is valid; sgtd_result_inlier_entries with more room gives the pairs)
   if (n_inl == 0) return SGTD_OK;
+  if (direct) { LAP("entries_in_place"); return SGTD_OK; }  // (the kernel wrote the caller's arrays)
   if ((size_t)n_inl > e->frame_inl_cap) {                   // more inlier pairs than the gather had room for: once more, with room
-    e->frame_inl_cap = (size_t)n_inl + (size_t)n_inl / 2;
+    e->frame_inl_cap = (size_t)n_inl + (size_t)n_inl / 2;   // (io, cf .. ioff were copied out above: the block may move)
     CHK(gather(e->frame_inl_cap));
+    HIPCHK(hipStreamSynchronize(e->stream));
   } else if ((size_t)n_inl * 2 > e->frame_inl_cap) {
-    e->frame_inl_cap = (size_t)n_inl * 2;                   // (room for the next frame)
+    e->frame_inl_cap = (size_t)n_inl * 2;                   // (room for the next frame; host_out still names this frame's arrays)
   }
-  if (io->inlier_q_idx) CHK(d2h(e, io->inlier_q_idx, e->frame_qi, (size_t)n_inl * sizeof(int)));
-  return copy_out(e, e->fetch, 0, (size_t)n_inl, &io->entries, 0);      // ---- wait 2
+  LAP("host_tables");
+  const size_t n = (size_t)n_inl;
+  if (io->inlier_q_idx) std::memcpy(io->inlier_q_idx, host_qi, n * sizeof(int));
+  if (o.side) std::memcpy(o.side, host_out.side, n * 24);
+  if (o.angle) std::memcpy(o.angle, host_out.angle, n * 24);
+  if (o.center) std::memcpy(o.center, host_out.center, n * 24);
+  if (o.vertex) std::memcpy(o.vertex, host_out.vertex, n * 36);
+  if (o.label) std::memcpy(o.label, host_out.label, n * 12);
+  if (o.node_id) std::memcpy(o.node_id, host_out.node_id, n * 12);
+  if (o.frame) std::memcpy(o.frame, host_out.frame, n * 4);
+  LAP("entries_out");
+  return SGTD_OK;
 }
+#undef LAP
 
 int sgtd_save_table(sgtd_handle e, const char *path) {
   if (e && e->grp) { e->err = "not available on a multi-device handle (use the per-device form, sgtd_amd/dist.py)"; return SGTD_ERR_UNSUPPORTED; }

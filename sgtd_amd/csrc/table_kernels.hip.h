@@ -444,14 +444,35 @@ __global__ void gather_entries_counted_kernel(const long long *idx, const long l
   if (i >= *n_p || i >= cap) return;
   gather_entry(idx, i, tab, out);
 }
-// the two in one launch (one frame per call): inlier pair i (q_idx << 32 | g) -> its query index and its table entry
-__global__ void gather_pair_entries_kernel(const u64 *pairs, const long long *n_p, long long cap, int *q_idx, DescArrays tab, DescArrays out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= *n_p || i >= cap) return;
-  const u64 pr = pairs[i];
-  q_idx[i] = (int)(pr >> 32);
-  const long long g = (long long)(pr & 0xFFFFFFFFull);
-  gather_entry(&g, 0, tab, out, i);
+// the two in one launch (one frame per call): inlier pair i (q_idx << 32 | g) -> its query index and its table entry.  Eight lanes
+// per pair, each with three or four words of the entry (the entry's seven arrays are seven scattered reads: spread over eight
+// times the waves they overlap instead of queueing behind one another in one lane); the launch is a fixed number of
+// workgroups that stride over the count, which is still on the device
+// (`out` and `q_idx` may be page-locked HOST memory — sgtd_search_frame hands the caller's own arrays when the device can write them: the
+// entries then cross the link once, inside this kernel, at the link's rate; members that are NULL are skipped)
+__global__ __launch_bounds__(256) void gather_pair_entries_kernel(const u64 *pairs, const long long *n_p, long long cap, int *q_idx, DescArrays tab, DescArrays out) {
+  const long long n = *n_p < cap ? *n_p : cap;
+  const int part = threadIdx.x & 7;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += ((long long)gridDim.x * blockDim.x) >> 3) {
+    const u64 pr = pairs[i];
+    const size_t g = (size_t)(pr & 0xFFFFFFFFull);
+    switch (part) {
+      case 0: if (out.side) for (int k = 0; k < 3; k++) out.side[i * 3 + k] = tab.side[g * 3 + k]; break;
+      case 1: if (out.angle) for (int k = 0; k < 3; k++) out.angle[i * 3 + k] = tab.angle[g * 3 + k]; break;
+      case 2: if (out.center) for (int k = 0; k < 3; k++) out.center[i * 3 + k] = tab.center[g * 3 + k]; break;
+      case 3:
+        if (out.label) for (int k = 0; k < 3; k++) out.label[i * 3 + k] = tab.label[g * 3 + k];
+        if (out.frame) out.frame[i] = tab.frame[g];
+        break;
+      case 4:
+        if (out.node_id) for (int k = 0; k < 3; k++) out.node_id[i * 3 + k] = tab.node_id[g * 3 + k];
+        if (q_idx) q_idx[i] = (int)(pr >> 32);
+        break;
+      default:
+        if (out.vertex) { const int k0 = (part - 5) * 3; for (int k = k0; k < k0 + 3; k++) out.vertex[i * 9 + k] = tab.vertex[g * 9 + k]; }
+        break;
+    }
+  }
 }
 // pairs (q_idx << 32 | g) -> the two index lists
 __global__ void split_pairs_kernel(const u64 *pairs, const long long *n_p, long long cap, long long *idx, int *q_idx) {

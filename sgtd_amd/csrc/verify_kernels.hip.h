@@ -59,6 +59,8 @@ struct VerifyParams {
   float *tau;                  // [nq * cand_num][2][SGTD_VERIFY_MAX_HYP] |t|^2 (NaN: exact test only) and |t|_1 of the hypotheses
   const u32 *order;            // or NULL: the (query, candidate) indices in dispatch order (by candidate frame), n_blocks of them
   u32 n_blocks;
+  u32 *inl_count;              // or NULL: [nq * cand_num] inlier pairs of every candidate (0 where there is no result) — what
+                               // inlier_count_kernel would count from the flags (sgtd_search_frame: one launch less)
   const int *overflow;         // or NULL: the batch's overflow flags — set: the lists are not final (the batch will be re-run), nothing
                                // is read (sgtd_search_frame enqueues the verification behind the batch without a host round trip)
 };
@@ -626,14 +628,15 @@ __global__ __launch_bounds__(SGTD_INLIER_CAND_THREADS) void inlier_compact_kerne
 
 // everything of a one-query batch the host needs after sgtd_search_frame's first (and usually only) wait, in one block:
 //   u32 ctr[12] | i32 n_cand, u32 q_M, u32 pairs_total, u32 q_count | u64 q_P | i32 cand_frame[cn] | i32 cand_votes[cn] |
-//   i64 pair_off[cn + 1] | f64 score[cn] | f64 pose[cn * 12] | i64 inl_off[cn + 1]
+//   i64 pair_off[cn + 1] | f64 score[cn] | f64 pose[cn * 12] | i64 inl_off[cn + 1] | u64 totals[3] (behind frame_pack_bytes: the handle's running counts)
+// `out` is page-locked host memory: the block is on the host when the stream has been waited for
 __host__ __device__ __forceinline__ size_t frame_pack_bytes(int cn) {
   return 48 + 16 + 8 + (size_t)cn * 8 + (size_t)(cn + 1) * 8 + (size_t)cn * 8 + (size_t)cn * 96 + (size_t)(cn + 1) * 8;
 }
 __global__ __launch_bounds__(256) void pack_frame_kernel(const u32 *ctr, const int *n_cand, const u32 *q_M, const u32 *q_pair_base, const u32 *q_count,
                                                          const unsigned long long *q_P, const int *cand_frame, const int *cand_votes,
                                                          const long long *pair_off, const double *score, const double *pose, const long long *inl_off,
-                                                         int cn, unsigned char *out) {
+                                                         int cn, unsigned char *out, const unsigned long long *totals) {
   const int t = threadIdx.x;
   u32 *w = reinterpret_cast<u32 *>(out);
   if (t < 12) w[t] = ctr[t];
@@ -645,4 +648,5 @@ __global__ __launch_bounds__(256) void pack_frame_kernel(const u32 *ctr, const i
   for (int k = t; k < cn; k += 256) { cf[k] = cand_frame[k]; cv[k] = cand_votes[k]; sc[k] = score[k]; }
   for (int k = t; k <= cn; k += 256) { po[k] = pair_off[k]; io[k] = inl_off[k]; }
   for (int k = t; k < cn * 12; k += 256) ps[k] = pose[k];
+  if (t < 3) reinterpret_cast<unsigned long long *>(out + frame_pack_bytes(cn))[t] = totals ? totals[t] : 0ull;
 }

@@ -144,7 +144,11 @@ __global__ __launch_bounds__(NW * SGTD_WAVE) __attribute__((amdgpu_waves_per_eu(
   const int q = (int)(bid / (u32)P.cand_num), c = (int)(bid % (u32)P.cand_num);
   double *score = P.score + (size_t)q * P.cand_num + c;
   double *pose = P.pose + ((size_t)q * P.cand_num + c) * 12;      // (zero where there is no result: no memset before the kernel)
-  if (c >= P.n_cand[q] || (P.keep && !((P.keep[q] >> c) & 1ull))) { if (tid == 0) *score = -1.0; if (tid < 12) pose[tid] = 0.0; return; }
+  if (c >= P.n_cand[q] || (P.keep && !((P.keep[q] >> c) & 1ull))) {
+    if (tid == 0) { *score = -1.0; if (P.inl_count) P.inl_count[bid] = 0u; }
+    if (tid < 12) pose[tid] = 0.0;
+    return;
+  }
   const long long *po = P.pair_off + (size_t)q * (P.cand_num + 1);
   const u32 base = P.q_pair_base[q] + (u32)po[c];
   const u32 n = (u32)(po[c + 1] - po[c]);          // (a batch's pairs are indexed with 32 bits)
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(NW * SGTD_WAVE) __attribute__((amdgpu_waves_per_eu(
   __syncthreads();
   const u32 best = s_best;
   if (best == 0xFFFFFFFFu) {
-    if (tid == 0) *score = -1.0;                    // :541
+    if (tid == 0) { *score = -1.0; if (P.inl_count) P.inl_count[bid] = 0u; }                   // :541
     if (tid < 12) pose[tid] = 0.0;
     for (u32 jj = tid; jj < n; jj += THREADS) P.inlier[base + jj] = 0;
     return;
@@ -460,6 +464,6 @@ __global__ __launch_bounds__(NW * SGTD_WAVE) __attribute__((amdgpu_waves_per_eu(
   mine = wave_sum(mine);
   if (lane == 0 && mine) atomicAdd(&s_count, mine);
   __syncthreads();
-  if (tid == 0) *score = (double)s_count;           // :539
+  if (tid == 0) { *score = (double)s_count; if (P.inl_count) P.inl_count[bid] = s_count; }          // :539
   if (tid < 12) pose[tid] = P.hyp64[((size_t)bid * SGTD_VERIFY_MAX_HYP + best) * SGTD_HYP_F64 + tid];
 }

@@ -389,29 +389,54 @@ class STDescManager:
         self._check(self._L.sgtd_search_loop(self._h, float(icp_threshold), _p(bc), _p(bf), _p(bs)))
         return bc, bf, bs
 
-    def search_frame(self, stds_vec, capacity=16384):
+    def search_frame(self, stds_vec, capacity=16384, page_locked=False):
         """sgtd_search_frame: candidate_selector + candidate_verify + the inlier pairs of every candidate with their table
         entries for ONE query frame given as descriptors, in one call -> dict(n_cand, cand_frame, cand_votes, pair_off,
-        score, rot, t, inlier_off, inlier_q_idx, entries (Descs), n_inliers, status)"""
+        score, rot, t, inlier_off, inlier_q_idx, entries (Descs), n_inliers, status).  page_locked: the arrays the inlier
+        pairs arrive in come from sgtd_host_alloc, as adapter/STDesc_shim.hpp keeps them — the device then writes them in
+        place and the call has one wait (ordinary arrays are filled from the handle's own page-locked block)"""
         from ._lib import FrameSearch
         cn = self.config_setting_["candidate_num"]
+        cap = max(int(capacity), 1)
         out = dict(cand_frame=np.zeros(cn, np.int32), cand_votes=np.zeros(cn, np.int32), pair_off=np.zeros(cn + 1, np.int64),
-                   score=np.zeros(cn, np.float64), pose=np.zeros((cn, 12), np.float64), inlier_off=np.zeros(cn + 1, np.int64),
-                   inlier_q_idx=np.zeros(max(capacity, 1), np.int32))
-        ent = Descs(max(capacity, 1))
-        fs = FrameSearch()
-        for k in ("cand_frame", "cand_votes", "pair_off", "score", "pose", "inlier_off", "inlier_q_idx"):
-            setattr(fs, k, out[k].ctypes.data)
-        fs.entries = ent.soa()
-        fs.capacity = int(capacity)
-        s = stds_vec.soa()
-        self._nq = 1
-        st = self._L.sgtd_search_frame(self._h, C.byref(s), stds_vec.n, C.byref(fs))
-        if st not in (0, -4):
-            self._check(st)
-        n = int(fs.n_inliers)
-        out.update(status=st, n_cand=int(fs.n_cand), n_inliers=n, rot=out["pose"][:, :9].reshape(cn, 3, 3).copy(), t=out["pose"][:, 9:].copy(),
-                   inlier_q_idx=out["inlier_q_idx"][:min(n, capacity)].copy(), entries=ent.head(min(n, capacity)))
+                   score=np.zeros(cn, np.float64), pose=np.zeros((cn, 12), np.float64), inlier_off=np.zeros(cn + 1, np.int64))
+        blocks = []
+        if page_locked:
+            def room(dt, w):
+                p = C.c_void_p()
+                self._check(self._L.sgtd_host_alloc(cap * w * np.dtype(dt).itemsize, C.byref(p)))
+                blocks.append(p)
+                a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(cap * w * np.dtype(dt).itemsize,)).view(dt)
+                return a.reshape((cap, w)) if w > 1 else a
+            ent = Descs(0)
+            ent.n = cap
+            for name, dt, w in Descs.FIELDS:
+                setattr(ent, name, room(dt, w))
+            out["inlier_q_idx"] = room(np.int32, 1)
+        else:
+            ent = Descs(cap)
+            out["inlier_q_idx"] = np.zeros(cap, np.int32)
+        try:
+            fs = FrameSearch()
+            for k in ("cand_frame", "cand_votes", "pair_off", "score", "pose", "inlier_off", "inlier_q_idx"):
+                setattr(fs, k, out[k].ctypes.data)
+            fs.entries = ent.soa()
+            fs.capacity = int(capacity)
+            s = stds_vec.soa()
+            self._nq = 1
+            st = self._L.sgtd_search_frame(self._h, C.byref(s), stds_vec.n, C.byref(fs))
+            if st not in (0, -4):
+                self._check(st)
+            n = int(fs.n_inliers)
+            out.update(status=st, n_cand=int(fs.n_cand), n_inliers=n, rot=out["pose"][:, :9].reshape(cn, 3, 3).copy(), t=out["pose"][:, 9:].copy(),
+                       inlier_q_idx=out["inlier_q_idx"][:min(n, capacity)].copy(), entries=ent.head(min(n, capacity)))
+            if page_locked:     # (head() of a contiguous slice is a view: the results leave the block before it is given back)
+                for name, _, _ in Descs.FIELDS:
+                    setattr(out["entries"], name, getattr(out["entries"], name).copy())
+        finally:
+            ent = None
+            for p in blocks:
+                self._L.sgtd_host_free(p)
         return out
 
     def SearchLoop(self, stds_vec, icp_threshold=None):

@@ -56,6 +56,8 @@ struct Scenario {
   unsigned long long sweeps = 0, packs = 0;
 };
 
+std::vector<const void *> g_gathers_into;      // gather_pair_entries_kernel launches: the `side` array each was handed
+
 void hook(const char *name, void **args, void *user) {
   Scenario &S = *static_cast<Scenario *>(user);
   if (strstr(name, "probe_sorted_kernel")) {
@@ -95,12 +97,36 @@ void hook(const char *name, void **args, void *user) {
     REQUIRE(sgtd_stub_block_size(q_pair_base) >= (size_t)(nq + 1) * sizeof(u32));
     for (int q = 0; q <= nq; q++) q_pair_base[q] = (u32)((unsigned long long)S.pairs_total * q / nq);
     if (S.pair_overflows > 0) { S.pair_overflows--; overflow[1] = 1; }
+  } else if (strstr(name, "block_scan_kernel")) {
+    // a one-query batch: the scan leaves the query's base and total itself (no query_base_kernel launch)
+    u32 *base_of_one = *static_cast<u32 **>(args[7]);
+    int *overflow = *static_cast<int **>(args[6]);
+    if (base_of_one) {
+      REQUIRE(sgtd_stub_block_size(base_of_one) >= 2 * sizeof(u32));
+      base_of_one[0] = 0; base_of_one[1] = S.pairs_total;
+      if (S.pair_overflows > 0) { S.pair_overflows--; overflow[1] = 1; }
+    }
+  } else if (strstr(name, "gather_pair_entries_kernel")) {
+    // where the entries go, and that every array the kernel is handed has the room it is told
+    const long long cap = *static_cast<long long *>(args[2]);
+    int *qi = *static_cast<int **>(args[3]);
+    const kernels_of_the_engine::DescArrays &out = *static_cast<const kernels_of_the_engine::DescArrays *>(args[5]);
+    auto room_of = [](const void *p) {        // bytes from p to the end of the block it lies in
+      hipDeviceptr_t base; size_t size;
+      REQUIRE(hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) == hipSuccess);
+      return size - (size_t)(static_cast<const char *>(p) - static_cast<const char *>(base));
+    };
+    REQUIRE(room_of(out.side) >= (size_t)cap * 24 && room_of(out.angle) >= (size_t)cap * 24 && room_of(out.center) >= (size_t)cap * 24);
+    REQUIRE(room_of(out.vertex) >= (size_t)cap * 36 && room_of(out.label) >= (size_t)cap * 12 && room_of(out.node_id) >= (size_t)cap * 12);
+    REQUIRE(room_of(out.frame) >= (size_t)cap * 4 && room_of(qi) >= (size_t)cap * 4);
+    g_gathers_into.push_back(out.side);
   } else if (strstr(name, "pack_frame_kernel")) {
     S.packs++;
     const int cn = *static_cast<int *>(args[12]);
     unsigned char *out = *static_cast<unsigned char **>(args[13]);
     REQUIRE(sgtd_stub_block_size(out) >= frame_pack_bytes(cn));
     u32 *w = reinterpret_cast<u32 *>(out);
+    memcpy(w, *static_cast<const u32 **>(args[0]), 12 * sizeof(u32));      // (the batch's counters and flags, as the kernel copies them)
     if (S.frame_overflow > 0) { S.frame_overflow--; w[10] = 1; return; }
     if (S.frame_inliers >= 0) {
       w[12] = 1; w[13] = 100; w[14] = (u32)S.frame_inliers; w[15] = 64;
@@ -244,6 +270,26 @@ int main(int argc, char **argv) {
     S.frame_inliers = -1;
     OK(sgtd_get_stats(h, &st));
     REQUIRE(st.batches_total >= 0);
+    // the caller's arrays page-locked (sgtd_host_alloc): the gather is handed them as they are — each must hold `capacity` entries.
+    // One array shorter than that (the caller's mistake would be a kernel writing past it): the engine must see it and take its own block
+    g_gathers_into.clear();
+    void *pl[8];
+    const size_t room = 2000, widths[8] = {24, 24, 24, 36, 12, 4, 12, 4};
+    for (int k = 0; k < 8; k++) OK(sgtd_host_alloc(room * widths[k], &pl[k]));
+    sgtd_frame_search d = io;
+    d.entries = sgtd_desc_soa{(double *)pl[0], (double *)pl[1], (double *)pl[2], (float *)pl[3], (int32_t *)pl[4], (uint32_t *)pl[5], (int32_t *)pl[6]};
+    d.inlier_q_idx = (int32_t *)pl[7];
+    d.capacity = (int64_t)room; S.frame_inliers = 100;
+    OK(sgtd_search_frame(h, &qs, 700, &d));
+    REQUIRE(d.n_inliers == 100 && !g_gathers_into.empty() && g_gathers_into.back() == pl[0]);
+    d.capacity = (int64_t)room + 1;             // one more than the arrays hold
+    OK(sgtd_search_frame(h, &qs, 700, &d));
+    REQUIRE(g_gathers_into.back() != pl[0]);
+    d.capacity = (int64_t)room; d.entries.vertex = ent.vertex.data();       // one ordinary array among them
+    OK(sgtd_search_frame(h, &qs, 700, &d));
+    REQUIRE(g_gathers_into.back() != pl[0]);
+    S.frame_inliers = -1;
+    for (int k = 0; k < 8; k++) OK(sgtd_host_free(pl[k]));
   }
 
   // ---- views: a second handle on the same table; its pending batch after the owner's table changed; destroy order

@@ -25,6 +25,8 @@ namespace {
 std::mutex &mu() { static std::mutex m; return m; }
 std::map<const void *, std::string> &kernels() { static std::map<const void *, std::string> k; return k; }      // host stub address -> device name
 std::map<void *, size_t> &blocks() { static std::map<void *, size_t> b; return b; }                             // "device" allocations
+std::map<void *, size_t> &host_blocks() { static std::map<void *, size_t> b; return b; }                        // page-locked host allocations
+#define g_host_blocks host_blocks()
 #define g_mu mu()
 #define g_kernels kernels()
 #define g_blocks blocks()
@@ -50,7 +52,9 @@ size_t sgtd_stub_device_blocks() { return g_blocks.size(); }
 size_t sgtd_stub_block_size(const void *p) {           // bytes of the allocation that starts at p (0: not one)
   std::lock_guard<std::mutex> l(g_mu);
   auto it = g_blocks.find(const_cast<void *>(p));
-  return it == g_blocks.end() ? 0 : it->second;
+  if (it != g_blocks.end()) return it->second;
+  it = g_host_blocks.find(const_cast<void *>(p));
+  return it == g_host_blocks.end() ? 0 : it->second;
 }
 
 // ---- what hipcc's host code calls
@@ -130,11 +134,55 @@ hipError_t hipFree(void *p) {
   free(p);
   return hipSuccess;
 }
-hipError_t hipHostMalloc(void **p, size_t n, unsigned int) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+// (page-locked host memory is device-visible: a kernel may be handed it, so its blocks are known by size too)
+hipError_t hipHostMalloc(void **p, size_t n, unsigned int) {
+  *p = calloc(n ? n : 1, 1);
+  if (!*p) return hipErrorOutOfMemory;
+  std::lock_guard<std::mutex> l(g_mu);
+  g_host_blocks[*p] = n;
+  return hipSuccess;
+}
+hipError_t hipHostFree(void *p) {
+  if (!p) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> l(g_mu);
+    auto it = g_host_blocks.find(p);
+    if (it == g_host_blocks.end()) { fprintf(stderr, "hip_stub: hipHostFree of a pointer that is not an allocation: %p\n", p); abort(); }
+    g_host_blocks.erase(it);
+  }
+  free(p);
+  return hipSuccess;
+}
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+
+// (what the engine asks before it lets a kernel write a caller's array: page-locked blocks are device-visible at their own address)
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {
+  std::lock_guard<std::mutex> l(g_mu);
+  for (auto *m : {&g_host_blocks, &g_blocks}) {
+    auto it = m->upper_bound(const_cast<void *>(p));
+    if (it == m->begin()) continue;
+    --it;
+    if (static_cast<const char *>(p) < static_cast<const char *>(it->first) + it->second) {
+      memset(a, 0, sizeof(*a));
+      a->type = m == &g_host_blocks ? hipMemoryTypeHost : hipMemoryTypeDevice;
+      a->devicePointer = const_cast<void *>(p); a->hostPointer = m == &g_host_blocks ? const_cast<void *>(p) : nullptr;
+      return hipSuccess;
+    }
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t hipMemGetAddressRange(hipDeviceptr_t *base, size_t *size, hipDeviceptr_t p) {
+  std::lock_guard<std::mutex> l(g_mu);
+  for (auto *m : {&g_host_blocks, &g_blocks}) {
+    auto it = m->upper_bound(p);
+    if (it == m->begin()) continue;
+    --it;
+    if (static_cast<const char *>(p) < static_cast<const char *>(it->first) + it->second) { *base = it->first; *size = it->second; return hipSuccess; }
+  }
+  return hipErrorInvalidValue;
+}
 
 // ---- streams and events
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

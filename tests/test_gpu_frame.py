@@ -61,6 +61,15 @@ def test_search_frame_equals_the_calls_it_stands_for(mods, monkeypatch):
         # the one-wait path leaves the handle's running totals and stage times as a waited batch does
         st = g.stats()
         assert st["batches_total"] == before + 1 and st["last_queries"] == 1 and st["ms_total"] >= 0
+        # the caller's arrays page-locked (sgtd_host_alloc): the device writes the inlier pairs in place — the same pairs, with room
+        # to spare, with exactly enough, and with one pair too little (then nothing but the pairs is missing)
+        for cap in (room, fs["n_inliers"]):
+            pl = g.search_frame(d, capacity=cap, page_locked=True)
+            assert pl["status"] == 0
+            _same(pl, ref, cn)
+        tight = g.search_frame(d, capacity=fs["n_inliers"] - 1, page_locked=True)
+        assert tight["status"] == -4 and tight["n_inliers"] == fs["n_inliers"]
+        _same(tight, ref, cn)
         # the handle is left as the five calls leave it: the lists of the same batch can still be read, and are the oracle's
         r = o.select()
         qi, de = g.result_pairs(0, g.results())
@@ -84,7 +93,7 @@ def test_search_frame_equals_the_calls_it_stands_for(mods, monkeypatch):
     monkeypatch.delenv("SGTD_REC_CAP")
     h.add_frames(m.xyz, m.label)
     d = h.BuildSingleScanSTD(qs.xyz[2], qs.label[2])
-    fs = h.search_frame(d, capacity=1 << 20)
+    fs = h.search_frame(d, capacity=1 << 20, page_locked=True)
     assert h.stats()["overflowed"] == 1 and fs["status"] == 0
     _same(fs, _five_calls(h, d), cn)
     h.close()
