@@ -44,10 +44,13 @@
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -57,7 +60,11 @@
 #endif
 
 #ifndef SGTD_SHIM_FILL_THREADS
-#define SGTD_SHIM_FILL_THREADS 12u  // host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call (2 / 4 / 8 / 12 measured: 6.4 / 5.4 / 4.1 / 3.1 ms for the fill; never more than the host has)
+// host threads that fill LOOP_RESULT::loop_std_pair of one SearchLoop call (never more than the host has).  155 000 pairs in 50
+// lists on a 256-thread host (tools/fill_bench.cpp): one thread 20 ms; threads started and joined per call 3.4 / 2.6 / 2.4 / 3.3 ms
+// with 12 / 24 / 48 / 96 of them — starting and joining them alone costs 0.4 / 0.7 / 1.4 / 2.6 ms; the team below, which sleeps
+// between calls, 2.0 / 1.8 / 1.1 / 1.4 ms
+#define SGTD_SHIM_FILL_THREADS 48u
 #endif
 
 namespace sgtd_shim {
@@ -245,31 +252,81 @@ int AddSTDescs(sgtd_handle h, const std::vector<Desc> &stds_vec, unsigned int &c
 // ---- STDesc.cpp:318-460 --------------------------------------------------------------------
 // the device part of candidate_selector: candidates, votes, list offsets and the (query
 // descriptor, table entry) index pairs of every list, in the reference's order
-// fill(k0, k1) builds the lists k0 .. k1 - 1; the n lists (off: n + 1 offsets into the pairs) are dealt to up to
-// SGTD_SHIM_FILL_THREADS short-lived threads in runs of about equal numbers of pairs, the last run on the caller.
-// Threads that exit, not an OpenMP team: an idle team spins after its region and slowed the HIP calls that
-// follow (8 threads: 38.7 ms per frame against 27.9 single-threaded, 256 threads: 180 ms at the time).
+// fill(k0, k1) builds the lists k0 .. k1 - 1; the n lists (off: n + 1 offsets into the pairs) are handed one by one, in their
+// order (candidates come by votes: the long lists first), to a team of up to SGTD_SHIM_FILL_THREADS threads, the caller among
+// them.  The team is started at the first call that needs it and SLEEPS on a condition variable between calls: threads started
+// and joined per call cost more than they filled (above), and an OpenMP team, which spins after its region, slowed the HIP calls
+// that follow (8 threads: 38.7 ms per frame against 27.9 single-threaded).  A fill that throws (std::bad_alloc on a match list
+// of 10^5 pairs) is rethrown on the caller once every list that was started has finished.  Callers on several threads take
+// turns.  The team's threads end with the process (the function-local static's destructor wakes and joins them).
+class FillTeam {
+  std::mutex m_, turn_;
+  std::condition_variable work_, done_;
+  std::vector<std::thread> th_;
+  void (*call_)(void *, int) = nullptr;
+  void *ctx_ = nullptr;
+  int n_jobs_ = 0, next_ = 0, running_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+  std::exception_ptr failed_;
+  void take(std::unique_lock<std::mutex> &l) {      // (m_ held) run jobs until none is left to start
+    while (next_ < n_jobs_) {
+      const int j = next_++;
+      running_++;
+      l.unlock();
+      std::exception_ptr ex;
+      try { call_(ctx_, j); } catch (...) { ex = std::current_exception(); }
+      l.lock();
+      running_--;
+      if (ex) { if (!failed_) failed_ = ex; next_ = n_jobs_; }      // (nothing new is started after a failure)
+    }
+  }
+  void loop() {
+    unsigned long seen = 0;
+    std::unique_lock<std::mutex> l(m_);
+    for (;;) {
+      work_.wait(l, [&] { return stop_ || gen_ != seen; });
+      if (stop_) return;
+      seen = gen_;
+      take(l);
+      if (running_ == 0) done_.notify_all();
+    }
+  }
+
+ public:
+  FillTeam() = default;
+  FillTeam(const FillTeam &) = delete;
+  FillTeam &operator=(const FillTeam &) = delete;
+  ~FillTeam() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    work_.notify_all();
+    for (auto &t : th_) if (t.joinable()) t.join();
+  }
+  // f(j) for j = 0 .. n - 1 on up to `threads` threads (the caller included); returns when all have finished
+  template <class F>
+  void run(int n, unsigned threads, F &f) {
+    std::lock_guard<std::mutex> turn(turn_);
+    std::unique_lock<std::mutex> l(m_);
+    // (a thread that cannot be started — std::system_error — leaves a smaller team: the caller fills what nobody takes)
+    try { while (th_.size() + 1 < threads) th_.emplace_back([this] { loop(); }); } catch (const std::system_error &) {}
+    call_ = [](void *c, int j) { (*static_cast<F *>(c))(j); };
+    ctx_ = &f; n_jobs_ = n; next_ = 0; failed_ = nullptr; gen_++;
+    work_.notify_all();
+    take(l);
+    done_.wait(l, [&] { return running_ == 0; });
+    n_jobs_ = 0; ctx_ = nullptr;
+    if (failed_) { std::exception_ptr ex = failed_; failed_ = nullptr; std::rethrow_exception(ex); }
+  }
+};
+inline FillTeam &fill_team() { static FillTeam t; return t; }
+
 template <class F>
 void deal_lists(int n, const int64_t *off, F &&fill) {
   const int64_t total = off[n] - off[0];
-  const int n_thr = total > 8192 ? (int)std::min<unsigned>(SGTD_SHIM_FILL_THREADS, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  // (joined on every way out: a fill that throws — std::bad_alloc on a match list of 10^5 pairs — or a thread that cannot be
-  // started must not leave joinable threads behind, whose destructors would end the process)
-  struct Team {
-    std::vector<std::thread> t;
-    ~Team() { for (auto &th : t) if (th.joinable()) th.join(); }
-  } joined;
-  std::vector<std::thread> &team = joined.t;
-  int k0 = 0;
-  for (int t = 0; t < n_thr; t++) {
-    int k1 = k0;
-    const int64_t until = off[0] + total * (t + 1) / n_thr;
-    while (k1 < n && (t == n_thr - 1 || off[k1 + 1] <= until)) k1++;
-    if (t == n_thr - 1) fill(k0, n);
-    else if (k1 > k0) team.emplace_back(fill, k0, k1);
-    k0 = k1;
-  }
-  for (auto &th : team) th.join();
+  const unsigned n_thr = total > 8192 ? std::min<unsigned>(SGTD_SHIM_FILL_THREADS, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  if (n_thr <= 1 || n <= 1) { fill(0, n); return; }
+  auto one = [&](int k) { fill(k, k + 1); };
+  fill_team().run(n, n_thr, one);
 }
 
 // Which candidates' LOOP_RESULT::loop_std_pair SearchLoop builds.  0 (default): every candidate's, as the reference does
@@ -445,8 +502,8 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   // LOOP_RESULT::loop_std_pair of EVERY candidate is filled: the caller copies the list of whichever
   // candidate its registration step prefers (semantic_graph_localization.cpp:622,672-718), and the
   // member is a plain std::vector — nothing can be deferred.
-  // The ~10^5 descriptors (416 bytes and a heap-allocated node_id each) are written by a few
-  // short-lived threads, every candidate's list by one of them (deal_lists).  Filling the query side of
+  // The ~10^5 descriptors (416 bytes and a heap-allocated node_id each) are written by a team of
+  // threads, every candidate's list by one of them (deal_lists).  Filling the query side of
   // the pairs while the table side is still being fetched was measured too: the fetch then takes 18-22 ms
   // instead of 3-4 (the copy's own host threads lose their cores) — the fill starts after it.
   // Every pair is CONSTRUCTED in place (reserve + emplace_back: the query descriptor copied, the table

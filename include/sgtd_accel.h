@@ -344,7 +344,10 @@ int sgtd_search_loop(sgtd_handle h, double icp_threshold, int32_t *best_cand, in
  * candidate_num (pair_off, inlier_off: candidate_num + 1; pose: candidate_num * 12) elements; any pointer may be NULL.
  * capacity = room (pairs) in inlier_q_idx / entries; n_inliers = needed.  SGTD_ERR_CAPACITY leaves everything but the
  * inlier pairs valid — sgtd_result_inlier_entries(h, 0, ...) with more room fetches them.  The handle afterwards is in
- * the state the five calls leave (every sgtd_result_* call works).  Not on a multi-device handle (SGTD_ERR_UNSUPPORTED). */
+ * the state the five calls leave (every sgtd_result_* call works).  Not on a multi-device handle (SGTD_ERR_UNSUPPORTED).
+ * inlier_q_idx and the members of `entries` are best given as sgtd_host_alloc memory (page-locked, `capacity` entries each): the
+ * device then writes the inlier pairs in place and the call has one wait; ordinary arrays are filled from a page-locked block of
+ * the handle's with memcpy (same results).  On SGTD_ERR_CAPACITY the first `capacity` pairs may or may not have been written. */
 typedef struct sgtd_frame_search {
   int32_t n_cand;           /* out */
   int32_t reserved;

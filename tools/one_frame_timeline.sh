@@ -43,22 +43,27 @@ call = rows[a:b]
 t0 = call[0][0]
 kern = [{"us_from_build": (s - t0) / 1e3, "us": (e - s) / 1e3, "grid": g, "kernel": k[:70]} for s, e, k, g in call]
 search = [k for k in kern if "build_frames_kernel" not in k["kernel"]]
-# the search chain: from thr2 / small_order to the last kernel before the host's long wait (gap > 1 ms)
+# the search chain: from the copy of the query descriptors' count to pack_frame_kernel, the call's last kernel (what follows belongs to the next
+# call: the host is filling loop_std_pair in between)
 chain = []
 for k in search:
-    if chain and k["us_from_build"] - (chain[-1]["us_from_build"] + chain[-1]["us"]) > 1000.0:
-        break
     chain.append(k)
+    if "pack_frame_kernel" in k["kernel"]:
+        break
+entries = [k for k in chain if "gather_pair_entries_kernel" in k["kernel"]]
 res = {"what": "rocprofv3 --kernel-trace of examples/localize LOCALIZE_PER_FRAME=32 on the 10 000-frame map: the kernels of ONE BuildSingleScanSTD + SearchLoop call through adapter/STDesc_shim.hpp (sgtd_build + sgtd_search_frame)",
        "tag": tag, "commit": commit, "kernels_in_the_call": len(kern), "search_kernels": len(chain),
        "search_chain_us_first_to_last_kernel": (chain[-1]["us_from_build"] + chain[-1]["us"] - chain[0]["us_from_build"]) if chain else None,
-       "search_kernel_us_sum": sum(k["us"] for k in chain), "one_call": kern}
+       "search_kernel_us_sum": sum(k["us"] for k in chain),
+       "of_it_gather_pair_entries_us": entries[0]["us"] if entries else None,
+       "gather_note": "gather_pair_entries_kernel writes the inlier pairs' table entries (136 B + 4 B per pair, some 160 000 pairs of this map's frames) over the link into the caller's page-locked arrays: it runs at the link's rate and replaces eight device -> host copies and the call's second wait",
+       "one_call": kern}
 try:
     res["localize_output"] = [l.strip() for l in open(os.path.join(out, "localize.out")) if "per-frame calls" in l or "SearchLoop by part" in l]
 except Exception:
     pass
 json.dump(res, open(os.path.join(out, "%s_one_frame_kernel_timeline.json" % tag), "w"), indent=1)
-print("kernels in the call", len(kern), "search kernels", len(chain), "chain us", res["search_chain_us_first_to_last_kernel"], "sum of kernel us", res["search_kernel_us_sum"])
+print("kernels in the call", len(kern), "search kernels", len(chain), "chain us", res["search_chain_us_first_to_last_kernel"], "sum of kernel us", res["search_kernel_us_sum"], "of it the entries over the link", res["of_it_gather_pair_entries_us"])
 for k in chain:
     print("%8.1f %7.1f %8d %s" % (k["us_from_build"], k["us"], k["grid"], k["kernel"][:60]))
 PY
