@@ -10,6 +10,7 @@
 //   g++ -std=c++17 -O1 -g -fsanitize=thread            (the same)
 #include <cstdio>
 #include <cstdlib>
+#include <new>
 #include <thread>
 
 #include "sgtd/STDescManager.hpp"
@@ -68,8 +69,45 @@ static int run(int seed, int frames, int calls) {
   return 0;
 }
 
+// the fill team by itself (sgtd_shim::deal_lists): every list built exactly once by some thread; a fill that throws reaches the
+// caller as the exception it threw, after which the team works as before; two callers at once take turns
+static int team_checks() {
+  const int n = 37;
+  std::vector<int64_t> off((size_t)n + 1, 0);
+  for (int k = 0; k < n; k++) off[(size_t)k + 1] = off[(size_t)k] + 400 + 50 * (k % 7);      // (above the 8192 pairs below which the caller fills alone)
+  auto round = [&](int throw_at) {
+    std::vector<std::vector<int64_t>> built((size_t)n);
+    std::vector<int> times((size_t)n, 0);
+    sgtd_shim::deal_lists(n, off.data(), [&](int k0, int k1) {
+      for (int k = k0; k < k1; k++) {
+        if (k == throw_at) throw std::bad_alloc();
+        times[(size_t)k]++;                                   // (every list is one thread's: no two touch the same element)
+        for (int64_t j = off[(size_t)k]; j < off[(size_t)k + 1]; j++) built[(size_t)k].push_back(j * 3);
+      }
+    });
+    for (int k = 0; k < n; k++) {
+      if (times[(size_t)k] != 1 || (int64_t)built[(size_t)k].size() != off[(size_t)k + 1] - off[(size_t)k]) return 1;
+      if (!built[(size_t)k].empty() && built[(size_t)k].back() != (off[(size_t)k + 1] - 1) * 3) return 2;
+    }
+    return 0;
+  };
+  if (int r = round(-1)) return 20 + r;
+  for (int at : {0, 11, n - 1}) {
+    bool caught = false;
+    try { (void)round(at); } catch (const std::bad_alloc &) { caught = true; }
+    if (!caught) return 23;
+    if (int r = round(-1)) return 24 + r;                     // the team after a failed call
+  }
+  int rc[2] = {0, 0};
+  std::thread a([&] { for (int i = 0; i < 20 && !rc[0]; i++) rc[0] = round(-1); });
+  std::thread b([&] { for (int i = 0; i < 20 && !rc[1]; i++) rc[1] = round(-1); });
+  a.join(); b.join();
+  return rc[0] || rc[1] ? 27 : 0;
+}
+
 int main(int argc, char **argv) {
   const int calls = argc > 1 ? std::atoi(argv[1]) : 24;
+  if (const int t = team_checks()) { std::printf("FAILED fill team %d\n", t); return 1; }
   int rc[2] = {0, 0};
   std::thread a([&] { rc[0] = run(0, 40, calls); });
   std::thread b([&] { rc[1] = run(1, 25, calls); });
