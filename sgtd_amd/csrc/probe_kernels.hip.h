@@ -1044,10 +1044,18 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
 
   u32 matches[K];
   char *list_base[K];   // wave-uniform: the list's first record; record r of the list is at byte 4 r
+#ifdef SGTD_EXP_SHADOW16
+  // experiment (never shipped): a second, 2-byte stream of the records' frames behind the record buffer (the host
+  // allocates half as much again): what the extra store per test costs the sweep
+  char *shadow_base[K];
+#endif
 #pragma unroll
   for (int k = 0; k < K; k++) {
     matches[k] = 0;
     list_base[k] = reinterpret_cast<char *>(B.rec_at(next0[k]));
+#ifdef SGTD_EXP_SHADOW16
+    shadow_base[k] = reinterpret_cast<char *>(B.rec_at(B.rec_cap)) + 64 + ((size_t)next0[k] << (SGTD_REC_SHIFT + 1));
+#endif
   }
   // wave-uniform constants of the columns in vector registers
   u32 qfv[K];
@@ -1175,6 +1183,9 @@ __device__ __forceinline__ void sweep_pass(const TableView &T, const ProbeBuffer
         if (at == 0xFFFFFFF0u)
 #endif
         if (hit && fits) *reinterpret_cast<u32 *>(list_base[k] + (at << 2)) = id;
+#ifdef SGTD_EXP_SHADOW16
+        if (hit && fits) *reinterpret_cast<unsigned short *>(shadow_base[k] + (at << 1)) = (unsigned short)(id >> id_bits);
+#endif
         if constexpr (DIAG) {
           if (hit && fits) { B.rec_cell[B.rec_index(next0[k]) + at] = (unsigned char)cellv[u]; B.rec_dis[B.rec_index(next0[k]) + at] = dis; }
         }
@@ -1726,7 +1737,14 @@ __device__ __forceinline__ void votes_of_block(const QueryView &Q, const ProbeBu
         u32 dd, addr, k;
         sub_locate_quad(s_pre, s_ptr, s_cnt, r < RQ ? r : 0u, dd, addr, k);
         nk[u] = r < RQ ? k : 0u;
+#ifdef SGTD_EXP_VOTES16
+        // experiment (never shipped): the pass as it would read a 2-byte frame stream — half the bytes per granule at
+        // the same places; the halves of the records it finds there stand in for frames (the counts are wrong, the time is what is asked)
+        const uint2 h = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(B.rec) + ((size_t)addr << 3));
+        nrec[u] = make_uint4((h.x & 0xFFFFu) << B.id_bits, (h.x >> 16) << B.id_bits, (h.y & 0xFFFFu) << B.id_bits, (h.y >> 16) << B.id_bits);
+#else
         nrec[u] = *reinterpret_cast<const uint4 *>(B.rec_at(addr));      // (a granule: 16-byte aligned)
+#endif
       }
     };
     if (RQ) load2(0);

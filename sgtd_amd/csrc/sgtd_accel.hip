@@ -818,7 +818,11 @@ int do_finalize(sgtd_engine *e, bool force_merge = false) {
 // the query pipeline on descriptors already in e->qd (strided)
 // ---------------------------------------------------------------------------
 int rec_alloc(sgtd_engine *e, bool compact_lists) {
+#ifdef SGTD_EXP_SHADOW16
+  CHK(ensure(e, e->rec, (e->rec_cap + 16) * sizeof(u32) * 3 / 2 + 256));     // (experiment build: the 2-byte shadow stream behind the records)
+#else
   CHK(ensure(e, e->rec, (e->rec_cap + 16) * sizeof(u32)));     // + a few quads: the list passes read four records at the last list's tail
+#endif
   // (the compact candidate lists between block_count and block_write: every block reserves room for all of its records —
   // twice the record buffer; the per-query list pass needs none)
   if (compact_lists) CHK(ensure(e, e->c_pair, std::min(e->rec_cap, kIndexLimit) * sizeof(u64)));

@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
     for (size_t j = k * per; j < (k + 1) * per; j++) lp.emplace_back(stds[(size_t)iq[j]], desc_from(j));
   };
   Team team(n_thr);
-  double t_spawn = 0, t_team = 0, t_noop_spawn = 0, t_noop_team = 0, t_free = 0, t_one = 0;
+  double t_chunk = 0, t_free_team = 0, t_spawn = 0, t_team = 0, t_noop_spawn = 0, t_noop_team = 0, t_free = 0, t_one = 0;
   for (int r = 0; r < reps + 2; r++) {
     std::vector<std::vector<std::pair<Desc, Desc>>> a(cn), b(cn), c(cn);
     double t0 = now_ms();
@@ -81,6 +81,23 @@ int main(int argc, char **argv) {
     double t1 = now_ms();
     team.run(cn, [&](int k) { fill_list(b[k], k); });
     double t2 = now_ms();
+    // the team in two rounds: every list sized by a thread (value-initialised pairs), then chunks of 1024 pairs assigned — no
+    // thread is left with a whole long list
+    {
+      std::vector<std::vector<std::pair<Desc, Desc>>> e(cn);
+      double u0 = now_ms();
+      team.run(cn, [&](int k) { e[k].resize(per); });
+      const int chunk = 1024, per_list = (int)((per + chunk - 1) / chunk);
+      team.run(cn * per_list, [&](int j) {
+        const int k = j / per_list; const size_t a = (size_t)(j % per_list) * chunk, b = std::min(per, a + chunk);
+        for (size_t i = a; i < b; i++) e[k][i] = std::pair<Desc, Desc>(stds[(size_t)iq[k * per + i]], desc_from(k * per + i));
+      });
+      if (r >= 2) t_chunk += now_ms() - u0;
+      double u1 = now_ms();
+      team.run(cn, [&](int k) { std::vector<std::pair<Desc, Desc>>().swap(e[k]); });      // the lists freed by the team as well
+      if (r >= 2) t_free_team += now_ms() - u1;
+    }
+    const double t2b = now_ms();
     { std::vector<std::thread> th; for (int t = 0; t < n_thr - 1; t++) th.emplace_back([] {}); for (auto &t : th) t.join(); }
     double t3 = now_ms();
     team.run(n_thr, [](int) {});
@@ -89,9 +106,9 @@ int main(int argc, char **argv) {
     double t5 = now_ms();
     a.clear(); b.clear();
     double t6 = now_ms();
-    if (r >= 2) { t_spawn += t1 - t0; t_team += t2 - t1; t_noop_spawn += t3 - t2; t_noop_team += t4 - t3; t_free += (t6 - t5) / 2; }
+    if (r >= 2) { t_spawn += t1 - t0; t_team += t2 - t1; t_noop_spawn += t3 - t2b; t_noop_team += t4 - t3; t_free += (t6 - t5) / 2; }
   }
-  std::printf("%d threads, %zu pairs in %d lists: short-lived threads %.3f ms, sleeping team %.3f ms | starting and joining idle threads %.3f ms, waking the idle team %.3f ms | one thread %.3f ms | freeing a frame's lists %.3f ms\n",
-              n_thr, total, cn, t_spawn / reps, t_team / reps, t_noop_spawn / reps, t_noop_team / reps, t_one, t_free / reps);
+  std::printf("%d threads, %zu pairs in %d lists: short-lived threads %.3f ms, sleeping team %.3f ms | starting and joining idle threads %.3f ms, waking the idle team %.3f ms | one thread %.3f ms | freeing a frame's lists %.3f ms | team in two rounds (sized by list, assigned in chunks of 1024) %.3f ms, lists freed by the team %.3f ms\n",
+              n_thr, total, cn, t_spawn / reps, t_team / reps, t_noop_spawn / reps, t_noop_team / reps, t_one, t_free / reps, t_chunk / reps, t_free_team / reps);
   return 0;
 }
