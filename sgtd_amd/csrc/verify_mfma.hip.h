@@ -9,32 +9,37 @@
 //   |R v + t - w|^2 - 9  =  sum_ij (-2 R_ij)(w_i v_j) + sum_j (2 (R^T t)_j) v_j + sum_i (-2 t_i) w_i + (|v|^2 + |w|^2 - 9) + |t|^2
 //
 // (|R v|^2 = |v|^2: the solve kernel measures |R^T R - I|_max and leaves a hypothesis beyond 1e-6 to the exact test), a
-// bilinear form of sixteen PAIR features (w_i v_j, v_j, w_i, |v|^2 + |w|^2 - 9: per vertex) and sixteen HYPOTHESIS
-// features (-2 R_ij, 2 (R^T t)_j, -2 t_i, 1), plus |t|^2 per hypothesis.  One v_mfma_f32_32x32x16_f16 multiplies 32 pairs
-// by 32 hypotheses over 16 products; every feature enters as TWO f16 values (x = hi + lo, hi = the top 11 significant
-// bits, lo = the next 11) and all four partial products are summed, so a feature carries 2^-20 of relative error, not
-// 2^-11.  Four MFMAs per (vertex, 32 hypotheses) give the 32 x 32 values in 16 registers per lane — lane = hypothesis,
-// register = pair — which the vector unit only has to take the maximum of over the three vertices and look at the sign of.
+// bilinear form of sixteen PAIR features ((w0, w1, w2, 1)_i x s (v0, v1, v2, 1)_j per vertex; the pair's own term
+// kap = s (|v|^2 + |w|^2 - 9) starts the accumulators instead) and sixteen HYPOTHESIS features (M = [-2 R, -2 t; 2 (R^T t)^T,
+// |t|^2], written by the solve kernel as the MFMAs' B operands: vm_write_hypothesis).  One v_mfma_f32_32x32x16_f16 multiplies
+// 32 pairs by 32 hypotheses over 16 products; every feature enters as TWO f16 values (x = hi + lo, hi = the top 11
+// significant bits, lo = the next 11) and three of the four partial products are summed — hi x hi, lo x hi, hi x lo; lo x lo
+// is below 2^-20 of the product and belongs to the error — so a product carries 3 x 2^-20 of relative error, not 2^-11.
+// Three MFMAs per (vertex, 32 hypotheses) give the 32 x 32 values in 16 registers per lane — lane = hypothesis, register =
+// pair — which the vector unit only has to take the maximum of over the three vertices and look at the sign of.
 //
 // The result of the matrix pass is only ever used where it is CERTAIN.  With the pair's features scaled by s (a power of
-// two, the same for the 32 pairs of a tile) the lane computes z = s (d^2 - 9) + 1 for the worst of the three vertices; the
-// scale is chosen so that the total error of z stays below 0.8 (bound below), hence
-//     z < 0   ==>  every vertex has d^2 < 9: the reference's three tests pass, a vote
-//     z > 2   ==>  some vertex has d^2 > 9: no vote
+// two, the same for the 32 pairs of a tile) the lane has zhat = s (d^2 - 9) up to an error below e for the worst of the
+// three vertices, e = s EPS B_h + 0.12 for the lane's hypothesis (B_h below), hence with z = zhat + e
+//     z < 0     ==>  every vertex has d^2 < 9: the reference's three tests pass, a vote
+//     z > 2 e   ==>  some vertex has d^2 > 9: no vote
 // and whatever lies between (or is not a number) is queued and decided exactly as the reference computes it — f64,
-// vertex_close of verify_kernels.hip.h — so that every decision equals the reference's.
+// vertex_close of verify_kernels.hip.h — so that every decision equals the reference's (0.2 % of the combinations on the
+// benchmark's batch, profiles/r06v_verify_profile.json).
 //
-// Error of z.  Let V = max_m |v_m|_1, W = max_m |w_m|_1 over the pair's vertices, T = max |t|_1 and rho = max(1, max |R_ij|)
-// over the candidate's hypotheses.  The absolute values of the seventeen terms of the expansion sum to at most
-// B = (rho V + T + W)^2 + 16.  Sources of error, relative to B: the two-part f16 representation of both factors (each
-// part truncated: 2^-20 per factor, 2^-19 together), the f32 roundings of the pair features (3 x 2^-24), the f32
-// accumulation of 64 products per value (at most one rounding of at most 2^-23 B each, whatever the order: 7.7e-6), the
-// orthogonality defect (1e-6).  Together below 1.1e-5 B; EPS = 2e-5 is used.  With s <= 0.75 / (EPS B) the scaled error is
-// below 0.75; the f16 subnormal grid (2^-24 absolute on a part, times a partner below 2.5e4: 0.0015 per product, 64
-// products: the parts that can be subnormal are low parts, whose partners are far smaller — 0.04 is a generous total), the
-// rounding of s |t|^2 + 1 and of the final addition (2^-24 x 4e4 each) stay below 0.05.  No feature can overflow f16:
-// s |w_i v_j| <= 0.75 / (4 EPS), s (|v|^2 + |w|^2 + 9) <= 0.75 / EPS = 37 500 < 65 504; hypothesis features are checked
-// by the solve kernel (|b| < 2.5e4, else the hypothesis is left to the exact test).
+// Error of zhat.  Let V = max_m |v_m|_1, W = max_m |w_m|_1 over the tile's pairs and vertices, T = |t|_1 of the hypothesis
+// and rho = max(1, max |R_ij|) over the candidate's hypotheses.  The absolute values of the terms of the expansion sum to at
+// most B_h = (rho V + T + W)^2 + 16.  Sources of error, relative to B_h: the two-part f16 representation (each factor's low
+// part truncated: 2^-20 per factor; the product lo x lo left out: 2^-20: 2.9e-6 together), the f32 roundings of the pair
+// features (3 x 2^-24), the f32 accumulation of 48 products and kap per value (at most one rounding of at most 2^-23 B_h
+// each, whatever the order the matrix pipe sums in: 5.8e-6), the orthogonality defect (1e-6).  Together below 1.0e-5 B_h;
+// SGTD_VM_EPS = 1.3e-5 is used.  s is the largest power of two <= 2.9 / (EPS B_max), B_max with the candidate's largest |t|_1:
+// the scaled error s EPS B_h stays below 2.9; the f16 subnormal grid (2^-24 absolute on a part, times a partner below 2.5e4:
+// 0.0015 per product, 48 products: the parts that can be subnormal are low parts, whose partners are far smaller — 0.04 is a
+// generous total) and the roundings of kap and of the final additions are the 0.12.  No feature can overflow f16:
+// s |w_i v_j| <= s V W <= 2.9 / (4 EPS) = 55 800 < 65 504 (f16's largest); hypothesis features are checked by the solve
+// kernel (|b| < 2.5e4, else the hypothesis is left to the exact test: tau = NaN), a pair with a coordinate that is not a
+// number or beyond 1e6 is left to it as well.
 #pragma once
 #include "verify_kernels.hip.h"
 
