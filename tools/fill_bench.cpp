@@ -108,6 +108,23 @@ int main(int argc, char **argv) {
     double t6 = now_ms();
     if (r >= 2) { t_spawn += t1 - t0; t_team += t2 - t1; t_noop_spawn += t3 - t2b; t_noop_team += t4 - t3; t_free += (t6 - t5) / 2; }
   }
+  // BuildSingleScanSTD's result: 7 000 descriptors from the structure of arrays, by the caller and by the team in chunks of 512
+  {
+    double t_one7 = 0, t_team7 = 0;
+    const size_t n7 = 7000;
+    for (int r = 0; r < reps + 2; r++) {
+      std::vector<Desc> a, b;
+      double u0 = now_ms();
+      a.reserve(n7);
+      for (size_t i = 0; i < n7; i++) a.push_back(desc_from(i));
+      double u1 = now_ms();
+      b.resize(n7);
+      team.run((int)((n7 + 511) / 512), [&](int c) { for (size_t i = (size_t)c * 512; i < std::min(n7, ((size_t)c + 1) * 512); i++) b[i] = desc_from(i); });
+      double u2 = now_ms();
+      if (r >= 2) { t_one7 += u1 - u0; t_team7 += u2 - u1; }
+    }
+    std::printf("7000 descriptors out of the arrays: the caller alone %.3f ms, sized by the caller and assigned by the team in chunks of 512 %.3f ms\n", t_one7 / reps, t_team7 / reps);
+  }
   std::printf("%d threads, %zu pairs in %d lists: short-lived threads %.3f ms, sleeping team %.3f ms | starting and joining idle threads %.3f ms, waking the idle team %.3f ms | one thread %.3f ms | freeing a frame's lists %.3f ms | team in two rounds (sized by list, assigned in chunks of 1024) %.3f ms, lists freed by the team %.3f ms\n",
               n_thr, total, cn, t_spawn / reps, t_team / reps, t_noop_spawn / reps, t_noop_team / reps, t_one, t_free / reps, t_chunk / reps, t_free_team / reps);
   return 0;
