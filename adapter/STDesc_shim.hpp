@@ -444,6 +444,9 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   {
     SoaBuf qb(stds_vec.size());
     to_soa(stds_vec, qb);
+#ifdef SGTD_SHIM_TIMING
+    std::fprintf(stderr, "  [shim] to_soa done at %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t1).count());
+#endif
     s.frame.assign(cn, -1); s.votes.assign(cn, 0); s.off.assign((size_t)cn + 1, 0);
     pe.reserve(16384);
     sgtd_frame_search fs{};
@@ -451,6 +454,9 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
     fs.score = score.data(); fs.pose = pose.data(); fs.inlier_off = ioff.data();
     fs.inlier_q_idx = pe.q_idx; fs.entries = pe.v; fs.capacity = (int64_t)pe.cap;
     st = sgtd_search_frame(h, &qb.v, (int64_t)stds_vec.size(), &fs);
+#ifdef SGTD_SHIM_TIMING
+    std::fprintf(stderr, "  [shim] sgtd_search_frame back at %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t1).count());
+#endif
     s.n_cand = fs.n_cand;
     n_inl = fs.n_inliers;
     if (st == SGTD_ERR_CAPACITY) {         // more inlier pairs than there was room for: everything else is there

@@ -172,6 +172,7 @@ struct sgtd_engine {
   DevBuf inl_pairs, inl_off;                  // sgtd_result_inlier_pairs staging
   bool verify_counted = false;                // the last verify_enqueue left the inlier counts in inl_counts
   DevBuf inl_counts;                          // sgtd_search_frame: inlier pairs per candidate
+  DevBuf in_block;                            // copy_in: a frame's descriptors as they arrive, one block
   size_t frame_inl_cap = 0;                   // ... entries its gather has room for (grown when a frame has more inlier pairs)
   char *frame_host = nullptr;                 // ... page-locked host memory the call's last kernels write straight into: the packed small results,
   size_t frame_host_bytes = 0;                //     then the inlier pairs' entries field by field and their query indices (no copy, no second wait)
@@ -526,6 +527,31 @@ int copy_out(sgtd_engine *e, const DescStore &s, size_t first, size_t n, sgtd_de
 
 int copy_in(sgtd_engine *e, DescStore &s, size_t first, size_t n, const sgtd_desc_soa *in, bool wait = true) {
   if (n == 0) return SGTD_OK;
+  // a frame's descriptors (up to a few MB): the seven fields side by side in the page-locked staging, ONE transfer into a block on
+  // the device and a kernel that deals the words to the arrays — seven transfers of ~100 KB took ~0.2 ms before the first kernel
+  // of a one-frame call could start, one takes 0.04
+  const DescBlockOffsets bo = desc_block_offsets(n);
+  static const bool block_on = [] { const char *o = getenv("SGTD_COPY_IN_BLOCK"); return !(o && !atoi(o)); }();
+  if (block_on && bo.total <= (4u << 20)) {
+    size_t off;
+    CHK(pin_room(e, bo.total, &off));
+    const void *src[7] = {in->side, in->angle, in->center, in->vertex, in->label, in->frame, in->node_id};
+    void *dst[7] = {s.side.as<double>() + first * 3, s.angle.as<double>() + first * 3, s.center.as<double>() + first * 3, s.vertex.as<float>() + first * 9,
+                    s.label.as<int>() + first * 3, s.frame.as<u32>() + first, s.node_id.as<int>() + first * 3};
+    const size_t bytes[7] = {n * 24, n * 24, n * 24, n * 36, n * 12, n * 4, n * 12};
+    u32 present = 0;
+    for (int f = 0; f < 7; f++) {
+      if (src[f]) { std::memcpy(e->pin + off + bo.off[f], src[f], bytes[f]); present |= 1u << f; }
+      else HIPCHK(hipMemsetAsync(dst[f], 0, bytes[f], e->stream));
+    }
+    CHK(ensure(e, e->in_block, bo.total));
+    HIPCHK(hipMemcpyAsync(e->in_block.p, e->pin + off, bo.total, hipMemcpyHostToDevice, e->stream));
+    unpack_desc_block_kernel<<<(unsigned)std::min<long long>(grid_for((long long)n * 34, 256), 512), 256, 0, e->stream>>>(e->in_block.as<unsigned char>(), (u32)n, present, s.view(),
+                                                                                                                       (long long)first);
+    HIPCHK(hipGetLastError());
+    if (wait) CHK(xfer_sync(e));
+    return SGTD_OK;
+  }
 #define CP(field, T, w)                                                                        \
   if (in->field)                                                                               \
     CHK(h2d(e, s.field.as<T>() + first * (w), in->field, n * (w) * sizeof(T)));               \
@@ -1736,7 +1762,7 @@ int sgtd_destroy(sgtd_handle e) {
                     &e->votes, &e->slot_of, &e->q_M, &e->q_P, &e->q_pairs, &e->q_pair_base,
                     &e->blk_count, &e->c_pair, &e->c_blk, &e->amb_queue, &e->rec, &e->rec_cell, &e->rec_dis, &e->rough_qi,
                     &e->rough_entry, &e->rough_frame, &e->rough_cell, &e->rough_dis, &e->n_cand, &e->cand_frame,
-                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals, &e->inl_counts, &e->b_in, &e->b_out,
+                    &e->cand_votes, &e->pair_off, &e->pairs, &e->totals, &e->inl_counts, &e->in_block, &e->b_in, &e->b_out,
                     // (the entry-id map: missing from this list until the engine's host code ran under the sanitizers — every destroyed
                     // handle kept them, 8 bytes per map frame and, with frame ids out of insertion order, 8 bytes per entry)
                     &e->frame_first, &e->by_frame, &e->id_of_g, &e->longest};
@@ -2706,7 +2732,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
                                               cn, reinterpret_cast<unsigned char *>(e->frame_host), e->totals.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   LAP("verify_and_result_launches");
-  HIPCHK(hipStreamSynchronize(e->stream));                  // ---- the call's one wait
+  CHK(xfer_sync(e));                                        // ---- the call's one wait (nothing is queued for it: it also gives the staging back)
   struct { const unsigned char *p; const unsigned char *data() const { return p; } } pack{reinterpret_cast<const unsigned char *>(e->frame_host)};
   unsigned long long tot[3];                                // the handle's running totals, as sync_batch reads them
   std::memcpy(tot, pack.data() + frame_pack_bytes(cn), sizeof(tot));

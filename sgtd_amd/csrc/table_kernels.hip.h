@@ -498,6 +498,34 @@ __device__ __forceinline__ void gather_entry(const long long *idx, long long i, 
   out.frame[i] = tab.frame[g];
 }
 
+// descriptors that arrived as ONE block (side | angle | center | vertex | label | frame | node_id, `n` entries each, every field on
+// a 16-byte boundary: desc_block_offsets) to the store's seven arrays from entry `first` on, word by word (every field is a
+// multiple of four bytes).  `present` bit f: field f is in the block (an absent field was zeroed by a memset).
+struct DescBlockOffsets { u32 off[7]; u32 total; };
+__host__ __device__ __forceinline__ DescBlockOffsets desc_block_offsets(size_t n) {
+  const u32 bytes[7] = {24, 24, 24, 36, 12, 4, 12};
+  DescBlockOffsets o;
+  u32 at = 0;
+  for (int f = 0; f < 7; f++) { o.off[f] = at; at += (u32)((n * bytes[f] + 15) & ~(size_t)15); }
+  o.total = at;
+  return o;
+}
+__global__ void unpack_desc_block_kernel(const unsigned char *block, u32 n, u32 present, DescArrays out, long long first) {
+  const DescBlockOffsets o = desc_block_offsets(n);
+  u32 *dst[7] = {reinterpret_cast<u32 *>(out.side + first * 3), reinterpret_cast<u32 *>(out.angle + first * 3), reinterpret_cast<u32 *>(out.center + first * 3),
+                 reinterpret_cast<u32 *>(out.vertex + first * 9), reinterpret_cast<u32 *>(out.label + first * 3), reinterpret_cast<u32 *>(out.frame + first),
+                 reinterpret_cast<u32 *>(out.node_id + first * 3)};
+  const u32 words[7] = {6, 6, 6, 9, 3, 1, 3};
+  const u32 per = 34u;     // words of one entry over all fields
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n * per; i += gridDim.x * blockDim.x) {
+    // word i of the block's payload, field by field
+    u32 r = i, f = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const u32 span = n * words[k]; if (f == (u32)k && r >= span) { r -= span; f = (u32)k + 1; } }
+    if ((present >> f) & 1u) dst[f][r] = reinterpret_cast<const u32 *>(block + o.off[f])[r];
+  }
+}
+
 // scatter of a strided build result into the table's cold arrays (append):
 // frame k's count[k] descriptors go to g = gbase[k] + r
 struct AppendParams {

@@ -125,6 +125,28 @@ int main(int argc, char **argv) {
     }
     std::printf("7000 descriptors out of the arrays: the caller alone %.3f ms, sized by the caller and assigned by the team in chunks of 512 %.3f ms\n", t_one7 / reps, t_team7 / reps);
   }
+  // SearchLoop's way in: the frame's 7 000 STDesc into the structure of arrays (adapter: to_soa), by the caller and by the team
+  {
+    double t_one = 0, t_team8 = 0;
+    std::vector<double> so(nq * 9); std::vector<float> vo(nq * 9); std::vector<int> lo_(nq * 6); std::vector<unsigned> fo(nq);
+    auto put = [&](size_t i) {
+      for (int k = 0; k < 3; k++) {
+        so[3 * i + k] = stds[i].side_length_[k]; so[3 * nq + 3 * i + k] = stds[i].angle_[k]; so[6 * nq + 3 * i + k] = stds[i].center_[k];
+        vo[9 * i + k] = (float)stds[i].vertex_A_[k]; vo[9 * i + 3 + k] = (float)stds[i].vertex_B_[k]; vo[9 * i + 6 + k] = (float)stds[i].vertex_C_[k];
+        lo_[3 * i + k] = (int)stds[i].vertex_attached_[k]; lo_[3 * nq + 3 * i + k] = stds[i].node_id.size() == 3 ? stds[i].node_id[k] : 0;
+      }
+      fo[i] = stds[i].frame_id_;
+    };
+    for (int r = 0; r < reps + 2; r++) {
+      double u0 = now_ms();
+      for (size_t i = 0; i < nq; i++) put(i);
+      double u1 = now_ms();
+      team.run((int)((nq + 511) / 512), [&](int c) { for (size_t i = (size_t)c * 512; i < std::min(nq, ((size_t)c + 1) * 512); i++) put(i); });
+      double u2 = now_ms();
+      if (r >= 2) { t_one += u1 - u0; t_team8 += u2 - u1; }
+    }
+    std::printf("7000 descriptors into the arrays: the caller alone %.3f ms, the team in chunks of 512 %.3f ms\n", t_one / reps, t_team8 / reps);
+  }
   std::printf("%d threads, %zu pairs in %d lists: short-lived threads %.3f ms, sleeping team %.3f ms | starting and joining idle threads %.3f ms, waking the idle team %.3f ms | one thread %.3f ms | freeing a frame's lists %.3f ms | team in two rounds (sized by list, assigned in chunks of 1024) %.3f ms, lists freed by the team %.3f ms\n",
               n_thr, total, cn, t_spawn / reps, t_team / reps, t_noop_spawn / reps, t_noop_team / reps, t_one, t_free / reps, t_chunk / reps, t_free_team / reps);
   return 0;
