@@ -94,7 +94,7 @@ def one_round(rng, rnd):
                 sc, rot, tt = g.result_verify(0)
                 cap = int(r1.pair_off[0, -1])
                 off, qi1, ent1 = g.result_inlier_entries(0, cap)
-                fs = g.search_frame(d0, capacity=max(cap, 1))
+                fs = g.search_frame(d0, capacity=max(cap, 1), page_locked=bool(rng.random() < 0.5))      # (page-locked arrays: written in place by the device)
                 assert fs["status"] == 0 and fs["n_cand"] == int(r1.n_cand[0]), desc + " frame"
                 assert np.array_equal(fs["cand_frame"], r1.cand_frame[0]) and np.array_equal(fs["cand_votes"], r1.cand_votes[0]) and np.array_equal(fs["pair_off"], r1.pair_off[0]), desc + " frame tables"
                 assert np.array_equal(fs["score"], sc) and np.array_equal(fs["rot"], rot) and np.array_equal(fs["t"], tt), desc + " frame verify"
