@@ -178,8 +178,11 @@ __device__ __forceinline__ bool vertex_close(const double *Rt, const double v[3]
 
 #define SGTD_VM_BLIMIT 2.5e4        // largest hypothesis feature the matrix pass accepts
 // ---- the hypothesis side, written by verify_solve_kernel's thread h for hypothesis h (NaN tau: exact test only) -----------
-// Layout = the B operand of the four MFMAs as the lanes read it: block (T, mi), T = h / 32, mi = 2 u + part; lane
+// Layout = the B operands of the three MFMAs as the lanes read them: block (T, mi), T = h / 32, mi = 2 u + part; lane
 // (h % 32) + 32 hh holds for k = 0..3 the feature of term 8 hh + 4 u + k, its high part (part 0) or low part (part 1), twice.
+// (Measured against this layout in round 6, same box, back to back: the plain one — a block of high parts and a block of low
+// parts on both sides, the products' high parts used by two of the three MFMAs, eight vector instructions and six registers
+// less per tile — 12.26-12.30 ms per batch against 11.76-11.87: not adopted.)
 __device__ __forceinline__ void vm_split(float x, _Float16 &hi, _Float16 &lo) {
   const float h = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);   // the top 11 significant bits
   hi = (_Float16)h;
