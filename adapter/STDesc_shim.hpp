@@ -370,12 +370,40 @@ int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::ve
                        unsigned int current_frame_id, int candidate_num, int &CS1) {
   const auto t1 = std::chrono::high_resolution_clock::now();
   Selection s;
-  int st = select(h, stds_vec, candidate_num, s);
-  if (st != SGTD_OK) return st;
-  const int64_t total = s.off[s.n_cand];
-  PinnedSoa &pe = fetched_entries();               // the table side of every pair<STDesc, STDesc>: page-locked, reused
-  pe.reserve((size_t)total);
-  st = sgtd_fetch_entries(h, s.entry.data(), total, &pe.v);
+  PinnedSoa &pe = fetched_entries();               // the table side of every pair<STDesc, STDesc> and its query index: page-locked, reused
+  const int32_t *qip = nullptr;                    // query descriptor of pair r
+  int64_t total = 0;
+  // ONE call and one wait: the selection, and every pair of every match list with the table entry it names written in place by the
+  // device (sgtd_search_frame, SGTD_FRAME_LISTS_ONLY) — sgtd_query_descs + sgtd_result_candidates + sgtd_result_pairs +
+  // sgtd_fetch_entries before: four waits, the entry ids down and up again, seven transfers for the entries
+  int st = SGTD_ERR_UNSUPPORTED;
+  if (!stds_vec.empty()) {
+    const int cn = candidate_num;
+    SoaBuf qb(stds_vec.size());
+    to_soa(stds_vec, qb);
+    s.frame.assign(cn, -1); s.votes.assign(cn, 0); s.off.assign((size_t)cn + 1, 0);
+    pe.reserve(16384);
+    for (int attempt = 0; attempt < 4; attempt++) {
+      sgtd_frame_search fs{};
+      fs.flags = SGTD_FRAME_LISTS_ONLY;
+      fs.cand_frame = s.frame.data(); fs.cand_votes = s.votes.data(); fs.pair_off = s.off.data();
+      fs.inlier_q_idx = pe.q_idx; fs.entries = pe.v; fs.capacity = (int64_t)pe.cap;
+      st = sgtd_search_frame(h, &qb.v, (int64_t)stds_vec.size(), &fs);
+      s.n_cand = fs.n_cand;
+      total = fs.n_inliers;
+      if (st != SGTD_ERR_CAPACITY) break;
+      pe.reserve((size_t)total + (size_t)total / 4);     // (a first frame, a frame with longer lists than any before: once more, with room)
+    }
+    qip = pe.q_idx;
+  }
+  if (st == SGTD_ERR_UNSUPPORTED) {                // (an empty frame; a handle over several devices: the calls one after the other)
+    st = select(h, stds_vec, candidate_num, s);
+    if (st != SGTD_OK) return st;
+    total = s.off[s.n_cand];
+    pe.reserve((size_t)total);
+    st = sgtd_fetch_entries(h, s.entry.data(), total, &pe.v);
+    qip = s.q_idx.data();
+  }
   if (st != SGTD_OK) return st;
   const sgtd_desc_soa &ent = pe.v;
   const size_t first = candidate_matcher_vec.size();
@@ -388,7 +416,7 @@ int candidate_selector(sgtd_handle h, const std::vector<Desc> &stds_vec, std::ve
       ml.match_id_.second = s.frame[k];              // :437
       ml.match_list_.reserve((size_t)(s.off[k + 1] - s.off[k]));
       for (int64_t r = s.off[k]; r < s.off[k + 1]; r++)
-        ml.match_list_.emplace_back(stds_vec[(size_t)s.q_idx[(size_t)r]], desc_from<Desc>(ent, (size_t)r));
+        ml.match_list_.emplace_back(stds_vec[(size_t)qip[(size_t)r]], desc_from<Desc>(ent, (size_t)r));
     }
   });
   const auto t2 = std::chrono::high_resolution_clock::now();

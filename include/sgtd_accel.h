@@ -347,10 +347,17 @@ int sgtd_search_loop(sgtd_handle h, double icp_threshold, int32_t *best_cand, in
  * the state the five calls leave (every sgtd_result_* call works).  Not on a multi-device handle (SGTD_ERR_UNSUPPORTED).
  * inlier_q_idx and the members of `entries` are best given as sgtd_host_alloc memory (page-locked, `capacity` entries each): the
  * device then writes the inlier pairs in place and the call has one wait; ordinary arrays are filled from a page-locked block of
- * the handle's with memcpy (same results).  On SGTD_ERR_CAPACITY the first `capacity` pairs may or may not have been written. */
+ * the handle's with memcpy (same results).  On SGTD_ERR_CAPACITY the first `capacity` pairs may or may not have been written.
+ * flags = SGTD_FRAME_LISTS_ONLY: candidate_selector ALONE (STDesc.cpp:318-460), for a node that keeps its own candidate_verify —
+ * no verification (score and pose are not written; the handle is left as sgtd_query_descs leaves it), and the pairs handed
+ * back are ALL pairs of every candidate's match_list_, in the reference's order: inlier_off = pair_off, n_inliers = their
+ * number, inlier_q_idx / entries = the query descriptor and the table entry of every pair.  Equal to sgtd_query_descs +
+ * sgtd_result_candidates + sgtd_result_pairs + sgtd_fetch_entries, in one call and one wait.  On SGTD_ERR_CAPACITY call again
+ * with room for n_inliers pairs. */
+#define SGTD_FRAME_LISTS_ONLY 1   /* sgtd_frame_search.flags: candidate_selector alone (below) */
 typedef struct sgtd_frame_search {
   int32_t n_cand;           /* out */
-  int32_t reserved;
+  int32_t flags;            /* in: 0, or SGTD_FRAME_LISTS_ONLY (the field was `reserved`, always 0, before)                 */
   int32_t *cand_frame;      /* out [candidate_num]: match_id_.second, votes descending / frame ascending            */
   int32_t *cand_votes;      /* out [candidate_num]                                                                  */
   int64_t *pair_off;        /* out [candidate_num + 1]: offsets of the candidates' match lists (their lengths)      */

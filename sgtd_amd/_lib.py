@@ -61,7 +61,7 @@ class DescSoa(C.Structure):
 
 class FrameSearch(C.Structure):
     """sgtd_frame_search"""
-    _fields_ = [("n_cand", C.c_int32), ("reserved", C.c_int32), ("cand_frame", C.c_void_p), ("cand_votes", C.c_void_p),
+    _fields_ = [("n_cand", C.c_int32), ("flags", C.c_int32), ("cand_frame", C.c_void_p), ("cand_votes", C.c_void_p),
                 ("pair_off", C.c_void_p), ("score", C.c_void_p), ("pose", C.c_void_p), ("inlier_off", C.c_void_p),
                 ("inlier_q_idx", C.c_void_p), ("entries", DescSoa), ("capacity", C.c_int64), ("n_inliers", C.c_int64)]
 

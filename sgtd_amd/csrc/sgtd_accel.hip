@@ -2629,6 +2629,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   if (!e || !io || nq < 0 || (nq > 0 && (!q || !q->side || !q->label || !q->frame)) || io->capacity < 0) return SGTD_ERR_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device_id));
   const int cn = e->dc.cand_num;
+  const bool lists_only = (io->flags & SGTD_FRAME_LISTS_ONLY) != 0;     // candidate_selector alone: no verification, every pair of every list
   io->n_cand = 0; io->n_inliers = 0;
 #ifdef SGTD_EXP_FRAME_LAPS      // host time of the call by part, to stderr (an experiment build)
   struct Laps {
@@ -2662,22 +2663,30 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   e->defer_lists = deferred;
   CHK(ls);
   LAP("select_launches");
-  // ---- candidate_verify behind it, sized by what the pair buffer holds
-  CHK(verify_enqueue(e, (int64_t)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), /*guard=*/true));
-  // ---- the inlier pairs of every candidate, compacted by one workgroup per candidate, and the entries they name
   const int *ovf = reinterpret_cast<const int *>(e->cursors.as<u32>() + 10);
-  CHK(ensure(e, e->inl_counts, (size_t)SGTD_MAX_CAND * sizeof(u32)));
-  CHK(ensure(e, e->inl_off, (size_t)(cn + 1) * sizeof(long long)));
-  CHK(ensure(e, e->inl_pairs, std::min<size_t>(e->pair_cap, 0xFFFFFFF0u) * sizeof(u64)));
-  if (!e->verify_counted) {     // (the packed-f32 form of the vote pass does not count)
-    inlier_count_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(), e->n_cand.as<int>(), ovf,
-                                                                         e->inl_counts.as<u32>());
+  // the pairs whose entries go to the caller, and their offsets per candidate: the inlier pairs (compacted below), or — lists only —
+  // the match lists as they stand (a one-query batch's pairs start at 0 of the pair buffer; pair_off[cn] = their number)
+  const u64 *out_pairs = e->pairs.as<u64>();
+  const long long *out_off = e->pair_off.as<long long>();
+  if (!lists_only) {
+    // ---- candidate_verify behind it, sized by what the pair buffer holds
+    CHK(verify_enqueue(e, (int64_t)std::min<size_t>(e->pair_cap, 0xFFFFFFF0u), /*guard=*/true));
+    // ---- the inlier pairs of every candidate, compacted by one workgroup per candidate, and the entries they name
+    CHK(ensure(e, e->inl_counts, (size_t)SGTD_MAX_CAND * sizeof(u32)));
+    CHK(ensure(e, e->inl_off, (size_t)(cn + 1) * sizeof(long long)));
+    CHK(ensure(e, e->inl_pairs, std::min<size_t>(e->pair_cap, 0xFFFFFFF0u) * sizeof(u64)));
+    if (!e->verify_counted) {     // (the packed-f32 form of the vote pass does not count)
+      inlier_count_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(), e->n_cand.as<int>(), ovf,
+                                                                           e->inl_counts.as<u32>());
+      HIPCHK(hipGetLastError());
+    }
+    inlier_compact_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->pairs.as<u64>(), e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(),
+                                                                           e->n_cand.as<int>(), ovf, e->inl_counts.as<u32>(), cn, e->inl_pairs.as<u64>(),
+                                                                           e->inl_off.as<long long>());
     HIPCHK(hipGetLastError());
+    out_pairs = e->inl_pairs.as<u64>();
+    out_off = e->inl_off.as<long long>();
   }
-  inlier_compact_kernel<<<cn, SGTD_INLIER_CAND_THREADS, 0, e->stream>>>(e->pairs.as<u64>(), e->v_inlier.as<unsigned char>(), e->pair_off.as<long long>(),
-                                                                         e->n_cand.as<int>(), ovf, e->inl_counts.as<u32>(), cn, e->inl_pairs.as<u64>(),
-                                                                         e->inl_off.as<long long>());
-  HIPCHK(hipGetLastError());
   // the results go where the host reads them: page-locked memory the kernels write over the link — the packed block first (the
   // handle's), then the inlier pairs' entries and query indices: straight into the CALLER's arrays when those are page-locked
   // (sgtd_host_alloc: the 23 MB of a frame's 160 000 pairs on a 10 000-frame map cross the link once, at its rate, and the call
@@ -2705,7 +2714,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
     if (direct) {
       DescArrays user{};
       user.side = o.side; user.angle = o.angle; user.center = o.center; user.vertex = o.vertex; user.label = o.label; user.frame = o.frame; user.node_id = o.node_id;
-      gather_pair_entries_kernel<<<1024, 256, 0, e->stream>>>(e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)ucap, io->inlier_q_idx, e->tab.view(), user);
+      gather_pair_entries_kernel<<<1024, 256, 0, e->stream>>>(out_pairs, out_off + cn, (long long)ucap, io->inlier_q_idx, e->tab.view(), user, ovf);
       HIPCHK(hipGetLastError());
       return SGTD_OK;
     }
@@ -2720,7 +2729,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
     host_qi = reinterpret_cast<int *>(at);
     host_out.qrec = nullptr;
     gather_pair_entries_kernel<<<(unsigned)std::min<long long>(grid_for((long long)room * 8, 256), 1024), 256, 0, e->stream>>>(
-        e->inl_pairs.as<u64>(), e->inl_off.as<long long>() + cn, (long long)room, host_qi, e->tab.view(), host_out);
+        out_pairs, out_off + cn, (long long)room, host_qi, e->tab.view(), host_out, ovf);
     HIPCHK(hipGetLastError());
     return SGTD_OK;
   };
@@ -2728,7 +2737,7 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   CHK(gather(direct ? ucap : e->frame_inl_cap));
   pack_frame_kernel<<<1, 256, 0, e->stream>>>(e->cursors.as<u32>(), e->n_cand.as<int>(), e->q_M.as<u32>(), e->q_pair_base.as<u32>(), e->q_count.as<u32>(),
                                               e->q_P.as<unsigned long long>(), e->cand_frame.as<int>(), e->cand_votes.as<int>(),
-                                              e->pair_off.as<long long>(), e->v_score.as<double>(), e->v_pose.as<double>(), e->inl_off.as<long long>(),
+                                              e->pair_off.as<long long>(), lists_only ? nullptr : e->v_score.as<double>(), lists_only ? nullptr : e->v_pose.as<double>(), out_off,
                                               cn, reinterpret_cast<unsigned char *>(e->frame_host), e->totals.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   LAP("verify_and_result_launches");
@@ -2742,6 +2751,22 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
     // the batch outgrew a work buffer (a first frame, a frame unlike the ones before): sgtd_sync re-runs it, then the
     // calls this one stands for, one after the other
     CHK(sync_batch(e));
+    if (lists_only) {
+      std::vector<int64_t> off((size_t)cn + 1, 0);
+      CHK(sgtd_result_candidates(e, &io->n_cand, io->cand_frame, io->cand_votes, off.data()));
+      if (io->pair_off) std::memcpy(io->pair_off, off.data(), off.size() * sizeof(int64_t));
+      if (io->inlier_off) std::memcpy(io->inlier_off, off.data(), off.size() * sizeof(int64_t));
+      const int64_t total = off[(size_t)io->n_cand];
+      io->n_inliers = total;
+      if (total > io->capacity) return SGTD_ERR_CAPACITY;
+      if (total == 0) return SGTD_OK;
+      std::vector<int64_t> ids((size_t)total);
+      std::vector<int32_t> qi;
+      int64_t got = 0;
+      if (!io->inlier_q_idx) qi.resize((size_t)total);
+      CHK(sgtd_result_pairs(e, 0, io->inlier_q_idx ? io->inlier_q_idx : qi.data(), ids.data(), total, &got));
+      return sgtd_fetch_entries(e, ids.data(), total, &io->entries);
+    }
     CHK(sgtd_verify(e));
     CHK(sgtd_result_candidates(e, &io->n_cand, io->cand_frame, io->cand_votes, io->pair_off));
     CHK(sgtd_result_verify(e, 0, io->score, io->pose));
@@ -2776,13 +2801,13 @@ int sgtd_search_frame(sgtd_handle e, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   }
   stage_times(e);
   e->batch_synced = true;
-  e->verified = true;
+  e->verified = !lists_only;
   io->n_cand = (int32_t)w[12];
   if (io->cand_frame) std::memcpy(io->cand_frame, cf, (size_t)cn * 4);
   if (io->cand_votes) std::memcpy(io->cand_votes, cv, (size_t)cn * 4);
   if (io->pair_off) std::memcpy(io->pair_off, po, ((size_t)cn + 1) * 8);
-  if (io->score) std::memcpy(io->score, sc, (size_t)cn * 8);
-  if (io->pose) std::memcpy(io->pose, ps, (size_t)cn * 96);
+  if (io->score && !lists_only) std::memcpy(io->score, sc, (size_t)cn * 8);
+  if (io->pose && !lists_only) std::memcpy(io->pose, ps, (size_t)cn * 96);
   if (io->inlier_off) std::memcpy(io->inlier_off, ioff, ((size_t)cn + 1) * 8);
   const int64_t n_inl = ioff[cn];
   io->n_inliers = n_inl;

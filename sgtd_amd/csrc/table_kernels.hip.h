@@ -450,7 +450,10 @@ __global__ void gather_entries_counted_kernel(const long long *idx, const long l
 // workgroups that stride over the count, which is still on the device
 // (`out` and `q_idx` may be page-locked HOST memory — sgtd_search_frame hands the caller's own arrays when the device can write them: the
 // entries then cross the link once, inside this kernel, at the link's rate; members that are NULL are skipped)
-__global__ __launch_bounds__(256) void gather_pair_entries_kernel(const u64 *pairs, const long long *n_p, long long cap, int *q_idx, DescArrays tab, DescArrays out) {
+// (`overflow`, or NULL: the batch's two flags — set: the pairs are not final and name nothing, nothing is read)
+__global__ __launch_bounds__(256) void gather_pair_entries_kernel(const u64 *pairs, const long long *n_p, long long cap, int *q_idx, DescArrays tab, DescArrays out,
+                                                                  const int *overflow) {
+  if (overflow && (overflow[0] | overflow[1])) return;
   const long long n = *n_p < cap ? *n_p : cap;
   const int part = threadIdx.x & 7;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += ((long long)gridDim.x * blockDim.x) >> 3) {

@@ -648,8 +648,9 @@ __global__ __launch_bounds__(256) void pack_frame_kernel(const u32 *ctr, const i
   long long *po = reinterpret_cast<long long *>(out + 72 + (size_t)cn * 8);
   double *sc = reinterpret_cast<double *>(po + cn + 1), *ps = sc + cn;
   long long *io = reinterpret_cast<long long *>(ps + (size_t)cn * 12);
-  for (int k = t; k < cn; k += 256) { cf[k] = cand_frame[k]; cv[k] = cand_votes[k]; sc[k] = score[k]; }
+  // (score / pose NULL: a call without verification — zeros)
+  for (int k = t; k < cn; k += 256) { cf[k] = cand_frame[k]; cv[k] = cand_votes[k]; sc[k] = score ? score[k] : 0.0; }
   for (int k = t; k <= cn; k += 256) { po[k] = pair_off[k]; io[k] = inl_off[k]; }
-  for (int k = t; k < cn * 12; k += 256) ps[k] = pose[k];
+  for (int k = t; k < cn * 12; k += 256) ps[k] = pose ? pose[k] : 0.0;
   if (t < 3) reinterpret_cast<unsigned long long *>(out + frame_pack_bytes(cn))[t] = totals ? totals[t] : 0ull;
 }

@@ -389,12 +389,14 @@ class STDescManager:
         self._check(self._L.sgtd_search_loop(self._h, float(icp_threshold), _p(bc), _p(bf), _p(bs)))
         return bc, bf, bs
 
-    def search_frame(self, stds_vec, capacity=16384, page_locked=False):
+    def search_frame(self, stds_vec, capacity=16384, page_locked=False, lists_only=False):
         """sgtd_search_frame: candidate_selector + candidate_verify + the inlier pairs of every candidate with their table
         entries for ONE query frame given as descriptors, in one call -> dict(n_cand, cand_frame, cand_votes, pair_off,
         score, rot, t, inlier_off, inlier_q_idx, entries (Descs), n_inliers, status).  page_locked: the arrays the inlier
         pairs arrive in come from sgtd_host_alloc, as adapter/STDesc_shim.hpp keeps them — the device then writes them in
-        place and the call has one wait (ordinary arrays are filled from the handle's own page-locked block)"""
+        place and the call has one wait (ordinary arrays are filled from the handle's own page-locked block).
+        lists_only (SGTD_FRAME_LISTS_ONLY): candidate_selector alone — no verification, inlier_off = pair_off and the pairs
+        handed back are all pairs of every candidate's match list"""
         from ._lib import FrameSearch
         cn = self.config_setting_["candidate_num"]
         cap = max(int(capacity), 1)
@@ -422,6 +424,7 @@ class STDescManager:
                 setattr(fs, k, out[k].ctypes.data)
             fs.entries = ent.soa()
             fs.capacity = int(capacity)
+            fs.flags = 1 if lists_only else 0
             s = stds_vec.soa()
             self._nq = 1
             st = self._L.sgtd_search_frame(self._h, C.byref(s), stds_vec.n, C.byref(fs))

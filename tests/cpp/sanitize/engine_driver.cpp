@@ -288,6 +288,20 @@ int main(int argc, char **argv) {
     d.capacity = (int64_t)room; d.entries.vertex = ent.vertex.data();       // one ordinary array among them
     OK(sgtd_search_frame(h, &qs, 700, &d));
     REQUIRE(g_gathers_into.back() != pl[0]);
+    // candidate_selector alone in the one call (SGTD_FRAME_LISTS_ONLY): no verification is enqueued, the pairs are the lists' own; its
+    // three ways out (one wait, too little room, the fall-back after an overflow) with page-locked and with ordinary arrays
+    d.entries.vertex = (float *)pl[3];
+    d.flags = SGTD_FRAME_LISTS_ONLY; d.capacity = (int64_t)room; S.frame_inliers = 100;
+    OK(sgtd_search_frame(h, &qs, 700, &d));
+    REQUIRE(d.n_inliers == 100 && g_gathers_into.back() == pl[0]);
+    d.capacity = 10;
+    REQUIRE(sgtd_search_frame(h, &qs, 700, &d) == SGTD_ERR_CAPACITY && d.n_inliers == 100);
+    d.capacity = (int64_t)room; S.frame_overflow = 1;
+    OK(sgtd_search_frame(h, &qs, 700, &d));
+    io.flags = SGTD_FRAME_LISTS_ONLY; io.capacity = 40000; S.frame_inliers = 30000;
+    OK(sgtd_search_frame(h, &qs, 700, &io));
+    REQUIRE(io.n_inliers == 30000);
+    io.flags = 0;
     S.frame_inliers = -1;
     for (int k = 0; k < 8; k++) OK(sgtd_host_free(pl[k]));
   }

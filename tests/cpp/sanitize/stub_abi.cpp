@@ -207,6 +207,20 @@ int sgtd_search_frame(sgtd_handle h, const sgtd_desc_soa *q, int64_t nq, sgtd_fr
   if (!h || !io) return SGTD_ERR_INVALID;
   int st = sgtd_query_descs(h, q, nq);
   if (st != SGTD_OK) return st;
+  if (io->flags & SGTD_FRAME_LISTS_ONLY) {         // candidate_selector alone: every pair of every list, no verification
+    std::vector<int64_t> off((size_t)h->cfg.candidate_num + 1);
+    if ((st = sgtd_result_candidates(h, &io->n_cand, io->cand_frame, io->cand_votes, off.data())) != SGTD_OK) return st;
+    if (io->pair_off) memcpy(io->pair_off, off.data(), off.size() * sizeof(int64_t));
+    if (io->inlier_off) memcpy(io->inlier_off, off.data(), off.size() * sizeof(int64_t));
+    const int64_t n = (int64_t)h->entry.size();
+    io->n_inliers = n;
+    if (n > io->capacity) return SGTD_ERR_CAPACITY;
+    for (int64_t i = 0; i < n; i++) {
+      if (io->inlier_q_idx) io->inlier_q_idx[i] = h->q_idx[(size_t)i];
+      copy_entry(h, h->entry[(size_t)i], &io->entries, i);
+    }
+    return SGTD_OK;
+  }
   if ((st = sgtd_verify(h)) != SGTD_OK) return st;
   if ((st = sgtd_result_candidates(h, &io->n_cand, io->cand_frame, io->cand_votes, io->pair_off)) != SGTD_OK) return st;
   if ((st = sgtd_result_verify(h, 0, io->score, io->pose)) != SGTD_OK) return st;

@@ -67,6 +67,24 @@ def test_search_frame_equals_the_calls_it_stands_for(mods, monkeypatch):
             pl = g.search_frame(d, capacity=cap, page_locked=True)
             assert pl["status"] == 0
             _same(pl, ref, cn)
+        # candidate_selector alone in the one call (SGTD_FRAME_LISTS_ONLY): every pair of every match list with its table entry, in the
+        # reference's order — the four calls it stands for give the same; ordinary and page-locked arrays; too little room
+        qi_all, de_all = g.result_pairs(0, ref[1])
+        ent_all = g.fetch_entries(de_all)
+        for pl_mem in (False, True):
+            lo = g.search_frame(d, capacity=room, page_locked=pl_mem, lists_only=True)
+            assert lo["status"] == 0 and lo["n_cand"] == int(ref[1].n_cand[0]) and lo["n_inliers"] == room
+            assert np.array_equal(lo["cand_frame"], ref[1].cand_frame[0]) and np.array_equal(lo["cand_votes"], ref[1].cand_votes[0])
+            assert np.array_equal(lo["pair_off"], ref[1].pair_off[0]) and np.array_equal(lo["inlier_off"], ref[1].pair_off[0])
+            assert np.array_equal(lo["inlier_q_idx"], qi_all)
+            for name, _, _ in ent_all.FIELDS:
+                assert np.array_equal(getattr(lo["entries"], name), getattr(ent_all, name)), name
+        short = g.search_frame(d, capacity=room - 1, page_locked=True, lists_only=True)
+        assert short["status"] == -4 and short["n_inliers"] == room
+        # (the handle is left as sgtd_query_descs leaves it: verification is a call of its own again)
+        g.verify()
+        sc2, _, _ = g.result_verify(0)
+        assert np.array_equal(sc2, fs["score"])
         tight = g.search_frame(d, capacity=fs["n_inliers"] - 1, page_locked=True)
         assert tight["status"] == -4 and tight["n_inliers"] == fs["n_inliers"]
         _same(tight, ref, cn)
@@ -96,6 +114,19 @@ def test_search_frame_equals_the_calls_it_stands_for(mods, monkeypatch):
     fs = h.search_frame(d, capacity=1 << 20, page_locked=True)
     assert h.stats()["overflowed"] == 1 and fs["status"] == 0
     _same(fs, _five_calls(h, d), cn)
+    h.close()
+    # ... and the same for the lists alone
+    monkeypatch.setenv("SGTD_REC_CAP", "4096")
+    h = manager.STDescManager()
+    monkeypatch.delenv("SGTD_REC_CAP")
+    h.add_frames(m.xyz, m.label)
+    d = h.BuildSingleScanSTD(qs.xyz[2], qs.label[2])
+    lo = h.search_frame(d, capacity=1 << 20, lists_only=True)
+    assert h.stats()["overflowed"] == 1 and lo["status"] == 0
+    h.candidate_selector(d)
+    r1 = h.results()
+    qi_all, de_all = h.result_pairs(0, r1)
+    assert lo["n_inliers"] == len(qi_all) and np.array_equal(lo["inlier_q_idx"], qi_all) and np.array_equal(lo["entries"].side, h.fetch_entries(de_all).side)
     h.close()
 
 
