@@ -99,6 +99,13 @@ def one_round(rng, rnd):
                 assert np.array_equal(fs["cand_frame"], r1.cand_frame[0]) and np.array_equal(fs["cand_votes"], r1.cand_votes[0]) and np.array_equal(fs["pair_off"], r1.pair_off[0]), desc + " frame tables"
                 assert np.array_equal(fs["score"], sc) and np.array_equal(fs["rot"], rot) and np.array_equal(fs["t"], tt), desc + " frame verify"
                 assert np.array_equal(fs["inlier_off"], off) and np.array_equal(fs["inlier_q_idx"], qi1) and np.array_equal(fs["entries"].side, ent1.side) and np.array_equal(fs["entries"].vertex, ent1.vertex), desc + " frame inliers"
+                # candidate_selector alone in the one call: every pair of every list with its entry, against the calls it stands for
+                if rng.random() < 0.5:
+                    qa, da = g.result_pairs(0, r1)
+                    lo = g.search_frame(d0, capacity=max(cap, 1), page_locked=bool(rng.random() < 0.5), lists_only=True)
+                    assert lo["status"] == 0 and lo["n_inliers"] == cap and np.array_equal(lo["inlier_off"], r1.pair_off[0]) and np.array_equal(lo["inlier_q_idx"], qa), desc + " frame lists"
+                    ea = g.fetch_entries(da) if len(da) else None
+                    assert ea is None or (np.array_equal(lo["entries"].side, ea.side) and np.array_equal(lo["entries"].node_id, ea.node_id) and np.array_equal(lo["entries"].frame, ea.frame)), desc + " frame lists entries"
                 # ... and the verification itself against the oracle's (same one-sided Jacobi SVD restated on the CPU)
                 o.build(q.xyz[1], q.label[1], export=False)
                 ow = o.select()
