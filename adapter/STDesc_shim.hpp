@@ -465,7 +465,7 @@ int SearchLoop(sgtd_handle h, const std::vector<Desc> &stds_vec, std::pair<int, 
   int64_t n_inl = 0;
   PinnedSoa &pe = fetched_entries();      // page-locked, reused from frame to frame
   // ONE call for candidate_selector (:98), candidate_verify of every candidate (:105-118) and the inlier pairs of every
-  // candidate (sucess_match_vec, :516-539) with the table entries they name: two waits for the device instead of eight
+  // candidate (sucess_match_vec, :516-539) with the table entries they name: one wait for the device instead of eight
   // (sgtd_search_frame).  Room for the inlier pairs: what the frames before needed, with slack; a frame that needs more
   // says so and its pairs are fetched by the second call below.
   int st;

@@ -340,7 +340,7 @@ int sgtd_search_loop(sgtd_handle h, double icp_threshold, int32_t *best_cand, in
  * reference's one-frame-per-call pattern (semantic_graph_localization.cpp:590-603).  Equal, value for value, to
  * sgtd_query_descs + sgtd_verify + sgtd_result_candidates + sgtd_result_verify(0) + sgtd_result_inlier_entries(0), which
  * wait for the device eight times and issue some sixty small copies between them; this call enqueues everything behind
- * the batch, waits once for one packed block of the small results and once for the entries.  Output arrays of
+ * the batch and waits once: the small results arrive as one packed block, the entries where the caller wants them.  Output arrays of
  * candidate_num (pair_off, inlier_off: candidate_num + 1; pose: candidate_num * 12) elements; any pointer may be NULL.
  * capacity = room (pairs) in inlier_q_idx / entries; n_inliers = needed.  SGTD_ERR_CAPACITY leaves everything but the
  * inlier pairs valid — sgtd_result_inlier_entries(h, 0, ...) with more room fetches them.  The handle afterwards is in
